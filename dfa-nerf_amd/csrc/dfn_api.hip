@@ -1,0 +1,246 @@
+// dfn_api.hip - the C ABI of libdfanerf.so (declared in include/dfanerf.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "dfanerf.h"
+#include "dfn_layout.h"
+#include "dfn_misc.h"
+#include "dfn_params.h"
+#include "dfn_plan.h"
+
+using namespace dfn;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+    return fail(DFN_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+bool tier_ok(int tier) { return tier == DFN_TIER_F32 || tier == DFN_TIER_BF16; }
+bool field_ok(int field) { return field >= 0 && field <= 2; }
+int prog_field(int field) { return field == DFN_FIELD_TORSO ? FIELD_TORSO : FIELD_HEAD; }
+
+// cached pack plans: host copy + lazily uploaded device copy (per device the first caller uses)
+struct PlanEntry {
+    std::vector<int32_t> host;
+    long n_frags = 0;
+    int32_t* dev = nullptr;
+};
+std::mutex g_plan_mu;
+PlanEntry g_plans[2][3];
+
+PlanEntry& plan_of(int tier, int field) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    PlanEntry& e = g_plans[tier][field];
+    if (e.host.empty()) e.n_frags = build_pack_plan(tier, field, e.host);
+    return e;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dfn_last_error(void) { return g_err.c_str(); }
+const char* dfn_version(void) { return "dfanerf 0.1 gfx950"; }
+
+long dfn_packed_bytes(int tier, int field) {
+    if (!tier_ok(tier) || !field_ok(field)) return fail(DFN_E_ARG, "dfn_packed_bytes: bad tier/field");
+    ProgramInfo pi;
+    program_info(tier, prog_field(field), &pi);
+    return (long)pi.n_slabs * SLAB_BYTES;
+}
+
+long dfn_pack_plan(int tier, int field, int32_t* plan_host, long capacity) {
+    if (!tier_ok(tier) || !field_ok(field)) return fail(DFN_E_ARG, "dfn_pack_plan: bad tier/field");
+    PlanEntry& e = plan_of(tier, field);
+    ProgramInfo pi;
+    program_info(tier, prog_field(field), &pi);
+    if (e.n_frags != pi.n_frags)
+        return fail(DFN_E_ARG, "dfn_pack_plan: planner and kernel disagree on the fragment count (" +
+                                   std::to_string(e.n_frags) + " vs " + std::to_string(pi.n_frags) + ")");
+    const long n = (long)e.host.size();
+    if (plan_host) {
+        if (capacity < n) return fail(DFN_E_SIZE, "dfn_pack_plan: capacity too small");
+        std::memcpy(plan_host, e.host.data(), n * sizeof(int32_t));
+    }
+    return n;
+}
+
+int dfn_pack_weights(int tier, int field, const float* params, void* packed, void* stream) {
+    if (!tier_ok(tier) || !field_ok(field) || !params || !packed)
+        return fail(DFN_E_ARG, "dfn_pack_weights: bad argument");
+    if (param_offset(P_COUNT) != N_DECODER_PARAMS) return fail(DFN_E_ARG, "internal: parameter table size");
+    const long n = dfn_pack_plan(tier, field, nullptr, 0);
+    if (n < 0) return (int)n;
+    PlanEntry& e = plan_of(tier, field);
+    hipStream_t st = (hipStream_t)stream;
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        if (!e.dev) {
+            hipError_t err = hipMalloc((void**)&e.dev, n * sizeof(int32_t));
+            if (err != hipSuccess) return hip_fail(err, "hipMalloc(plan)");
+            err = hipMemcpy(e.dev, e.host.data(), n * sizeof(int32_t), hipMemcpyHostToDevice);
+            if (err != hipSuccess) return hip_fail(err, "hipMemcpy(plan)");
+        }
+    }
+    hipError_t err = launch_pack(e.dev, params, packed, n, tier == DFN_TIER_BF16, st);
+    if (err != hipSuccess) return hip_fail(err, "pack_kernel");
+    return DFN_OK;
+}
+
+long dfn_bias_floats(int tier, int field) {
+    if (!tier_ok(tier) || !field_ok(field)) return fail(DFN_E_ARG, "dfn_bias_floats: bad tier/field");
+    ProgramInfo pi;
+    program_info(tier, prog_field(field), &pi);
+    return pi.n_bias;
+}
+
+int dfn_fold_bias(int tier, int field, const float* params, const float* signal, const float* z_shape,
+                  const float* z_app, float* bias, void* stream) {
+    if (!tier_ok(tier) || !field_ok(field) || !params || !z_shape || !z_app || !bias)
+        return fail(DFN_E_ARG, "dfn_fold_bias: bad argument");
+    if (field != DFN_FIELD_LISTENER && !signal) return fail(DFN_E_ARG, "dfn_fold_bias: signal is NULL");
+    const int n = (int)dfn_bias_floats(tier, field);
+    hipError_t err = launch_fold(field, params, signal, z_shape, z_app, bias, n, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "fold_kernel");
+    return DFN_OK;
+}
+
+int dfn_render_fwd(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
+                   const float* bias_head, const float* bias_torso, const float* bg_f32,
+                   const uint8_t* bg_u8, const int32_t* pix_index, float* rgb_head, float* rgb_com,
+                   float* weights_head, float* weights_com, void* stream) {
+    if (!tier_ok(tier) || !frame || !packed_head || !bias_head || !rgb_head)
+        return fail(DFN_E_ARG, "dfn_render_fwd: bad argument");
+    const DfnFrame& F = *frame;
+    if (F.n_coarse != 64) return fail(DFN_E_ARG, "dfn_render_fwd: n_coarse must be 64");
+    if (F.n_fine != 0 && F.n_fine != 64 && F.n_fine != 128)
+        return fail(DFN_E_ARG, "dfn_render_fwd: n_fine must be 0, 64 or 128");
+    if (F.fields != 1 && F.fields != 2) return fail(DFN_E_ARG, "dfn_render_fwd: fields must be 1 or 2");
+    if (F.fields == 2 && (!packed_torso || !bias_torso || !rgb_com))
+        return fail(DFN_E_ARG, "dfn_render_fwd: torso inputs / rgb_com missing for fields == 2");
+    if (!bg_f32 && !bg_u8) return fail(DFN_E_ARG, "dfn_render_fwd: no background given");
+    if (F.ray_count <= 0) return DFN_OK;
+    if (F.H <= 0 || F.W <= 0 || (!pix_index && (F.ray_begin < 0 || F.ray_begin + F.ray_count > F.H * F.W)))
+        return fail(DFN_E_ARG, "dfn_render_fwd: ray range outside the image");
+    // the kernel reads [head | torso] biases from one LDS image: they must be adjacent in memory
+    ProgramInfo ph, pt;
+    program_info(tier, FIELD_HEAD, &ph);
+    program_info(tier, FIELD_TORSO, &pt);
+    if (F.fields == 2 && bias_torso != bias_head + ph.n_bias)
+        return fail(DFN_E_ARG, "dfn_render_fwd: bias_torso must directly follow bias_head in memory");
+    RenderArgs A;
+    A.frame = F;
+    A.wblob[0] = (const char*)packed_head;
+    A.wblob[1] = (const char*)(F.fields == 2 ? packed_torso : packed_head);
+    A.nslab[0] = ph.n_slabs;
+    A.nslab[1] = F.fields == 2 ? pt.n_slabs : ph.n_slabs;
+    A.bias = bias_head;
+    A.bg_f32 = bg_f32;
+    A.bg_u8 = bg_u8;
+    A.pix_index = pix_index;
+    A.rgb_head = rgb_head;
+    A.rgb_com = rgb_com;
+    A.w_head = weights_head;
+    A.w_com = weights_com;
+    hipError_t err = launch_render(tier, A, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "render_kernel");
+    return DFN_OK;
+}
+
+int dfn_decoder_fwd(int tier, int field, const void* packed, const float* bias, const float* points,
+                    const float* dirs, long n, float* feat, float* sigma, void* stream) {
+    if (!tier_ok(tier) || !field_ok(field) || !packed || !bias || !points || !dirs || !feat || !sigma)
+        return fail(DFN_E_ARG, "dfn_decoder_fwd: bad argument");
+    if (n <= 0) return DFN_OK;
+    ProgramInfo pi;
+    program_info(tier, prog_field(field), &pi);
+    DecoderArgs A;
+    A.wblob = (const char*)packed;
+    A.nslab = pi.n_slabs;
+    A.field = prog_field(field);
+    A.bias = bias;
+    A.n_bias = pi.n_bias;
+    A.points = points;
+    A.dirs = dirs;
+    A.n_points = n;
+    A.feat = feat;
+    A.sigma = sigma;
+    hipError_t err = launch_decoder(tier, A, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "decoder_kernel");
+    return DFN_OK;
+}
+
+int dfn_get_rays(int H, int W, float focal, float cx, float cy, const float* c2w_host, float* rays_o,
+                 float* rays_d, void* stream) {
+    if (H <= 0 || W <= 0 || !c2w_host || !rays_o || !rays_d) return fail(DFN_E_ARG, "dfn_get_rays: bad argument");
+    hipError_t err = launch_get_rays(H, W, focal, cx, cy, c2w_host, rays_o, rays_d, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "get_rays_kernel");
+    return DFN_OK;
+}
+
+int dfn_ndc_rays(int H, int W, float focal, float z_near, const float* rays_o, const float* rays_d, long n,
+                 float* out_o, float* out_d, void* stream) {
+    if (!rays_o || !rays_d || !out_o || !out_d || n < 0) return fail(DFN_E_ARG, "dfn_ndc_rays: bad argument");
+    if (n == 0) return DFN_OK;
+    hipError_t err = launch_ndc_rays(H, W, focal, z_near, rays_o, rays_d, n, out_o, out_d, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "ndc_rays_kernel");
+    return DFN_OK;
+}
+
+int dfn_sample_pdf(const float* bins, const float* weights, long R, int nb, int ns, const float* u, float* samples,
+                   void* stream) {
+    if (!bins || !weights || !samples || R < 0 || ns <= 0) return fail(DFN_E_ARG, "dfn_sample_pdf: bad argument");
+    if (nb < 2 || nb > 256) return fail(DFN_E_ARG, "dfn_sample_pdf: need 2 <= nb <= 256");
+    if (R == 0) return DFN_OK;
+    hipError_t err = launch_sample_pdf(bins, weights, R, nb, ns, u, samples, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "sample_pdf_kernel");
+    return DFN_OK;
+}
+
+int dfn_composite(const float* sigma, const float* feat, int K, long N, float* sigma_sum, float* feat_w,
+                  void* stream) {
+    if (!sigma || !feat || !sigma_sum || !feat_w || K < 1 || N < 0) return fail(DFN_E_ARG, "dfn_composite: bad argument");
+    if (N == 0) return DFN_OK;
+    hipError_t err = launch_composite(sigma, feat, K, N, sigma_sum, feat_w, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "composite_kernel");
+    return DFN_OK;
+}
+
+int dfn_volume_weights(const float* z, const float* ray, const float* sigma, long R, int S, float last_dist,
+                       float* weights, void* stream) {
+    if (!z || !ray || !sigma || !weights || R < 0) return fail(DFN_E_ARG, "dfn_volume_weights: bad argument");
+    if (S < 1 || S > 1024) return fail(DFN_E_ARG, "dfn_volume_weights: need 1 <= S <= 1024");
+    if (R == 0) return DFN_OK;
+    hipError_t err = launch_volume_weights(z, ray, sigma, R, S, last_dist, weights, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "volume_weights_kernel");
+    return DFN_OK;
+}
+
+int dfn_to8b(const float* x, long n, uint8_t* out, void* stream) {
+    if (!x || !out || n < 0) return fail(DFN_E_ARG, "dfn_to8b: bad argument");
+    if (n == 0) return DFN_OK;
+    hipError_t err = launch_to8b(x, n, out, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "to8b_kernel");
+    return DFN_OK;
+}
+
+int dfn_debug_mfma_layout(float* out, void* stream) {
+    if (!out) return fail(DFN_E_ARG, "dfn_debug_mfma_layout: bad argument");
+    hipError_t err = launch_mfma_probe(out, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "mfma_probe_kernel");
+    return DFN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,358 @@
+// dfn_misc.hip - the small kernels around the fused renderer: weight packing, per-frame bias folding and
+// the stand-alone building blocks kept for API parity with the reference's Python functions.
+//
+// Reference (paths under /root/reference/NeRFs/DFANeRF/): get_rays run_nerf_helpers.py:449-465;
+// ndc_rays :484-503; sample_pdf :537-581; composite_function run_nerf_com_trainExpLater.py:146-166;
+// calc_volume_weights :169-179; to8b run_nerf_helpers.py:17.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include "dfn_layout.h"
+#include "dfn_mlp.h"
+#include "dfn_misc.h"
+
+namespace dfn {
+
+// ---- pack: gather flat params through the plan ---------------------------------------------------------
+__global__ void pack_kernel(const int* __restrict__ plan, const float* __restrict__ params, void* out, long n,
+                            int bf16) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int src = plan[i];
+    const float v = src >= 0 ? params[src] : 0.f;
+    if (bf16) ((__bf16*)out)[i] = (__bf16)v;       // round-to-nearest-even
+    else ((float*)out)[i] = v;
+}
+hipError_t launch_pack(const int* plan, const float* params, void* out, long n, int bf16, hipStream_t st) {
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, plan, params, out, n,
+                       bf16);
+    return hipGetLastError();
+}
+
+// ---- fold: per-frame bias vectors ----------------------------------------------------------------------------
+__device__ float pval(const float* P, int pid, int r, int c) {
+    return P[param_offset(pid) + r * param_shape(pid).cols + c];
+}
+// dot(W[pid][row, c0:c0+n], v[0:n])
+__device__ float rowdot(const float* P, int pid, int row, int c0, int n, const float* v) {
+    const float* w = P + param_offset(pid) + row * param_shape(pid).cols + c0;
+    float a = 0.f;
+    for (int k = 0; k < n; ++k) a = fmaf(w[k], v[k], a);
+    return a;
+}
+
+// One thread per bias element.  Blob layout = Prog<TIER>::*_B_* offsets; within a vector, element
+// t*32 + h*16 + r is feature 32*t + tile_feat(h, r).  The bias layout does not depend on the tier.
+__global__ void fold_kernel(int field, const float* __restrict__ P, const float* __restrict__ sig,
+                            const float* __restrict__ zs, const float* __restrict__ za, float* out, int n) {
+    using PG = Prog<TIER_BF16>;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // locate the vector this element belongs to
+    int base, f;
+    auto feat_of = [](int e) { return 32 * (e >> 5) + tile_feat((e >> 4) & 1, e & 15); };
+    float v = 0.f;
+    if (field != FIELD_TORSO) {
+        const bool lis = (field == 2);
+        const int in_w = lis ? P_FCINL_W : P_FCIN_W, in_b = lis ? P_FCINL_B : P_FCIN_B;
+        const int sk_w = lis ? P_FCPSKL_W : P_FCPSK_W, sk_b = lis ? P_FCPSKL_B : P_FCPSK_B;
+        if (i < PG::H_B_L1) {                      // IN: fc_in.b + fc_in.W[:,60:]·sig + fc_z(z_shape)
+            f = feat_of(i);
+            v = pval(P, in_b, f, 0) + pval(P, P_FCZ_B, f, 0) + rowdot(P, P_FCZ_W, f, 0, ZDIM, zs);
+            if (!lis) v += rowdot(P, in_w, f, NPE, NSIG, sig);
+        } else if (i < PG::H_B_SKIP) {             // L1..L4: blocks[0..3].bias
+            base = i - PG::H_B_L1;
+            f = feat_of(base & 255);
+            v = pval(P, P_BLK0_B + 2 * (base >> 8), f, 0);
+        } else if (i < PG::H_B_L5) {               // SKIP: fc_z_skips(z) + fc_p_skips.b + W[:,60:]·sig
+            f = feat_of(i - PG::H_B_SKIP);
+            v = pval(P, P_FCZSK_B, f, 0) + rowdot(P, P_FCZSK_W, f, 0, ZDIM, zs) + pval(P, sk_b, f, 0);
+            if (!lis) v += rowdot(P, sk_w, f, NPE, NSIG, sig);
+        } else if (i < PG::H_B_VIEW) {             // L5..L7
+            base = i - PG::H_B_L5;
+            f = feat_of(base & 255);
+            v = pval(P, P_BLK4_B + 2 * (base >> 8), f, 0);
+        } else if (i < PG::H_B_OUT) {              // VIEW: feat_view.b + fc_z_view(z_app) + fc_view.b ; sigma row
+            f = feat_of(i - PG::H_B_VIEW);
+            if (f < 256)
+                v = pval(P, P_FEATV_B, f, 0) + pval(P, P_FCZV_B, f, 0) + rowdot(P, P_FCZV_W, f, 0, ZDIM, za) +
+                    pval(P, P_FCV_B, f, 0);
+            else v = (f == 256) ? pval(P, P_SIGMA_B, 0, 0) : 0.f;
+        } else {                                   // OUT: feat_out.b
+            f = feat_of(i - PG::H_B_OUT);
+            v = f < 3 ? pval(P, P_FEATO_B, f, 0) : 0.f;
+        }
+    } else {
+        if (i < PG::T_B_IN) {                      // deformation nets: 14 vectors of 64
+            const int vec = i >> 6;
+            f = feat_of(i & 63);
+            switch (vec) {
+            case 0: v = pval(P, P_DE0_B, f, 0) + rowdot(P, P_DE0_W, f, NPE, NET, sig); break;
+            case 1: v = pval(P, P_DS0_B, f, 0) + rowdot(P, P_DS0_W, f, NPE, NET, sig); break;
+            case 2: v = pval(P, P_DE1_B, f, 0); break;
+            case 3: v = pval(P, P_DS1_B, f, 0); break;
+            case 4: v = pval(P, P_DE2_B, f, 0); break;
+            case 5: v = pval(P, P_DS2_B, f, 0); break;
+            case 6: v = pval(P, P_DE3_B, f, 0); break;
+            case 7: v = pval(P, P_DESK_B, f, 0); break;                                        // ESKIP
+            case 8: v = pval(P, P_DS3_B, f, 0); break;
+            case 9: v = pval(P, P_DSSK_B, f, 0) + rowdot(P, P_DSSK_W, f, 0, NET, sig); break;  // SSKIP
+            case 10: v = pval(P, P_DE4_B, f, 0); break;
+            case 11: v = pval(P, P_DS4_B, f, 0); break;
+            case 12: v = f < NPE ? pval(P, P_DEO_B, f, 0) : 0.f; break;                         // EO
+            default: v = f < NET ? pval(P, P_DSO_B, f, 0) + sig[f] : 0.f; break;               // SO + signal
+            }
+        } else if (i < PG::T_B_L1) {               // IN: fc_in_torso.b + fc_z(z_shape)
+            f = feat_of(i - PG::T_B_IN);
+            v = pval(P, P_FCINT_B, f, 0) + pval(P, P_FCZ_B, f, 0) + rowdot(P, P_FCZ_W, f, 0, ZDIM, zs);
+        } else if (i < PG::T_B_SKIP) {
+            base = i - PG::T_B_L1;
+            f = feat_of(base & 255);
+            v = pval(P, P_BLK0_B + 2 * (base >> 8), f, 0);
+        } else if (i < PG::T_B_L5) {
+            f = feat_of(i - PG::T_B_SKIP);
+            v = pval(P, P_FCZSK_B, f, 0) + rowdot(P, P_FCZSK_W, f, 0, ZDIM, zs) + pval(P, P_FCPSKT_B, f, 0);
+        } else if (i < PG::T_B_VIEW) {
+            base = i - PG::T_B_L5;
+            f = feat_of(base & 255);
+            v = pval(P, P_BLK4_B + 2 * (base >> 8), f, 0);
+        } else if (i < PG::T_B_OUT) {
+            f = feat_of(i - PG::T_B_VIEW);
+            if (f < 256)
+                v = pval(P, P_FEATV_B, f, 0) + pval(P, P_FCZV_B, f, 0) + rowdot(P, P_FCZV_W, f, 0, ZDIM, za) +
+                    pval(P, P_FCV_B, f, 0);
+            else v = (f == 256) ? pval(P, P_SIGMA_B, 0, 0) : 0.f;
+        } else {
+            f = feat_of(i - PG::T_B_OUT);
+            v = f < 3 ? pval(P, P_FEATO_B, f, 0) : 0.f;
+        }
+    }
+    out[i] = v;
+}
+hipError_t launch_fold(int field, const float* params, const float* sig, const float* zs, const float* za,
+                       float* out, int n, hipStream_t st) {
+    hipLaunchKernelGGL(fold_kernel, dim3((n + 63) / 64), dim3(64), 0, st, field, params, sig, zs, za, out, n);
+    return hipGetLastError();
+}
+
+// ---- get_rays / ndc_rays ----------------------------------------------------------------------------------------
+struct Pose12 { float m[12]; };
+__global__ void get_rays_kernel(int H, int W, float focal, float cx, float cy, Pose12 c2w, float* ro, float* rd) {
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= H * W) return;
+    const int y = pix / W, x = pix - y * W;
+    const float dx = __fdiv_rn(__fsub_rn((float)x, cx), focal);
+    const float dy = __fdiv_rn(-__fsub_rn((float)y, cy), focal);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, c2w.m[4 * k]), __fmul_rn(dy, c2w.m[4 * k + 1])),
+                                  __fmul_rn(-1.0f, c2w.m[4 * k + 2]));
+        rd[(size_t)pix * 3 + k] = d;
+        ro[(size_t)pix * 3 + k] = c2w.m[4 * k + 3];
+    }
+}
+hipError_t launch_get_rays(int H, int W, float focal, float cx, float cy, const float* c2w_host, float* ro,
+                           float* rd, hipStream_t st) {
+    Pose12 p;
+    for (int i = 0; i < 12; ++i) p.m[i] = c2w_host[i];
+    hipLaunchKernelGGL(get_rays_kernel, dim3((H * W + 255) / 256), dim3(256), 0, st, H, W, focal, cx, cy, p, ro, rd);
+    return hipGetLastError();
+}
+
+__global__ void ndc_rays_kernel(float kx, float ky, float z_near, const float* ro, const float* rd, long n,
+                                float* oo, float* od) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float o0 = ro[i * 3], o1 = ro[i * 3 + 1], o2 = ro[i * 3 + 2];
+    const float d0 = rd[i * 3], d1 = rd[i * 3 + 1], d2 = rd[i * 3 + 2];
+    const float t = __fdiv_rn(-__fadd_rn(z_near, o2), d2);
+    const float p0 = __fadd_rn(o0, __fmul_rn(t, d0)), p1 = __fadd_rn(o1, __fmul_rn(t, d1)),
+                p2 = __fadd_rn(o2, __fmul_rn(t, d2));
+    oo[i * 3 + 0] = __fdiv_rn(__fmul_rn(kx, p0), p2);
+    oo[i * 3 + 1] = __fdiv_rn(__fmul_rn(ky, p1), p2);
+    oo[i * 3 + 2] = __fadd_rn(1.0f, __fdiv_rn(__fmul_rn(2.0f, z_near), p2));
+    od[i * 3 + 0] = __fmul_rn(kx, __fsub_rn(__fdiv_rn(d0, d2), __fdiv_rn(p0, p2)));
+    od[i * 3 + 1] = __fmul_rn(ky, __fsub_rn(__fdiv_rn(d1, d2), __fdiv_rn(p1, p2)));
+    od[i * 3 + 2] = __fdiv_rn(__fmul_rn(-2.0f, z_near), p2);
+}
+hipError_t launch_ndc_rays(int H, int W, float focal, float z_near, const float* ro, const float* rd, long n,
+                           float* oo, float* od, hipStream_t st) {
+    // -1./(W/(2.*focal)) evaluated in double like the Python scalar expression, then used as an f32 scalar
+    const float kx = (float)(-1.0 / ((double)W / (2.0 * (double)focal)));
+    const float ky = (float)(-1.0 / ((double)H / (2.0 * (double)focal)));
+    hipLaunchKernelGGL(ndc_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, kx, ky, z_near, ro, rd,
+                       n, oo, od);
+    return hipGetLastError();
+}
+
+// ---- sample_pdf: one wavefront per ray -----------------------------------------------------------------------------
+__device__ float linspace01_(int i, int n) {
+    const float step = __fdiv_rn(1.0f, (float)(n - 1));
+    return (i < n / 2) ? __fmul_rn(step, (float)i) : fmaf(-step, (float)(n - 1 - i), 1.0f);
+}
+__global__ void sample_pdf_kernel(const float* bins, const float* weights, long R, int nb, int ns, const float* u_in,
+                                  float* out) {
+    __shared__ float cdf_s[4][256];
+    __shared__ float bin_s[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long ray = (long)blockIdx.x * 4 + w;
+    if (ray >= R) return;                       // whole wave exits together
+    float* cdf = cdf_s[w];
+    float* bn = bin_s[w];
+    const int nw = nb - 1;
+    // weights + 1e-5, sum
+    float part = 0.f;
+    for (int k = lane; k < nw; k += 64) part += __fadd_rn(weights[ray * nw + k], 1e-5f);
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+    for (int k = lane; k < nw; k += 64) cdf[k + 1] = __fdiv_rn(__fadd_rn(weights[ray * nw + k], 1e-5f), part);
+    for (int k = lane; k < nb; k += 64) bn[k] = bins[ray * nb + k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0) {                            // sequential cumsum like torch.cumsum
+        float c = 0.f;
+        cdf[0] = 0.f;
+        for (int k = 1; k < nb; ++k) {
+            c = __fadd_rn(c, cdf[k]);
+            cdf[k] = c;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int j = lane; j < ns; j += 64) {
+        const float u = u_in ? u_in[ray * ns + j] : linspace01_(j, ns);
+        int lo = 0, hi = nb;                    // first index with cdf > u  == searchsorted(right=True)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        const int below = max(lo - 1, 0), above = min(lo, nb - 1);
+        float den = __fsub_rn(cdf[above], cdf[below]);
+        if (den < 1e-5f) den = 1.0f;
+        const float t = __fdiv_rn(__fsub_rn(u, cdf[below]), den);
+        out[ray * ns + j] = __fadd_rn(bn[below], __fmul_rn(t, __fsub_rn(bn[above], bn[below])));
+    }
+}
+hipError_t launch_sample_pdf(const float* bins, const float* weights, long R, int nb, int ns, const float* u,
+                             float* out, hipStream_t st) {
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, bins, weights, R, nb, ns, u,
+                       out);
+    return hipGetLastError();
+}
+
+// ---- composite_function ------------------------------------------------------------------------------------------------
+__global__ void composite_kernel(const float* sigma, const float* feat, int K, long N, float* ssum, float* fw) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (K == 1) {
+        ssum[i] = sigma[i];
+        for (int c = 0; c < 3; ++c) fw[i * 3 + c] = feat[i * 3 + c];
+        return;
+    }
+    float tot = 0.f;
+    for (int k = 0; k < K; ++k) tot = __fadd_rn(tot, sigma[k * N + i]);
+    const float den = (tot == 0.f) ? 1e-4f : tot;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < K; ++k) {
+        const float w = __fdiv_rn(sigma[k * N + i], den);
+        for (int c = 0; c < 3; ++c) acc[c] = __fadd_rn(acc[c], __fmul_rn(feat[(k * N + i) * 3 + c], w));
+    }
+    ssum[i] = tot;
+    for (int c = 0; c < 3; ++c) fw[i * 3 + c] = acc[c];
+}
+hipError_t launch_composite(const float* sigma, const float* feat, int K, long N, float* ssum, float* fw,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(composite_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, sigma, feat, K, N, ssum,
+                       fw);
+    return hipGetLastError();
+}
+
+// ---- calc_volume_weights: one wavefront per ray, sequential-in-lane cumprod blocks + wave scan -----------------------
+__global__ void volume_weights_kernel(const float* z, const float* ray, const float* sigma, long R, int S,
+                                      float last_dist, float* wout) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long r = (long)blockIdx.x * 4 + w;
+    if (r >= R) return;
+    const float dx = ray[r * 3], dy = ray[r * 3 + 1], dzv = ray[r * 3 + 2];
+    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dzv, dzv)));
+    const int per = (S + 63) / 64;             // consecutive samples per lane
+    const int s0 = lane * per;
+    float alpha[16], pre[16];
+    float prod = 1.0f;
+    for (int k = 0; k < per && k < 16; ++k) {
+        const int s = s0 + k;
+        float a = 0.f;
+        if (s < S) {
+            const float d = (s == S - 1) ? last_dist : __fsub_rn(z[r * S + s + 1], z[r * S + s]);
+            const float dist = __fmul_rn(d, nrm);
+            a = __fsub_rn(1.0f, expf(-__fmul_rn(__fadd_rn(fmaxf(sigma[r * S + s], 0.f), 1e-6f), dist)));
+        }
+        alpha[k] = a;
+        pre[k] = prod;                         // product of this lane's earlier factors
+        if (s < S) prod = prod * __fadd_rn(__fsub_rn(1.0f, a), 1e-10f);
+    }
+    float inc = prod;                          // inclusive scan of lane products
+    for (int d = 1; d < 64; d <<= 1) {
+        const float up = __shfl_up(inc, d);
+        if (lane >= d) inc *= up;
+    }
+    float exc = __shfl_up(inc, 1);
+    if (lane == 0) exc = 1.0f;
+    for (int k = 0; k < per && k < 16; ++k) {
+        const int s = s0 + k;
+        if (s < S) wout[r * S + s] = alpha[k] * (exc * pre[k]);
+    }
+}
+hipError_t launch_volume_weights(const float* z, const float* ray, const float* sigma, long R, int S,
+                                 float last_dist, float* w, hipStream_t st) {
+    hipLaunchKernelGGL(volume_weights_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, z, ray, sigma, R, S,
+                       last_dist, w);
+    return hipGetLastError();
+}
+
+// ---- to8b ---------------------------------------------------------------------------------------------------------------
+__global__ void to8b_kernel(const float* x, long n, unsigned char* out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = fminf(fmaxf(x[i], 0.f), 1.f);
+    out[i] = (unsigned char)(int)__fmul_rn(255.0f, v);      // truncation, like numpy astype(uint8)
+}
+hipError_t launch_to8b(const float* x, long n, unsigned char* out, hipStream_t st) {
+    hipLaunchKernelGGL(to8b_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, out);
+    return hipGetLastError();
+}
+
+// ---- MFMA fragment-map probe ------------------------------------------------------------------------------------------------
+// A[i][k] = 1 + i + 64*kslot ... chosen so that D[i][j] identifies both the row/col map and the (half, slot)
+// pairing: A(i, half h, slot e) = (i+1) * (1 if (h,e)==(H0,E0) else 0), B(j, h, e) likewise with (j+1)*...
+// -> D[i][j] = (i+1)*(j+1) iff the same (half, slot) of A and B are paired; written out through the map
+// the kernels assume (row = tile_feat(h, r), col = lane&31).
+__global__ void mfma_probe_kernel(float* out) {
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    // bf16: slot (h=1, e=5)
+    {
+        bf16x8 a, b;
+        for (int e = 0; e < 8; ++e) {
+            a[e] = (__bf16)((h == 1 && e == 5) ? (float)(i + 1) : 0.f);
+            b[e] = (__bf16)((h == 1 && e == 5) ? (float)(2 * i + 1) : 0.f);
+        }
+        f32x16 c;
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) out[(tile_feat(h, r)) * 32 + i] = c[r];
+    }
+    // f32: k-slot h == 1
+    {
+        const float a = (h == 1) ? (float)(i + 1) : 0.f, b = (h == 1) ? (float)(2 * i + 1) : 0.f;
+        f32x16 c;
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) out[1024 + (tile_feat(h, r)) * 32 + i] = c[r];
+    }
+}
+hipError_t launch_mfma_probe(float* out, hipStream_t st) {
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, st, out);
+    return hipGetLastError();
+}
+
+}  // namespace dfn

@@ -1,0 +1,473 @@
+// dfn_mlp.h - the fused decoder MLP for one wavefront = 32 sample points, gfx950 only.
+//
+// Reference semantics: /root/reference/NeRFs/DFANeRF/decoder.py:277-349 (Decoder.forward, head and
+// torso branches) and :109-134 (DeformationField_ori.forward).
+//
+// Data flow (see dfn_layout.h for the fragment maps):
+//   * weights arrive as a stream of 1 KiB A-fragments, packed on the host side of the C-ABI in exactly
+//     the order this file consumes them (dfn_plan.cpp mirrors the op order below), moved L2 -> LDS by
+//     LDS-DMA (global_load_lds_dwordx4) into a 3-slot ring of 32-fragment slabs shared by all waves of
+//     the workgroup;
+//   * activations never leave registers: the accumulator registers of layer l ARE the B operand of
+//     layer l+1 (after bias/ReLU and, in the bf16 tier, a pairwise f32->bf16 pack);
+//   * GEMMs run tile-major: two 32-feature output tiles (2 x 16 accumulator registers) are finished over
+//     the whole K before the next pair starts, so only 32 accumulator registers are live and the
+//     bias/ReLU/pack epilogue of one pair overlaps the MFMAs of the next;
+//   * per-frame constant inputs (audio/expression signal, pose signal, z_shape, z_app) are folded into
+//     bias vectors by dfn_fold_kernel and enter as accumulator initial values.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dfn_layout.h"
+
+namespace dfn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define DFN_DEV __device__ __forceinline__
+// explicit LDS address space: every LDS access must be a ds_* instruction (a flat access would wait on
+// vmcnt and drain the weight prefetch)
+#define DFN_LDS __attribute__((address_space(3)))
+typedef DFN_LDS char lds_char;
+typedef DFN_LDS float lds_f32;
+typedef DFN_LDS f32x4 lds_f32x4;
+typedef DFN_LDS u32x4 lds_u32x4;
+
+template <int TIER> struct TierCfg;
+template <> struct TierCfg<TIER_BF16> {
+    static constexpr int E = 8, UPT = 2, WAVES = 8, THREADS = 512, LOADS_PER_SLAB = 4;
+};
+template <> struct TierCfg<TIER_F32> {
+    static constexpr int E = 4, UPT = 4, WAVES = 4, THREADS = 256, LOADS_PER_SLAB = 8;
+};
+
+constexpr int RING_SLOTS = 3;
+constexpr int RING_BYTES = RING_SLOTS * SLAB_BYTES;
+
+// ---- a vector of NT 32-feature tiles held as MFMA B operand ------------------------------------------
+// local slot L (0..16*NT-1) of this lane = tile L>>4, accumulator register L&15.
+template <int TIER, int NT> struct Vec;
+template <int NT> struct Vec<TIER_BF16, NT> {
+    bf16x8 u[2 * NT];
+    DFN_DEV void set(int L, float x) { u[L >> 3][L & 7] = (__bf16)x; }
+    DFN_DEV float get(int L) const { return (float)u[L >> 3][L & 7]; }
+};
+template <int NT> struct Vec<TIER_F32, NT> {
+    float v[16 * NT];
+    DFN_DEV void set(int L, float x) { v[L] = x; }
+    DFN_DEV float get(int L) const { return v[L]; }
+};
+
+// ---- weight stream -------------------------------------------------------------------------------------
+// All state is wave-uniform.  The stream of one MLP pass is nslab[field] slabs; passes alternate
+// head/torso when two fields are rendered (pass p -> field p & 1), else always field 0.
+struct Stream {
+    const char* base[2];     // packed blobs (global)
+    int nslab[2];
+    int two_fields;
+    // prefetch cursor
+    const char* pf_ptr;
+    int pf_left;             // slabs left in the pass the cursor is in
+    int pf_pass;
+    unsigned pf_slot;        // ring slot the next prefetch lands in
+    unsigned rd_off;         // LDS byte offset (within the ring) of the slab being consumed
+    unsigned rd_slot;
+};
+
+template <int TIER>
+DFN_DEV void stream_issue(Stream& s, lds_char* ring, int wave, int lane) {
+    using C = TierCfg<TIER>;
+    const char* src = s.pf_ptr + (size_t)lane * 16;
+    lds_char* dst = ring + s.pf_slot * SLAB_BYTES;
+#pragma unroll
+    for (int k = 0; k < C::LOADS_PER_SLAB; ++k) {
+        const int f = k * C::WAVES + wave;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + f * FRAG_BYTES),
+            (DFN_LDS void*)(dst + f * FRAG_BYTES), 16, 0, 0);
+    }
+    // advance the cursor (cyclic: running past the last pass just re-reads the first slabs)
+    s.pf_slot = (s.pf_slot + 1 == RING_SLOTS) ? 0u : s.pf_slot + 1;
+    s.pf_ptr += SLAB_BYTES;
+    if (--s.pf_left == 0) {
+        s.pf_pass++;
+        const int f = s.two_fields ? (s.pf_pass & 1) : 0;
+        s.pf_ptr = s.base[f];
+        s.pf_left = s.nslab[f];
+    }
+}
+
+template <int TIER>
+DFN_DEV void stream_begin(Stream& s, lds_char* ring, int wave, int lane) {
+    s.pf_ptr = s.base[0];
+    s.pf_left = s.nslab[0];
+    s.pf_pass = 0;
+    s.pf_slot = 0;
+    s.rd_slot = RING_SLOTS - 1;     // the first slab_advance moves it to slot 0
+    s.rd_off = 0;
+    stream_issue<TIER>(s, ring, wave, lane);     // slab 0
+    stream_issue<TIER>(s, ring, wave, lane);     // slab 1
+}
+
+// Called by every wave right before it reads the first fragment of the next slab.
+template <int TIER>
+DFN_DEV void slab_advance(Stream& s, lds_char* ring, int wave, int lane) {
+    using C = TierCfg<TIER>;
+    // my share of the slab about to be consumed has landed (only the next slab's loads are younger)
+    // ... and my fragment reads of the slab being released have returned (the DMA issued below reuses
+    // its slot; the compiler knows nothing about that hazard)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::LOADS_PER_SLAB) : "memory");
+    __builtin_amdgcn_s_barrier();   // everyone's share landed; everyone is done with the previous slab
+    asm volatile("" ::: "memory");
+    s.rd_slot = (s.rd_slot + 1 == RING_SLOTS) ? 0u : s.rd_slot + 1;
+    s.rd_off = s.rd_slot * SLAB_BYTES;
+    stream_issue<TIER>(s, ring, wave, lane);     // two slabs ahead, into the slot just released
+}
+
+// ---- GEMM pieces ------------------------------------------------------------------------------------------
+struct Ctx {                // per-wave constants threaded through the ops
+    lds_char* ring;
+    int wave, lane, half;
+};
+
+// The A-fragment stream of a pass is strictly sequential (fragment f lives in slab f/32 at position f%32),
+// so fragments are prefetched PF_DEPTH ahead into a small register ring that is carried across ops and
+// layers: LDS latency hides behind the MFMAs of earlier fragments.  `fp` = index of the next fragment to
+// PREFETCH; both indices are compile-time after inlining/unrolling (in the runtime layer loops only their
+// slab phase matters, and one 256x256 layer is a whole number of slabs and of ring turns).
+constexpr int PF_DEPTH = 4;
+template <int TIER> struct Fetch {
+    u32x4 buf[PF_DEPTH];
+    DFN_DEV void load(int slot, int fp, Stream& s, const Ctx& c) {
+        if (fp % SLAB_FRAGS == 0) slab_advance<TIER>(s, c.ring, c.wave, c.lane);
+        buf[slot] = *(const lds_u32x4*)(c.ring + c.lane * 16 + s.rd_off + (fp % SLAB_FRAGS) * FRAG_BYTES);
+    }
+    // start of a pass: fragments 0..PF_DEPTH-1
+    DFN_DEV void prime(Stream& s, const Ctx& c) {
+#pragma unroll
+        for (int i = 0; i < PF_DEPTH; ++i) load(i, i, s, c);
+    }
+};
+
+// One tile-group: acc[g] (g < G output tiles) += W x b over k-units [0, KU) of b.
+// Fragments are consumed in stream order [ku][g]; `f` is the running fragment index of the pass.
+// TAIL: number of fragments that follow this group in the pass (-1 = plenty): no prefetch past the end.
+template <int TIER, int G, int KU, int NTB, int TAIL = -1>
+DFN_DEV void gemm_group(f32x16 (&acc)[G], const Vec<TIER, NTB>& b, int& f, Fetch<TIER>& fe, Stream& s,
+                        const Ctx& c) {
+#pragma unroll
+    for (int ku = 0; ku < KU; ++ku) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const u32x4 a = fe.buf[f % PF_DEPTH];
+            const int left = (KU - ku) * G - g - 1;           // fragments after this one in the group
+            if (TAIL < 0 || left + TAIL >= PF_DEPTH) fe.load(f % PF_DEPTH, f + PF_DEPTH, s, c);
+            ++f;
+            if constexpr (TIER == TIER_BF16) {
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), b.u[ku],
+                                                                 acc[g], 0, 0, 0);
+            } else {
+                const f32x4 af = __builtin_bit_cast(f32x4, a);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], b.v[4 * ku + e], acc[g], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// ReLU as a signed-integer max: negative floats (sign bit set) are negative ints; one v_max_i32, no
+// canonicalisation of the MFMA result
+DFN_DEV float relu_(float x) { return __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0)); }
+
+// bias vectors live in LDS as [tile][half][16]
+template <int G>
+DFN_DEV void acc_init(f32x16 (&acc)[G], const lds_f32* bias_lds, int half) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const lds_f32x4* p = (const lds_f32x4*)(bias_lds + g * 32 + half * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = p[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[g][4 * q + e] = v[e];
+        }
+    }
+}
+// acc = relu(acc) + bias   (where a constant joins after the ReLU: decoder.py:316-321, 118-119)
+template <int G>
+DFN_DEV void acc_relu_add(f32x16 (&acc)[G], const lds_f32* bias_lds, int half) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const lds_f32x4* p = (const lds_f32x4*)(bias_lds + g * 32 + half * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = p[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[g][4 * q + e] = relu_(acc[g][4 * q + e]) + v[e];
+        }
+    }
+}
+// accumulators of G tiles -> tiles [t0, t0+G) of the next layer's B operand
+template <int TIER, int G, int NT, bool RELU>
+DFN_DEV void acc_to_vec(const f32x16 (&acc)[G], Vec<TIER, NT>& v, int t0) {
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float x = RELU ? relu_(acc[g][r]) : acc[g][r];
+            v.set(16 * (t0 + g) + r, x);
+        }
+}
+
+// out[OT tiles] = act( bias + W x in ), tile pairs; KU = k-units of `in` used
+template <int TIER, int OT, int KU, int NTB, bool RELU>
+DFN_DEV void layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_f32* bias, int& f, Fetch<TIER>& fe,
+                   Stream& s, const Ctx& c) {
+    static_assert(OT % 2 == 0, "tile pairs");
+#pragma unroll
+    for (int tg = 0; tg < OT / 2; ++tg) {
+        f32x16 acc[2];
+        acc_init<2>(acc, bias + tg * 64, c.half);
+        gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c);
+        acc_to_vec<TIER, 2, OT, RELU>(acc, out, 2 * tg);
+    }
+}
+// out = relu(bias + W x in) + bias2 + W2 x in2      (no activation after the skip)
+template <int TIER, int OT, int KU, int NTB, int KU2, int NTB2>
+DFN_DEV void layer_skip(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_f32* bias,
+                        const Vec<TIER, NTB2>& in2, const lds_f32* bias2, int& f, Fetch<TIER>& fe,
+                        Stream& s, const Ctx& c) {
+#pragma unroll
+    for (int tg = 0; tg < OT / 2; ++tg) {
+        f32x16 acc[2];
+        acc_init<2>(acc, bias + tg * 64, c.half);
+        gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c);
+        acc_relu_add<2>(acc, bias2 + tg * 64, c.half);
+        gemm_group<TIER, 2, KU2, NTB2>(acc, in2, f, fe, s, c);
+        acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);
+    }
+}
+
+// ---- positional encodings ----------------------------------------------------------------------------------
+// decoder.py:257-275: p/2, then per octave [sin(c_i p)(3), cos(c_i p)(3)], c_i = float32(2^i * pi).
+// Slot s of the PE vector is reference column s = 6*octave + 3*is_cos + axis (identity map, dfn_layout.h);
+// this lane (half h) holds, in local slot L, column 32*(L>>4) + tile_feat(h, L&15).
+__device__ __constant__ float PE_FREQ[10] = {
+    (float)(1.0 * 3.14159265358979323846),   (float)(2.0 * 3.14159265358979323846),
+    (float)(4.0 * 3.14159265358979323846),   (float)(8.0 * 3.14159265358979323846),
+    (float)(16.0 * 3.14159265358979323846),  (float)(32.0 * 3.14159265358979323846),
+    (float)(64.0 * 3.14159265358979323846),  (float)(128.0 * 3.14159265358979323846),
+    (float)(256.0 * 3.14159265358979323846), (float)(512.0 * 3.14159265358979323846)};
+
+template <int TIER, int NT, int NCOL>
+DFN_DEV void posenc(Vec<TIER, NT>& v, const float (&p)[3], int half) {
+    const float ph[3] = {p[0] * 0.5f, p[1] * 0.5f, p[2] * 0.5f};    // p / downscale_p_by (exact)
+#pragma unroll
+    for (int L = 0; L < 16 * NT; ++L) {
+        const int c0 = 32 * (L >> 4) + tile_feat(0, L & 15), c1 = c0 + 4;      // compile-time
+        const bool ok0 = c0 < NCOL, ok1 = c1 < NCOL;
+        if (!ok0 && !ok1) {
+            v.set(L, 0.f);
+            continue;
+        }
+        const int o0 = ok0 ? c0 / 6 : 0, o1 = ok1 ? c1 / 6 : 0;
+        const int a0 = (c0 % 6) % 3, a1 = (c1 % 6) % 3;
+        const bool cos0 = (c0 % 6) >= 3, cos1 = (c1 % 6) >= 3;
+        float val;
+        if constexpr (TIER == TIER_F32) {
+            // argument rounded like the reference: fl32(fl32(2^i*pi) * fl32(p/2)); accurate sin/cos
+            const float x = half ? __fmul_rn(PE_FREQ[o1], ph[a1]) : __fmul_rn(PE_FREQ[o0], ph[a0]);
+            if (cos0 == cos1) {
+                val = cos0 ? cosf(x) : sinf(x);
+            } else {
+                float sv, cv;
+                sincosf(x, &sv, &cv);
+                val = (half ? cos1 : cos0) ? cv : sv;
+            }
+        } else {
+            // hardware sin takes revolutions: 2^i*pi*(p/2) = 2*pi * (2^(i-1) * p/2) (exact power-of-two
+            // scaling, no rounded pi); cos(x) = sin(x + 1/4 rev)
+            const float r0 = ph[a0] * ((float)(1 << o0) * 0.5f), r1 = ph[a1] * ((float)(1 << o1) * 0.5f);
+            const float q0 = cos0 ? 0.25f : 0.f, q1 = cos1 ? 0.25f : 0.f;
+            const float rev = __builtin_amdgcn_fractf(half ? r1 : r0) + (half ? q1 : q0);
+            val = __builtin_amdgcn_sinf(rev);
+        }
+        const bool ok = half ? ok1 : ok0;
+        v.set(L, ok ? val : 0.f);
+    }
+}
+
+// ---- per-field programs: fragment and bias-blob offsets ------------------------------------------------------
+// Op order of one pass (dfn_plan.cpp mirrors it):
+//   head : IN(PE) | L1 L2 L3 | L4+SKIP(PE) | L5 L6 L7 | VIEW(act+view, 9 tiles) | OUT(1 tile)
+//   torso: E0 S0 (PE) | E1 S1 E2 S2 | E3+ESKIP(PE) S3 | E4 S4 | EO SO | IN(pd) | L1..L3 | L4+SKIP(pd) |
+//          L5..L7 | VIEW | OUT
+template <int TIER> struct Prog {
+    static constexpr int UPT = TierCfg<TIER>::UPT;
+    static constexpr int KU_PE = 2 * UPT, KU_VIEW = UPT, KU_ACT = 8 * UPT, KU_D = 2 * UPT, KU_PD = 4 * UPT;
+    static constexpr int F_LAYER = 8 * KU_ACT;          // fragments of one 256x256 layer (multiple of 32)
+    static constexpr int F_TAIL = 9 * (KU_ACT + KU_VIEW) + KU_ACT;
+    // head
+    static constexpr int H_FRAGS = 8 * KU_PE + 7 * F_LAYER + 8 * KU_PE + F_TAIL;
+    static constexpr int H_SLABS = (H_FRAGS + SLAB_FRAGS - 1) / SLAB_FRAGS;
+    // head bias blob (floats): in(256) L1..L4(4x256) skip(256) L5..L7(3x256) view(288) out(32)
+    static constexpr int H_B_IN = 0, H_B_L1 = 256, H_B_SKIP = 5 * 256, H_B_L5 = 6 * 256, H_B_VIEW = 9 * 256,
+                         H_B_OUT = 9 * 256 + 288, H_NBIAS = 9 * 256 + 288 + 32;
+    // torso
+    static constexpr int F_D = 2 * KU_D;                // fragments of one 64x64 layer
+    static constexpr int T_F_DEFORM = 4 * KU_PE + 10 * F_D + 2 * KU_PE;   // E0 S0 | 10 64x64 layers | ESKIP
+    static constexpr int T_FRAGS = T_F_DEFORM + 8 * KU_PD + 7 * F_LAYER + 8 * KU_PD + F_TAIL;
+    static constexpr int T_SLABS = (T_FRAGS + SLAB_FRAGS - 1) / SLAB_FRAGS;
+    // torso bias blob: E0 S0 E1 S1 E2 S2 E3 ESKIP S3 SSKIP E4 S4 EO SO (14 x 64), then the trunk like head
+    static constexpr int T_B_E0 = 0, T_B_S0 = 64, T_B_E1 = 128, T_B_S1 = 192, T_B_E2 = 256, T_B_S2 = 320,
+                         T_B_E3 = 384, T_B_ESKIP = 448, T_B_S3 = 512, T_B_SSKIP = 576, T_B_E4 = 640,
+                         T_B_S4 = 704, T_B_EO = 768, T_B_SO = 832, T_B_IN = 896;
+    static constexpr int T_B_L1 = T_B_IN + 256, T_B_SKIP = T_B_IN + 5 * 256, T_B_L5 = T_B_IN + 6 * 256,
+                         T_B_VIEW = T_B_IN + 9 * 256, T_B_OUT = T_B_VIEW + 288, T_NBIAS = T_B_OUT + 32;
+};
+
+// d/|d| of the point's ray, read from LDS only when the view layer needs it (keeps it out of registers)
+struct DhatRef {
+    const volatile lds_f32* p;
+    int stride;
+    DFN_DEV void load(float (&d)[3]) const {
+        d[0] = p[0];
+        d[1] = p[stride];
+        d[2] = p[2 * stride];
+    }
+};
+
+struct MlpOut {
+    float sigma, r, g, b;      // valid in lanes 0..31 (half 0): raw sigma, sigmoid rgb of point lane&31
+};
+
+DFN_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// shared trunk: L1..L3, L4+skip, L5..L7, view layer, rgb head.  `act` holds relu(first layer) on entry;
+// f_l1 is the slab phase (fragment index mod 32) at L1.
+template <int TIER, int NTP, int KUP>
+DFN_DEV MlpOut mlp_trunk(Vec<TIER, 8>& act, const Vec<TIER, NTP>& pvec, const DhatRef& dref,
+                         const lds_f32* bias, int b_l1, int b_skip, int b_l5, int b_view, int b_out,
+                         int f_l1, Fetch<TIER>& fe, Stream& s, const Ctx& c) {
+    using P = Prog<TIER>;
+    Vec<TIER, 8> nxt;
+    // blocks[0..2]
+    for (int l = 0; l < 3; ++l) {
+        int f = f_l1;                                       // same slab phase every iteration
+        layer<TIER, 8, P::KU_ACT, 8, true>(nxt, act, bias + b_l1 + 256 * l, f, fe, s, c);
+        act = nxt;
+    }
+    int f = f_l1;
+    // blocks[3], then the skip: relu(.) + fc_z_skips(z) + fc_p_skips(p)   (decoder.py:316-325)
+    layer_skip<TIER, 8, P::KU_ACT, 8, KUP, NTP>(nxt, act, bias + b_l1 + 256 * 3, pvec, bias + b_skip, f, fe, s, c);
+    act = nxt;
+    const int f_l5 = f % SLAB_FRAGS;
+    // blocks[4..6]
+    for (int l = 0; l < 3; ++l) {
+        f = f_l5;
+        layer<TIER, 8, P::KU_ACT, 8, true>(nxt, act, bias + b_l5 + 256 * l, f, fe, s, c);
+        act = nxt;
+    }
+    // feat_view (+ sigma_out as row 0 of a 9th tile) on [act ; view PE]   (decoder.py:329-340)
+    MlpOut o;
+    {
+        Vec<TIER, 1> vview;
+        float dhat[3];
+        dref.load(dhat);
+        posenc<TIER, 1, NPEV>(vview, dhat, c.half);
+#pragma unroll
+        for (int tg = 0; tg < 4; ++tg) {
+            f32x16 acc[2];
+            acc_init<2>(acc, bias + b_view + tg * 64, c.half);
+            gemm_group<TIER, 2, P::KU_ACT, 8>(acc, act, f, fe, s, c);
+            gemm_group<TIER, 2, P::KU_VIEW, 1>(acc, vview, f, fe, s, c);
+            acc_to_vec<TIER, 2, 8, true>(acc, nxt, 2 * tg);
+        }
+        f32x16 acc1[1];
+        acc_init<1>(acc1, bias + b_view + 256, c.half);
+        gemm_group<TIER, 1, P::KU_ACT, 8>(acc1, act, f, fe, s, c);
+        gemm_group<TIER, 1, P::KU_VIEW, 1>(acc1, vview, f, fe, s, c);
+        o.sigma = acc1[0][0];
+    }
+    // feat_out + sigmoid   (decoder.py:344-347)
+    {
+        f32x16 acc1[1];
+        acc_init<1>(acc1, bias + b_out, c.half);
+        gemm_group<TIER, 1, P::KU_ACT, 8, 0>(acc1, nxt, f, fe, s, c);     // last op of the pass
+        o.r = sigmoidf_(acc1[0][0]);
+        o.g = sigmoidf_(acc1[0][1]);
+        o.b = sigmoidf_(acc1[0][2]);
+    }
+    return o;
+}
+
+// ---- head pass: decoder.py:291-349 with head_or_torso == 'head' ----------------------------------------------
+template <int TIER>
+DFN_DEV MlpOut mlp_head(const float (&p)[3], const DhatRef& dhat, const lds_f32* bias, Stream& s,
+                        const Ctx& c) {
+    using P = Prog<TIER>;
+    Vec<TIER, 2> pe;
+    posenc<TIER, 2, NPE>(pe, p, c.half);
+    Vec<TIER, 8> act;
+    int f = 0;
+    Fetch<TIER> fe;
+    fe.prime(s, c);
+    layer<TIER, 8, P::KU_PE, 2, true>(act, pe, bias + P::H_B_IN, f, fe, s, c);
+    return mlp_trunk<TIER, 2, P::KU_PE>(act, pe, dhat, bias, P::H_B_L1, P::H_B_SKIP, P::H_B_L5, P::H_B_VIEW,
+                                        P::H_B_OUT, f % SLAB_FRAGS, fe, s, c);
+}
+
+// ---- torso pass: deformation field (decoder.py:109-134, 297-299) then the trunk ---------------------------
+template <int TIER>
+DFN_DEV MlpOut mlp_torso(const float (&p)[3], const DhatRef& dhat, const lds_f32* bias, Stream& s,
+                         const Ctx& c) {
+    using P = Prog<TIER>;
+    Vec<TIER, 2> pe;
+    posenc<TIER, 2, NPE>(pe, p, c.half);
+    Vec<TIER, 2> ve, vs, vn;
+    int f = 0;
+    Fetch<TIER> fe;
+    fe.prime(s, c);
+    layer<TIER, 2, P::KU_PE, 2, true>(ve, pe, bias + P::T_B_E0, f, fe, s, c);
+    layer<TIER, 2, P::KU_PE, 2, true>(vs, pe, bias + P::T_B_S0, f, fe, s, c);
+    layer<TIER, 2, P::KU_D, 2, true>(vn, ve, bias + P::T_B_E1, f, fe, s, c);  ve = vn;
+    layer<TIER, 2, P::KU_D, 2, true>(vn, vs, bias + P::T_B_S1, f, fe, s, c);  vs = vn;
+    layer<TIER, 2, P::KU_D, 2, true>(vn, ve, bias + P::T_B_E2, f, fe, s, c);  ve = vn;
+    layer<TIER, 2, P::KU_D, 2, true>(vn, vs, bias + P::T_B_S2, f, fe, s, c);  vs = vn;
+    // skips join after the ReLU of layer idx 3 (decoder.py:118-119, 128-129)
+    layer_skip<TIER, 2, P::KU_D, 2, P::KU_PE, 2>(vn, ve, bias + P::T_B_E3, pe, bias + P::T_B_ESKIP, f, fe, s, c);
+    ve = vn;
+    {   // signal net: its skip input is the per-frame pose signal -> a constant added after the ReLU
+        f32x16 acc[2];
+        acc_init<2>(acc, bias + P::T_B_S3, c.half);
+        gemm_group<TIER, 2, P::KU_D, 2>(acc, vs, f, fe, s, c);
+        acc_relu_add<2>(acc, bias + P::T_B_SSKIP, c.half);
+        acc_to_vec<TIER, 2, 2, false>(acc, vn, 0);
+        vs = vn;
+    }
+    layer<TIER, 2, P::KU_D, 2, true>(vn, ve, bias + P::T_B_E4, f, fe, s, c);  ve = vn;
+    layer<TIER, 2, P::KU_D, 2, true>(vn, vs, bias + P::T_B_S4, f, fe, s, c);  vs = vn;
+    // p = deform(p) + p  (decoder.py:299): PE column j sits in the register where the GEMM leaves output
+    // j (identity slot map); the signal half of the residual is folded into the SO bias by the fold kernel.
+    Vec<TIER, 4> pd;      // tiles 0,1: deformed PE (60 valid); tiles 2,3: deformed pose signal (42 valid)
+    {
+        f32x16 acc[2];
+        acc_init<2>(acc, bias + P::T_B_EO, c.half);
+        gemm_group<TIER, 2, P::KU_D, 2>(acc, ve, f, fe, s, c);
+#pragma unroll
+        for (int L = 0; L < 32; ++L) pd.set(L, acc[L >> 4][L & 15] + pe.get(L));
+        acc_init<2>(acc, bias + P::T_B_SO, c.half);
+        gemm_group<TIER, 2, P::KU_D, 2>(acc, vs, f, fe, s, c);
+#pragma unroll
+        for (int L = 0; L < 32; ++L) pd.set(32 + L, acc[L >> 4][L & 15]);
+    }
+    Vec<TIER, 8> act;
+    layer<TIER, 8, P::KU_PD, 4, true>(act, pd, bias + P::T_B_IN, f, fe, s, c);
+    return mlp_trunk<TIER, 4, P::KU_PD>(act, pd, dhat, bias, P::T_B_L1, P::T_B_SKIP, P::T_B_L5, P::T_B_VIEW,
+                                        P::T_B_OUT, f % SLAB_FRAGS, fe, s, c);
+}
+
+}  // namespace dfn

@@ -1,0 +1,40 @@
+// dfn_params.h - kernel argument blocks (internal; the public structs live in include/dfanerf.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dfanerf.h"
+#include "dfn_layout.h"
+
+namespace dfn {
+
+struct RenderArgs {
+    DfnFrame frame;
+    const char* wblob[2];       // packed weight streams: head, torso
+    int nslab[2];
+    const float* bias;          // [head blob | torso blob], global
+    const float* bg_f32;
+    const unsigned char* bg_u8;
+    const int* pix_index;
+    float* rgb_head;
+    float* rgb_com;
+    float* w_head;
+    float* w_com;
+};
+
+struct DecoderArgs {
+    const char* wblob;
+    int nslab;
+    int field;                  // FIELD_HEAD (also listener weights) or FIELD_TORSO
+    const float* bias;
+    int n_bias;
+    const float* points;
+    const float* dirs;
+    long n_points;
+    float* feat;
+    float* sigma;
+};
+
+hipError_t launch_render(int tier, const RenderArgs& A, hipStream_t st);
+hipError_t launch_decoder(int tier, const DecoderArgs& A, hipStream_t st);
+void program_info(int tier, int field, ProgramInfo* out);
+
+}  // namespace dfn

@@ -1,0 +1,75 @@
+"""ctypes binding of libdfanerf.so (the C ABI declared in include/dfanerf.h).
+
+The library is the product: there is no Python/CPU fallback.  If the shared object is missing the import
+fails loudly and tells the caller how to build it."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdfanerf.so")
+
+TIER_F32, TIER_BF16 = 0, 1
+FIELD_HEAD, FIELD_TORSO, FIELD_LISTENER = 0, 1, 2
+N_DECODER_PARAMS = 955242
+
+
+class DfnFrame(C.Structure):
+    _fields_ = [("pose", C.c_float * 12), ("pose_body", C.c_float * 12), ("H", C.c_int), ("W", C.c_int),
+                ("focal", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("z_near", C.c_float),
+                ("z_far", C.c_float), ("last_dist", C.c_float), ("ray_begin", C.c_int), ("ray_count", C.c_int),
+                ("n_coarse", C.c_int), ("n_fine", C.c_int), ("fields", C.c_int), ("concate_bg", C.c_int)]
+
+
+class DfnError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP library first "
+            f"(python -c 'import __graft_entry__ as g; g.build()' or dfa-nerf_amd/build.sh). "
+            f"There is no CPU fallback for the render path.")
+    lib = C.CDLL(LIB_PATH)
+    vp, fp, ip, lg, i32 = C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int
+    sig = {
+        "dfn_last_error": (C.c_char_p, []),
+        "dfn_version": (C.c_char_p, []),
+        "dfn_packed_bytes": (lg, [i32, i32]),
+        "dfn_pack_weights": (i32, [i32, i32, fp, vp, vp]),
+        "dfn_pack_plan": (lg, [i32, i32, ip, lg]),
+        "dfn_bias_floats": (lg, [i32, i32]),
+        "dfn_fold_bias": (i32, [i32, i32, fp, fp, fp, fp, fp, vp]),
+        "dfn_render_fwd": (i32, [i32, C.POINTER(DfnFrame), vp, vp, fp, fp, fp, vp, ip, fp, fp, fp, fp, vp]),
+        "dfn_decoder_fwd": (i32, [i32, i32, vp, fp, fp, fp, lg, fp, fp, vp]),
+        "dfn_get_rays": (i32, [i32, i32, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), fp, fp, vp]),
+        "dfn_ndc_rays": (i32, [i32, i32, C.c_float, C.c_float, fp, fp, lg, fp, fp, vp]),
+        "dfn_sample_pdf": (i32, [fp, fp, lg, i32, i32, fp, fp, vp]),
+        "dfn_composite": (i32, [fp, fp, i32, lg, fp, fp, vp]),
+        "dfn_volume_weights": (i32, [fp, fp, fp, lg, i32, C.c_float, fp, vp]),
+        "dfn_to8b": (i32, [fp, lg, vp, vp]),
+        "dfn_debug_mfma_layout": (i32, [fp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here = header and library out of sync
+        fn.restype = res
+        fn.argtypes = args
+    return lib, sorted(sig)
+
+
+lib, EXPORTS = _load()
+
+
+def check(rc, what=""):
+    if rc < 0:
+        raise DfnError(f"{what}: {lib.dfn_last_error().decode()} (code {rc})")
+    return rc
+
+
+def pack_plan(tier, field):
+    """Host-side pack plan as a numpy int32 array (no GPU needed)."""
+    import numpy as np
+    n = check(lib.dfn_pack_plan(tier, field, None, 0), "dfn_pack_plan")
+    out = np.empty(n, np.int32)
+    check(lib.dfn_pack_plan(tier, field, out.ctypes.data, n), "dfn_pack_plan")
+    return out

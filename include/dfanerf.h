@@ -1,0 +1,128 @@
+/* dfanerf.h - C ABI of the MI355X-native DFA-NeRF rendering path (libdfanerf.so).
+ *
+ * The reference (ShunyuYao/DFA-NeRF) has no plugin / operator / FFI interface on this path: the
+ * renderer is plain Python calling ATen.  This header is therefore the interface a
+ * maintainer would bind INSTEAD of the Python bodies listed below; every entry point names the
+ * reference code it replaces (paths relative to NeRFs/DFANeRF/ of the reference tree):
+ *
+ *   MAIN = run_nerf_com_trainExpLater.py   HELP = run_nerf_helpers.py   DEC = decoder.py
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless a parameter is documented as host memory;
+ *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and returns without
+ *     synchronising the device; the library never allocates memory the caller can see;
+ *   - return value 0 = ok, negative = error (DFN_E_*); dfn_last_error() gives a thread-local message;
+ *   - tensors are row-major fp32 unless stated; ray index = y*W + x (MAIN:635-636).
+ *   - only the architecture built by scripts/test_obama.sh / train_obama.sh is supported:
+ *     Decoder(hidden 256, z_dim 256, 8 blocks, skip at 4, dim_signal 96, dim_et_embed 42,
+ *     10/4 PE octaves, deformation field on, expression off)  -> 955,242 decoder parameters.
+ */
+#ifndef DFANERF_H_
+#define DFANERF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFN_OK 0
+#define DFN_E_ARG (-1)      /* bad argument / unsupported configuration */
+#define DFN_E_HIP (-2)      /* HIP runtime error (message has hipGetErrorString) */
+#define DFN_E_SIZE (-3)     /* buffer too small */
+
+#define DFN_TIER_F32 0      /* v_mfma_f32_32x32x2_f32: exact f32 products, k-ordered accumulate */
+#define DFN_TIER_BF16 1     /* v_mfma_f32_32x32x16_bf16: bf16 operands, f32 accumulate */
+
+#define DFN_FIELD_HEAD 0        /* DEC:303-305  fc_in / fc_p_skips       */
+#define DFN_FIELD_TORSO 1       /* DEC:297-299, 308-309, 324-325 deform_net + fc_in_torso / fc_p_skips_torso */
+#define DFN_FIELD_LISTENER 2    /* DEC:306-307, 322-323 fc_in_listener / fc_p_skips_listener (signal None) */
+
+#define DFN_N_DECODER_PARAMS 955242
+
+const char* dfn_last_error(void);
+/* library build info: "dfanerf <version> gfx950" */
+const char* dfn_version(void);
+
+/* ---- geometry of one frame (host struct, passed by value inside the calls below) -------------------- */
+typedef struct DfnFrame {
+    float pose[12];        /* head camera-to-world, rows of the 3x4 (MAIN:634 poses[img_i,:3,:4]) */
+    float pose_body[12];   /* torso/body camera-to-world (MAIN:645 pose_body[:3,:4]) */
+    int H, W;
+    float focal, cx, cy;   /* LOAD:35-36 */
+    float z_near, z_far;   /* MAIN:612-618 */
+    float last_dist;       /* --last_dist, MAIN:171 */
+    int ray_begin;         /* first ray (y*W+x) rendered when pix_index == NULL */
+    int ray_count;         /* number of rays rendered by this call */
+    int n_coarse;          /* --N_samples; must be 64 */
+    int n_fine;            /* 0 (live reference renderer) or 64/128 */
+    int fields;            /* 1 = head only, 2 = head + torso composite (MAIN:681-709) */
+    int concate_bg;        /* --concate_bg, MAIN:669-671, 678-679, 692-694 */
+} DfnFrame;
+
+/* ---- weights ---------------------------------------------------------------------------------------
+ * `params` is decoder.state_dict() flattened in registration order (DEC:207-251), 955,242 floats.
+ * dfn_packed_bytes gives the size of the kernel-ready stream for one (tier, field); dfn_pack_weights
+ * fills it (a gather through a cached plan: run it again after every optimizer step). */
+long dfn_packed_bytes(int tier, int field);
+int dfn_pack_weights(int tier, int field, const float* params, void* packed, void* stream);
+/* Host-side view of the same plan, for tests: plan[i] = flat index into `params` of packed element i,
+ * or -1 for a structural zero.  Returns the element count (call with plan == NULL to query). */
+long dfn_pack_plan(int tier, int field, int32_t* plan_host, long capacity);
+
+/* Per-frame constants folded into bias vectors (replaces the per-point `signal.expand` + cat at
+ * DEC:293-295, and fc_z / fc_z_skips / fc_z_view at DEC:311, 318, 332 which are per-frame constants).
+ *   sig_head  [96]  encode_signal(...)[0]  (MAIN:28-75); NULL for the listener field
+ *   sig_torso [42]  encode_signal_torso(...) (MAIN:78-111)
+ *   z_shape, z_app [256] the latent rows used by this field (MAIN:664-665 / 673-674)
+ * Output `bias`: dfn_bias_floats(tier, field) floats. */
+long dfn_bias_floats(int tier, int field);
+int dfn_fold_bias(int tier, int field, const float* params, const float* signal, const float* z_shape,
+                  const float* z_app, float* bias, void* stream);
+
+/* ---- the fused renderer: replaces the frame loop MAIN:611-713 (and its training twin MAIN:829-899) --
+ * packed_head/packed_torso, bias_head/bias_torso: from the calls above (torso ones may be NULL when
+ * frame.fields == 1).  bg: background as f32 [H*W,3] in [0,1] (MAIN:477) or u8 [H*W,3]; give one.
+ * pix_index: optional int32 [ray_count] of pixel ids y*W+x (training: MAIN:818-836); NULL = contiguous.
+ * rgb_head [ray_count,3] (MAIN:713 rgb_head), rgb_com [ray_count,3] (MAIN:712 rgb; NULL if fields==1).
+ * weights_head / weights_com: optional [ray_count, n_coarse+n_fine] volume weights of the final pass. */
+int dfn_render_fwd(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
+                   const float* bias_head, const float* bias_torso, const float* bg_f32,
+                   const uint8_t* bg_u8, const int32_t* pix_index, float* rgb_head, float* rgb_com,
+                   float* weights_head, float* weights_com, void* stream);
+
+/* ---- Decoder.forward on explicit points: replaces DEC:277-349 -------------------------------------------
+ * points, dirs [n,3]; feat [n,3] (after sigmoid), sigma [n] (raw). */
+int dfn_decoder_fwd(int tier, int field, const void* packed, const float* bias, const float* points,
+                    const float* dirs, long n, float* feat, float* sigma, void* stream);
+
+/* ---- building blocks kept for API parity ---------------------------------------------------------------- */
+/* get_rays, HELP:449-465: rays_o, rays_d [H*W,3] for c2w (3x4, host memory, 12 floats). */
+int dfn_get_rays(int H, int W, float focal, float cx, float cy, const float* c2w_host, float* rays_o,
+                 float* rays_d, void* stream);
+/* ndc_rays, HELP:484-503 (n rays). */
+int dfn_ndc_rays(int H, int W, float focal, float z_near, const float* rays_o, const float* rays_d, long n,
+                 float* out_o, float* out_d, void* stream);
+/* sample_pdf, HELP:537-581: bins [R,nb], weights [R,nb-1] -> samples [R,ns].  u: optional [R,ns] uniform
+ * draws (the reference's rand / pytest modes); NULL = det=True (linspace). nb <= 256. */
+int dfn_sample_pdf(const float* bins, const float* weights, long R, int nb, int ns, const float* u,
+                   float* samples, void* stream);
+/* composite_function, MAIN:146-166: sigma [K,N], feat [K,N,3] -> sigma_sum [N], feat_w [N,3]. */
+int dfn_composite(const float* sigma, const float* feat, int K, long N, float* sigma_sum, float* feat_w,
+                  void* stream);
+/* calc_volume_weights, MAIN:169-179: z [R,S], ray [R,3], sigma [R,S] -> weights [R,S]. S <= 1024. */
+int dfn_volume_weights(const float* z, const float* ray, const float* sigma, long R, int S,
+                       float last_dist, float* weights, void* stream);
+/* to8b, HELP:17: (255*clip(x,0,1)) truncated to u8. */
+int dfn_to8b(const float* x, long n, uint8_t* out, void* stream);
+
+/* ---- debug / self-test ------------------------------------------------------------------------------------ */
+/* Runs one v_mfma_f32_32x32x16_bf16 and one v_mfma_f32_32x32x2_f32 with A = (row,k) / B = (k,col) probes
+ * and writes D as the kernels interpret it: out[2][32][32].  Used by tests to pin the fragment maps. */
+int dfn_debug_mfma_layout(float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFANERF_H_ */

@@ -1,0 +1,183 @@
+"""CPU-only checks of the host side of the C ABI: the library loads, exports every symbol of
+include/dfanerf.h, and the pack plan (dfn_plan.cpp) reproduces the reference decoder when the kernel's
+dataflow is emulated from it in numpy (no compute call into the library, no GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import dfa_oracle as O
+from conftest import ROOT
+from dfanerf import _lib, synth
+
+E = {0: 4, 1: 8}
+UPT = {0: 4, 1: 2}
+
+
+def tile_feat(h, r):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def kslot_to_slot(tier, u, h, e):
+    t, r = u // UPT[tier], (u % UPT[tier]) * E[tier] + e
+    return 32 * t + tile_feat(h, r)
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "dfanerf.h")).read()
+    decl = set(re.findall(r"\b(dfn_[a-z0-9_]+)\s*\(", hdr))
+    assert decl, "no declarations found"
+    import ctypes
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(decl):
+        assert hasattr(lib, name), f"{name} declared in dfanerf.h but not exported"
+    assert set(_lib.EXPORTS) == decl
+    assert b"gfx950" in _lib.lib.dfn_version()
+
+
+def test_error_paths_without_gpu():
+    assert _lib.lib.dfn_packed_bytes(7, 0) < 0 and b"bad tier" in _lib.lib.dfn_last_error()
+    assert _lib.lib.dfn_bias_floats(0, 9) < 0
+    assert _lib.lib.dfn_pack_plan(1, 0, None, 0) == 1152 * 512
+    small = np.zeros(4, np.int32)
+    assert _lib.lib.dfn_pack_plan(1, 0, small.ctypes.data, 4) == -3      # DFN_E_SIZE
+    with pytest.raises(_lib.DfnError):
+        _lib.check(_lib.lib.dfn_pack_weights(1, 0, None, None, None), "pack")
+
+
+class Reader:
+    """Walks the packed stream in consumption order and rebuilds dense weights of each tile group."""
+
+    def __init__(self, tier, field, flat):
+        self.tier, self.plan, self.flat, self.pos = tier, _lib.pack_plan(tier, field), flat, 0
+
+    def group(self, G, KU, nslots):
+        W = np.zeros((32 * G, nslots))
+        e_n = E[self.tier]
+        for ku in range(KU):
+            for g in range(G):
+                frag = self.plan[self.pos:self.pos + 64 * e_n].reshape(64, e_n)
+                self.pos += 64 * e_n
+                for lane in range(64):
+                    i, h = lane & 31, lane >> 5
+                    for e in range(e_n):
+                        idx = frag[lane, e]
+                        if idx >= 0:
+                            W[32 * g + i, kslot_to_slot(self.tier, ku, h, e)] = self.flat[idx]
+        return W
+
+    def layer(self, OT, KU, nslots):
+        return np.concatenate([self.group(2, KU, nslots) for _ in range(OT // 2)], 0)
+
+    def layer_skip(self, OT, KU, nslots, KU2, nslots2):
+        a, b = [], []
+        for _ in range(OT // 2):
+            a.append(self.group(2, KU, nslots))
+            b.append(self.group(2, KU2, nslots2))
+        return np.concatenate(a, 0), np.concatenate(b, 0)
+
+
+def flat_params(state):
+    return np.concatenate([np.asarray(v, np.float32).reshape(-1) for v in state.values()])
+
+
+def emulate(tier, field, st, pe, pev, sig, zs, za):
+    """numpy restatement of mlp_head / mlp_torso (dfn_mlp.h) driven by the packed stream.
+    pe [N,60], pev [N,24] -> feat [N,3], sigma [N].  Biases folded like dfn_misc.hip:fold_kernel."""
+    P = {k: np.asarray(v, np.float64) for k, v in st.items()}
+    rd = Reader(tier, field, flat_params(st).astype(np.float64))
+    u = UPT[tier]
+    relu = lambda x: np.maximum(x, 0)
+    N = pe.shape[0]
+    pe64 = np.zeros((N, 64)); pe64[:, :60] = pe
+    v32 = np.zeros((N, 32)); v32[:, :24] = pev
+    fcz = P["fc_z.weight"] @ zs + P["fc_z.bias"]
+    fczs = P["fc_z_skips.0.weight"] @ zs + P["fc_z_skips.0.bias"]
+    fczv = P["fc_z_view.weight"] @ za + P["fc_z_view.bias"]
+    if field in (0, 2):
+        nm = ("fc_in", "fc_p_skips.0") if field == 0 else ("fc_in_listener", "fc_p_skips_listener.0")
+        b_in = P[nm[0] + ".bias"] + fcz
+        b_sk = P[nm[1] + ".bias"] + fczs
+        if field == 0:
+            b_in = b_in + P[nm[0] + ".weight"][:, 60:] @ sig
+            b_sk = b_sk + P[nm[1] + ".weight"][:, 60:] @ sig
+        act = relu(pe64 @ rd.layer(8, 2 * u, 64).T + b_in)
+        pvec, kup, nps = pe64, 2 * u, 64
+    else:
+        w = lambda n: P[f"deform_net.{n}.weight"]
+        b = lambda n: P[f"deform_net.{n}.bias"]
+        ve = relu(pe64 @ rd.layer(2, 2 * u, 64).T + b("blocks_embed.0") + w("blocks_embed.0")[:, 60:] @ sig)
+        vs = relu(pe64 @ rd.layer(2, 2 * u, 64).T + b("blocks_signal.0") + w("blocks_signal.0")[:, 60:] @ sig)
+        ve = relu(ve @ rd.layer(2, 2 * u, 64).T + b("blocks_embed.1"))
+        vs = relu(vs @ rd.layer(2, 2 * u, 64).T + b("blocks_signal.1"))
+        ve = relu(ve @ rd.layer(2, 2 * u, 64).T + b("blocks_embed.2"))
+        vs = relu(vs @ rd.layer(2, 2 * u, 64).T + b("blocks_signal.2"))
+        w3, wsk = rd.layer_skip(2, 2 * u, 64, 2 * u, 64)
+        ve = relu(ve @ w3.T + b("blocks_embed.3")) + b("fc_embed_skips.0") + pe64 @ wsk.T
+        vs = relu(vs @ rd.layer(2, 2 * u, 64).T + b("blocks_signal.3")) + b("fc_signal_skips.0") + \
+            w("fc_signal_skips.0") @ sig
+        ve = relu(ve @ rd.layer(2, 2 * u, 64).T + b("blocks_embed.4"))
+        vs = relu(vs @ rd.layer(2, 2 * u, 64).T + b("blocks_signal.4"))
+        eo = ve @ rd.layer(2, 2 * u, 64).T + np.pad(b("out_embed"), (0, 4))
+        so = vs @ rd.layer(2, 2 * u, 64).T + np.pad(b("out_signal") + sig, (0, 22))
+        pd = np.concatenate([eo + pe64, so], 1)
+        act = relu(pd @ rd.layer(8, 4 * u, 128).T + P["fc_in_torso.bias"] + fcz)
+        b_sk = P["fc_p_skips_torso.0.bias"] + fczs
+        pvec, kup, nps = pd, 4 * u, 128
+    for l in range(3):
+        act = relu(act @ rd.layer(8, 8 * u, 256).T + P[f"blocks.{l}.bias"])
+    w4, wsk = rd.layer_skip(8, 8 * u, 256, kup, nps)
+    act = relu(act @ w4.T + P["blocks.3.bias"]) + b_sk + pvec @ wsk.T
+    for l in range(4, 7):
+        act = relu(act @ rd.layer(8, 8 * u, 256).T + P[f"blocks.{l}.bias"])
+    rows = []
+    for tg in range(4):
+        rows.append(act @ rd.group(2, 8 * u, 256).T + v32 @ rd.group(2, u, 32).T)
+    hid = relu(np.concatenate(rows, 1) + P["feat_view.bias"] + fczv + P["fc_view.bias"])
+    sg = act @ rd.group(1, 8 * u, 256).T + v32 @ rd.group(1, u, 32).T
+    sigma = sg[:, 0] + P["sigma_out.bias"][0]
+    assert np.abs(sg[:, 1:]).max() == 0          # rows 1..31 of the sigma tile are structural zeros
+    out = hid @ rd.group(1, 8 * u, 256).T
+    assert np.abs(out[:, 3:]).max() == 0
+    feat = 1 / (1 + np.exp(-(out[:, :3] + P["feat_out.bias"])))
+    frag_elems = 64 * E[tier]
+    assert rd.pos % frag_elems == 0 and (rd.plan[rd.pos:] == -1).all()     # only slab padding remains
+    return feat, sigma
+
+
+@pytest.mark.parametrize("tier", [0, 1])
+@pytest.mark.parametrize("field", [0, 1, 2])
+def test_plan_reproduces_reference_decoder(tier, field, golden, states, latents):
+    g = golden("g3_decoder")
+    st = states["decoder"]
+    zs, za = latents
+    p, r = torch.from_numpy(g["p_64"][:, :48]), torch.from_numpy(g["r_64"][:, :48])
+    pe = O.posenc(p, 10)[0].double().numpy()
+    pev = O.posenc(r / torch.norm(r, dim=-1, keepdim=True), 4)[0].double().numpy()
+    fi = 1 if field == 1 else 0
+    sig = {0: g["sig_aud"][0], 1: g["sig_torso"][0], 2: None}[field]
+    feat, sigma = emulate(tier, field, st, pe, pev, None if sig is None else sig.astype(np.float64),
+                          zs[0, fi].astype(np.float64), za[0, fi].astype(np.float64))
+    name = {0: "head", 1: "torso", 2: "listener"}[field]
+    np.testing.assert_allclose(feat, g[f"feat_{name}_64"][0, :48], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(sigma, g[f"sigma_{name}_64"][0, :48], atol=2e-4, rtol=1e-5)
+
+
+def test_flat_param_order_matches_state_dict(states):
+    """dfn_layout.h:ParamId order == decoder.state_dict() order: spot-check offsets through the plan."""
+    st = states["decoder"]
+    off, offs = 0, {}
+    for k, v in st.items():
+        offs[k] = off
+        off += v.size
+    assert off == _lib.N_DECODER_PARAMS
+    plan = _lib.pack_plan(1, 0)
+    used = plan[plan >= 0]
+    lo, hi = offs["fc_in.weight"], offs["fc_in.weight"] + st["fc_in.weight"].size
+    first = plan[:64 * 8 * 8]                 # first tile pair of fc_in
+    assert ((first < 0) | ((first >= lo) & (first < hi))).all()
+    for unused in ("fc_in_listener.weight", "fc_in_torso.weight", "deform_net.out_embed.weight"):
+        lo, hi = offs[unused], offs[unused] + st[unused].size
+        assert not ((used >= lo) & (used < hi)).any()
