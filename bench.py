@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py - throughput of the fused DFA-NeRF renderer on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" = one 450x450 audio-driven frame through the hot path: per-frame conditioning signals ->
+bias fold -> fused render (rays -> 64 coarse -> sample_pdf -> 64+128 merged samples -> decoder MLP ->
+compositing) -> (N > 1) RCCL all-gather of the RGB shards.  Weights, background and the audio/expression/
+pose features are resident in HBM before the timed region.  For N > 1 the rays of every frame are sharded
+across the ranks (strong scaling: total work per step is fixed), the partition SURVEY.md 8(e) names.
+
+Prints ONE JSON line on rank 0 (fields: see the driver contract), including
+  roofline     - MFMA roofline of the dominant kernel (render_kernel), from algorithmic FLOPs and HIP-event
+                 timings of the launches inside the timed region;
+  cpu_baseline - the oracle (oracle/dfa_oracle.py, a port of the reference's CPU path) timed on a bounded
+                 sample of the same workload on this host's cores (rank 0, N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "dfa-nerf_amd"))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+# algorithmic FLOPs per sample point: 2 * MACs of the layers the reference evaluates
+FLOP_PT_HEAD, FLOP_PT_TORSO = 1222656.0, 1285120.0
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}       # dense MFMA peaks, MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (n_fine, fields, description)
+    "c1": (0, 1, "Obama head NeRF, 450x450, coarse-only 64 samples/ray (configs[0] geometry, on GPU)"),
+    "c2": (128, 1, "Obama head NeRF inference, 450x450, 64+128 hierarchical (configs[1])"),
+    "c3": (128, 2, "Obama head+torso two-NeRF composite render, 450x450, 64+128 (configs[2])"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--tier", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, sc, st, zs, za, n_fine, fields):
+    """Oracle (port of the reference CPU path) on whole 2048-ray chunks of frame 0 until ~cpu-seconds."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dfa_oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or cores
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    P = O.params_to_torch(st["decoder"])
+    nets = {k: O.params_to_torch(v) for k, v in st.items() if k != "decoder"}
+    auds, exps, poses = [torch.from_numpy(sc[k]) for k in ("aud", "exp", "poses")]
+    H, W = sc["H"], sc["W"]
+    bg = torch.from_numpy(sc["bg"]).float() / 255.0
+    with torch.no_grad():
+        sig = O.encode_signal(nets, auds, exps, 0, 300000, 300000, 4, auds.shape[0])
+        sigt = O.encode_signal_torso(nets, poses, 0, 300000, 300000, 8, poses.shape[0])
+        chunk, done, t_used = 2048, 0, 0.0
+        # warm-up chunk (not timed)
+        O.render_frame(P, H, W, sc["focal"], sc["cx"], sc["cy"], sc["poses"][0], sc["pose_body"], bg, sc["near"],
+                       sc["far"], torch.from_numpy(zs), torch.from_numpy(za), sig, sigt, 64, n_fine, fields, chunk,
+                       ray_begin=0, ray_count=256)
+        while t_used < args.cpu_seconds and done < H * W:
+            n = min(chunk, H * W - done)
+            t0 = time.perf_counter()
+            O.render_frame(P, H, W, sc["focal"], sc["cx"], sc["cy"], sc["poses"][0], sc["pose_body"], bg,
+                           sc["near"], sc["far"], torch.from_numpy(zs), torch.from_numpy(za), sig, sigt, 64, n_fine,
+                           fields, chunk, ray_begin=done, ray_count=n)
+            t_used += time.perf_counter() - t0
+            done += n
+    return {"value": done / t_used, "unit": "rays/s", "cores": int(cores), "kind": "port",
+            "sample": f"{done} rays ({done // chunk} chunks of 2048) of frame 0, same workload, fp32, "
+                      f"torch {torch.__version__} CPU, {cores} threads, {t_used:.1f} s"}
+
+
+def main():
+    args = parse()
+    n_fine, fields, desc = WORKLOADS[args.workload]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}; using {world}", file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from dfanerf import engine, nets, synth
+    F = 8                                              # frames of the audio-driven sequence (configs[4] batch)
+    sc = synth.bench_scene(0, n_frames=F)
+    st = synth.synth_all_states(0)
+    zs, za = synth.synth_latents(0)
+    H, W = sc["H"], sc["W"]
+    R = H * W
+
+    # ---- everything resident on the device before timing --------------------------------------------------
+    flat = engine.flatten_state(st["decoder"], dev)
+    pk = engine.PackedDecoder(flat, args.tier, fields=(0, 1) if fields == 2 else (0,))
+    bg = torch.from_numpy(sc["bg"]).reshape(-1, 3).to(dev)                       # uint8, as the loader has it
+    aud_net, exp_net = nets.AudioNet_W2L().to(dev), nets.ExpressionEnc().to(dev)
+    att, patt = nets.AudioAttNet(96, 4).to(dev), nets.AudioAttNet(42, 8).to(dev)
+    for m, k in ((aud_net, "AudNet"), (exp_net, "ExpNet"), (att, "AudAttNet"), (patt, "PoseAttNet")):
+        m.load_state_dict({kk: torch.from_numpy(v) for kk, v in st[k].items()})
+    ds = [{"auds": torch.from_numpy(sc["aud"]).to(dev), "exp": torch.from_numpy(sc["exp"]).to(dev),
+           "poses": torch.from_numpy(sc["poses"]).to(dev)}]
+    embed_fn, _ = nets.get_embedder(3, 0)
+
+    class A:
+        nosmo_iters, smo_size, smo_torse_size = 300000, 4, 8
+    zs_d, za_d = torch.from_numpy(zs[0]).to(dev), torch.from_numpy(za[0]).to(dev)
+
+    per = (R + world - 1) // world                       # rank r renders [r*per, min(R,(r+1)*per))
+    begin = rank * per
+    count = max(0, min(R, begin + per) - begin)
+    shard = torch.zeros(per, 3, dtype=torch.float32, device=dev)
+    gathered = torch.empty(world * per, 3, dtype=torch.float32, device=dev) if world > 1 else None
+    bias_buf = None
+    ev = []
+
+    def step(i, timed):
+        nonlocal bias_buf
+        f = i % F
+        with torch.no_grad():
+            sig = nets.encode_signal(ds, 0, f, 96, aud_net, exp_net, att, 300000, A, F, embed_fn=embed_fn)[0]
+            sigt = nets.encode_signal_torso(ds, 0, f, patt, 300000, A, F, embed_fn=embed_fn) if fields == 2 else None
+        bias_buf = pk.fold(sig, sigt, zs_d, za_d, out=bias_buf)
+        fr = engine.make_frame(H, W, sc["focal"], sc["cx"], sc["cy"], sc["poses"][f], sc["pose_body"], sc["near"],
+                               sc["far"], ray_begin=begin, ray_count=count, n_fine=n_fine, fields=fields)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        engine.render(pk, bias_buf, fr, bg, out_head=shard[:count], out_com=None)
+        if timed:
+            e1.record()
+            ev.append((e0, e1))
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, shard)
+            return gathered[:R]
+        return shard
+
+    for i in range(args.warmup):
+        step(i, False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        img = step(args.warmup + i, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+    assert torch.isfinite(img).all()
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        flop_ray = (64 + n_fine) * (FLOP_PT_HEAD + (FLOP_PT_TORSO if fields == 2 else 0.0))
+        if n_fine > 0:
+            flop_ray += 64 * (FLOP_PT_HEAD + (FLOP_PT_TORSO if fields == 2 else 0.0))   # coarse pass
+        achieved = flop_ray * count / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "rays/sec (whole node) at 450x450, 64c+128f samples" if n_fine else
+                      "rays/sec (whole node) at 450x450, 64 coarse samples",
+            "value": R * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "ms_per_frame": ms_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": args.tier, "data": "synthetic",
+            "config": {"workload": desc, "H": H, "W": W, "n_coarse": 64, "n_fine": n_fine, "fields": fields,
+                       "frames": F, "rays_per_step": R,
+                       "parallelism": f"rays sharded over {world} GPU(s), all_gather of RGB" if world > 1
+                       else "single GPU"},
+            "roofline": {"bound": "mfma", "kernel": "render_kernel", "achieved": achieved,
+                         "peak": PEAK_TFLOPS[args.tier], "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.tier],
+                         "traffic": None, "kernel_ms": kern_ms, "flop_per_ray": flop_ray,
+                         "rays_per_launch": count},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, sc, st, zs, za, n_fine, fields)
+            out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,7 +6,7 @@ SRC="$HERE/csrc"
 OUT="$HERE/dfanerf/libdfanerf.so"
 OBJ="$HERE/build"
 mkdir -p "$OBJ"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$SRC -I$HERE/../include"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I$SRC -I$HERE/../include"
 pids=()
 for f in dfn_render dfn_misc dfn_api; do
   ( if [ ! -f "$OBJ/$f.o" ] || [ -n "$(find "$SRC" "$HERE/../include" -newer "$OBJ/$f.o" \( -name '*.h' -o -name "$f.hip" \) -print -quit)" ]; then

@@ -120,7 +120,7 @@ int dfn_fold_bias(int tier, int field, const float* params, const float* signal,
 int dfn_render_fwd(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
                    const float* bias_head, const float* bias_torso, const float* bg_f32,
                    const uint8_t* bg_u8, const int32_t* pix_index, float* rgb_head, float* rgb_com,
-                   float* weights_head, float* weights_com, void* stream) {
+                   float* weights_head, float* weights_com, float* z_vals, void* stream) {
     if (!tier_ok(tier) || !frame || !packed_head || !bias_head || !rgb_head)
         return fail(DFN_E_ARG, "dfn_render_fwd: bad argument");
     const DfnFrame& F = *frame;
@@ -154,6 +154,7 @@ int dfn_render_fwd(int tier, const DfnFrame* frame, const void* packed_head, con
     A.rgb_com = rgb_com;
     A.w_head = weights_head;
     A.w_com = weights_com;
+    A.z_out = z_vals;
     hipError_t err = launch_render(tier, A, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "render_kernel");
     return DFN_OK;

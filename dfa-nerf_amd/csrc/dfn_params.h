@@ -18,6 +18,7 @@ struct RenderArgs {
     float* rgb_com;
     float* w_head;
     float* w_com;
+    float* z_out;
 };
 
 struct DecoderArgs {

@@ -258,6 +258,7 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
             if (final_stage && valid && lane < 32) {
                 if (A.w_head) A.w_head[(size_t)r_raw * S + si] = w_h;
                 if (A.w_com && two) A.w_com[(size_t)r_raw * S + si] = w_c;
+                if (A.z_out) A.z_out[(size_t)r_raw * S + si] = z;
             }
         }
 

@@ -5,6 +5,8 @@ fails loudly and tells the caller how to build it."""
 import ctypes as C
 import os
 
+import torch  # noqa: F401  (first: the library must bind to the HIP runtime torch has loaded, not a second copy)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdfanerf.so")
 
@@ -40,7 +42,7 @@ def _load():
         "dfn_pack_plan": (lg, [i32, i32, ip, lg]),
         "dfn_bias_floats": (lg, [i32, i32]),
         "dfn_fold_bias": (i32, [i32, i32, fp, fp, fp, fp, fp, vp]),
-        "dfn_render_fwd": (i32, [i32, C.POINTER(DfnFrame), vp, vp, fp, fp, fp, vp, ip, fp, fp, fp, fp, vp]),
+        "dfn_render_fwd": (i32, [i32, C.POINTER(DfnFrame), vp, vp, fp, fp, fp, vp, ip, fp, fp, fp, fp, fp, vp]),
         "dfn_decoder_fwd": (i32, [i32, i32, vp, fp, fp, fp, lg, fp, fp, vp]),
         "dfn_get_rays": (i32, [i32, i32, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), fp, fp, vp]),
         "dfn_ndc_rays": (i32, [i32, i32, C.c_float, C.c_float, fp, fp, lg, fp, fp, vp]),

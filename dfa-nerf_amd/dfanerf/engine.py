@@ -1,0 +1,239 @@
+"""Host-side driver of libdfanerf.so: device buffers, streams and argument marshalling.
+
+PyTorch is plumbing here (device memory, the current HIP stream, torch.distributed); every number on the
+render path comes out of the HIP kernels behind the C ABI (include/dfanerf.h).  Nothing in this module
+computes on the CPU and nothing falls back to ATen."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (DfnFrame, FIELD_HEAD, FIELD_LISTENER, FIELD_TORSO, N_DECODER_PARAMS, TIER_BF16, TIER_F32, check,
+                   lib)
+
+TIERS = {"f32": TIER_F32, "bf16": TIER_BF16, TIER_F32: TIER_F32, TIER_BF16: TIER_BF16}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32c(t, device):
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(np.asarray(t))
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("dfanerf: no HIP device visible; the render path has no CPU fallback")
+
+
+def flatten_state(state, device):
+    """decoder.state_dict() -> flat f32 device vector in registration order (dfn_layout.h:ParamId)."""
+    parts = [_f32c(v, device).reshape(-1) for v in state.values()]
+    flat = torch.cat(parts)
+    if flat.numel() != N_DECODER_PARAMS:
+        raise ValueError(f"decoder has {flat.numel()} parameters; the HIP path supports the "
+                         f"scripts/test_obama.sh architecture ({N_DECODER_PARAMS})")
+    return flat
+
+
+class PackedDecoder:
+    """Kernel-ready weight streams of one decoder, per (tier, field).  Call repack() after an optimizer step."""
+
+    def __init__(self, flat_params, tier="bf16", fields=(FIELD_HEAD, FIELD_TORSO)):
+        require_gpu()
+        self.tier = TIERS[tier]
+        self.flat = flat_params
+        self.device = flat_params.device
+        self.packed = {}
+        for f in fields:
+            nbytes = check(lib.dfn_packed_bytes(self.tier, f), "dfn_packed_bytes")
+            self.packed[f] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.repack()
+
+    def repack(self):
+        for f, buf in self.packed.items():
+            check(lib.dfn_pack_weights(self.tier, f, _ptr(self.flat), _ptr(buf), _stream()), "dfn_pack_weights")
+
+    def bias_floats(self, field):
+        return check(lib.dfn_bias_floats(self.tier, field), "dfn_bias_floats")
+
+    def fold(self, sig_head, sig_torso, z_shape, z_app, head_field=FIELD_HEAD, out=None):
+        """Per-frame bias blob [head | torso].  z_shape / z_app: [2,256] rows (head, torso) or [256] for
+        a single field.  sig_head [96] (None for the listener), sig_torso [42] (None = head only)."""
+        dev = self.device
+        nh = self.bias_floats(head_field)
+        nt = self.bias_floats(FIELD_TORSO) if sig_torso is not None else 0
+        if out is None:
+            out = torch.empty(nh + nt, dtype=torch.float32, device=dev)
+        zs = _f32c(z_shape, dev).reshape(-1, 256)
+        za = _f32c(z_app, dev).reshape(-1, 256)
+        sh = None if sig_head is None else _f32c(sig_head, dev).reshape(-1)
+        check(lib.dfn_fold_bias(self.tier, head_field, _ptr(self.flat), _ptr(sh), _ptr(zs[0]), _ptr(za[0]),
+                                _ptr(out), _stream()), "dfn_fold_bias(head)")
+        if nt:
+            st = _f32c(sig_torso, dev).reshape(-1)
+            row = 1 if zs.shape[0] > 1 else 0
+            check(lib.dfn_fold_bias(self.tier, FIELD_TORSO, _ptr(self.flat), _ptr(st), _ptr(zs[row]), _ptr(za[row]),
+                                    C.c_void_p(out.data_ptr() + 4 * nh), _stream()), "dfn_fold_bias(torso)")
+        return out
+
+    def fold_single(self, field, signal, z_shape, z_app):
+        dev = self.device
+        out = torch.empty(self.bias_floats(field), dtype=torch.float32, device=dev)
+        # keep every temporary alive until the launch is enqueued (the caching allocator would otherwise
+        # hand the same block to the next temporary)
+        sg = None if signal is None else _f32c(signal, dev).reshape(-1)
+        zs = _f32c(z_shape, dev).reshape(-1)
+        za = _f32c(z_app, dev).reshape(-1)
+        check(lib.dfn_fold_bias(self.tier, field, _ptr(self.flat), _ptr(sg), _ptr(zs), _ptr(za), _ptr(out),
+                                _stream()), "dfn_fold_bias")
+        return out
+
+
+def make_frame(H, W, focal, cx, cy, pose, pose_body, near, far, last_dist=1e10, ray_begin=0, ray_count=None,
+               n_coarse=64, n_fine=0, fields=2, concate_bg=True):
+    fr = DfnFrame()
+    p = np.asarray(pose, np.float32)[:3, :4].reshape(-1)
+    pb = np.asarray(pose_body if pose_body is not None else pose, np.float32)[:3, :4].reshape(-1)
+    for i in range(12):
+        fr.pose[i] = float(p[i])
+        fr.pose_body[i] = float(pb[i])
+    fr.H, fr.W = int(H), int(W)
+    fr.focal, fr.cx, fr.cy = float(focal), float(cx), float(cy)
+    fr.z_near, fr.z_far, fr.last_dist = float(near), float(far), float(last_dist)
+    fr.ray_begin = int(ray_begin)
+    fr.ray_count = int(H * W - ray_begin if ray_count is None else ray_count)
+    fr.n_coarse, fr.n_fine, fr.fields, fr.concate_bg = int(n_coarse), int(n_fine), int(fields), int(bool(concate_bg))
+    return fr
+
+
+def render(packed, bias, frame, bg, pix_index=None, want_weights=False, out_head=None, out_com=None, want_z=False):
+    """dfn_render_fwd.  bg: f32 [H*W,3] in [0,1] or uint8 [H*W,3] device tensor.
+    Returns (rgb_head [n,3], rgb_com [n,3] or None[, w_head, w_com])."""
+    dev = packed.device
+    n = frame.ray_count
+    two = frame.fields == 2
+    rgb_h = out_head if out_head is not None else torch.empty(n, 3, dtype=torch.float32, device=dev)
+    rgb_c = (out_com if out_com is not None else torch.empty(n, 3, dtype=torch.float32, device=dev)) if two else None
+    S = frame.n_coarse + frame.n_fine
+    w_h = torch.empty(n, S, dtype=torch.float32, device=dev) if want_weights else None
+    w_c = torch.empty(n, S, dtype=torch.float32, device=dev) if (want_weights and two) else None
+    z_v = torch.empty(n, S, dtype=torch.float32, device=dev) if want_z else None
+    bg_f32 = bg if bg.dtype == torch.float32 else None
+    bg_u8 = bg if bg.dtype == torch.uint8 else None
+    if bg_f32 is None and bg_u8 is None:
+        raise TypeError("bg must be float32 or uint8")
+    nh = packed.bias_floats(FIELD_HEAD)
+    bias_t = C.c_void_p(bias.data_ptr() + 4 * nh) if two else None
+    if pix_index is not None:
+        pix_index = pix_index.to(device=dev, dtype=torch.int32).contiguous()
+    check(lib.dfn_render_fwd(packed.tier, C.byref(frame), _ptr(packed.packed[FIELD_HEAD]),
+                             _ptr(packed.packed.get(FIELD_TORSO)) if two else None, _ptr(bias), bias_t,
+                             _ptr(bg_f32), _ptr(bg_u8), _ptr(pix_index), _ptr(rgb_h), _ptr(rgb_c), _ptr(w_h),
+                             _ptr(w_c), _ptr(z_v), _stream()), "dfn_render_fwd")
+    out = (rgb_h, rgb_c)
+    if want_weights:
+        out += (w_h, w_c)
+    if want_z:
+        out += (z_v,)
+    return out
+
+
+def decoder_forward(packed, field, bias, points, dirs):
+    """dfn_decoder_fwd: points/dirs [N,3] -> feat [N,3], sigma [N]."""
+    dev = packed.device
+    pts = _f32c(points, dev).reshape(-1, 3)
+    dr = _f32c(dirs, dev).reshape(-1, 3)
+    n = pts.shape[0]
+    feat = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    sigma = torch.empty(n, dtype=torch.float32, device=dev)
+    if n == 0:
+        return feat, sigma
+    check(lib.dfn_decoder_fwd(packed.tier, field, _ptr(packed.packed[field]), _ptr(bias), _ptr(pts), _ptr(dr), n,
+                              _ptr(feat), _ptr(sigma), _stream()), "dfn_decoder_fwd")
+    return feat, sigma
+
+
+# ---- building blocks ------------------------------------------------------------------------------------------
+def get_rays(H, W, focal, c2w, cx=None, cy=None, device="cuda"):
+    require_gpu()
+    cx = W * .5 if cx is None else cx
+    cy = H * .5 if cy is None else cy
+    m = (c2w.detach().cpu().numpy() if isinstance(c2w, torch.Tensor) else np.asarray(c2w)).astype(np.float32)
+    m = np.ascontiguousarray(m[:3, :4]).reshape(-1)
+    arr = (C.c_float * 12)(*[float(v) for v in m])
+    ro = torch.empty(H, W, 3, dtype=torch.float32, device=device)
+    rd = torch.empty(H, W, 3, dtype=torch.float32, device=device)
+    check(lib.dfn_get_rays(int(H), int(W), float(focal), float(cx), float(cy), arr, _ptr(ro), _ptr(rd), _stream()),
+          "dfn_get_rays")
+    return ro, rd
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    dev = rays_o.device
+    ro, rd = _f32c(rays_o, dev), _f32c(rays_d, dev)
+    oo, od = torch.empty_like(ro), torch.empty_like(rd)
+    check(lib.dfn_ndc_rays(int(H), int(W), float(focal), float(near), _ptr(ro), _ptr(rd), ro.numel() // 3, _ptr(oo),
+                           _ptr(od), _stream()), "dfn_ndc_rays")
+    return oo, od
+
+
+def sample_pdf(bins, weights, n_samples, det=False, u=None):
+    dev = bins.device
+    b, w = _f32c(bins, dev), _f32c(weights, dev)
+    R, nb = b.shape
+    if u is None and not det:
+        u = torch.rand(R, n_samples, device=dev)
+    uu = None if u is None else _f32c(u, dev)
+    out = torch.empty(R, n_samples, dtype=torch.float32, device=dev)
+    if R == 0:
+        return out
+    check(lib.dfn_sample_pdf(_ptr(b), _ptr(w), R, nb, int(n_samples), _ptr(uu), _ptr(out), _stream()),
+          "dfn_sample_pdf")
+    return out
+
+
+def composite(sigma, feat):
+    """sigma [K,...], feat [K,...,3] -> sigma_sum [...], feat_w [...,3]."""
+    dev = sigma.device
+    K = sigma.shape[0]
+    s, f = _f32c(sigma, dev), _f32c(feat, dev)
+    N = s.numel() // K
+    ss = torch.empty(s.shape[1:], dtype=torch.float32, device=dev)
+    fw = torch.empty(f.shape[1:], dtype=torch.float32, device=dev)
+    check(lib.dfn_composite(_ptr(s), _ptr(f), K, N, _ptr(ss), _ptr(fw), _stream()), "dfn_composite")
+    return ss, fw
+
+
+def volume_weights(z_vals, ray_vector, sigma, last_dist=1e10):
+    dev = sigma.device
+    S = z_vals.shape[-1]
+    z = _f32c(z_vals, dev).reshape(-1, S)
+    r = _f32c(ray_vector, dev).reshape(-1, 3)
+    sg = _f32c(sigma, dev).reshape(-1, S)
+    w = torch.empty_like(sg)
+    check(lib.dfn_volume_weights(_ptr(z), _ptr(r), _ptr(sg), z.shape[0], S, float(last_dist), _ptr(w), _stream()),
+          "dfn_volume_weights")
+    return w.reshape(sigma.shape)
+
+
+def to8b(x):
+    dev = x.device
+    xx = _f32c(x, dev)
+    out = torch.empty(xx.shape, dtype=torch.uint8, device=dev)
+    check(lib.dfn_to8b(_ptr(xx), xx.numel(), _ptr(out), _stream()), "dfn_to8b")
+    return out
+
+
+def mfma_layout_probe(device="cuda"):
+    out = torch.zeros(2, 32, 32, dtype=torch.float32, device=device)
+    check(lib.dfn_debug_mfma_layout(_ptr(out), _stream()), "dfn_debug_mfma_layout")
+    return out

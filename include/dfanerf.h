@@ -86,11 +86,13 @@ int dfn_fold_bias(int tier, int field, const float* params, const float* signal,
  * frame.fields == 1).  bg: background as f32 [H*W,3] in [0,1] (MAIN:477) or u8 [H*W,3]; give one.
  * pix_index: optional int32 [ray_count] of pixel ids y*W+x (training: MAIN:818-836); NULL = contiguous.
  * rgb_head [ray_count,3] (MAIN:713 rgb_head), rgb_com [ray_count,3] (MAIN:712 rgb; NULL if fields==1).
- * weights_head / weights_com: optional [ray_count, n_coarse+n_fine] volume weights of the final pass. */
+ * weights_head / weights_com: optional [ray_count, n_coarse+n_fine] volume weights of the final pass.
+ * z_vals: optional [ray_count, n_coarse+n_fine] sample depths of the final pass (the merged, sorted
+ * z of row H; the coarse z when n_fine == 0). */
 int dfn_render_fwd(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
                    const float* bias_head, const float* bias_torso, const float* bg_f32,
                    const uint8_t* bg_u8, const int32_t* pix_index, float* rgb_head, float* rgb_com,
-                   float* weights_head, float* weights_com, void* stream);
+                   float* weights_head, float* weights_com, float* z_vals, void* stream);
 
 /* ---- Decoder.forward on explicit points: replaces DEC:277-349 -------------------------------------------
  * points, dirs [n,3]; feat [n,3] (after sigmoid), sigma [n] (raw). */

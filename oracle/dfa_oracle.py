@@ -417,6 +417,14 @@ def render_rays_chunk(P, o_h, d_h, o_t, d_t, bg, near, far, z_shape, z_app, sign
     return rgb_h, rgb_c
 
 
+def render_fixed_samples(P, o_h, d_h, o_t, d_t, bg, z, z_shape, z_app, signal, signal_torso, fields=2,
+                         last_dist=1e10):
+    """Decoder + compositing (MAIN:660-709) at given per-ray sample depths z [C,S]."""
+    s_h, f_h, s_t, f_t = _eval_fields(P, o_h, d_h, o_t, d_t, z, z_shape, z_app, signal, signal_torso, fields)
+    rgb_h, _, rgb_c, _ = integrate_fields(z, d_h, d_t, s_h, f_h, s_t, f_t, bg, last_dist)
+    return rgb_h, rgb_c
+
+
 def render_frame(P, H, W, focal, cx, cy, pose, pose_body, bg_img, near, far, z_shape, z_app,
                  signal, signal_torso, n_coarse=64, n_fine=0, fields=2, chunk=2048,
                  last_dist=1e10, ray_begin=0, ray_count=None):
