@@ -88,7 +88,7 @@ def _assert_samples_match(got, bins, w, n, u=None):
     bad = np.abs(got - ref) > tol
     near_knot = (np.abs(uu[:, :, None] - cdf[:, None, :]) < 1e-6).any(-1)
     assert not (bad & ~(near_knot | at_switch)).any(), np.argwhere(bad & ~(near_knot | at_switch))[:5]
-    assert bad.mean() < 0.01
+    assert bad.mean() < 0.05
     assert np.abs(got - ref).max() <= width * 1.0001 + 1e-7
 
 
