@@ -1,0 +1,555 @@
+"""Host-side mirror of the reference driver run_nerf_com_trainExpLater.py: same CLI, same function names,
+same dataset / checkpoint formats; the renderer behind them is the fused HIP kernel.
+
+Reference: /root/reference/NeRFs/DFANeRF/run_nerf_com_trainExpLater.py (MAIN below).
+  config_parser  MAIN:235-436 (all flags accepted; configargparse replaced by a small argparse subclass)
+  encode_signal* MAIN:28-111          rot_to_euler / pose_to_euler_trans / euler2rot  MAIN:182-232
+  composite_function MAIN:146-166     calc_volume_weights MAIN:169-179
+  render_rays    MAIN:114-143 is dead upstream (TypeError at :138); here it works, with the semantics of the
+                 live inline renderer MAIN:653-709 for one field
+  train          MAIN:439-1246: render-person loop :590-734 -> FrameRenderer (one fused launch per frame
+                 instead of 99 chunks x ~80 ATen launches); training loop :737-941; periodic test :943-1077;
+                 LR schedule :1079-1094 (optimizer_Exp is never rescheduled - kept); checkpoints :1099-1117.
+  run_network / create_nerf: names the task's north star asks for; thin shims (no upstream semantics exist).
+Fixes relative to upstream: rot_to_euler uses the input's device instead of a
+hard-coded .cuda(); the in-place `sigma[-1,:,:,-1] += 1e-6` on a relu output (rejected by current autograd) is
+formed out of place; --render_final_video (broken upstream: .reshape on a list, MAIN:1163) uses the
+render-person path."""
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import parallel
+from .decoder import Decoder
+from .helpers import (AudioAttNet, AudioNet_W2L, ExpressionEnc, get_embedder, get_rays, img2mse, mse2psnr, sample_pdf,
+                      to8b)
+from .nets import encode_signal, encode_signal_torso, pose_to_euler_trans, rot_to_euler  # noqa: F401
+
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# CLI
+# ------------------------------------------------------------------------------------------------------------
+class ConfigArgParser(argparse.ArgumentParser):
+    """argparse + `--config file` of `key = value` lines (what configargparse gives the reference):
+    file values act as defaults, explicit command-line flags win."""
+
+    def parse_args(self, args=None, namespace=None):
+        import sys
+        argv = list(sys.argv[1:] if args is None else args)
+        pre = argparse.ArgumentParser(add_help=False)
+        pre.add_argument('--config')
+        known, _ = pre.parse_known_args(argv)
+        file_args = []
+        if known.config:
+            actions = {a.dest: a for a in self._actions}
+            with open(known.config) as f:
+                for line in f:
+                    line = line.split('#')[0].strip()
+                    if not line or '=' not in line:
+                        continue
+                    key, val = [s.strip() for s in line.split('=', 1)]
+                    act = actions.get(key)
+                    if act is None:
+                        continue
+                    if act.nargs == 0:
+                        if val.lower() in ('true', '1', 'yes'):
+                            file_args.append('--' + key)
+                    else:
+                        file_args += ['--' + key, val]
+        return super().parse_args(file_args + argv, namespace)
+
+
+# (flag, type, default) ; type None = store_true, 'sf' = store_false (quirk kept: --use_viewdirs, --no_batching
+# and --white_bkgd are store_false upstream)
+_FLAGS = [
+    ("expname", str, None), ("basedir", str, './logs/'), ("datadir", str, './data/llff/fern'),
+    ("netdepth", int, 8), ("netwidth", int, 256), ("netdepth_fine", int, 8), ("netwidth_fine", int, 256),
+    ("N_rand", int, 2048), ("lrate", float, 5e-4), ("lrate_decay", int, 500), ("chunk", int, 4096),
+    ("netchunk", int, 1024 * 64), ("no_batching", 'sf', None), ("no_reload", None, None), ("ft_path", str, None),
+    ("N_iters", int, 400000), ("N_samples", int, 64), ("N_importance", int, 128), ("perturb", float, 1.),
+    ("use_viewdirs", 'sf', None), ("i_embed", int, 0), ("multires", int, 10), ("multires_views", int, 4),
+    ("raw_noise_std", float, 0.), ("render_only", None, None), ("render_test", None, None),
+    ("render_factor", int, 0), ("precrop_iters", int, 0), ("precrop_frac", float, .5),
+    ("dataset_type", str, 'audface'), ("testskip", int, 1), ("shape", str, 'greek'), ("white_bkgd", 'sf', None),
+    ("half_res", None, None), ("with_test", int, 0), ("dim_aud", int, 64), ("sample_rate", float, 0.95),
+    ("near", float, 0.3), ("far", float, 0.9), ("test_file", str, ''), ("aud_file", str, 'aud.npy'),
+    ("exp_file", str, 'exp.pt'), ("win_size", int, 16), ("smo_size", int, 8), ("smo_torse_size", int, 4),
+    ("nosmo_iters", int, 300000), ("noexp_iters", int, 300000), ("factor", int, 8), ("no_ndc", None, None),
+    ("lindisp", None, None), ("spherify", None, None), ("llffhold", int, 8), ("i_print", int, 100),
+    ("i_img", int, 500), ("i_weights", int, 10000), ("i_video", int, 50000), ("z_dim", int, 256),
+    ("n_feat", int, 256), ("image_size", int, 256), ("n_object", int, 2), ("use_giraffe", None, None),
+    ("resume", str, None), ("render_video", None, None), ("render_together", None, None),
+    ("alpha_sigma_loss", float, None), ("concate_bg_render", None, None), ("concate_bg", None, None),
+    ("stride", int, 2), ("render_person", None, None), ("i_test_separate", int, 1000), ("i_test_person", int, 1000),
+    ("train_together", None, None), ("train_separate", None, None), ("dim_signal", int, 128),
+    ("last_dist", float, 1e10), ("use_deformation_field", None, None), ("use_expression", None, None),
+    ("use_et_embed", None, None), ("use_ba", None, None), ("render_final_video", None, None), ("no_com", None, None),
+    ("use_L1", None, None), ("all_speaker", None, None), ("sample_rate_mouth", float, 0.7), ("use_exp", None, None),
+    ("use_aud_net", None, None), ("use_ori", None, None), ("test_offset", int, 0),
+]
+# build-side additions (not in the reference): precision tier of the HIP renderer and the hierarchical mode
+_EXTRA_FLAGS = [("hip_tier", str, 'f32'), ("hierarchical", None, None)]
+
+
+def config_parser():
+    parser = ConfigArgParser()
+    parser.add_argument('--config', help='config file path')
+    for name, typ, default in _FLAGS + _EXTRA_FLAGS:
+        if typ is None:
+            parser.add_argument('--' + name, action='store_true')
+        elif typ == 'sf':
+            parser.add_argument('--' + name, action='store_false')
+        else:
+            parser.add_argument('--' + name, type=typ, default=default)
+    return parser
+
+
+def parse_config_file(config_path):
+    with open(config_path, "r") as f:
+        lines = f.readlines()
+    return float(lines[3].split("=")[-1].strip()), float(lines[4].split("=")[-1].strip())
+
+
+def euler2rot(euler_angle):
+    """Batched XYZ euler -> rotation (MAIN:207-232; unused by the driver, kept for API parity)."""
+    b = euler_angle.shape[0]
+    th, ph, ps = [euler_angle[:, k].reshape(-1, 1, 1) for k in range(3)]
+    one = torch.ones((b, 1, 1), dtype=torch.float32, device=euler_angle.device)
+    zero = torch.zeros_like(one)
+    rx = torch.cat((torch.cat((one, zero, zero), 1), torch.cat((zero, th.cos(), th.sin()), 1),
+                    torch.cat((zero, -th.sin(), th.cos()), 1)), 2)
+    ry = torch.cat((torch.cat((ph.cos(), zero, -ph.sin()), 1), torch.cat((zero, one, zero), 1),
+                    torch.cat((ph.sin(), zero, ph.cos()), 1)), 2)
+    rz = torch.cat((torch.cat((ps.cos(), -ps.sin(), zero), 1), torch.cat((ps.sin(), ps.cos(), zero), 1),
+                    torch.cat((zero, zero, one), 1)), 2)
+    return torch.bmm(rx, torch.bmm(ry, rz))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# compositing API
+# ------------------------------------------------------------------------------------------------------------
+def _use_hip(*tensors):
+    return all(t.is_cuda for t in tensors) and not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors))
+
+
+def composite_function(sigma, feat):
+    """sigma [K,B,R,S], feat [K,B,R,S,3] -> sigma_sum [B,R,S], feat_weighted [B,R,S,3]."""
+    if _use_hip(sigma, feat):
+        from . import engine
+        return engine.composite(sigma, feat)
+    if sigma.shape[0] > 1:
+        denom = torch.sum(sigma, dim=0, keepdim=True)
+        denom = torch.where(denom == 0, torch.full_like(denom, 1e-4), denom)
+        return torch.sum(sigma, dim=0), (feat * (sigma / denom).unsqueeze(-1)).sum(0)
+    return sigma.squeeze(0), feat.squeeze(0)
+
+
+def calc_volume_weights(z_vals, ray_vector, sigma, last_dist=1e10):
+    """z [B,R,S], ray_vector [B,R,3], sigma [B,R,S] -> weights [B,R,S]."""
+    if _use_hip(z_vals, ray_vector, sigma):
+        from . import engine
+        return engine.volume_weights(z_vals, ray_vector, sigma, last_dist)
+    dists = z_vals[..., 1:] - z_vals[..., :-1]
+    dists = torch.cat([dists, torch.full_like(dists[..., :1], last_dist)], dim=-1)
+    dists = dists * torch.norm(ray_vector, dim=-1, keepdim=True)
+    alpha = 1. - torch.exp(-(F.relu(sigma) + 1e-6) * dists)
+    trans = torch.cumprod(torch.cat([torch.ones_like(alpha[..., :1]), (1. - alpha + 1e-10)], dim=-1), dim=-1)
+    return alpha * trans[..., :-1]
+
+
+def _bump_last(sigma, on):
+    """relu(sigma) with +1e-6 on the last sample of the last stacked field (MAIN:692-694), out of place."""
+    sigma = F.relu(sigma)
+    if not on:
+        return sigma
+    bump = torch.zeros(sigma.shape[-1], device=sigma.device, dtype=sigma.dtype)
+    bump[-1] = 1e-6
+    return torch.cat([sigma[:-1], sigma[-1:] + bump], 0)
+
+
+def render_rays(decoder, p_i, r_i, z_shape_i, z_app_i, signal, head_or_torso, batch_size, bc_rgb, view_dir, z_vals,
+                args, coarse_or_fine='coarse', raw_noise_std=0):
+    """One field through decoder -> bg / sigma fix-ups -> composite -> weights -> (rgb, weights).
+    p_i, r_i [B, R*S, 3]; bc_rgb [B,R,1,3]; view_dir [B,R,3]; z_vals [B,R,S]."""
+    S = args.N_samples + (args.N_importance if coarse_or_fine == 'fine' else 0)
+    feat_i, sigma_i = decoder(p_i, r_i, z_shape_i, z_app_i, signal, head_or_torso)
+    sigma_i = sigma_i.reshape(batch_size, -1, S)
+    feat_i = feat_i.reshape(batch_size, -1, S, 3)
+    if args.concate_bg:
+        feat_i = torch.cat((feat_i[..., :-1, :], bc_rgb), dim=-2)
+    sigma = _bump_last(torch.stack([sigma_i], dim=0), args.concate_bg)
+    feat = torch.stack([feat_i], dim=0)
+    sigma_sum, feat_weighted = composite_function(sigma, feat)
+    weights = calc_volume_weights(z_vals, view_dir, sigma_sum, last_dist=args.last_dist)
+    rgb = torch.sum(weights.unsqueeze(-1) * feat_weighted, dim=-2).squeeze(0)
+    return rgb, weights
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the fused renderer behind the frame loops
+# ------------------------------------------------------------------------------------------------------------
+class FrameRenderer:
+    """Replaces the chunked frame loop (MAIN:633-715): one fused launch per frame (per rank)."""
+
+    def __init__(self, decoder, z_shape, z_app, bc_img, hwfcxy, near, far, args, itr_obj=0, tier=None):
+        from . import engine
+        self.engine = engine
+        self.decoder, self.args = decoder, args
+        self.tier = tier or getattr(args, "hip_tier", "f32")
+        H, W, focal, cx, cy = hwfcxy
+        self.H, self.W, self.focal, self.cx, self.cy = int(H), int(W), float(focal), float(cx), float(cy)
+        self.near, self.far = float(near), float(far)
+        dev = next(decoder.parameters()).device
+        self.bg = bc_img.reshape(-1, 3).to(dev).float().contiguous()          # [H*W,3] in [0,1]
+        self.zs = z_shape[0, 2 * itr_obj:2 * itr_obj + 2].to(dev).float().contiguous()
+        self.za = z_app[0, 2 * itr_obj:2 * itr_obj + 2].to(dev).float().contiguous()
+        self.n_fine = args.N_importance if getattr(args, "hierarchical", False) else 0
+
+    def render(self, pose, pose_body, signal, signal_torso, ray_begin=0, ray_count=None, pix_index=None, fields=2):
+        """-> rgb_head [n,3], rgb_com [n,3] (None if fields == 1)."""
+        eng = self.engine
+        pk = self.decoder.packed(self.tier)
+        bias = pk.fold(signal[0] if isinstance(signal, (list, tuple)) else signal,
+                       signal_torso if fields == 2 else None, self.zs, self.za)
+        n = (self.H * self.W - ray_begin) if ray_count is None else ray_count
+        if pix_index is not None:
+            n = pix_index.numel()
+        fr = eng.make_frame(self.H, self.W, self.focal, self.cx, self.cy, pose.detach().cpu().numpy(),
+                            pose_body.detach().cpu().numpy(), self.near, self.far, self.args.last_dist, ray_begin, n,
+                            self.args.N_samples, self.n_fine, fields, self.args.concate_bg)
+        return eng.render(pk, bias, fr, self.bg, pix_index=pix_index)
+
+    def render_image(self, pose, pose_body, signal, signal_torso, fields=2):
+        """Whole frame, sharded over the ranks when torch.distributed is initialised -> [H,W,3] images."""
+        import torch.distributed as dist
+        R = self.H * self.W
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            begin, count, per = parallel.shard_range(R, dist.get_world_size(), dist.get_rank())
+            rh, rc = self.render(pose, pose_body, signal, signal_torso, begin, count, fields=fields)
+            pad = lambda x: torch.cat([x, x.new_zeros(per - x.shape[0], 3)]) if x.shape[0] < per else x
+            rh = parallel.gather_rays(pad(rh), R)
+            rc = parallel.gather_rays(pad(rc), R) if rc is not None else None
+        else:
+            rh, rc = self.render(pose, pose_body, signal, signal_torso, fields=fields)
+        return rh.reshape(self.H, self.W, 3), (rc.reshape(self.H, self.W, 3) if rc is not None else None)
+
+
+def run_network(inputs, viewdirs, decoder, z_shape, z_app, signal, head_or_torso='head'):
+    """North-star shim: evaluate the decoder at points `inputs` [..., 3] with directions `viewdirs` [..., 3]."""
+    feat, sigma = decoder(inputs.reshape(1, -1, 3), viewdirs.reshape(1, -1, 3), z_shape, z_app, signal, head_or_torso)
+    return feat.reshape(*inputs.shape[:-1], 3), sigma.reshape(inputs.shape[:-1])
+
+
+def create_nerf(args, dev=None):
+    """North-star shim: build the networks and optimizers exactly as train() does (MAIN:512-547)."""
+    dev = dev or device
+    embed_fn, dim_torso_signal = None, None
+    if args.use_et_embed:
+        embed_fn, input_ch = get_embedder(3, 0)
+        dim_torso_signal = 2 * input_ch
+    nets = {"decoder": Decoder(z_dim=args.z_dim, hidden_size=args.n_feat, dim_signal=args.dim_signal,
+                               use_deformation_field=args.use_deformation_field,
+                               use_expression=args.use_expression, use_aud_net=args.use_aud_net).to(dev),
+            "AudNet": AudioNet_W2L().to(dev), "ExpNet": ExpressionEnc().to(dev),
+            "AudAttNet": AudioAttNet(dim_aud=args.dim_aud, seq_len=args.smo_size).to(dev)}
+    if args.use_et_embed:
+        nets["PoseAttNet"] = AudioAttNet(dim_aud=dim_torso_signal, seq_len=args.smo_torse_size).to(dev)
+    opts = {k: torch.optim.Adam(params=list(m.parameters()), lr=args.lrate, betas=(0.9, 0.999))
+            for k, m in nets.items()}
+    return nets, opts, embed_fn
+
+
+# checkpoint layout (MAIN:1101-1115)
+_CKPT_NET = {"decoder": "network_decoder_state_dict", "AudNet": "network_AudNet_state_dict",
+             "ExpNet": "network_ExpNet_state_dict", "AudAttNet": "network_AudAttNet_state_dict",
+             "PoseAttNet": "network_PoseAttNet_state_dict"}
+_CKPT_OPT = {"decoder": "optimizer_decoder_state_dict", "AudNet": "optimizer_Aud_state_dict",
+             "ExpNet": "optimizer_Exp_state_dict", "AudAttNet": "optimizer_AudAtt_state_dict",
+             "PoseAttNet": "optimizer_PoseAtt_state_dict"}
+
+
+def save_checkpoint(path, global_step, z_shape, z_app, nets, opts):
+    ck = {'global_step': global_step, 'z_shape': z_shape, 'z_app': z_app}
+    for k, m in nets.items():
+        ck[_CKPT_NET[k]] = m.state_dict()
+        ck[_CKPT_OPT[k]] = opts[k].state_dict()
+    torch.save(ck, path)
+
+
+def load_checkpoint(path, nets, opts, map_location=None):
+    """MAIN:553-580: decoder + its optimizer are mandatory, the rest optional."""
+    ck = torch.load(path, map_location=map_location, weights_only=False)
+    nets["decoder"].load_state_dict(ck[_CKPT_NET["decoder"]])
+    opts["decoder"].load_state_dict(ck[_CKPT_OPT["decoder"]])
+    for k in nets:
+        if k != "decoder" and _CKPT_NET[k] in ck:
+            nets[k].load_state_dict(ck[_CKPT_NET[k]])
+        if k != "decoder" and _CKPT_OPT[k] in ck:
+            opts[k].load_state_dict(ck[_CKPT_OPT[k]])
+    return ck['global_step'], ck['z_shape'], ck['z_app']
+
+
+def _imread(path):
+    from PIL import Image
+    return np.asarray(Image.open(path).convert('RGB'))
+
+
+def _imwrite(path, arr):
+    from PIL import Image
+    Image.fromarray(np.asarray(arr, np.uint8)).save(path, quality=95)
+
+
+def _mimwrite(path, frames, fps=25):
+    try:
+        import imageio
+        imageio.mimwrite(path, frames, fps=fps, quality=8)
+        return True
+    except Exception as e:       # imageio / ffmpeg are not part of this image
+        print(f'[dfanerf] video not written ({e.__class__.__name__}: {e}); frames are saved as jpg')
+        return False
+
+
+def select_coords(H, W, N_rand, sample_rate, rect, rng=np.random):
+    """Pixel sampling of MAIN:786-820 on the host (np.random as upstream); returns int64 [N_rand, 2] (y, x)."""
+    if sample_rate > 0:
+        ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+        ys, xs = ys.reshape(-1), xs.reshape(-1)
+        in_rect = (ys >= rect[0]) & (ys <= rect[0] + rect[2]) & (xs >= rect[1]) & (xs <= rect[1] + rect[3])
+        in_torso = (ys >= H / 2) & (ys <= H) & (xs >= 0) & (xs <= W)
+        m = in_rect | in_torso
+        rect_num = int(N_rand * sample_rate)
+        idx_in, idx_out = np.nonzero(m)[0], np.nonzero(~m)[0]
+        a = rng.choice(idx_in.shape[0], size=[rect_num], replace=False)
+        b = rng.choice(idx_out.shape[0], size=[N_rand - rect_num], replace=False)
+        sel = np.concatenate([idx_in[a], idx_out[b]])
+    else:
+        sel = rng.choice(H * W, size=[N_rand], replace=False)
+    return np.stack([sel // W, sel % W], 1).astype(np.int64)
+
+
+def train_step_loss(nets, dataset, itr_obj, img_i, sel_yx, target_head, target_com, z_shape, z_app, global_step, args,
+                    len_train, embed_fn, pose_torso):
+    """Forward of one training step (MAIN:779-907) on the selected pixels; autograd-capable (ATen) path.
+    Returns loss, loss_head, loss_com, rgb_head, rgb_com."""
+    dec = nets["decoder"]
+    dev = next(dec.parameters()).device
+    poses, bc_img = dataset[itr_obj]['poses'], dataset[itr_obj]['bc_img']
+    H, W, focal, cx, cy = dataset[itr_obj]['hwfcxy']
+    H, W = int(H), int(W)
+    N = sel_yx.shape[0]
+    signal = encode_signal(dataset, itr_obj, img_i, args.dim_aud, nets["AudNet"], nets["ExpNet"], nets["AudAttNet"],
+                           global_step, args, len_train, embed_fn=embed_fn)
+    signal_torso = encode_signal_torso(dataset, itr_obj, img_i, nets.get("PoseAttNet"), global_step, args, len_train,
+                                       embed_fn=embed_fn)
+    ys, xs = torch.as_tensor(sel_yx[:, 0], device=dev), torch.as_tensor(sel_yx[:, 1], device=dev)
+    t_vals = torch.linspace(0., 1., steps=args.N_samples, device=dev)
+    z_vals = (dataset[itr_obj]['near'] * (1. - t_vals) + dataset[itr_obj]['far'] * t_vals).expand(N, args.N_samples)
+
+    def rays(pose):
+        ro, rd = _get_rays_any(H, W, focal, pose, cx, cy, dev)
+        ro, rd = ro[ys, xs], rd[ys, xs]
+        p = (ro[..., None, :] + rd[..., None, :] * z_vals[..., :, None]).reshape(1, -1, 3)
+        r = rd.unsqueeze(1).expand(N, args.N_samples, 3).reshape(1, -1, 3)
+        return rd, p, r
+    rd_h, p_h, r_h = rays(poses[img_i, :3, :4])
+    rd_t, p_t, r_t = rays(pose_torso)
+    bc_rgb = bc_img[ys, xs].reshape(1, N, 1, 3)
+    feat_h, sig_h = dec(p_h, r_h, z_shape[:, itr_obj * 2], z_app[:, itr_obj * 2], signal, 'head')
+    feat_t, sig_t = dec(p_t, r_t, z_shape[:, itr_obj * 2 + 1], z_app[:, itr_obj * 2 + 1], signal_torso, 'torso')
+    sig_h, feat_h = sig_h.reshape(1, N, -1), feat_h.reshape(1, N, args.N_samples, -1)
+    sig_t, feat_t = sig_t.reshape(1, N, -1), feat_t.reshape(1, N, args.N_samples, -1)
+    if args.concate_bg:
+        feat_h = torch.cat((feat_h[..., :-1, :], bc_rgb), dim=-2)
+        sig_t = torch.cat((sig_t[..., :-1], torch.zeros_like(sig_t[..., -1:])), -1)
+    sigma = _bump_last(torch.stack([sig_h], 0), args.concate_bg)
+    sigma_to = _bump_last(torch.stack([sig_h, sig_t], 0), args.concate_bg)
+    ssum, fw = composite_function(sigma, torch.stack([feat_h], 0))
+    ssum_t, fw_t = composite_function(sigma_to, torch.stack([feat_h, feat_t], 0))
+    w_h = calc_volume_weights(z_vals.unsqueeze(0), rd_h.unsqueeze(0), ssum, last_dist=args.last_dist)
+    w_c = calc_volume_weights(z_vals.unsqueeze(0), rd_t.unsqueeze(0), ssum_t, last_dist=args.last_dist)
+    rgb_head = torch.sum(w_h.unsqueeze(-1) * fw, dim=-2).squeeze(0)
+    rgb_com = torch.sum(w_c.unsqueeze(-1) * fw_t, dim=-2).squeeze(0)
+    l_head = img2mse(rgb_head, target_head)
+    l_com = img2mse(rgb_com, target_com)
+    return l_com + l_head, l_head, l_com, rgb_head, rgb_com
+
+
+def _get_rays_any(H, W, focal, c2w, cx, cy, dev):
+    """get_rays on the GPU through the HIP kernel; on CPU (unit tests of the host logic) in ATen."""
+    if torch.device(dev).type == 'cuda':
+        return get_rays(H, W, focal, c2w.to(dev), cx, cy)
+    xs = torch.arange(W, dtype=torch.float32)[None, :].expand(H, W)
+    ys = torch.arange(H, dtype=torch.float32)[:, None].expand(H, W)
+    dirs = torch.stack([(xs - cx) / focal, -(ys - cy) / focal, -torch.ones_like(xs)], -1)
+    c2w = c2w.float().cpu()
+    rd = torch.stack([(dirs[..., 0] * c2w[k, 0] + dirs[..., 1] * c2w[k, 1]) + dirs[..., 2] * c2w[k, 2]
+                      for k in range(3)], -1)
+    return c2w[:3, 3].expand(rd.shape), rd
+
+
+def optimizer_steps(opts, global_step, args):
+    """Gating of MAIN:924-931."""
+    opts["decoder"].step()
+    opts["AudNet"].step()
+    if global_step >= args.nosmo_iters:
+        opts["AudAttNet"].step()
+        if args.use_et_embed and "PoseAttNet" in opts:
+            opts["PoseAttNet"].step()
+    if global_step >= args.noexp_iters:
+        opts["ExpNet"].step()
+
+
+def update_lrate(opts, global_step, args):
+    """MAIN:1081-1094: exponential decay; x2 for the attention nets; optimizer_Exp is never touched."""
+    new_lrate = args.lrate * (0.1 ** (global_step / (args.lrate_decay * 1500)))
+    for k, mult in (("decoder", 1), ("AudNet", 1), ("AudAttNet", 2), ("PoseAttNet", 2)):
+        if k in opts:
+            for g in opts[k].param_groups:
+                g['lr'] = new_lrate * mult
+    return new_lrate
+
+
+def train():
+    from .load_audface import load_audface_data_split
+    args = config_parser().parse_args()
+    world, rank, local = parallel.init()
+    dev = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
+    if dev.type != "cuda":
+        raise RuntimeError("train(): no HIP device visible; the render path has no CPU fallback")
+    print("args.near: ", args.near)
+    print("args.far: ", args.far)
+    tf = 'transforms_train_ba.json' if args.use_ba else 'transforms_train.json'
+    with open(os.path.join(args.datadir, tf), 'r') as fp:
+        pose_body = torch.Tensor(json.load(fp)['frames'][0]['transform_matrix']).to(dev).float()
+    ds = load_audface_data_split(args.datadir, args.testskip, test_file=args.test_file, aud_file=args.aud_file,
+                                 exp_file=args.exp_file, no_com=args.no_com, all_speaker=args.all_speaker,
+                                 use_ori=args.use_ori, use_ba=args.use_ba, test_offset=args.test_offset)
+    ds['near'], ds['far'] = args.near, args.far
+    if not args.render_person:
+        ds['i_train'], ds['i_val'] = ds['i_split']
+        ds['i_train'] = np.intersect1d(ds['i_train'], np.where(ds['speak_frames'] > 0))
+    for k in ('poses', 'auds', 'exp'):
+        ds[k] = torch.Tensor(ds[k]).to(dev).float()
+    ds['bc_img'] = torch.Tensor(ds['bc_img']).to(dev).float() / 255.0
+    datasets = [ds]
+    batch_size = 1
+    basedir = os.path.join('dataset/train_together', args.expname)
+    imgdir = [os.path.join(basedir, args.datadir.split('/')[-1])]
+    if rank == 0:
+        os.makedirs(os.path.join(imgdir[0], 'person'), exist_ok=True)
+        with open(os.path.join(basedir, 'args.txt'), 'w') as f:
+            for arg in sorted(vars(args)):
+                f.write('{} = {}\n'.format(arg, getattr(args, arg)))
+        if args.config is not None:
+            with open(os.path.join(basedir, 'config.txt'), 'w') as f:
+                f.write(open(args.config, 'r').read())
+    nets, opts, embed_fn = create_nerf(args, dev)
+    z_shape = torch.randn(batch_size, args.n_object * 2, args.z_dim).to(dev)
+    z_app = torch.randn(batch_size, args.n_object * 2, args.z_dim).to(dev)
+    global_step = 0
+    if args.resume is not None:
+        global_step, z_shape, z_app = load_checkpoint(args.resume, nets, opts, map_location=dev)
+        z_shape, z_app = z_shape.to(dev), z_app.to(dev)
+    print('N_rand', args.N_rand, 'no_batching', args.no_batching, 'sample_rate', args.sample_rate)
+    print('Begin')
+    itr_obj = 0
+    H, W, focal, cx, cy = ds['hwfcxy']
+    H, W = int(H), int(W)
+    renderer = FrameRenderer(nets["decoder"], z_shape, z_app, ds['bc_img'], ds['hwfcxy'], args.near, args.far, args)
+
+    def render_frames(frame_ids, len_sig, outdir_com, outdir_head, pose_body_t, tag='test_{:06d}.jpg'):
+        rgbs = []
+        for img_i in frame_ids:
+            with torch.no_grad():
+                signal = encode_signal(datasets, itr_obj, img_i, args.dim_aud, nets["AudNet"], nets["ExpNet"],
+                                       nets["AudAttNet"], global_step, args, len_sig, embed_fn=embed_fn)
+                signal_torso = encode_signal_torso(datasets, itr_obj, img_i, nets.get("PoseAttNet"), global_step,
+                                                   args, len_sig, embed_fn=embed_fn)
+                rgb_head, rgb = renderer.render_image(ds['poses'][img_i, :3, :4], pose_body_t, signal, signal_torso)
+                rgb8, rgb8_head = to8b(rgb).cpu().numpy(), to8b(rgb_head).cpu().numpy()
+            if rank == 0:
+                _imwrite(os.path.join(outdir_com, tag.format(img_i)), rgb8)
+                if outdir_head:
+                    _imwrite(os.path.join(outdir_head, tag.format(img_i)), rgb8_head)
+                print('Saved test img at {}'.format(os.path.join(outdir_com, tag.format(img_i))))
+            rgbs.append(rgb8)
+        return rgbs
+
+    if args.render_person:
+        print('RENDER PERSON')
+        out_com = os.path.join(imgdir[0], 'person', 'render_com')
+        out_head = os.path.join(imgdir[0], 'person', 'render_head')
+        if rank == 0:
+            os.makedirs(out_com, exist_ok=True)
+            os.makedirs(out_head, exist_ok=True)
+        n_items = ds['auds'].shape[0]
+        print("num_items: ", n_items)
+        rgbs = render_frames(range(n_items), n_items, out_com, out_head, pose_body[:3, :4])
+        if args.render_video and rank == 0:
+            _mimwrite(os.path.join(out_com, '{}.mp4'.format(args.expname)), rgbs)
+        return
+
+    bucket = parallel.FlatGradBucket(list(nets.values())) if world > 1 else None
+    rng = np.random.RandomState(1234 + rank) if world > 1 else np.random
+    i_train = ds['i_train']
+    from tqdm import trange, tqdm
+    for i in trange(global_step + 1, args.N_iters + 1, disable=rank != 0):
+        img_i = rng.choice(i_train)
+        target_com = torch.as_tensor(_imread(ds['imgs_com'][img_i])).to(dev).float() / 255.0
+        target_head = torch.as_tensor(_imread(ds['imgs'][img_i])).to(dev).float() / 255.0
+        sel = select_coords(H, W, args.N_rand, args.sample_rate, ds['sample_rects'][img_i], rng)
+        ys, xs = torch.as_tensor(sel[:, 0], device=dev), torch.as_tensor(sel[:, 1], device=dev)
+        loss, l_head, l_com, _, _ = train_step_loss(nets, datasets, itr_obj, img_i, sel, target_head[ys, xs],
+                                                    target_com[ys, xs], z_shape, z_app, global_step, args,
+                                                    len(i_train), embed_fn, ds['poses'][0, :3, :4])
+        for o in opts.values():
+            o.zero_grad()
+        loss.backward()
+        if bucket is not None:
+            bucket.all_reduce_()
+        optimizer_steps(opts, global_step, args)
+        if i % args.i_print == 0 and rank == 0:
+            msg = (f"[TRAIN] Iter: {i} Object: {itr_obj} Com Loss: {l_com.item()}  Head Neck PSNR: "
+                   f"{mse2psnr(l_head).item()} Com PSNR: {mse2psnr(l_com).item()}")
+            tqdm.write(msg)
+            with open(os.path.join(basedir, 'loss.txt'), 'a') as f:
+                f.write(msg + "\n")
+        if (i % args.i_test_person == 0 and i > 0) or (i in [100, 500, 1000, 3000]):
+            outdir = os.path.join(imgdir[0], 'person', 'test_{}'.format(i))
+            if rank == 0:
+                os.makedirs(outdir, exist_ok=True)
+            i_val = ds['i_val']
+            ids = [i_val[k] for k in range(0, len(i_val), 100)]
+            imgs = render_frames(ids, len(i_train) + len(i_val), outdir, None, ds['poses'][0, :3, :4],
+                                 tag='test_{:03d}.jpg')
+            if rank == 0:
+                for img_id, rgb8 in zip(ids, imgs):
+                    tgt = torch.as_tensor(_imread(ds['imgs_com'][img_id])).float() / 255.0
+                    ps = mse2psnr(img2mse(torch.as_tensor(rgb8).float() / 255.0, tgt))
+                    print('Saved test person img, psnr: {}'.format(ps.item()))
+                    with open(os.path.join(basedir, 'loss.txt'), 'a') as f:
+                        f.write(f"[TEST] Iter: {i} Object: {itr_obj}_person PSNR: {ps.item()}\n")
+        update_lrate(opts, global_step, args)
+        global_step += 1
+        if i % args.i_weights == 0 and rank == 0:
+            path = os.path.join(basedir, '{:06d}.tar'.format(i))
+            save_checkpoint(path, global_step, z_shape, z_app, nets, opts)
+            print('Saved checkpoints at', path)
+    if args.render_final_video:
+        outdir = os.path.join(imgdir[0], 'person')
+        rgbs = render_frames(list(ds['i_val']), len(ds['i_val']), outdir, None, pose_body[:3, :4],
+                             tag='final_{:06d}.jpg')
+        if rank == 0:
+            _mimwrite(os.path.join(outdir, 'test_{}_{}.mp4'.format(args.N_iters, args.expname)), rgbs)
+
+
+if __name__ == '__main__':
+    train()

@@ -372,6 +372,29 @@ def main():
                 "network_PoseAttNet_state_dict optimizer_PoseAtt_state_dict\n")
         f.write("n_params decoder %d\n" % sum(p.numel() for p in dec.parameters()))
 
+    # ---- G11: CLI surface (flag name, kind, default) parsed from the driver's config_parser ------------------
+    import ast
+    import json as _json
+    tree = ast.parse(open(os.path.join(REF, "run_nerf_com_trainExpLater.py")).read())
+    flags = []
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Call) and getattr(node.func, "attr", "") == "add_argument":
+            name = node.args[0].value.lstrip("-")
+            kw = {k.arg: k.value for k in node.keywords}
+            kind = "value"
+            if "action" in kw:
+                kind = kw["action"].value
+            default = None
+            if "default" in kw:
+                default = eval(compile(ast.Expression(kw["default"]), "<flag>", "eval"))
+            typ = kw["type"].id if "type" in kw else None
+            if kw.get("is_config_file") is not None:
+                kind = "config_file"
+            flags.append({"name": name, "kind": kind, "type": typ, "default": default})
+    with open(os.path.join(HERE, "g11_cli_flags.json"), "w") as f:
+        _json.dump(flags, f, indent=0)
+    print("g11_cli_flags:", len(flags), "flags")
+
     # ---- G10: to8b / psnr ---------------------------------------------------------------
     x = np.array([-0.1, 0.0, 0.5 / 255, 0.999 / 255, 1.0 / 255, 0.5, 254.999 / 255, 1.0, 1.2,
                   0.99999994, 0.1, 0.2, 0.3], np.float32)

@@ -1,0 +1,246 @@
+"""CPU tests of the host-side mirror of the reference's Python surface (dfa-nerf_amd/dfanerf/*.py and the
+drop-in modules under NeRFs/DFANeRF/): CLI flags, state_dict / checkpoint compatibility, the autograd
+(training) path against golden G8, and the multi-process partitioning with gloo, world_size 2."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+from dfanerf import nets, parallel, run_nerf, synth
+from dfanerf.decoder import Decoder
+
+torch.set_num_threads(8)
+
+
+def t(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+def _modules(states):
+    dec = Decoder(z_dim=256, hidden_size=256, dim_signal=96, use_deformation_field=True)
+    mods = {"decoder": dec, "AudNet": nets.AudioNet_W2L(), "ExpNet": nets.ExpressionEnc(),
+            "AudAttNet": nets.AudioAttNet(96, 4), "PoseAttNet": nets.AudioAttNet(42, 8)}
+    for k, m in mods.items():
+        m.load_state_dict({kk: t(v) for kk, v in states[k].items()})
+    return mods
+
+
+def test_cli_flags_match_reference():
+    want = json.load(open(os.path.join(GOLDEN, "g11_cli_flags.json")))
+    parser = run_nerf.config_parser()
+    acts = {a.dest: a for a in parser._actions}
+    for f in want:
+        a = acts[f["name"]]
+        if f["kind"] == "store_true":
+            assert a.const is True and a.default is False, f
+        elif f["kind"] == "store_false":
+            assert a.const is False and a.default is True, f
+        elif f["kind"] == "value":
+            assert a.default == f["default"], f
+            if f["type"]:
+                assert a.type.__name__ == f["type"], f
+    extra = set(acts) - {f["name"] for f in want} - {"help"}
+    assert extra == {"hip_tier", "hierarchical"}
+
+
+def test_config_file_and_script_flags(tmp_path):
+    cfg = tmp_path / "HeadNeRF_config_ba.txt"
+    cfg.write_text("expname = obama_head\ndatadir = dataset/obama\nbasedir = dataset/obama/logs\n"
+                   "near = 0.3127\nfar = 0.9127\ntestskip = 1\n")
+    # the flag bundle of scripts/test_obama.sh
+    argv = ("--config %s --last_dist=1e10 --datadir dataset/obama --concate_bg --N_rand=2048 --sample_rate=0 "
+            "--i_print=100 --i_test_person=10000 --chunk=2048 --win_size=16 --smo_size=4 --smo_torse_size 8 "
+            "--train_together --i_weights=100000 --all_speaker --sample_rate_mouth=0 --lrate_decay=500 --lrate=5e-4 "
+            "--use_et_embed --nosmo_iters=300000 --dim_signal=96 --dim_aud=96 --n_object=1 --N_iters=600000 "
+            "--expname=obama_TrainExpLater_smoMix --aud_file=obama_aud.pt --use_deformation_field "
+            "--exp_file=obama_64_32.pt --use_ba --render_person --noexp_iters 400000 "
+            "--resume x/280000.tar --test_file transforms_val_ba.json --render_video" % cfg).split()
+    a = run_nerf.config_parser().parse_args(argv)
+    assert a.near == 0.3127 and a.far == 0.9127 and a.testskip == 1         # from the config file
+    assert a.expname == "obama_TrainExpLater_smoMix"                         # command line wins over the file
+    assert a.chunk == 2048 and a.smo_size == 4 and a.render_person and a.concate_bg and a.use_ba
+    assert run_nerf.parse_config_file(str(cfg)) == (0.3127, 0.9127)
+
+
+def test_state_dict_manifest(states):
+    lines = open(os.path.join(GOLDEN, "g9_manifest.txt")).read().strip().split("\n")
+    mods = _modules(states)
+    for tag, m in mods.items():
+        want = [(ln.split(" ", 2)[1], eval(ln.split(" ", 2)[2])) for ln in lines if ln.startswith(tag + " ")]
+        got = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+        assert got == want, tag
+    assert mods["decoder"].hip_supported()
+    assert not Decoder().hip_supported()
+
+
+def test_decoder_aten_path_vs_golden(states, latents, golden):
+    g = golden("g3_decoder")
+    dec = _modules(states)["decoder"]
+    zs, za = [t(v) for v in latents]
+    p, r = t(g["p_64"]), t(g["r_64"])
+    with torch.enable_grad():
+        fh, sh = dec(p, r, zs[:, 0], za[:, 0], [t(g["sig_aud"]), None], 'head')
+        ft, st = dec(p, r, zs[:, 1], za[:, 1], t(g["sig_torso"]), 'torso')
+        fl, sl = dec(p, r, zs[:, 0], za[:, 0], [None, None], 'head')
+    for got, ref in ((fh, "feat_head_64"), (sh, "sigma_head_64"), (ft, "feat_torso_64"), (st, "sigma_torso_64"),
+                     (fl, "feat_listener_64"), (sl, "sigma_listener_64")):
+        np.testing.assert_allclose(got.detach().numpy(), g[ref], rtol=1e-5, atol=2e-5)
+    assert np.array_equal(dec.transform_points(p[:, :8]).numpy(), g["pe_p"])
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
+        dec(p, r, zs[:, 0], za[:, 0], [t(g["sig_aud"]), None], 'head')       # no silent CPU path for inference
+
+
+def _args():
+    a = run_nerf.config_parser().parse_args(
+        "--expname t --concate_bg --N_rand=256 --sample_rate=0 --smo_size=4 --smo_torse_size 8 --use_et_embed "
+        "--dim_signal=96 --dim_aud=96 --n_object=1 --use_deformation_field --noexp_iters 400000".split())
+    return a
+
+
+@pytest.mark.parametrize("step", [0, 300000, 400000])
+def test_training_step_vs_golden(states, scene, latents, golden, step):
+    """train_step_loss (MAIN:779-907) + gated Adam steps (MAIN:916-931) against golden G8."""
+    g = golden("g8_train_step")
+    mods = _modules(states)
+    args = _args()
+    H, W = scene["H"], scene["W"]
+    ds = [{"auds": t(scene["aud"]), "exp": t(scene["exp"]), "poses": t(scene["poses"]),
+           "bc_img": t(scene["bg"]).float() / 255.0, "hwfcxy": [H, W, scene["focal"], scene["cx"], scene["cy"]],
+           "near": 0.3, "far": 0.9}]
+    sel = g["sel_yx"]
+    tgt_h = t(synth.synth_tensor(0, "g8/th", (H, W, 3), 0.5)) + 0.5
+    tgt_c = t(synth.synth_tensor(0, "g8/tc", (H, W, 3), 0.5)) + 0.5
+    zs, za = [t(v) for v in latents]
+    embed_fn, _ = nets.get_embedder(3, 0)
+    opts = {k: torch.optim.Adam(m.parameters(), lr=5e-4, betas=(0.9, 0.999)) for k, m in mods.items()}
+    loss, lh, lc, _, _ = run_nerf.train_step_loss(mods, ds, 0, 3, sel, tgt_h[sel[:, 0], sel[:, 1]],
+                                                  tgt_c[sel[:, 0], sel[:, 1]], zs, za, step, args, scene["aud"].shape[0],
+                                                  embed_fn, ds[0]["poses"][0, :3, :4])
+    np.testing.assert_allclose([loss.item(), lh.item(), lc.item()], g[f"loss_{step}"], rtol=3e-6)
+    for o in opts.values():
+        o.zero_grad()
+    loss.backward()
+    for tag, m in mods.items():
+        for k, p in m.named_parameters():
+            ref = float(g[f"gnorm_{step}/{tag}/{k}"])
+            got = 0.0 if p.grad is None else p.grad.double().norm().item()
+            if ref < 0:
+                assert got == 0
+            else:
+                assert abs(got - ref) <= 3e-4 * ref + 1e-9, (tag, k, got, ref)
+    run_nerf.optimizer_steps(opts, step, args)
+    for key in [k for k in g if k.startswith(f"after_{step}/")]:
+        _, tag, name = key.split("/", 2)
+        got = dict(mods[tag].named_parameters())[name].detach().reshape(-1)[: g[key].size].numpy()
+        np.testing.assert_allclose(got, g[key].reshape(-1), rtol=0, atol=3e-6)
+    lr = run_nerf.update_lrate(opts, step, args)
+    assert opts["AudAttNet"].param_groups[0]["lr"] == 2 * lr and opts["ExpNet"].param_groups[0]["lr"] == 5e-4
+
+
+def test_checkpoint_roundtrip(tmp_path, states, latents):
+    mods = _modules(states)
+    opts = {k: torch.optim.Adam(m.parameters(), lr=5e-4) for k, m in mods.items()}
+    zs, za = [t(v) for v in latents]
+    path = str(tmp_path / "000010.tar")
+    run_nerf.save_checkpoint(path, 11, zs, za, mods, opts)
+    ck = torch.load(path, weights_only=False)
+    want = open(os.path.join(GOLDEN, "g9_manifest.txt")).read().strip().split("\n")
+    keys = [ln for ln in want if ln.startswith("ckpt_keys ")][0].split(" ")[1:]
+    assert sorted(ck.keys()) == sorted(keys)
+    mods2 = _modules({k: {kk: np.zeros_like(v) for kk, v in st.items()} for k, st in states.items()})
+    opts2 = {k: torch.optim.Adam(m.parameters(), lr=5e-4) for k, m in mods2.items()}
+    step, zs2, za2 = run_nerf.load_checkpoint(path, mods2, opts2)
+    assert step == 11 and torch.equal(zs2, zs) and torch.equal(za2, za)
+    for k in mods:
+        for a, b in zip(mods[k].state_dict().values(), mods2[k].state_dict().values()):
+            assert torch.equal(a, b)
+
+
+def test_select_coords_and_shards():
+    rng = np.random.RandomState(0)
+    sel = run_nerf.select_coords(450, 450, 2048, 0, None, rng)
+    assert sel.shape == (2048, 2) and len({(a, b) for a, b in sel}) == 2048
+    sel = run_nerf.select_coords(450, 450, 2048, 0.95, np.array([100, 120, 80, 90]), rng)
+    inside = ((sel[:, 0] >= 100) & (sel[:, 0] <= 180) & (sel[:, 1] >= 120) & (sel[:, 1] <= 210)) | (sel[:, 0] >= 225)
+    assert inside.sum() == int(2048 * 0.95)
+    for R, P in ((202500, 8), (202500, 1), (7, 8), (64, 3)):
+        cover = []
+        for r in range(P):
+            b, n, per = parallel.shard_range(R, P, r)
+            assert per == -(-R // P) and 0 <= n <= per
+            cover += list(range(b, b + n))
+        assert cover == list(range(R))
+    assert parallel.shard_range(202500, 8, 7) == (177191, 25309, 25313)
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    R = 1001
+    begin, count, per = parallel.shard_range(R, world, rank)
+    full = torch.arange(R * 3, dtype=torch.float32).reshape(R, 3)
+    shard = torch.zeros(per, 3)
+    shard[:count] = full[begin:begin + count]
+    img = parallel.gather_rays(shard, R)
+    ok_gather = torch.equal(img, full)
+    torch.manual_seed(0)
+    mods = [torch.nn.Linear(5, 3), torch.nn.Linear(3, 2)]
+    x = torch.full((4, 5), float(rank + 1))
+    mods[1](mods[0](x)).sum().backward()
+    mods[1].bias.grad = None                           # a missing grad counts as zero
+    g_local = [None if p.grad is None else p.grad.clone() for m in mods for p in m.parameters()]
+    bucket = parallel.FlatGradBucket(mods)
+    bucket.all_reduce_()
+    q.put((rank, ok_gather, bucket.numel, g_local, [p.grad.clone() for m in mods for p in m.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_gather_and_grad_bucket():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res) and res[0][2] == 5 * 3 + 3 + 3 * 2 + 2
+    for k in range(4):
+        a, b = res[0][3][k], res[1][3][k]
+        z = torch.zeros_like(res[0][4][k])
+        want = ((a if a is not None else z) + (b if b is not None else z)) / 2
+        assert torch.allclose(res[0][4][k], want) and torch.allclose(res[1][4][k], want)
+
+
+def test_dropin_modules_importable():
+    d = os.path.join(ROOT, "NeRFs", "DFANeRF")
+    sys.path.insert(0, d)
+    try:
+        import run_nerf_com_trainExpLater as M
+        import run_nerf_helpers as Hm
+        import decoder as D
+        import load_audface as L
+        for name in ("render_rays", "composite_function", "calc_volume_weights", "encode_signal",
+                     "encode_signal_torso", "config_parser", "train", "run_network", "create_nerf"):
+            assert callable(getattr(M, name))
+        for name in ("get_rays", "ndc_rays", "sample_pdf", "get_embedder", "AudioNet_W2L", "ExpressionEnc",
+                     "AudioAttNet", "img2mse", "mse2psnr", "to8b"):
+            assert hasattr(Hm, name)
+        assert hasattr(D, "Decoder") and callable(L.load_audface_data_split)
+    finally:
+        sys.path.remove(d)
+        for m in ("run_nerf_com_trainExpLater", "run_nerf_helpers", "decoder", "load_audface", "_bootstrap"):
+            sys.modules.pop(m, None)
