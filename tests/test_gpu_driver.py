@@ -1,0 +1,114 @@
+"""End-to-end GPU tests of the drop-in driver: the reference's command lines (scripts/test_obama.sh and
+scripts/train_obama.sh flag bundles) run against NeRFs/DFANeRF/run_nerf_com_trainExpLater.py of this repo on a
+small synthetic dataset written in the reference's on-disk format."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import dfa_oracle as O
+from conftest import ROOT
+from dfanerf import synth
+
+pytestmark = pytest.mark.gpu
+H, W, F_TRAIN, F_VAL = 40, 56, 5, 3
+
+
+def t(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+@pytest.fixture(scope="module")
+def dataset(tmp_path_factory, states, latents):
+    from PIL import Image
+    from dfanerf import nets, run_nerf
+    from dfanerf.decoder import Decoder
+    root = tmp_path_factory.mktemp("run")
+    d = root / "dataset" / "obama"
+    for sub in ("head_imgs", "com_imgs"):
+        (d / sub).mkdir(parents=True)
+    sc = synth.bench_scene(0, n_frames=F_TRAIN + F_VAL, H=H, W=W)
+    rng = np.random.RandomState(0)
+    Image.fromarray(sc["bg"]).save(d / "bc.jpg", quality=100, subsampling=0)
+    for split, ids in (("train", range(F_TRAIN)), ("val", range(F_TRAIN, F_TRAIN + F_VAL))):
+        frames = []
+        for i in ids:
+            frames.append({"img_id": i, "aud_id": i, "transform_matrix": sc["poses"][i].tolist(),
+                           "face_rect": [5, 8, 20, 24]})
+            for sub in ("head_imgs", "com_imgs"):
+                Image.fromarray(rng.randint(0, 255, (H, W, 3), dtype=np.uint8)).save(d / sub / f"{i:06d}.jpg")
+        json.dump({"focal_len": 150.0, "cx": W / 2.0, "cy": H / 2.0, "frames": frames},
+                  open(d / f"transforms_{split}_ba.json", "w"))
+    torch.save(t(sc["aud"]), d / "obama_aud.pt")
+    torch.save({"exp_o": t(sc["exp"])}, d / "obama_64_32.pt")
+    (d / "HeadNeRF_config_ba.txt").write_text("expname = obama_head\ndatadir = dataset/obama\n"
+                                              "basedir = dataset/obama/logs\nnear = 0.3\nfar = 0.9\ntestskip = 1\n")
+    # a checkpoint in the reference's .tar format
+    mods = {"decoder": Decoder(z_dim=256, hidden_size=256, dim_signal=96, use_deformation_field=True),
+            "AudNet": nets.AudioNet_W2L(), "ExpNet": nets.ExpressionEnc(), "AudAttNet": nets.AudioAttNet(96, 4),
+            "PoseAttNet": nets.AudioAttNet(42, 8)}
+    for k, m in mods.items():
+        m.load_state_dict({kk: t(v) for kk, v in states[k].items()})
+    opts = {k: torch.optim.Adam(m.parameters(), lr=5e-4) for k, m in mods.items()}
+    ck = root / "dataset" / "train_together" / "obama_TrainExpLater_smoMix"
+    ck.mkdir(parents=True)
+    run_nerf.save_checkpoint(str(ck / "280000.tar"), 280000, t(latents[0]), t(latents[1]), mods, opts)
+    return root, sc
+
+
+COMMON = ("--config dataset/obama/HeadNeRF_config_ba.txt --last_dist=1e10 --datadir dataset/obama --concate_bg "
+          "--sample_rate=0 --i_print=1 --i_test_person=10000 --chunk=2048 --win_size=16 --smo_size=4 "
+          "--smo_torse_size 8 --train_together --all_speaker --sample_rate_mouth=0 --lrate_decay=500 --lrate=5e-4 "
+          "--use_et_embed --nosmo_iters=300000 --dim_signal=96 --dim_aud=96 --n_object=1 "
+          "--expname=obama_TrainExpLater_smoMix --aud_file=obama_aud.pt --use_deformation_field "
+          "--exp_file=obama_64_32.pt --use_ba --noexp_iters 400000 "
+          "--resume dataset/train_together/obama_TrainExpLater_smoMix/280000.tar")
+
+
+def _run(root, extra):
+    cmd = [sys.executable, os.path.join(ROOT, "NeRFs", "DFANeRF", "run_nerf_com_trainExpLater.py")] + \
+        (COMMON + " " + extra).split()
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+def test_render_person_cli(dataset, states, latents):
+    """scripts/test_obama.sh: --render_person over transforms_val_ba.json; images match the oracle frame loop."""
+    from PIL import Image
+    root, sc = dataset
+    _run(root, "--render_person --test_file transforms_val_ba.json --N_rand=2048 --N_iters=600000 --render_video")
+    out = root / "dataset" / "train_together" / "obama_TrainExpLater_smoMix" / "obama" / "person"
+    files = sorted(os.listdir(out / "render_com"))
+    assert files == [f"test_{i:06d}.jpg" for i in range(F_VAL)] and len(os.listdir(out / "render_head")) == F_VAL
+    # oracle for val frame 1 (the loader keeps bc.jpg as decoded by PIL)
+    P = O.params_to_torch(states["decoder"])
+    nets_o = {k: O.params_to_torch(v) for k, v in states.items() if k != "decoder"}
+    auds, exps, poses = [t(sc[k])[F_TRAIN:] for k in ("aud", "exp", "poses")]
+    bg = t(np.asarray(Image.open(root / "dataset" / "obama" / "bc.jpg").convert("RGB"))).float() / 255.0
+    pose_body = sc["poses"][0]                               # frame 0 of transforms_train_ba.json (MAIN:453-460)
+    with torch.no_grad():
+        sig = O.encode_signal(nets_o, auds, exps, 1, 280000, 300000, 4, F_VAL)
+        sigt = O.encode_signal_torso(nets_o, poses, 1, 280000, 300000, 8, F_VAL)
+        rh, rc = O.render_frame(P, H, W, 150.0, W / 2.0, H / 2.0, poses[1].numpy(), pose_body, bg, 0.3, 0.9,
+                                t(latents[0]), t(latents[1]), sig, sigt, 64, 0, 2)
+    for sub, ref in (("render_com", rc), ("render_head", rh)):
+        img = np.asarray(Image.open(out / sub / "test_000001.jpg")).astype(np.float32) / 255.0
+        err = np.abs(img - ref.reshape(H, W, 3).numpy())
+        assert err.mean() < 0.02, (sub, err.mean())          # JPEG (quality 95) on a noisy background
+
+
+def test_training_cli_writes_reference_checkpoint(dataset):
+    """scripts/train_obama.sh: three optimisation steps from the checkpoint, then a new .tar with the reference's keys."""
+    root, _ = dataset
+    out = _run(root, "--N_rand=512 --N_iters=280004 --i_weights=2")
+    base = root / "dataset" / "train_together" / "obama_TrainExpLater_smoMix"
+    log = open(base / "loss.txt").read().strip().split("\n")
+    assert len(log) == 4 and all(ln.startswith("[TRAIN] Iter: 28000") for ln in log), out[-500:]
+    ck = torch.load(base / "280002.tar", weights_only=False)
+    assert ck["global_step"] == 280002 and "network_PoseAttNet_state_dict" in ck and len(ck) == 13
+    assert all(np.isfinite(float(ln.split("Com Loss: ")[1].split()[0])) for ln in log)
