@@ -12,6 +12,7 @@
 #include "dfn_misc.h"
 #include "dfn_params.h"
 #include "dfn_plan.h"
+#include "dfn_train.h"
 
 using namespace dfn;
 
@@ -47,6 +48,45 @@ PlanEntry& plan_of(int tier, int field) {
     return e;
 }
 
+}  // namespace
+
+namespace {
+struct BwdPlanEntry {
+    std::vector<int32_t> host;
+    long n_frags = 0;
+    int32_t* dev = nullptr;
+};
+BwdPlanEntry g_bwd_plans[2][2];
+struct WgradEntry {
+    bool built = false;
+    std::vector<WOpHost> ops;
+    std::vector<int32_t> map, bias_rows;
+    std::vector<int> prefix;          // work items (32x32 tiles) prefix per op, without the k-split factor
+    WOp* ops_dev = nullptr;
+    int32_t* map_dev = nullptr;
+    int32_t* rows_dev = nullptr;
+    int* prefix_dev = nullptr;
+    int ksplit_uploaded = 0;
+};
+WgradEntry g_wgrad[2];
+constexpr int WGRAD_KSPLIT = 32;
+
+template <typename T> hipError_t upload(T** dev, const T* host, size_t n) {
+    hipError_t e = hipMalloc((void**)dev, n * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dev, host, n * sizeof(T), hipMemcpyHostToDevice);
+}
+WgradEntry& wgrad_of(int field) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    WgradEntry& w = g_wgrad[field];
+    if (!w.built) {
+        build_wgrad_plan(field, w.ops, w.map, w.bias_rows);
+        w.prefix.assign(1, 0);
+        for (const WOpHost& o : w.ops) w.prefix.push_back(w.prefix.back() + (o.M / 32) * (o.N / 32) * WGRAD_KSPLIT);
+        w.built = true;
+    }
+    return w;
+}
 }  // namespace
 
 extern "C" {
@@ -155,8 +195,188 @@ int dfn_render_fwd(int tier, const DfnFrame* frame, const void* packed_head, con
     A.w_head = weights_head;
     A.w_com = weights_com;
     A.z_out = z_vals;
+    A.samples_out = nullptr;
+    A.act_T[0] = A.act_T[1] = nullptr;
+    A.masks[0] = A.masks[1] = nullptr;
+    A.NP = 0;
     hipError_t err = launch_render(tier, A, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "render_kernel");
+    return DFN_OK;
+}
+
+// ---- training ---------------------------------------------------------------------------------------------------
+long dfn_train_rows(int field, int what) {
+    if (field != DFN_FIELD_HEAD && field != DFN_FIELD_TORSO) return fail(DFN_E_ARG, "dfn_train_rows: bad field");
+    const bool t = field == DFN_FIELD_TORSO;
+    switch (what) {
+    case 0: return t ? 64 + 640 + 128 + 9 * 256 + 32 : 64 + 9 * 256 + 32;          // activation rows (RecMap)
+    case 1: return t ? 896 + 10 * 256 + 64 : 10 * 256 + 64;                          // gradient rows (GradMap)
+    case 2: return t ? 10 + 36 : 36;                                                  // mask dwords per pass
+    case 3: return (long)wgrad_of(field).map.size();                                  // wgrad workspace floats
+    default: return fail(DFN_E_ARG, "dfn_train_rows: bad selector");
+    }
+}
+
+long dfn_packed_bwd_bytes(int tier, int field) {
+    if (!tier_ok(tier) || (field != 0 && field != 1)) return fail(DFN_E_ARG, "dfn_packed_bwd_bytes: bad tier/field");
+    ProgramInfo pi;
+    bwd_program_info(tier, field, &pi);
+    return (long)pi.n_slabs * SLAB_BYTES;
+}
+
+int dfn_pack_weights_bwd(int tier, int field, const float* params, void* packed_T, void* stream) {
+    if (!tier_ok(tier) || (field != 0 && field != 1) || !params || !packed_T)
+        return fail(DFN_E_ARG, "dfn_pack_weights_bwd: bad argument");
+    BwdPlanEntry& e = g_bwd_plans[tier][field];
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        if (e.host.empty()) {
+            e.n_frags = build_bwd_plan(tier, field, e.host);
+            ProgramInfo pi;
+            bwd_program_info(tier, field, &pi);
+            if (e.n_frags != pi.n_frags)
+                return fail(DFN_E_ARG, "backward planner and kernel disagree on the fragment count (" +
+                                           std::to_string(e.n_frags) + " vs " + std::to_string(pi.n_frags) + ")");
+        }
+        if (!e.dev) {
+            hipError_t err = upload(&e.dev, e.host.data(), e.host.size());
+            if (err != hipSuccess) return hip_fail(err, "upload(bwd plan)");
+        }
+    }
+    hipError_t err = launch_pack(e.dev, params, packed_T, (long)e.host.size(), tier == DFN_TIER_BF16,
+                                 (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "pack_kernel(bwd)");
+    return DFN_OK;
+}
+
+int dfn_train_fwd(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
+                  const float* bias_head, const float* bias_torso, const float* bg_f32, const uint8_t* bg_u8,
+                  const int32_t* pix_index, float* rgb_head, float* rgb_com, float* samples, void* act_head,
+                  uint32_t* masks_head, void* act_torso, uint32_t* masks_torso, void* stream) {
+    if (!tier_ok(tier) || !frame || !packed_head || !packed_torso || !bias_head || !bias_torso || !rgb_head ||
+        !rgb_com || !samples || !act_head || !masks_head || !act_torso || !masks_torso)
+        return fail(DFN_E_ARG, "dfn_train_fwd: bad argument");
+    const DfnFrame& F = *frame;
+    if (F.n_coarse != 64 || F.n_fine != 0 || F.fields != 2)
+        return fail(DFN_E_ARG, "dfn_train_fwd: the training step is coarse-only (64 samples), two fields (MAIN:855-899)");
+    if (!bg_f32 && !bg_u8) return fail(DFN_E_ARG, "dfn_train_fwd: no background given");
+    if (F.ray_count <= 0) return DFN_OK;
+    const long NP = (long)F.ray_count * 64;
+    if (dfn_train_rows(1, 0) * NP >= (1L << 32)) return fail(DFN_E_ARG, "dfn_train_fwd: too many rays per call");
+    ProgramInfo ph, pt;
+    program_info(tier, FIELD_HEAD, &ph);
+    program_info(tier, FIELD_TORSO, &pt);
+    if (bias_torso != bias_head + ph.n_bias)
+        return fail(DFN_E_ARG, "dfn_train_fwd: bias_torso must directly follow bias_head in memory");
+    RenderArgs A;
+    A.frame = F;
+    A.wblob[0] = (const char*)packed_head;
+    A.wblob[1] = (const char*)packed_torso;
+    A.nslab[0] = ph.n_slabs;
+    A.nslab[1] = pt.n_slabs;
+    A.bias = bias_head;
+    A.bg_f32 = bg_f32;
+    A.bg_u8 = bg_u8;
+    A.pix_index = pix_index;
+    A.rgb_head = rgb_head;
+    A.rgb_com = rgb_com;
+    A.w_head = A.w_com = A.z_out = nullptr;
+    A.samples_out = samples;
+    A.act_T[0] = act_head;
+    A.act_T[1] = act_torso;
+    A.masks[0] = masks_head;
+    A.masks[1] = masks_torso;
+    A.NP = NP;
+    hipError_t err = launch_render(tier, A, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "render_kernel(train)");
+    return DFN_OK;
+}
+
+int dfn_composite_bwd(const DfnFrame* frame, const int32_t* pix_index, const float* bg_f32, const uint8_t* bg_u8,
+                      const float* samples, const float* d_rgb_head, const float* d_rgb_com, float* dsamples,
+                      void* stream) {
+    if (!frame || !samples || !d_rgb_head || !dsamples || (!bg_f32 && !bg_u8))
+        return fail(DFN_E_ARG, "dfn_composite_bwd: bad argument");
+    if (frame->n_coarse != 64 || frame->n_fine != 0) return fail(DFN_E_ARG, "dfn_composite_bwd: 64 coarse samples only");
+    if (frame->ray_count <= 0) return DFN_OK;
+    CompositeBwdArgs A;
+    A.frame = *frame;
+    A.pix_index = pix_index;
+    A.bg_f32 = bg_f32;
+    A.bg_u8 = bg_u8;
+    A.samples = samples;
+    A.d_rgb_head = d_rgb_head;
+    A.d_rgb_com = d_rgb_com;
+    A.dsamples = dsamples;
+    hipError_t err = launch_composite_bwd(A, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "composite_bwd_kernel");
+    return DFN_OK;
+}
+
+int dfn_mlp_bwd(int tier, int field, const void* packed_T, const float* samples, const float* dsamples,
+                const uint32_t* masks, long NP, void* dy_T, void* stream) {
+    if (!tier_ok(tier) || (field != 0 && field != 1) || !packed_T || !samples || !dsamples || !masks || !dy_T ||
+        NP <= 0 || NP % 32)
+        return fail(DFN_E_ARG, "dfn_mlp_bwd: bad argument");
+    ProgramInfo pi;
+    bwd_program_info(tier, field, &pi);
+    MlpBwdArgs A;
+    A.wblob_T = (const char*)packed_T;
+    A.nslab = pi.n_slabs;
+    A.samples = samples;
+    A.dsamples = dsamples;
+    A.masks = masks;
+    A.dy_T = dy_T;
+    A.NP = NP;
+    hipError_t err = launch_mlp_bwd(tier, field, A, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "mlp_bwd_kernel");
+    return DFN_OK;
+}
+
+int dfn_weight_grad(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
+                    float* grad_flat, void* stream) {
+    if (!tier_ok(tier) || (field != 0 && field != 1) || !dy_T || !act_T || !workspace || !grad_flat || NP <= 0 ||
+        NP % (WGRAD_KSPLIT * 16))
+        return fail(DFN_E_ARG, "dfn_weight_grad: bad argument (NP must be a multiple of 512)");
+    WgradEntry& w = wgrad_of(field);
+    hipStream_t st = (hipStream_t)stream;
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        if (!w.ops_dev) {
+            std::vector<WOp> ops(w.ops.size());
+            for (size_t i = 0; i < ops.size(); ++i)
+                ops[i] = WOp{w.ops[i].a_row, w.ops[i].M, w.ops[i].b_row, w.ops[i].N, w.ops[i].c_off};
+            hipError_t e = upload(&w.ops_dev, ops.data(), ops.size());
+            if (e == hipSuccess) e = upload(&w.map_dev, w.map.data(), w.map.size());
+            if (e == hipSuccess) e = upload(&w.prefix_dev, w.prefix.data(), w.prefix.size());
+            if (e == hipSuccess) e = upload(&w.rows_dev, w.bias_rows.data(), w.bias_rows.size());
+            if (e != hipSuccess) return hip_fail(e, "upload(wgrad plan)");
+        }
+    }
+    hipError_t err = hipMemsetAsync(workspace, 0, w.map.size() * sizeof(float), st);
+    if (err != hipSuccess) return hip_fail(err, "memset(workspace)");
+    err = launch_wgrad(tier, w.ops_dev, (int)w.ops.size(), w.prefix_dev, w.prefix.back(), dy_T, act_T, NP,
+                       WGRAD_KSPLIT, workspace, st);
+    if (err != hipSuccess) return hip_fail(err, "wgrad_kernel");
+    err = launch_scatter_add(w.map_dev, workspace, (long)w.map.size(), grad_flat, st);
+    if (err != hipSuccess) return hip_fail(err, "scatter_add_kernel");
+    return DFN_OK;
+}
+
+int dfn_bias_grad(int tier, int field, const void* dy_T, long NP, float* dbias, void* stream) {
+    if (!tier_ok(tier) || (field != 0 && field != 1) || !dy_T || !dbias || NP <= 0)
+        return fail(DFN_E_ARG, "dfn_bias_grad: bad argument");
+    WgradEntry& w = wgrad_of(field);
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        if (!w.rows_dev) {
+            hipError_t e = upload(&w.rows_dev, w.bias_rows.data(), w.bias_rows.size());
+            if (e != hipSuccess) return hip_fail(e, "upload(bias rows)");
+        }
+    }
+    if ((long)w.bias_rows.size() != dfn_bias_floats(tier, field)) return fail(DFN_E_ARG, "internal: bias row table size");
+    hipError_t err = launch_bias_grad(tier, w.rows_dev, (int)w.bias_rows.size(), dy_T, NP, dbias, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "bias_grad_kernel");
     return DFN_OK;
 }
 

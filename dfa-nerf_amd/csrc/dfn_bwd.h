@@ -1,0 +1,227 @@
+// dfn_bwd.h - backward of the fused decoder MLP for one wavefront = 32 sample points (training).
+//
+// dL/d(input) of every layer is the SAME machinery as the forward (dfn_mlp.h) run on transposed weight
+// streams: G_in^T[i][n] = sum_o W[o][i] * DY^T[o][n], so A = W^T fragments (packed by dfn_plan.cpp:
+// build_bwd_plan in the op order of this file), B = the pre-activation gradient the previous backward GEMM
+// left in this lane's registers, masked with the forward's ReLU bits.  Every pre-activation gradient is also
+// written feature-major ([rows][NP]) for the weight-gradient GEMMs (dfn_train.hip: wgrad_kernel).
+//
+// Reference semantics being differentiated: decoder.py:277-349 and :109-134 (torch autograd of those ops;
+// pinned by golden G8).
+#pragma once
+#include "dfn_mlp.h"
+
+namespace dfn {
+
+// rows of the feature-major gradient array dy_T
+struct GradMap {
+    // trunk
+    static constexpr int T_DY0 = 0, T_DY4 = 4 * 256, T_G4 = 5 * 256, T_DY5 = 6 * 256, T_DYV = 9 * 256,
+                         T_DSIG = 10 * 256, T_DYO = 10 * 256 + 32, T_ROWS = 10 * 256 + 64;
+    static constexpr int H_TRUNK = 0, H_ROWS = T_ROWS;
+    // torso deformation nets: DE0 DS0 DE1 DS1 DE2 DS2 DE3 GE3 DS3 DE4 DS4 DEO DSO GS3 (14 x 64), then the trunk
+    static constexpr int S_DE0 = 0, S_DS0 = 64, S_DE1 = 128, S_DS1 = 192, S_DE2 = 256, S_DS2 = 320, S_DE3 = 384,
+                         S_GE3 = 448, S_DS3 = 512, S_DE4 = 576, S_DS4 = 640, S_DEO = 704, S_DSO = 768, S_GS3 = 832,
+                         S_TRUNK = 896, S_ROWS = 896 + T_ROWS;
+};
+
+struct BwdIO {
+    void* dy_T;                 // [rows][NP]
+    const unsigned* masks;      // forward ReLU bits [pass][mask_dwords][64]
+    long NP, p0, pass;
+    int mask_dwords;
+};
+
+// g (accumulators of a tile pair) *= ReLU mask bits (word = pair index)
+DFN_DEV void apply_mask(f32x16 (&acc)[2], unsigned bits) {
+#ifndef DFN_NOMASK
+#pragma unroll
+    for (int b = 0; b < 32; ++b)
+        if (!((bits >> b) & 1u)) acc[b >> 4][b & 15] = 0.f;
+#endif
+}
+DFN_DEV unsigned mask_word(const BwdIO& io, int dword, int lane) {
+    return io.masks[((long)io.pass * io.mask_dwords + dword) * 64 + lane];
+}
+
+// out[OT tiles] = (W^T x in) [* mask]; mask_dword0 < 0: no mask
+template <int TIER, int OT, int KU, int NTB>
+DFN_DEV void bwd_layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, int mask_dword0, const BwdIO& io, int& f,
+                       Fetch<TIER>& fe, Stream& s, const Ctx& c) {
+#pragma unroll
+    for (int tg = 0; tg < OT / 2; ++tg) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+        gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c);
+        if (mask_dword0 >= 0) apply_mask(acc, mask_word(io, mask_dword0 + tg, c.lane));
+        acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);
+    }
+}
+// out = (W1^T x in1 + W2^T x in2) [* mask]
+template <int TIER, int OT, int KU1, int NTB1, int KU2, int NTB2>
+DFN_DEV void bwd_layer2(Vec<TIER, OT>& out, const Vec<TIER, NTB1>& in1, const Vec<TIER, NTB2>& in2,
+                        int mask_dword0, const BwdIO& io, int& f, Fetch<TIER>& fe, Stream& s, const Ctx& c) {
+#pragma unroll
+    for (int tg = 0; tg < OT / 2; ++tg) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+        gemm_group<TIER, 2, KU1, NTB1>(acc, in1, f, fe, s, c);
+        gemm_group<TIER, 2, KU2, NTB2>(acc, in2, f, fe, s, c);
+        if (mask_dword0 >= 0) apply_mask(acc, mask_word(io, mask_dword0 + tg, c.lane));
+        acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);
+    }
+}
+
+template <int TIER, int NT>
+DFN_DEV void put(const BwdIO& io, int row0, const Vec<TIER, NT>& v, const Ctx& c) {
+#ifndef DFN_NOPUT
+    store_vec_T<TIER, NT>(io.dy_T, io.NP, io.p0, row0, v, c);
+#endif
+}
+
+// ---- backward fragment counts (transposed streams) -----------------------------------------------------------
+template <int TIER> struct BProg {
+    using P = Prog<TIER>;
+    static constexpr int UPT = P::UPT, KU_ACT = P::KU_ACT, KU_D = P::KU_D, KU_T = UPT;      // KU_T: one 32-row tile
+    // trunk: BO (8 tiles x 1-tile K), BV (8 x (256 + 32)), B7 B6 B5 (8 x 256), B4..B1 (8 x 256)
+    static constexpr int T_FRAGS = 8 * KU_T + 8 * (KU_ACT + KU_T) + 7 * 8 * KU_ACT;
+    static constexpr int H_FRAGS = T_FRAGS;
+    static constexpr int H_SLABS = (H_FRAGS + SLAB_FRAGS - 1) / SLAB_FRAGS;
+    // torso tail: skip path 4 tiles x 256 (right after B5), fc_in_torso^T 4 x 256, then the deformation nets:
+    // EO^T SO^T (2 x 64 each), E4 S4, E3 S3, E2 S2, E1 S1 (2 tiles x 64 each)
+    static constexpr int S_FRAGS = T_FRAGS + 2 * 4 * KU_ACT + 10 * 2 * KU_D;
+    static constexpr int S_SLABS = (S_FRAGS + SLAB_FRAGS - 1) / SLAB_FRAGS;
+};
+
+struct BwdIn {
+    float dsigma, dpre[3];      // dL/dsigma_raw and dL/d(pre-sigmoid rgb) of this lane's point (lanes 0..31)
+};
+
+// Backward of the trunk.  On return `dy0` holds dL/d(pre-activation of the first layer) (masked), and, when
+// TORSO, `gpd_skip` holds fc_p_skips_torso^T x g4 (the skip path's contribution to dL/d pd).
+template <int TIER, bool TORSO>
+DFN_DEV void bwd_trunk(const BwdIn& in, Vec<TIER, 8>& dy0, Vec<TIER, 4>& gpd_skip, const BwdIO& io, int g_trunk,
+                       int m_trunk, int& f, Fetch<TIER>& fe, Stream& s, const Ctx& c) {
+    using B = BProg<TIER>;
+    Vec<TIER, 8> cur, nxt;
+    // feat_out^T: d(pre-rgb) [3 of a 32-row tile] -> g_h, masked with h > 0
+    {
+        Vec<TIER, 1> dout;
+#pragma unroll
+        for (int L = 0; L < 16; ++L) dout.set(L, (c.half == 0 && L < 3) ? in.dpre[L < 3 ? L : 0] : 0.f);
+        put<TIER, 1>(io, g_trunk + GradMap::T_DYO, dout, c);
+        bwd_layer<TIER, 8, B::KU_T, 1>(cur, dout, m_trunk + RecMap::TM_H, io, f, fe, s, c);
+        put<TIER, 8>(io, g_trunk + GradMap::T_DYV, cur, c);
+    }
+    // [feat_view ; sigma_out]^T -> g_a7, masked with a7 > 0
+    {
+        Vec<TIER, 1> dsig;
+#pragma unroll
+        for (int L = 0; L < 16; ++L) dsig.set(L, (c.half == 0 && L == 0) ? in.dsigma : 0.f);
+        put<TIER, 1>(io, g_trunk + GradMap::T_DSIG, dsig, c);
+        bwd_layer2<TIER, 8, B::KU_ACT, 8, B::KU_T, 1>(nxt, cur, dsig, m_trunk + RecMap::TM_A5 + 8, io, f, fe, s, c);
+        cur = nxt;
+        put<TIER, 8>(io, g_trunk + GradMap::T_DY5 + 512, cur, c);                  // dy7
+    }
+    // blocks[6]^T, blocks[5]^T -> dy6, dy5
+    bwd_layer<TIER, 8, B::KU_ACT, 8>(nxt, cur, m_trunk + RecMap::TM_A5 + 4, io, f, fe, s, c);
+    cur = nxt;
+    put<TIER, 8>(io, g_trunk + GradMap::T_DY5 + 256, cur, c);
+    bwd_layer<TIER, 8, B::KU_ACT, 8>(nxt, cur, m_trunk + RecMap::TM_A5, io, f, fe, s, c);
+    cur = nxt;
+    put<TIER, 8>(io, g_trunk + GradMap::T_DY5, cur, c);
+    // blocks[4]^T -> g4 = dL/d a4 (post-skip, no activation)
+    bwd_layer<TIER, 8, B::KU_ACT, 8>(nxt, cur, -1, io, f, fe, s, c);
+    cur = nxt;
+    put<TIER, 8>(io, g_trunk + GradMap::T_G4, cur, c);
+    if constexpr (TORSO) bwd_layer<TIER, 4, B::KU_ACT, 8>(gpd_skip, cur, -1, io, f, fe, s, c);   // fc_p_skips_torso^T
+    // dy4 = g4 * [y4 > 0]
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const unsigned bits = mask_word(io, m_trunk + RecMap::TM_A4R + w, c.lane);
+#pragma unroll
+        for (int b = 0; b < 32; ++b)
+            if (!((bits >> b) & 1u)) cur.set(32 * w + b, 0.f);
+    }
+    put<TIER, 8>(io, g_trunk + GradMap::T_DY4, cur, c);
+    // blocks[3..0]^T -> dy3 .. dy0
+#pragma unroll
+    for (int l = 3; l >= 0; --l) {
+        bwd_layer<TIER, 8, B::KU_ACT, 8>(nxt, cur, m_trunk + RecMap::TM_A0 + 4 * l, io, f, fe, s, c);
+        cur = nxt;
+        put<TIER, 8>(io, g_trunk + GradMap::T_DY0 + 256 * l, cur, c);
+    }
+    dy0 = cur;
+}
+
+template <int TIER>
+DFN_DEV void bwd_head(const BwdIn& in, const BwdIO& io, Stream& s, const Ctx& c) {
+    int f = 0;
+    Fetch<TIER> fe;
+    fe.prime(s, c);
+    Vec<TIER, 8> dy0;
+    Vec<TIER, 4> unused;
+    bwd_trunk<TIER, false>(in, dy0, unused, io, GradMap::H_TRUNK, RecMap::H_MTRUNK, f, fe, s, c);
+}
+
+template <int TIER>
+DFN_DEV void bwd_torso(const BwdIn& in, const BwdIO& io, Stream& s, const Ctx& c) {
+    using B = BProg<TIER>;
+    int f = 0;
+    Fetch<TIER> fe;
+    fe.prime(s, c);
+    Vec<TIER, 8> dy0;
+    Vec<TIER, 4> gsk;
+    bwd_trunk<TIER, true>(in, dy0, gsk, io, GradMap::S_TRUNK, RecMap::S_MTRUNK, f, fe, s, c);
+    // dL/d pd = fc_in_torso^T x dy0 + (skip path)
+    Vec<TIER, 4> gpd;
+    bwd_layer<TIER, 4, B::KU_ACT, 8>(gpd, dy0, -1, io, f, fe, s, c);
+#pragma unroll
+    for (int L = 0; L < 64; ++L) gpd.set(L, gpd.get(L) + gsk.get(L));
+    // pd = [out_embed(.) + pe ; out_signal(.) + signal]: the GEMM outputs get g_pd unchanged
+    Vec<TIER, 2> ge, gs, gn;
+#pragma unroll
+    for (int L = 0; L < 32; ++L) {
+        ge.set(L, gpd.get(L));
+        gs.set(L, gpd.get(32 + L));
+    }
+    put<TIER, 2>(io, GradMap::S_DEO, ge, c);
+    put<TIER, 2>(io, GradMap::S_DSO, gs, c);
+    // out_embed^T / out_signal^T -> dE4, dS4 (masked with ve4 / vs4 > 0)
+    bwd_layer<TIER, 2, B::KU_D, 2>(gn, ge, RecMap::S_MD0 + 8, io, f, fe, s, c);  ge = gn;
+    put<TIER, 2>(io, GradMap::S_DE4, ge, c);
+    bwd_layer<TIER, 2, B::KU_D, 2>(gn, gs, RecMap::S_MD0 + 9, io, f, fe, s, c);  gs = gn;
+    put<TIER, 2>(io, GradMap::S_DS4, gs, c);
+    // blocks_*[4]^T -> gradient of the post-skip vectors ve3 / vs3; then the pre-skip ReLU masks
+    bwd_layer<TIER, 2, B::KU_D, 2>(gn, ge, -1, io, f, fe, s, c);  ge = gn;
+    put<TIER, 2>(io, GradMap::S_GE3, ge, c);
+    bwd_layer<TIER, 2, B::KU_D, 2>(gn, gs, -1, io, f, fe, s, c);  gs = gn;
+    put<TIER, 2>(io, GradMap::S_GS3, gs, c);
+    {
+        const unsigned be = mask_word(io, RecMap::S_MD0 + 6, c.lane), bs = mask_word(io, RecMap::S_MD0 + 7, c.lane);
+#pragma unroll
+        for (int b = 0; b < 32; ++b) {
+            if (!((be >> b) & 1u)) ge.set(b, 0.f);
+            if (!((bs >> b) & 1u)) gs.set(b, 0.f);
+        }
+    }
+    put<TIER, 2>(io, GradMap::S_DE3, ge, c);
+    put<TIER, 2>(io, GradMap::S_DS3, gs, c);
+    // blocks_*[3]^T, [2]^T, [1]^T
+    bwd_layer<TIER, 2, B::KU_D, 2>(gn, ge, RecMap::S_MD0 + 4, io, f, fe, s, c);  ge = gn;
+    put<TIER, 2>(io, GradMap::S_DE2, ge, c);
+    bwd_layer<TIER, 2, B::KU_D, 2>(gn, gs, RecMap::S_MD0 + 5, io, f, fe, s, c);  gs = gn;
+    put<TIER, 2>(io, GradMap::S_DS2, gs, c);
+    bwd_layer<TIER, 2, B::KU_D, 2>(gn, ge, RecMap::S_MD0 + 2, io, f, fe, s, c);  ge = gn;
+    put<TIER, 2>(io, GradMap::S_DE1, ge, c);
+    bwd_layer<TIER, 2, B::KU_D, 2>(gn, gs, RecMap::S_MD0 + 3, io, f, fe, s, c);  gs = gn;
+    put<TIER, 2>(io, GradMap::S_DS1, gs, c);
+    bwd_layer<TIER, 2, B::KU_D, 2>(gn, ge, RecMap::S_MD0 + 0, io, f, fe, s, c);  ge = gn;
+    put<TIER, 2>(io, GradMap::S_DE0, ge, c);
+    bwd_layer<TIER, 2, B::KU_D, 2>(gn, gs, RecMap::S_MD0 + 1, io, f, fe, s, c);  gs = gn;
+    put<TIER, 2>(io, GradMap::S_DS0, gs, c);
+}
+
+}  // namespace dfn

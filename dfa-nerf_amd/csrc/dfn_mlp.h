@@ -127,10 +127,70 @@ DFN_DEV void slab_advance(Stream& s, lds_char* ring, int wave, int lane) {
 }
 
 // ---- GEMM pieces ------------------------------------------------------------------------------------------
+// Training-mode recorder: the forward pass leaves what the backward kernels need (all null otherwise).
+//   act_T : feature-major activations [rows][NP] (bf16 / f32 by tier): the inputs of every GEMM, read by the
+//           weight-gradient GEMMs (contraction over the NP sample points);
+//   masks : ReLU masks as bits, [pass][dword][64 lanes], read by the dX chain.
+struct Rec {
+    void* act_T;
+    unsigned* masks;
+    long NP;        // sample points of this field in the launch
+    long p0;        // point index of lane n = 0 of this wave's tile
+    long pass;      // tile (pass) index of this field, for the mask array
+    int mask_dwords;
+};
+
 struct Ctx {                // per-wave constants threaded through the ops
     lds_char* ring;
     int wave, lane, half;
+    Rec rec;
 };
+
+template <int TIER> struct ActT;
+template <> struct ActT<TIER_BF16> { typedef __bf16 type; };
+template <> struct ActT<TIER_F32> { typedef float type; };
+
+// store a B-operand vector feature-major: element (row0 + feature, p0 + n) of a [rows][NP] array.
+// 32-bit element offsets (rows * NP < 2^32 is checked by the host) off a uniform base, four rows at a time
+// with a scheduling fence in between: 128 scattered 2/4-byte stores must not turn into 128 live addresses.
+template <int TIER, int NT>
+DFN_DEV void store_vec_T(void* arr, long NP, long p0, int row0, const Vec<TIER, NT>& v, const Ctx& c) {
+    typedef typename ActT<TIER>::type T;
+    T* base = (T*)arr;
+    const unsigned np = (unsigned)NP;
+    const unsigned off = (unsigned)(row0 + 4 * c.half) * np + (unsigned)p0 + (unsigned)(c.lane & 31);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned o = off + (unsigned)(32 * t + 8 * q) * np;       // rows 32t + 8q + {0,1,2,3} (+4 upper half)
+            base[o] = (T)v.get(16 * t + 4 * q + 0);
+            base[o + np] = (T)v.get(16 * t + 4 * q + 1);
+            base[o + 2 * np] = (T)v.get(16 * t + 4 * q + 2);
+            base[o + 3 * np] = (T)v.get(16 * t + 4 * q + 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+template <int TIER, int NT>
+DFN_DEV void rec_vec(const Ctx& c, int row0, const Vec<TIER, NT>& v) {
+    if (!c.rec.act_T) return;
+    store_vec_T<TIER, NT>(c.rec.act_T, c.rec.NP, c.rec.p0, row0, v, c);
+}
+// ReLU mask bits of a vector (bit L of this lane's words = local slot L is positive)
+template <int TIER, int NT>
+DFN_DEV void rec_mask(const Ctx& c, int dword0, const Vec<TIER, NT>& v) {
+    if (!c.rec.masks) return;
+#pragma unroll
+    for (int w = 0; w < (NT + 1) / 2; ++w) {
+        unsigned bits = 0;
+#pragma unroll
+        for (int b = 0; b < 32; ++b)
+            if (32 * w + b < 16 * NT) bits |= (v.get(32 * w + b) > 0.f) ? (1u << b) : 0u;
+        c.rec.masks[((long)c.rec.pass * c.rec.mask_dwords + dword0 + w) * 64 + c.lane] = bits;
+    }
+}
+
 
 // The A-fragment stream of a pass is strictly sequential (fragment f lives in slab f/32 at position f%32),
 // so fragments are prefetched PF_DEPTH ahead into a small register ring that is carried across ops and
@@ -239,12 +299,18 @@ DFN_DEV void layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_f32* 
 template <int TIER, int OT, int KU, int NTB, int KU2, int NTB2>
 DFN_DEV void layer_skip(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_f32* bias,
                         const Vec<TIER, NTB2>& in2, const lds_f32* bias2, int& f, Fetch<TIER>& fe,
-                        Stream& s, const Ctx& c) {
+                        Stream& s, const Ctx& c, int mask_dword0 = -1) {
 #pragma unroll
     for (int tg = 0; tg < OT / 2; ++tg) {
         f32x16 acc[2];
         acc_init<2>(acc, bias + tg * 64, c.half);
         gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c);
+        if (mask_dword0 >= 0 && c.rec.masks) {      // ReLU mask of the pre-skip activation (one dword per pair)
+            unsigned bits = 0;
+#pragma unroll
+            for (int b = 0; b < 32; ++b) bits |= (acc[b >> 4][b & 15] > 0.f) ? (1u << b) : 0u;
+            c.rec.masks[((long)c.rec.pass * c.rec.mask_dwords + mask_dword0 + tg) * 64 + c.lane] = bits;
+        }
         acc_relu_add<2>(acc, bias2 + tg * 64, c.half);
         gemm_group<TIER, 2, KU2, NTB2>(acc, in2, f, fe, s, c);
         acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);
@@ -340,6 +406,18 @@ struct DhatRef {
     }
 };
 
+// rows of act_T and dwords of the mask array (training recorder); trunk offsets are relative to R_TRUNK
+struct RecMap {
+    // trunk: a0..a7 (8 x 256), h (256), view PE (32)
+    static constexpr int T_A0 = 0, T_H = 8 * 256, T_VIEW = 9 * 256, T_ROWS = 9 * 256 + 32;
+    static constexpr int TM_A0 = 0, TM_A4R = 4 * 4, TM_A5 = 5 * 4, TM_H = 8 * 4, TM_DWORDS = 9 * 4;   // a0..a3,a4r,a5..a7,h
+    // head: pe(64) then the trunk
+    static constexpr int H_PE = 0, H_TRUNK = 64, H_ROWS = 64 + T_ROWS, H_MTRUNK = 0, H_MDWORDS = TM_DWORDS;
+    // torso: pe(64), ve0 vs0 ve1 vs1 ve2 vs2 ve3 vs3 ve4 vs4 (10 x 64), pd(128), trunk
+    static constexpr int S_PE = 0, S_D0 = 64, S_PD = 64 + 640, S_TRUNK = S_PD + 128, S_ROWS = S_TRUNK + T_ROWS;
+    static constexpr int S_MD0 = 0, S_MTRUNK = 10, S_MDWORDS = 10 + TM_DWORDS;     // one dword per 64-wide vector
+};
+
 struct MlpOut {
     float sigma, r, g, b;      // valid in lanes 0..31 (half 0): raw sigma, sigmoid rgb of point lane&31
 };
@@ -351,25 +429,33 @@ DFN_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 template <int TIER, int NTP, int KUP>
 DFN_DEV MlpOut mlp_trunk(Vec<TIER, 8>& act, const Vec<TIER, NTP>& pvec, const DhatRef& dref,
                          const lds_f32* bias, int b_l1, int b_skip, int b_l5, int b_view, int b_out,
-                         int f_l1, Fetch<TIER>& fe, Stream& s, const Ctx& c) {
+                         int f_l1, Fetch<TIER>& fe, Stream& s, const Ctx& c, int r_trunk, int m_trunk) {
     using P = Prog<TIER>;
     Vec<TIER, 8> nxt;
+    rec_vec<TIER, 8>(c, r_trunk + RecMap::T_A0, act);
+    rec_mask<TIER, 8>(c, m_trunk + RecMap::TM_A0, act);
     // blocks[0..2]
     for (int l = 0; l < 3; ++l) {
         int f = f_l1;                                       // same slab phase every iteration
         layer<TIER, 8, P::KU_ACT, 8, true>(nxt, act, bias + b_l1 + 256 * l, f, fe, s, c);
         act = nxt;
+        rec_vec<TIER, 8>(c, r_trunk + RecMap::T_A0 + 256 * (l + 1), act);
+        rec_mask<TIER, 8>(c, m_trunk + RecMap::TM_A0 + 4 * (l + 1), act);
     }
     int f = f_l1;
     // blocks[3], then the skip: relu(.) + fc_z_skips(z) + fc_p_skips(p)   (decoder.py:316-325)
-    layer_skip<TIER, 8, P::KU_ACT, 8, KUP, NTP>(nxt, act, bias + b_l1 + 256 * 3, pvec, bias + b_skip, f, fe, s, c);
+    layer_skip<TIER, 8, P::KU_ACT, 8, KUP, NTP>(nxt, act, bias + b_l1 + 256 * 3, pvec, bias + b_skip, f, fe, s, c,
+                                                m_trunk + RecMap::TM_A4R);
     act = nxt;
+    rec_vec<TIER, 8>(c, r_trunk + RecMap::T_A0 + 256 * 4, act);
     const int f_l5 = f % SLAB_FRAGS;
     // blocks[4..6]
     for (int l = 0; l < 3; ++l) {
         f = f_l5;
         layer<TIER, 8, P::KU_ACT, 8, true>(nxt, act, bias + b_l5 + 256 * l, f, fe, s, c);
         act = nxt;
+        rec_vec<TIER, 8>(c, r_trunk + RecMap::T_A0 + 256 * (5 + l), act);
+        rec_mask<TIER, 8>(c, m_trunk + RecMap::TM_A5 + 4 * l, act);
     }
     // feat_view (+ sigma_out as row 0 of a 9th tile) on [act ; view PE]   (decoder.py:329-340)
     MlpOut o;
@@ -378,6 +464,7 @@ DFN_DEV MlpOut mlp_trunk(Vec<TIER, 8>& act, const Vec<TIER, NTP>& pvec, const Dh
         float dhat[3];
         dref.load(dhat);
         posenc<TIER, 1, NPEV>(vview, dhat, c.half);
+        rec_vec<TIER, 1>(c, r_trunk + RecMap::T_VIEW, vview);
 #pragma unroll
         for (int tg = 0; tg < 4; ++tg) {
             f32x16 acc[2];
@@ -391,6 +478,8 @@ DFN_DEV MlpOut mlp_trunk(Vec<TIER, 8>& act, const Vec<TIER, NTP>& pvec, const Dh
         gemm_group<TIER, 1, P::KU_ACT, 8>(acc1, act, f, fe, s, c);
         gemm_group<TIER, 1, P::KU_VIEW, 1>(acc1, vview, f, fe, s, c);
         o.sigma = acc1[0][0];
+        rec_vec<TIER, 8>(c, r_trunk + RecMap::T_H, nxt);
+        rec_mask<TIER, 8>(c, m_trunk + RecMap::TM_H, nxt);
     }
     // feat_out + sigmoid   (decoder.py:344-347)
     {
@@ -411,13 +500,14 @@ DFN_DEV MlpOut mlp_head(const float (&p)[3], const DhatRef& dhat, const lds_f32*
     using P = Prog<TIER>;
     Vec<TIER, 2> pe;
     posenc<TIER, 2, NPE>(pe, p, c.half);
+    rec_vec<TIER, 2>(c, RecMap::H_PE, pe);
     Vec<TIER, 8> act;
     int f = 0;
     Fetch<TIER> fe;
     fe.prime(s, c);
     layer<TIER, 8, P::KU_PE, 2, true>(act, pe, bias + P::H_B_IN, f, fe, s, c);
     return mlp_trunk<TIER, 2, P::KU_PE>(act, pe, dhat, bias, P::H_B_L1, P::H_B_SKIP, P::H_B_L5, P::H_B_VIEW,
-                                        P::H_B_OUT, f % SLAB_FRAGS, fe, s, c);
+                                        P::H_B_OUT, f % SLAB_FRAGS, fe, s, c, RecMap::H_TRUNK, RecMap::H_MTRUNK);
 }
 
 // ---- torso pass: deformation field (decoder.py:109-134, 297-299) then the trunk ---------------------------
@@ -427,29 +517,44 @@ DFN_DEV MlpOut mlp_torso(const float (&p)[3], const DhatRef& dhat, const lds_f32
     using P = Prog<TIER>;
     Vec<TIER, 2> pe;
     posenc<TIER, 2, NPE>(pe, p, c.half);
+    rec_vec<TIER, 2>(c, RecMap::S_PE, pe);
     Vec<TIER, 2> ve, vs, vn;
     int f = 0;
     Fetch<TIER> fe;
     fe.prime(s, c);
-    layer<TIER, 2, P::KU_PE, 2, true>(ve, pe, bias + P::T_B_E0, f, fe, s, c);
-    layer<TIER, 2, P::KU_PE, 2, true>(vs, pe, bias + P::T_B_S0, f, fe, s, c);
-    layer<TIER, 2, P::KU_D, 2, true>(vn, ve, bias + P::T_B_E1, f, fe, s, c);  ve = vn;
-    layer<TIER, 2, P::KU_D, 2, true>(vn, vs, bias + P::T_B_S1, f, fe, s, c);  vs = vn;
-    layer<TIER, 2, P::KU_D, 2, true>(vn, ve, bias + P::T_B_E2, f, fe, s, c);  ve = vn;
-    layer<TIER, 2, P::KU_D, 2, true>(vn, vs, bias + P::T_B_S2, f, fe, s, c);  vs = vn;
+    // record(k, v): deformation vector k (0: ve0, 1: vs0, 2: ve1, ...) as GEMM input and its ReLU mask
+#define DFN_REC_D(k, v)                                   \
+    rec_vec<TIER, 2>(c, RecMap::S_D0 + 64 * (k), v);       \
+    rec_mask<TIER, 2>(c, RecMap::S_MD0 + (k), v)
+    layer<TIER, 2, P::KU_PE, 2, true>(ve, pe, bias + P::T_B_E0, f, fe, s, c);  DFN_REC_D(0, ve);
+    layer<TIER, 2, P::KU_PE, 2, true>(vs, pe, bias + P::T_B_S0, f, fe, s, c);  DFN_REC_D(1, vs);
+    layer<TIER, 2, P::KU_D, 2, true>(vn, ve, bias + P::T_B_E1, f, fe, s, c);  ve = vn;  DFN_REC_D(2, ve);
+    layer<TIER, 2, P::KU_D, 2, true>(vn, vs, bias + P::T_B_S1, f, fe, s, c);  vs = vn;  DFN_REC_D(3, vs);
+    layer<TIER, 2, P::KU_D, 2, true>(vn, ve, bias + P::T_B_E2, f, fe, s, c);  ve = vn;  DFN_REC_D(4, ve);
+    layer<TIER, 2, P::KU_D, 2, true>(vn, vs, bias + P::T_B_S2, f, fe, s, c);  vs = vn;  DFN_REC_D(5, vs);
     // skips join after the ReLU of layer idx 3 (decoder.py:118-119, 128-129)
-    layer_skip<TIER, 2, P::KU_D, 2, P::KU_PE, 2>(vn, ve, bias + P::T_B_E3, pe, bias + P::T_B_ESKIP, f, fe, s, c);
+    layer_skip<TIER, 2, P::KU_D, 2, P::KU_PE, 2>(vn, ve, bias + P::T_B_E3, pe, bias + P::T_B_ESKIP, f, fe, s, c,
+                                                 RecMap::S_MD0 + 6);
     ve = vn;
+    rec_vec<TIER, 2>(c, RecMap::S_D0 + 64 * 6, ve);
     {   // signal net: its skip input is the per-frame pose signal -> a constant added after the ReLU
         f32x16 acc[2];
         acc_init<2>(acc, bias + P::T_B_S3, c.half);
         gemm_group<TIER, 2, P::KU_D, 2>(acc, vs, f, fe, s, c);
+        if (c.rec.masks) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int b = 0; b < 32; ++b) bits |= (acc[b >> 4][b & 15] > 0.f) ? (1u << b) : 0u;
+            c.rec.masks[((long)c.rec.pass * c.rec.mask_dwords + RecMap::S_MD0 + 7) * 64 + c.lane] = bits;
+        }
         acc_relu_add<2>(acc, bias + P::T_B_SSKIP, c.half);
         acc_to_vec<TIER, 2, 2, false>(acc, vn, 0);
         vs = vn;
+        rec_vec<TIER, 2>(c, RecMap::S_D0 + 64 * 7, vs);
     }
-    layer<TIER, 2, P::KU_D, 2, true>(vn, ve, bias + P::T_B_E4, f, fe, s, c);  ve = vn;
-    layer<TIER, 2, P::KU_D, 2, true>(vn, vs, bias + P::T_B_S4, f, fe, s, c);  vs = vn;
+    layer<TIER, 2, P::KU_D, 2, true>(vn, ve, bias + P::T_B_E4, f, fe, s, c);  ve = vn;  DFN_REC_D(8, ve);
+    layer<TIER, 2, P::KU_D, 2, true>(vn, vs, bias + P::T_B_S4, f, fe, s, c);  vs = vn;  DFN_REC_D(9, vs);
+#undef DFN_REC_D
     // p = deform(p) + p  (decoder.py:299): PE column j sits in the register where the GEMM leaves output
     // j (identity slot map); the signal half of the residual is folded into the SO bias by the fold kernel.
     Vec<TIER, 4> pd;      // tiles 0,1: deformed PE (60 valid); tiles 2,3: deformed pose signal (42 valid)
@@ -464,10 +569,11 @@ DFN_DEV MlpOut mlp_torso(const float (&p)[3], const DhatRef& dhat, const lds_f32
 #pragma unroll
         for (int L = 0; L < 32; ++L) pd.set(32 + L, acc[L >> 4][L & 15]);
     }
+    rec_vec<TIER, 4>(c, RecMap::S_PD, pd);
     Vec<TIER, 8> act;
     layer<TIER, 8, P::KU_PD, 4, true>(act, pd, bias + P::T_B_IN, f, fe, s, c);
     return mlp_trunk<TIER, 4, P::KU_PD>(act, pd, dhat, bias, P::T_B_L1, P::T_B_SKIP, P::T_B_L5, P::T_B_VIEW,
-                                        P::T_B_OUT, f % SLAB_FRAGS, fe, s, c);
+                                        P::T_B_OUT, f % SLAB_FRAGS, fe, s, c, RecMap::S_TRUNK, RecMap::S_MTRUNK);
 }
 
 }  // namespace dfn

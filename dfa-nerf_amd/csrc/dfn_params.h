@@ -19,6 +19,11 @@ struct RenderArgs {
     float* w_head;
     float* w_com;
     float* z_out;
+    // training recorder (all null for inference): per-sample raw outputs and per-field activations / ReLU masks
+    float* samples_out;         // [ray_count][n_coarse][8]
+    void* act_T[2];
+    unsigned* masks[2];
+    long NP;
 };
 
 struct DecoderArgs {

@@ -129,7 +129,9 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     const int n = lane & 31;
     const DfnFrame& F = A.frame;
     lds_char* lds = (lds_char*)smem;
-    const Ctx ctx = {lds, wave, lane, lane >> 5};
+    Ctx ctx = {lds, wave, lane, lane >> 5, {}};
+    ctx.rec.act_T = nullptr;
+    ctx.rec.masks = nullptr;
 
     Stream s;
     s.base[0] = A.wblob[0];
@@ -216,14 +218,31 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
                 float p[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) p[k] = add_(st[RS_OH + k], mul_(st[RS_DH + k], z));
+                if (A.act_T[0] && valid && stage == 0) {
+                    ctx.rec = {A.act_T[0], A.masks[0], A.NP, (long)r_raw * 64 + tile * 32, (long)r_raw * 2 + tile,
+                               RecMap::H_MDWORDS};
+                }
                 a = mlp_head<TIER>(p, dref_h, bias_h, s, ctx);
+                ctx.rec.act_T = nullptr;
+                ctx.rec.masks = nullptr;
             }
             if (two) {
                 const float z = ((volatile lds_f32*)zall)[si];
                 float p[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) p[k] = add_(st[RS_OT + k], mul_(st[RS_DT + k], z));
+                if (A.act_T[1] && valid && stage == 0) {
+                    ctx.rec = {A.act_T[1], A.masks[1], A.NP, (long)r_raw * 64 + tile * 32, (long)r_raw * 2 + tile,
+                               RecMap::S_MDWORDS};
+                }
                 b = mlp_torso<TIER>(p, dref_t, bias_t, s, ctx);
+                ctx.rec.act_T = nullptr;
+                ctx.rec.masks = nullptr;
+            }
+            if (A.samples_out && valid && stage == 0 && lane < 32) {
+                float* so = A.samples_out + ((size_t)r_raw * 64 + si) * 8;
+                so[0] = a.sigma; so[1] = a.r; so[2] = a.g; so[3] = a.b;
+                so[4] = b.sigma; so[5] = b.r; so[6] = b.g; so[7] = b.b;
             }
             // results live in lanes 0..31; mirror them so that both halves run the same arithmetic
             const float z = ((volatile lds_f32*)zall)[si];
@@ -362,7 +381,9 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31;
     lds_char* lds = (lds_char*)smem;
-    const Ctx ctx = {lds, wave, lane, lane >> 5};
+    Ctx ctx = {lds, wave, lane, lane >> 5, {}};
+    ctx.rec.act_T = nullptr;
+    ctx.rec.masks = nullptr;
 
     Stream s;
     s.base[0] = s.base[1] = A.wblob;

@@ -1,0 +1,43 @@
+// dfn_train.h - argument blocks and launchers of the training kernels (dfn_train.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dfanerf.h"
+#include "dfn_layout.h"
+
+namespace dfn {
+
+struct MlpBwdArgs {
+    const char* wblob_T;        // transposed packed stream of the field
+    int nslab;
+    const float* samples;       // [NP][8] forward outputs (sigma_h, rgb_h, sigma_t, rgb_t)
+    const float* dsamples;      // [NP][8] gradients w.r.t. them
+    const unsigned* masks;      // forward ReLU bits of the field
+    void* dy_T;                 // out: [rows][NP] pre-activation gradients, feature-major
+    long NP;
+};
+
+struct CompositeBwdArgs {
+    DfnFrame frame;
+    const int* pix_index;
+    const float* bg_f32;
+    const unsigned char* bg_u8;
+    const float* samples;       // [rays][64][8]
+    const float* d_rgb_head;    // [rays][3]
+    const float* d_rgb_com;     // [rays][3] or null
+    float* dsamples;            // out [rays][64][8]
+};
+
+struct WOp {                    // one weight-gradient GEMM: C[M x N] = dy_T[a_row.., :] * act_T[b_row.., :]^T
+    int a_row, M, b_row, N, c_off;
+};
+
+hipError_t launch_mlp_bwd(int tier, int field, const MlpBwdArgs& A, hipStream_t st);
+void bwd_program_info(int tier, int field, ProgramInfo* out);
+hipError_t launch_composite_bwd(const CompositeBwdArgs& A, hipStream_t st);
+hipError_t launch_wgrad(int tier, const WOp* ops_dev, int n_ops, const int* prefix_dev, int total_items,
+                        const void* dy_T, const void* act_T, long NP, int ksplit, float* C, hipStream_t st);
+hipError_t launch_scatter_add(const int* map, const float* dense, long n, float* grad_flat, hipStream_t st);
+hipError_t launch_bias_grad(int tier, const int* row_of, int n, const void* dy_T, long NP, float* dbias,
+                            hipStream_t st);
+
+}  // namespace dfn

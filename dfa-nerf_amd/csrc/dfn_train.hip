@@ -1,0 +1,338 @@
+// dfn_train.hip - training kernels: MLP backward (dX chain), compositing backward, weight-gradient GEMMs,
+// gradient scatter and bias gradients.  The forward of a training step is render_kernel with the recorder
+// switched on (dfn_render.hip / dfn_mlp.h: Rec).
+//
+// Differentiates run_nerf_com_trainExpLater.py:855-907 (two fields, coarse samples, composite, weights,
+// weighted colour sums) and decoder.py:277-349 / 109-134.
+#include <hip/hip_runtime.h>
+#include "dfn_bwd.h"
+#include "dfn_layout.h"
+#include "dfn_mlp.h"
+#include "dfn_train.h"
+
+namespace dfn {
+
+// ================================================================================================
+// MLP backward: one wave = one 32-point tile, one pass of the transposed weight stream
+// ================================================================================================
+template <int TIER, bool TORSO>
+__global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 256) void mlp_bwd_kernel(
+    const MlpBwdArgs A) {
+    using C = TierCfg<TIER>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    lds_char* lds = (lds_char*)smem;
+    Ctx ctx = {lds, wave, lane, lane >> 5, {}};
+    ctx.rec.act_T = nullptr;
+    ctx.rec.masks = nullptr;
+    Stream s;
+    s.base[0] = s.base[1] = A.wblob_T;
+    s.nslab[0] = s.nslab[1] = A.nslab;
+    s.two_fields = 0;
+    stream_begin<TIER>(s, lds, wave, lane);
+    const long n_tiles = A.NP / 32;
+    const long tile_raw = (long)blockIdx.x * C::WAVES + wave;
+    const long tile = tile_raw < n_tiles ? tile_raw : n_tiles - 1;     // idle waves redo the last tile (same values)
+    const long p = tile * 32 + (lane & 31);
+    BwdIn in;
+    {
+        const int o = TORSO ? 4 : 0;
+        const float* ds = A.dsamples + p * 8 + o;
+        const float* sm = A.samples + p * 8 + o;
+        in.dsigma = ds[0];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float y = sm[1 + k];
+            in.dpre[k] = ds[1 + k] * (y * (1.0f - y));                 // sigmoid'
+        }
+    }
+    BwdIO io;
+    io.dy_T = A.dy_T;
+    io.masks = A.masks;
+    io.NP = A.NP;
+    io.p0 = tile * 32;
+    io.pass = tile;
+    io.mask_dwords = TORSO ? RecMap::S_MDWORDS : RecMap::H_MDWORDS;
+    __syncthreads();
+    if constexpr (TORSO) bwd_torso<TIER>(in, io, s, ctx);
+    else bwd_head<TIER>(in, io, s, ctx);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int TIER, bool TORSO> static hipError_t launch_mlp_bwd_t(const MlpBwdArgs& A, hipStream_t st) {
+    using C = TierCfg<TIER>;
+    const int lds = RING_BYTES;
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void*)mlp_bwd_kernel<TIER, TORSO>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    const long n_tiles = A.NP / 32;
+    const int blocks = (int)((n_tiles + C::WAVES - 1) / C::WAVES);
+    hipLaunchKernelGGL((mlp_bwd_kernel<TIER, TORSO>), dim3(blocks), dim3(C::THREADS), lds, st, A);
+    return hipGetLastError();
+}
+hipError_t launch_mlp_bwd(int tier, int field, const MlpBwdArgs& A, hipStream_t st) {
+    const bool torso = field == FIELD_TORSO;
+    if (tier == TIER_BF16)
+        return torso ? launch_mlp_bwd_t<TIER_BF16, true>(A, st) : launch_mlp_bwd_t<TIER_BF16, false>(A, st);
+    return torso ? launch_mlp_bwd_t<TIER_F32, true>(A, st) : launch_mlp_bwd_t<TIER_F32, false>(A, st);
+}
+void bwd_program_info(int tier, int field, ProgramInfo* out) {
+    const bool torso = field == FIELD_TORSO;
+    if (tier == TIER_BF16) {
+        using B = BProg<TIER_BF16>;
+        *out = torso ? ProgramInfo{B::S_FRAGS, B::S_SLABS, 0} : ProgramInfo{B::H_FRAGS, B::H_SLABS, 0};
+    } else {
+        using B = BProg<TIER_F32>;
+        *out = torso ? ProgramInfo{B::S_FRAGS, B::S_SLABS, 0} : ProgramInfo{B::H_FRAGS, B::H_SLABS, 0};
+    }
+}
+
+// ================================================================================================
+// compositing backward: one wave per ray, 64 coarse samples = 64 lanes
+// ================================================================================================
+__device__ __forceinline__ float wave_excl_prod(float v, int lane) {
+    float inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float up = __shfl_up(inc, d);
+        if (lane >= d) inc *= up;
+    }
+    float exc = __shfl_up(inc, 1);
+    return lane == 0 ? 1.0f : exc;
+}
+__device__ __forceinline__ float wave_suffix_sum_excl(float v, int lane) {      // sum over lanes > lane
+    float inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float dn = __shfl_down(inc, d);
+        if (lane + d < 64) inc += dn;
+    }
+    float exc = __shfl_down(inc, 1);
+    return lane == 63 ? 0.f : exc;
+}
+// weights w_i = a_i T_i of run_nerf_com_trainExpLater.py:169-179 and dL/d(sigma_i) given q_i = c_i . G
+struct WB {
+    float w, ds;
+};
+__device__ __forceinline__ WB weights_bwd(float sigma, float dist, float q, int lane) {
+    const float e = expf(-((fmaxf(sigma, 0.f) + 1e-6f) * dist));
+    const float a = 1.0f - e;
+    const float v = 1.0f - a + 1e-10f;
+    const float T = wave_excl_prod(v, lane);
+    const float w = a * T;
+    const float suf = wave_suffix_sum_excl(w * q, lane);
+    const float da = T * q - suf / v;
+    WB r;
+    r.w = w;
+    r.ds = da * dist * e;             // d a / d sigma = dist * exp(-(sigma + 1e-6) dist)
+    return r;
+}
+
+__global__ void composite_bwd_kernel(const CompositeBwdArgs A) {
+    const int lane = threadIdx.x & 63;
+    const long ray = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= A.frame.ray_count) return;
+    const DfnFrame& F = A.frame;
+    const int pix = A.pix_index ? A.pix_index[ray] : F.ray_begin + (int)ray;
+    // geometry (same arithmetic as the forward)
+    const int y = pix / F.W, x = pix - y * F.W;
+    const float dx = __fdiv_rn(__fsub_rn((float)x, F.cx), F.focal), dy = __fdiv_rn(-__fsub_rn((float)y, F.cy), F.focal);
+    float nrm[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const float* P = b ? F.pose_body : F.pose;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, P[4 * k]), __fmul_rn(dy, P[4 * k + 1])),
+                                      __fmul_rn(-1.0f, P[4 * k + 2]));
+            acc = __fadd_rn(acc, __fmul_rn(d, d));
+        }
+        nrm[b] = sqrtf(acc);
+    }
+    const float step = __fdiv_rn(1.0f, 63.0f);
+    auto tval = [&](int i) { return (i < 32) ? __fmul_rn(step, (float)i) : fmaf(-step, (float)(63 - i), 1.0f); };
+    auto zval = [&](int i) {
+        const float t = tval(i);
+        return __fadd_rn(__fmul_rn(F.z_near, __fsub_rn(1.0f, t)), __fmul_rn(F.z_far, t));
+    };
+    const bool last = lane == 63;
+    const float dz = last ? F.last_dist : __fsub_rn(zval(lane + 1), zval(lane));
+    const bool cbg = F.concate_bg != 0;
+    const float* sm = A.samples + (ray * 64 + lane) * 8;
+    float* out = A.dsamples + (ray * 64 + lane) * 8;
+    const float sg_h = sm[0], sg_t_raw = sm[4];
+    float ch[3] = {sm[1], sm[2], sm[3]}, ct[3] = {sm[5], sm[6], sm[7]};
+    const bool h_is_bg = cbg && last;
+    if (h_is_bg) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            ch[k] = A.bg_u8 ? __fdiv_rn((float)A.bg_u8[(size_t)pix * 3 + k], 255.0f) : A.bg_f32[(size_t)pix * 3 + k];
+    }
+    float Gh[3], Gc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        Gh[k] = A.d_rgb_head[ray * 3 + k];
+        Gc[k] = A.d_rgb_com ? A.d_rgb_com[ray * 3 + k] : 0.f;
+    }
+    // ---- head-only image: s = relu(sg_h) (+1e-6 at the last sample), colour ch
+    const float sh = fmaxf(sg_h, 0.f);
+    float d_sg_h = 0.f, d_ch[3] = {0, 0, 0}, d_sg_t = 0.f, d_ct[3] = {0, 0, 0};
+    {
+        const float s1 = h_is_bg ? sh + 1e-6f : sh;
+        const float q = ch[0] * Gh[0] + ch[1] * Gh[1] + ch[2] * Gh[2];
+        const WB r = weights_bwd(s1, dz * nrm[0], q, lane);
+        if (sg_h > 0.f) d_sg_h += r.ds;
+        if (!h_is_bg)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) d_ch[k] += r.w * Gh[k];
+    }
+    // ---- composite image (run_nerf_com_trainExpLater.py:146-166)
+    if (A.frame.fields == 2) {
+        const float sg_t = (cbg && last) ? 0.f : sg_t_raw;
+        float st = fmaxf(sg_t, 0.f);
+        if (cbg && last) st += 1e-6f;
+        const float ssum = sh + st;
+        const bool zero = ssum == 0.f;
+        const float den = zero ? 1e-4f : ssum;
+        const float wh = sh / den, wt = st / den;
+        float cm[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cm[k] = ch[k] * wh + ct[k] * wt;
+        const float q = cm[0] * Gc[0] + cm[1] * Gc[1] + cm[2] * Gc[2];
+        const WB r = weights_bwd(ssum, dz * nrm[1], q, lane);
+        const float gch = ch[0] * Gc[0] + ch[1] * Gc[1] + ch[2] * Gc[2];
+        const float gct = ct[0] * Gc[0] + ct[1] * Gc[1] + ct[2] * Gc[2];
+        const float dwh = r.w * gch, dwt = r.w * gct;
+        // wh = sh/den, wt = st/den, den = sh + st (or the constant 1e-4)
+        float dsh = r.ds + dwh / den, dst = r.ds + dwt / den;
+        if (!zero) {
+            const float common = (dwh * sh + dwt * st) / (den * den);
+            dsh -= common;
+            dst -= common;
+        }
+        if (sg_h > 0.f) d_sg_h += dsh;
+        if (sg_t > 0.f && !(cbg && last)) d_sg_t += dst;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (!h_is_bg) d_ch[k] += r.w * Gc[k] * wh;
+            d_ct[k] += r.w * Gc[k] * wt;
+        }
+    }
+    out[0] = d_sg_h;
+    out[4] = d_sg_t;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        out[1 + k] = d_ch[k];
+        out[5 + k] = d_ct[k];
+    }
+}
+hipError_t launch_composite_bwd(const CompositeBwdArgs& A, hipStream_t st) {
+    const int blocks = (A.frame.ray_count + 3) / 4;
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3(blocks), dim3(256), 0, st, A);
+    return hipGetLastError();
+}
+
+// ================================================================================================
+// weight gradients: C[M x N] += A[M x NP] * B[N x NP]^T, contraction over the sample points, split-K + atomics
+// ================================================================================================
+template <int TIER>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, const int* work_prefix, const void* dy_T,
+                                                    const void* act_T, long NP, int ksplit, float* C) {
+    typedef typename ActT<TIER>::type T;
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= work_prefix[n_ops]) return;
+    int op = 0;
+    while (item >= work_prefix[op + 1]) ++op;
+    const WOp o = ops[op];
+    long loc = item - work_prefix[op];
+    const int nt_n = o.N / 32;
+    const int ks = (int)(loc % ksplit);
+    loc /= ksplit;
+    const int nt = (int)(loc % nt_n), mt = (int)(loc / nt_n);
+    const long per = NP / ksplit;
+    const long k0 = ks * per, k1 = k0 + per;
+    const T* a = (const T*)dy_T + (long)(o.a_row + 32 * mt + (lane & 31)) * NP;
+    const T* b = (const T*)act_T + (long)(o.b_row + 32 * nt + (lane & 31)) * NP;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if constexpr (TIER == TIER_BF16) {
+        const int ko = 8 * (lane >> 5);
+        for (long k = k0; k < k1; k += 16) {
+            const bf16x8 av = *(const bf16x8*)(a + k + ko);
+            const bf16x8 bv = *(const bf16x8*)(b + k + ko);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+        }
+    } else {
+        const int h = lane >> 5;
+        for (long k = k0; k < k1; k += 4) {
+            const f32x4 av = *(const f32x4*)(a + k);
+            const f32x4 bv = *(const f32x4*)(b + k);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? av[1] : av[0], h ? bv[1] : bv[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? av[3] : av[2], h ? bv[3] : bv[2], acc, 0, 0, 0);
+        }
+    }
+    float* c = C + o.c_off;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = 32 * mt + tile_feat(lane >> 5, r), col = 32 * nt + (lane & 31);
+        atomicAdd(c + (long)row * o.N + col, acc[r]);
+    }
+}
+hipError_t launch_wgrad(int tier, const WOp* ops_dev, int n_ops, const int* prefix_dev, int total_items,
+                        const void* dy_T, const void* act_T, long NP, int ksplit, float* C, hipStream_t st) {
+    const int blocks = (total_items + 3) / 4;
+    if (tier == TIER_BF16)
+        hipLaunchKernelGGL(wgrad_kernel<TIER_BF16>, dim3(blocks), dim3(256), 0, st, ops_dev, n_ops, prefix_dev, dy_T,
+                           act_T, NP, ksplit, C);
+    else
+        hipLaunchKernelGGL(wgrad_kernel<TIER_F32>, dim3(blocks), dim3(256), 0, st, ops_dev, n_ops, prefix_dev, dy_T,
+                           act_T, NP, ksplit, C);
+    return hipGetLastError();
+}
+
+__global__ void scatter_add_kernel(const int* map, const float* dense, long n, float* grad_flat) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int dst = map[i];
+    if (dst >= 0) grad_flat[dst] += dense[i];          // every parameter appears at most once per field
+}
+hipError_t launch_scatter_add(const int* map, const float* dense, long n, float* grad_flat, hipStream_t st) {
+    hipLaunchKernelGGL(scatter_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, map, dense, n,
+                       grad_flat);
+    return hipGetLastError();
+}
+
+// d(bias blob)[e] = sum over points of dy_T[row_of[e]][:]
+template <typename T>
+__global__ void bias_grad_kernel(const int* row_of, const T* dy_T, long NP, float* dbias) {
+    __shared__ float red[4];
+    const int e = blockIdx.x;
+    const int row = row_of[e];
+    float acc = 0.f;
+    if (row >= 0) {
+        const T* p = dy_T + (long)row * NP;
+        for (long k = threadIdx.x; k < NP; k += 256) acc += (float)p[k];
+    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) dbias[e] = red[0] + red[1] + red[2] + red[3];
+}
+hipError_t launch_bias_grad(int tier, const int* row_of, int n, const void* dy_T, long NP, float* dbias,
+                            hipStream_t st) {
+    if (tier == TIER_BF16)
+        hipLaunchKernelGGL(bias_grad_kernel<__bf16>, dim3(n), dim3(256), 0, st, row_of, (const __bf16*)dy_T, NP, dbias);
+    else
+        hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(n), dim3(256), 0, st, row_of, (const float*)dy_T, NP, dbias);
+    return hipGetLastError();
+}
+
+}  // namespace dfn

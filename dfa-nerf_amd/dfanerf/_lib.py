@@ -51,6 +51,14 @@ def _load():
         "dfn_volume_weights": (i32, [fp, fp, fp, lg, i32, C.c_float, fp, vp]),
         "dfn_to8b": (i32, [fp, lg, vp, vp]),
         "dfn_debug_mfma_layout": (i32, [fp, vp]),
+        "dfn_train_rows": (lg, [i32, i32]),
+        "dfn_packed_bwd_bytes": (lg, [i32, i32]),
+        "dfn_pack_weights_bwd": (i32, [i32, i32, fp, vp, vp]),
+        "dfn_train_fwd": (i32, [i32, C.POINTER(DfnFrame), vp, vp, fp, fp, fp, vp, ip, fp, fp, fp, vp, vp, vp, vp, vp]),
+        "dfn_composite_bwd": (i32, [C.POINTER(DfnFrame), ip, fp, vp, fp, fp, fp, fp, vp]),
+        "dfn_mlp_bwd": (i32, [i32, i32, vp, fp, fp, vp, lg, vp, vp]),
+        "dfn_weight_grad": (i32, [i32, i32, vp, vp, lg, fp, fp, vp]),
+        "dfn_bias_grad": (i32, [i32, i32, vp, lg, fp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = header and library out of sync

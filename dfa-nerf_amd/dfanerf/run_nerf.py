@@ -96,7 +96,7 @@ _FLAGS = [
     ("use_aud_net", None, None), ("use_ori", None, None), ("test_offset", int, 0),
 ]
 # build-side additions (not in the reference): precision tier of the HIP renderer and the hierarchical mode
-_EXTRA_FLAGS = [("hip_tier", str, 'f32'), ("hierarchical", None, None)]
+_EXTRA_FLAGS = [("hip_tier", str, 'f32'), ("hierarchical", None, None), ("train_aten", None, None)]
 
 
 def config_parser():
@@ -382,6 +382,33 @@ def train_step_loss(nets, dataset, itr_obj, img_i, sel_yx, target_head, target_c
     return l_com + l_head, l_head, l_com, rgb_head, rgb_com
 
 
+def train_step_loss_hip(nets, dataset, itr_obj, img_i, sel_yx, target_head, target_com, z_shape, z_app, global_step,
+                        args, len_train, embed_fn, pose_torso, buf):
+    """Same step as train_step_loss, with the decoder forward+backward, ray generation, sampling and compositing
+    in the fused HIP kernels (dfanerf.training.RenderTrainFn).  `buf`: training.TrainBuffers for len(sel_yx) rays."""
+    from . import engine, training
+    dec = nets["decoder"]
+    dev = next(dec.parameters()).device
+    poses = dataset[itr_obj]['poses']
+    H, W, focal, cx, cy = dataset[itr_obj]['hwfcxy']
+    H, W = int(H), int(W)
+    signal = encode_signal(dataset, itr_obj, img_i, args.dim_aud, nets["AudNet"], nets["ExpNet"], nets["AudAttNet"],
+                           global_step, args, len_train, embed_fn=embed_fn)
+    signal_torso = encode_signal_torso(dataset, itr_obj, img_i, nets.get("PoseAttNet"), global_step, args, len_train,
+                                       embed_fn=embed_fn)
+    pix = torch.as_tensor(sel_yx[:, 0] * W + sel_yx[:, 1], dtype=torch.int32, device=dev)
+    frame = engine.make_frame(H, W, focal, cx, cy, poses[img_i].detach().cpu().numpy(),
+                              pose_torso.detach().cpu().numpy(), dataset[itr_obj]['near'], dataset[itr_obj]['far'],
+                              args.last_dist, 0, pix.numel(), args.N_samples, 0, 2, args.concate_bg)
+    bg = dataset[itr_obj]['bc_img'].reshape(-1, 3)
+    zs = z_shape[0, itr_obj * 2:itr_obj * 2 + 2]
+    za = z_app[0, itr_obj * 2:itr_obj * 2 + 2]
+    rgb_head, rgb_com = training.render_train(dec, buf, frame, bg, pix, signal[0], signal_torso, zs, za)
+    l_head = img2mse(rgb_head, target_head)
+    l_com = img2mse(rgb_com, target_com)
+    return l_com + l_head, l_head, l_com, rgb_head, rgb_com
+
+
 def _get_rays_any(H, W, focal, c2w, cx, cy, dev):
     """get_rays on the GPU through the HIP kernel; on CPU (unit tests of the host logic) in ATen."""
     if torch.device(dev).type == 'cuda':
@@ -497,6 +524,8 @@ def train():
             _mimwrite(os.path.join(out_com, '{}.mp4'.format(args.expname)), rgbs)
         return
 
+    from . import training
+    train_buf = training.TrainBuffers(getattr(args, "hip_tier", "f32"), args.N_rand, dev)
     bucket = parallel.FlatGradBucket(list(nets.values())) if world > 1 else None
     rng = np.random.RandomState(1234 + rank) if world > 1 else np.random
     i_train = ds['i_train']
@@ -507,9 +536,11 @@ def train():
         target_head = torch.as_tensor(_imread(ds['imgs'][img_i])).to(dev).float() / 255.0
         sel = select_coords(H, W, args.N_rand, args.sample_rate, ds['sample_rects'][img_i], rng)
         ys, xs = torch.as_tensor(sel[:, 0], device=dev), torch.as_tensor(sel[:, 1], device=dev)
-        loss, l_head, l_com, _, _ = train_step_loss(nets, datasets, itr_obj, img_i, sel, target_head[ys, xs],
-                                                    target_com[ys, xs], z_shape, z_app, global_step, args,
-                                                    len(i_train), embed_fn, ds['poses'][0, :3, :4])
+        step_fn = train_step_loss if args.train_aten else train_step_loss_hip
+        extra = () if args.train_aten else (train_buf,)
+        loss, l_head, l_com, _, _ = step_fn(nets, datasets, itr_obj, img_i, sel, target_head[ys, xs],
+                                            target_com[ys, xs], z_shape, z_app, global_step, args,
+                                            len(i_train), embed_fn, ds['poses'][0, :3, :4], *extra)
         for o in opts.values():
             o.zero_grad()
         loss.backward()

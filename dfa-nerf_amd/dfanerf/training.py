@@ -1,0 +1,130 @@
+"""Training step on the HIP path: torch autograd drives, the HIP kernels compute.
+
+  flat decoder params --\\
+  per-frame bias blob ---+--> RenderTrainFn (dfn_train_fwd | dfn_composite_bwd, dfn_mlp_bwd, dfn_weight_grad,
+  (fold_bias_torch)     /     dfn_bias_grad) --> rgb_head, rgb_com --> MSE losses (run_nerf_com_trainExpLater.py:902-907)
+
+The decoder's forward AND backward run in the fused HIP kernels; torch autograd only chains the result into
+the tiny per-frame pieces that surround it: the bias fold (fc_z, fc_z_skips, fc_z_view, signal columns) and the
+conditioning networks (AudioNet_W2L, ExpressionEnc, AudioAttNet) that produce the 96 + 42 signal floats."""
+import ctypes as C
+
+import torch
+
+from . import engine
+from ._lib import FIELD_HEAD, FIELD_TORSO, check, lib
+from .engine import TIERS, _ptr, _stream
+
+
+def _perm(n, device):
+    """blob order [tile][half][16] -> feature index."""
+    e = torch.arange(n, device=device)
+    return 32 * (e >> 5) + (e & 3) + 8 * ((e & 15) >> 2) + 4 * ((e >> 4) & 1)
+
+
+def _pad(v, n):
+    return torch.cat([v, v.new_zeros(n - v.shape[0])]) if v.shape[0] < n else v
+
+
+def fold_bias_torch(dec, sig_head, sig_torso, z_shape, z_app):
+    """Differentiable twin of dfn_fold_bias (dfn_misc.hip: fold_kernel): [head blob | torso blob].
+    z_shape, z_app: [2,256] rows (head, torso)."""
+    dev = z_shape.device
+    p256, p288, p64, p32 = _perm(256, dev), _perm(288, dev), _perm(64, dev), _perm(32, dev)
+    sh, st = sig_head.reshape(-1), sig_torso.reshape(-1)
+
+    def trunk(zs, za, b_in, b_skip):
+        fczv = dec.fc_z_view(za)
+        view = torch.cat([dec.feat_view.bias + fczv + dec.fc_view.bias, _pad(dec.sigma_out.bias, 32)])
+        parts = [b_in[p256]] + [dec.blocks[l].bias[p256] for l in range(4)] + [b_skip[p256]] + \
+                [dec.blocks[l].bias[p256] for l in range(4, 7)] + [view[p288], _pad(dec.feat_out.bias, 32)[p32]]
+        return torch.cat(parts)
+    zs0, zs1, za0, za1 = z_shape[0], z_shape[1], z_app[0], z_app[1]
+    head = trunk(zs0, za0,
+                 dec.fc_in.bias + dec.fc_in.weight[:, 60:] @ sh + dec.fc_z(zs0),
+                 dec.fc_z_skips[0](zs0) + dec.fc_p_skips[0].bias + dec.fc_p_skips[0].weight[:, 60:] @ sh)
+    d = dec.deform_net
+    dv = [d.blocks_embed[0].bias + d.blocks_embed[0].weight[:, 60:] @ st,
+          d.blocks_signal[0].bias + d.blocks_signal[0].weight[:, 60:] @ st,
+          d.blocks_embed[1].bias, d.blocks_signal[1].bias, d.blocks_embed[2].bias, d.blocks_signal[2].bias,
+          d.blocks_embed[3].bias, d.fc_embed_skips[0].bias, d.blocks_signal[3].bias, d.fc_signal_skips[0](st),
+          d.blocks_embed[4].bias, d.blocks_signal[4].bias, _pad(d.out_embed.bias, 64), _pad(d.out_signal.bias + st, 64)]
+    torso = torch.cat([v[p64] for v in dv] +
+                      [trunk(zs1, za1, dec.fc_in_torso.bias + dec.fc_z(zs1),
+                             dec.fc_z_skips[0](zs1) + dec.fc_p_skips_torso[0].bias)])
+    return torch.cat([head, torso])
+
+
+class TrainBuffers:
+    """Device buffers of one training step, sized for `n_rays` (reused across steps)."""
+
+    def __init__(self, tier, n_rays, device):
+        self.tier = TIERS[tier]
+        self.n_rays, self.NP = n_rays, n_rays * 64
+        assert self.NP % 512 == 0, "N_rand must be a multiple of 8"
+        dt = torch.bfloat16 if self.tier == 1 else torch.float32
+        rows = lambda f, w: check(lib.dfn_train_rows(f, w), "dfn_train_rows")
+        self.act = [torch.empty(rows(f, 0), self.NP, dtype=dt, device=device) for f in (0, 1)]
+        self.dy = [torch.empty(rows(f, 1), self.NP, dtype=dt, device=device) for f in (0, 1)]
+        self.masks = [torch.empty(self.NP // 32, rows(f, 2), 64, dtype=torch.int32, device=device) for f in (0, 1)]
+        self.ws = [torch.empty(rows(f, 3), dtype=torch.float32, device=device) for f in (0, 1)]
+        self.samples = torch.empty(self.NP, 8, dtype=torch.float32, device=device)
+        self.dsamples = torch.empty(self.NP, 8, dtype=torch.float32, device=device)
+        self.packed = [torch.empty(check(lib.dfn_packed_bytes(self.tier, f), "packed"), dtype=torch.uint8, device=device)
+                       for f in (0, 1)]
+        self.packed_T = [torch.empty(check(lib.dfn_packed_bwd_bytes(self.tier, f), "packed_T"), dtype=torch.uint8,
+                                     device=device) for f in (0, 1)]
+        self.nb = [check(lib.dfn_bias_floats(self.tier, f), "bias") for f in (0, 1)]
+
+
+class RenderTrainFn(torch.autograd.Function):
+    """(flat params [955242], bias blob [head|torso]) -> rgb_head [n,3], rgb_com [n,3] for the selected pixels."""
+
+    @staticmethod
+    def forward(ctx, flat, bias, buf, frame, bg, pix_index):
+        flat_c = flat.detach().contiguous()
+        bias_c = bias.detach().contiguous()
+        t, st = buf.tier, _stream()
+        for f in (0, 1):
+            check(lib.dfn_pack_weights(t, f, _ptr(flat_c), _ptr(buf.packed[f]), st), "dfn_pack_weights")
+            check(lib.dfn_pack_weights_bwd(t, f, _ptr(flat_c), _ptr(buf.packed_T[f]), st), "dfn_pack_weights_bwd")
+        n = frame.ray_count
+        rgb_h = torch.empty(n, 3, dtype=torch.float32, device=flat.device)
+        rgb_c = torch.empty(n, 3, dtype=torch.float32, device=flat.device)
+        bg_f32 = bg if bg.dtype == torch.float32 else None
+        bg_u8 = bg if bg.dtype == torch.uint8 else None
+        check(lib.dfn_train_fwd(t, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias_c),
+                                C.c_void_p(bias_c.data_ptr() + 4 * buf.nb[0]), _ptr(bg_f32), _ptr(bg_u8),
+                                _ptr(pix_index), _ptr(rgb_h), _ptr(rgb_c), _ptr(buf.samples), _ptr(buf.act[0]),
+                                _ptr(buf.masks[0]), _ptr(buf.act[1]), _ptr(buf.masks[1]), st), "dfn_train_fwd")
+        ctx.buf, ctx.frame, ctx.bg, ctx.pix = buf, frame, bg, pix_index
+        ctx.n_flat, ctx.dev = flat.numel(), flat.device
+        return rgb_h, rgb_c
+
+    @staticmethod
+    def backward(ctx, d_h, d_c):
+        buf, frame, bg, st = ctx.buf, ctx.frame, ctx.bg, _stream()
+        d_h = d_h.contiguous().float()
+        d_c = d_c.contiguous().float()
+        bg_f32 = bg if bg.dtype == torch.float32 else None
+        bg_u8 = bg if bg.dtype == torch.uint8 else None
+        check(lib.dfn_composite_bwd(C.byref(frame), _ptr(ctx.pix), _ptr(bg_f32), _ptr(bg_u8), _ptr(buf.samples),
+                                    _ptr(d_h), _ptr(d_c), _ptr(buf.dsamples), st), "dfn_composite_bwd")
+        g_flat = torch.zeros(ctx.n_flat, dtype=torch.float32, device=ctx.dev)
+        g_bias = torch.empty(buf.nb[0] + buf.nb[1], dtype=torch.float32, device=ctx.dev)
+        for f in (0, 1):
+            check(lib.dfn_mlp_bwd(buf.tier, f, _ptr(buf.packed_T[f]), _ptr(buf.samples), _ptr(buf.dsamples),
+                                  _ptr(buf.masks[f]), buf.NP, _ptr(buf.dy[f]), st), "dfn_mlp_bwd")
+            check(lib.dfn_weight_grad(buf.tier, f, _ptr(buf.dy[f]), _ptr(buf.act[f]), buf.NP, _ptr(buf.ws[f]),
+                                      _ptr(g_flat), st), "dfn_weight_grad")
+            check(lib.dfn_bias_grad(buf.tier, f, _ptr(buf.dy[f]), buf.NP,
+                                    C.c_void_p(g_bias.data_ptr() + (4 * buf.nb[0] if f else 0)), st), "dfn_bias_grad")
+        return g_flat, g_bias, None, None, None, None
+
+
+def render_train(dec, buf, frame, bg, pix_index, sig_head, sig_torso, z_shape, z_app):
+    """Differentiable (w.r.t. the decoder parameters and the two signals) coarse two-field render of the
+    pixels `pix_index` [n] (int32, y*W+x).  Returns rgb_head, rgb_com [n,3]."""
+    flat = torch.cat([p.reshape(-1) for p in dec.state_dict(keep_vars=True).values()])
+    bias = fold_bias_torch(dec, sig_head, sig_torso, z_shape, z_app)
+    return RenderTrainFn.apply(flat, bias, buf, frame, bg, pix_index)

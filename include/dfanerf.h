@@ -94,6 +94,34 @@ int dfn_render_fwd(int tier, const DfnFrame* frame, const void* packed_head, con
                    const uint8_t* bg_u8, const int32_t* pix_index, float* rgb_head, float* rgb_com,
                    float* weights_head, float* weights_com, float* z_vals, void* stream);
 
+/* ---- training step: replaces loss.backward() through MAIN:855-899 + DEC:277-349 (torch autograd upstream) ------
+ * One step = dfn_train_fwd (the fused renderer with its recorder on: coarse samples, both fields) ->
+ * [caller: loss and d loss / d rgb] -> dfn_composite_bwd -> per field: dfn_mlp_bwd (dX chain on transposed weight
+ * streams, writes every pre-activation gradient feature-major), dfn_weight_grad (gradient GEMMs over the sample
+ * points, scattered into a flat buffer laid out like `params`), dfn_bias_grad (gradient of the folded bias blob;
+ * the caller chains it into fc_z / fc_z_skips / fc_z_view / the signal columns / the conditioning networks).
+ * Buffers (element type = tier: bf16 or f32), NP = 64 * ray_count:
+ *   samples, dsamples  f32 [NP][8]  (sigma_h, rgb_h[3], sigma_t, rgb_t[3]) and their gradients
+ *   act_<field>        [dfn_train_rows(field,0)][NP]   inputs of every GEMM, feature-major
+ *   masks_<field>      u32 [NP/32][dfn_train_rows(field,2)][64]   ReLU bits
+ *   dy_T               [dfn_train_rows(field,1)][NP]   pre-activation gradients, feature-major
+ *   workspace          f32 [dfn_train_rows(field,3)]                                                        */
+long dfn_train_rows(int field, int what);
+long dfn_packed_bwd_bytes(int tier, int field);
+int dfn_pack_weights_bwd(int tier, int field, const float* params, void* packed_T, void* stream);
+int dfn_train_fwd(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
+                  const float* bias_head, const float* bias_torso, const float* bg_f32, const uint8_t* bg_u8,
+                  const int32_t* pix_index, float* rgb_head, float* rgb_com, float* samples, void* act_head,
+                  uint32_t* masks_head, void* act_torso, uint32_t* masks_torso, void* stream);
+int dfn_composite_bwd(const DfnFrame* frame, const int32_t* pix_index, const float* bg_f32, const uint8_t* bg_u8,
+                      const float* samples, const float* d_rgb_head, const float* d_rgb_com, float* dsamples,
+                      void* stream);
+int dfn_mlp_bwd(int tier, int field, const void* packed_T, const float* samples, const float* dsamples,
+                const uint32_t* masks, long NP, void* dy_T, void* stream);
+int dfn_weight_grad(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
+                    float* grad_flat, void* stream);
+int dfn_bias_grad(int tier, int field, const void* dy_T, long NP, float* dbias, void* stream);
+
 /* ---- Decoder.forward on explicit points: replaces DEC:277-349 -------------------------------------------
  * points, dirs [n,3]; feat [n,3] (after sigmoid), sigma [n] (raw). */
 int dfn_decoder_fwd(int tier, int field, const void* packed, const float* bias, const float* points,

@@ -1,0 +1,127 @@
+"""GPU tests of the HIP training step (forward with recorder, compositing backward, MLP backward on transposed
+streams, weight-gradient GEMMs, bias gradients) against the oracle's autograd and golden G8."""
+import numpy as np
+import pytest
+import torch
+
+import dfa_oracle as O
+from dfanerf import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def t(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+def _modules(states, dev):
+    from dfanerf import nets
+    from dfanerf.decoder import Decoder
+    mods = {"decoder": Decoder(z_dim=256, hidden_size=256, dim_signal=96, use_deformation_field=True),
+            "AudNet": nets.AudioNet_W2L(), "ExpNet": nets.ExpressionEnc(), "AudAttNet": nets.AudioAttNet(96, 4),
+            "PoseAttNet": nets.AudioAttNet(42, 8)}
+    for k, m in mods.items():
+        m.load_state_dict({kk: t(v) for kk, v in states[k].items()})
+        m.to(dev)
+    return mods
+
+
+def test_fold_bias_torch_matches_kernel(states, latents, golden):
+    from dfanerf import engine, training
+    g = golden("g3_decoder")
+    mods = _modules(states, "cuda")
+    zs, za = [t(v)[0].cuda() for v in latents]
+    sig, sigt = t(g["sig_aud"]).cuda(), t(g["sig_torso"]).cuda()
+    with torch.no_grad():
+        ref = training.fold_bias_torch(mods["decoder"], sig, sigt, zs, za)
+    pk = mods["decoder"].packed("f32")
+    got = pk.fold(sig, sigt, zs, za)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), atol=2e-5, rtol=1e-5)
+
+
+def test_composite_backward_vs_autograd(states, scene, latents, golden):
+    """dfn_composite_bwd against torch autograd through the oracle's integrate_fields on the same raw samples."""
+    import ctypes as C
+    from dfanerf import engine
+    from dfanerf._lib import check, lib
+    g8 = golden("g8_train_step")
+    sel = g8["sel_yx"][:64]
+    H, W = scene["H"], scene["W"]
+    n = sel.shape[0]
+    rs = np.random.RandomState(0)
+    samples = rs.randn(n, 64, 8).astype(np.float32)
+    samples[..., 0] = samples[..., 0] * 8 - 2
+    samples[..., 4] = samples[..., 4] * 8 - 2
+    samples[..., 1:4] = 1 / (1 + np.exp(-samples[..., 1:4]))
+    samples[..., 5:8] = 1 / (1 + np.exp(-samples[..., 5:8]))
+    samples[3, 10:20, 0] = -1.0
+    samples[3, 10:20, 4] = -1.0                        # both fields empty -> the 1e-4 denominator branch
+    d_h, d_c = rs.randn(n, 3).astype(np.float32), rs.randn(n, 3).astype(np.float32)
+    bg = (t(scene["bg"]).float() / 255.0).reshape(-1, 3)
+    pix = (sel[:, 0] * W + sel[:, 1]).astype(np.int32)
+    fr = engine.make_frame(H, W, scene["focal"], scene["cx"], scene["cy"], scene["poses"][3], scene["poses"][0],
+                           0.3, 0.9, ray_count=n, n_fine=0, fields=2)
+    dev = "cuda"
+    ds = torch.empty(n, 64, 8, device=dev)
+    S, DH, DC, PIX, BG = t(samples).to(dev), t(d_h).to(dev), t(d_c).to(dev), t(pix).to(dev), bg.to(dev).contiguous()
+    check(lib.dfn_composite_bwd(C.byref(fr), PIX.data_ptr(), BG.data_ptr(), None, S.data_ptr(), DH.data_ptr(),
+                                DC.data_ptr(), ds.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+          "composite_bwd")
+    # oracle autograd
+    sm = t(samples).clone().requires_grad_(True)
+    _, d_head = O.get_rays(H, W, scene["focal"], scene["poses"][3][:3, :4], scene["cx"], scene["cy"])
+    _, d_torso = O.get_rays(H, W, scene["focal"], scene["poses"][0][:3, :4], scene["cx"], scene["cy"])
+    ys, xs = t(sel[:, 0]), t(sel[:, 1])
+    z = O.coarse_z(0.3, 0.9, 64)[None].expand(n, 64)
+    rh, _, rc, _ = O.integrate_fields(z, d_head[ys, xs], d_torso[ys, xs], sm[..., 0], sm[..., 1:4], sm[..., 4],
+                                      sm[..., 5:8], bg[t(pix).long()])
+    ((rh * t(d_h)).sum() + (rc * t(d_c)).sum()).backward()
+    got, ref = ds.cpu().numpy(), sm.grad.numpy()
+    scale = np.abs(ref).max()
+    np.testing.assert_allclose(got, ref, atol=2e-5 * scale, rtol=2e-4)
+
+
+@pytest.mark.parametrize("tier,step", [("f32", 0), ("f32", 300000), ("bf16", 0)])
+def test_training_step_hip_vs_golden(states, scene, latents, golden, tier, step):
+    """One training step through the HIP forward+backward against golden G8 (loss, per-tensor gradient norms and
+    sampled entries of every parameter of all five networks; produced by the reference's modules + torch autograd)."""
+    from dfanerf import nets, run_nerf, training
+    g = golden("g8_train_step")
+    dev = torch.device("cuda")
+    mods = _modules(states, dev)
+    args = run_nerf.config_parser().parse_args(
+        "--expname t --concate_bg --N_rand=256 --sample_rate=0 --smo_size=4 --smo_torse_size 8 --use_et_embed "
+        "--dim_signal=96 --dim_aud=96 --n_object=1 --use_deformation_field --noexp_iters 400000".split())
+    H, W = scene["H"], scene["W"]
+    ds = [{"auds": t(scene["aud"]).to(dev), "exp": t(scene["exp"]).to(dev), "poses": t(scene["poses"]).to(dev),
+           "bc_img": (t(scene["bg"]).float() / 255.0).to(dev), "hwfcxy": [H, W, scene["focal"], scene["cx"], scene["cy"]],
+           "near": 0.3, "far": 0.9}]
+    sel = g["sel_yx"]
+    tgt_h = (t(synth.synth_tensor(0, "g8/th", (H, W, 3), 0.5)) + 0.5).to(dev)
+    tgt_c = (t(synth.synth_tensor(0, "g8/tc", (H, W, 3), 0.5)) + 0.5).to(dev)
+    zs, za = [t(v).to(dev) for v in latents]
+    embed_fn, _ = nets.get_embedder(3, 0)
+    buf = training.TrainBuffers(tier, sel.shape[0], dev)
+    ys, xs = t(sel[:, 0]).to(dev), t(sel[:, 1]).to(dev)
+    loss, lh, lc, _, _ = run_nerf.train_step_loss_hip(mods, ds, 0, 3, sel, tgt_h[ys, xs], tgt_c[ys, xs], zs, za, step,
+                                                      args, scene["aud"].shape[0], embed_fn, ds[0]["poses"][0], buf)
+    tol = 3e-5 if tier == "f32" else 2e-2
+    np.testing.assert_allclose([loss.item(), lh.item(), lc.item()], g[f"loss_{step}"], rtol=tol)
+    loss.backward()
+    rel = 1e-3 if tier == "f32" else 6e-2
+    worst = 0.0
+    for tag, m in mods.items():
+        for k, p in m.named_parameters():
+            ref = float(g[f"gnorm_{step}/{tag}/{k}"])
+            got = 0.0 if p.grad is None else p.grad.double().norm().item()
+            if ref <= 0:
+                assert got <= 1e-12, (tag, k, got)
+                continue
+            worst = max(worst, abs(got - ref) / ref)
+            assert abs(got - ref) <= rel * ref + 1e-9, (tag, k, got, ref)
+            if tier == "f32":
+                gs = p.grad.reshape(-1)
+                samp = gs[:: max(1, gs.numel() // 8)][:8].cpu().numpy()
+                np.testing.assert_allclose(samp, g[f"gsamp_{step}/{tag}/{k}"], rtol=2e-2,
+                                           atol=1e-3 * ref / np.sqrt(gs.numel()) + 1e-9)
+    print(f"{tier} step {step}: worst relative gradient-norm error {worst:.2e}")
