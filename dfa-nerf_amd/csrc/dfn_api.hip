@@ -336,8 +336,8 @@ int dfn_mlp_bwd(int tier, int field, const void* packed_T, const float* samples,
 int dfn_weight_grad(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
                     float* grad_flat, void* stream) {
     if (!tier_ok(tier) || (field != 0 && field != 1) || !dy_T || !act_T || !workspace || !grad_flat || NP <= 0 ||
-        NP % (WGRAD_KSPLIT * 16))
-        return fail(DFN_E_ARG, "dfn_weight_grad: bad argument (NP must be a multiple of 512)");
+        NP % 32)
+        return fail(DFN_E_ARG, "dfn_weight_grad: bad argument (NP must be a multiple of 32)");
     WgradEntry& w = wgrad_of(field);
     hipStream_t st = (hipStream_t)stream;
     {
@@ -355,7 +355,7 @@ int dfn_weight_grad(int tier, int field, const void* dy_T, const void* act_T, lo
     }
     hipError_t err = hipMemsetAsync(workspace, 0, w.map.size() * sizeof(float), st);
     if (err != hipSuccess) return hip_fail(err, "memset(workspace)");
-    err = launch_wgrad(tier, w.ops_dev, (int)w.ops.size(), w.prefix_dev, w.prefix.back(), dy_T, act_T, NP,
+    err = launch_wgrad(tier, field, w.ops_dev, (int)w.ops.size(), w.prefix_dev, w.prefix.back(), dy_T, act_T, NP,
                        WGRAD_KSPLIT, workspace, st);
     if (err != hipSuccess) return hip_fail(err, "wgrad_kernel");
     err = launch_scatter_add(w.map_dev, workspace, (long)w.map.size(), grad_flat, st);
@@ -375,7 +375,7 @@ int dfn_bias_grad(int tier, int field, const void* dy_T, long NP, float* dbias, 
         }
     }
     if ((long)w.bias_rows.size() != dfn_bias_floats(tier, field)) return fail(DFN_E_ARG, "internal: bias row table size");
-    hipError_t err = launch_bias_grad(tier, w.rows_dev, (int)w.bias_rows.size(), dy_T, NP, dbias, (hipStream_t)stream);
+    hipError_t err = launch_bias_grad(tier, field, w.rows_dev, (int)w.bias_rows.size(), dy_T, NP, dbias, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "bias_grad_kernel");
     return DFN_OK;
 }

@@ -4,7 +4,7 @@
 // streams: G_in^T[i][n] = sum_o W[o][i] * DY^T[o][n], so A = W^T fragments (packed by dfn_plan.cpp:
 // build_bwd_plan in the op order of this file), B = the pre-activation gradient the previous backward GEMM
 // left in this lane's registers, masked with the forward's ReLU bits.  Every pre-activation gradient is also
-// written feature-major ([rows][NP]) for the weight-gradient GEMMs (dfn_train.hip: wgrad_kernel).
+// written feature-major per 32-point tile ([tile][rows][32]) for the weight-gradient GEMMs (dfn_train.hip: wgrad_kernel).
 //
 // Reference semantics being differentiated: decoder.py:277-349 and :109-134 (torch autograd of those ops;
 // pinned by golden G8).
@@ -26,9 +26,10 @@ struct GradMap {
 };
 
 struct BwdIO {
-    void* dy_T;                 // [rows][NP]
+    void* dy_T;                 // tile-major [pass][rows][32]
     const unsigned* masks;      // forward ReLU bits [pass][mask_dwords][64]
-    long NP, p0, pass;
+    int rows;
+    long pass;
     int mask_dwords;
 };
 
@@ -45,9 +46,9 @@ DFN_DEV unsigned mask_word(const BwdIO& io, int dword, int lane) {
 }
 
 // out[OT tiles] = (W^T x in) [* mask]; mask_dword0 < 0: no mask
-template <int TIER, int OT, int KU, int NTB>
+template <int TIER, int OT, int KU, int NTB, class CT>
 DFN_DEV void bwd_layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, int mask_dword0, const BwdIO& io, int& f,
-                       Fetch<TIER>& fe, Stream& s, const Ctx& c) {
+                       Fetch<TIER>& fe, Stream& s, const CT& c) {
 #pragma unroll
     for (int tg = 0; tg < OT / 2; ++tg) {
         f32x16 acc[2];
@@ -59,9 +60,9 @@ DFN_DEV void bwd_layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, int mask_dw
     }
 }
 // out = (W1^T x in1 + W2^T x in2) [* mask]
-template <int TIER, int OT, int KU1, int NTB1, int KU2, int NTB2>
+template <int TIER, int OT, int KU1, int NTB1, int KU2, int NTB2, class CT>
 DFN_DEV void bwd_layer2(Vec<TIER, OT>& out, const Vec<TIER, NTB1>& in1, const Vec<TIER, NTB2>& in2,
-                        int mask_dword0, const BwdIO& io, int& f, Fetch<TIER>& fe, Stream& s, const Ctx& c) {
+                        int mask_dword0, const BwdIO& io, int& f, Fetch<TIER>& fe, Stream& s, const CT& c) {
 #pragma unroll
     for (int tg = 0; tg < OT / 2; ++tg) {
         f32x16 acc[2];
@@ -74,10 +75,10 @@ DFN_DEV void bwd_layer2(Vec<TIER, OT>& out, const Vec<TIER, NTB1>& in1, const Ve
     }
 }
 
-template <int TIER, int NT>
-DFN_DEV void put(const BwdIO& io, int row0, const Vec<TIER, NT>& v, const Ctx& c) {
+template <int TIER, int NT, class CT>
+DFN_DEV void put(const BwdIO& io, int row0, const Vec<TIER, NT>& v, const CT& c) {
 #ifndef DFN_NOPUT
-    store_vec_T<TIER, NT>(io.dy_T, io.NP, io.p0, row0, v, c);
+    store_vec_T<TIER, NT>(io.dy_T, io.rows, io.pass, row0, v, c);
 #endif
 }
 
@@ -101,9 +102,9 @@ struct BwdIn {
 
 // Backward of the trunk.  On return `dy0` holds dL/d(pre-activation of the first layer) (masked), and, when
 // TORSO, `gpd_skip` holds fc_p_skips_torso^T x g4 (the skip path's contribution to dL/d pd).
-template <int TIER, bool TORSO>
+template <int TIER, bool TORSO, class CT>
 DFN_DEV void bwd_trunk(const BwdIn& in, Vec<TIER, 8>& dy0, Vec<TIER, 4>& gpd_skip, const BwdIO& io, int g_trunk,
-                       int m_trunk, int& f, Fetch<TIER>& fe, Stream& s, const Ctx& c) {
+                       int m_trunk, int& f, Fetch<TIER>& fe, Stream& s, const CT& c) {
     using B = BProg<TIER>;
     Vec<TIER, 8> cur, nxt;
     // feat_out^T: d(pre-rgb) [3 of a 32-row tile] -> g_h, masked with h > 0
@@ -156,8 +157,8 @@ DFN_DEV void bwd_trunk(const BwdIn& in, Vec<TIER, 8>& dy0, Vec<TIER, 4>& gpd_ski
     dy0 = cur;
 }
 
-template <int TIER>
-DFN_DEV void bwd_head(const BwdIn& in, const BwdIO& io, Stream& s, const Ctx& c) {
+template <int TIER, class CT>
+DFN_DEV void bwd_head(const BwdIn& in, const BwdIO& io, Stream& s, const CT& c) {
     int f = 0;
     Fetch<TIER> fe;
     fe.prime(s, c);
@@ -166,8 +167,8 @@ DFN_DEV void bwd_head(const BwdIn& in, const BwdIO& io, Stream& s, const Ctx& c)
     bwd_trunk<TIER, false>(in, dy0, unused, io, GradMap::H_TRUNK, RecMap::H_MTRUNK, f, fe, s, c);
 }
 
-template <int TIER>
-DFN_DEV void bwd_torso(const BwdIn& in, const BwdIO& io, Stream& s, const Ctx& c) {
+template <int TIER, class CT>
+DFN_DEV void bwd_torso(const BwdIn& in, const BwdIO& io, Stream& s, const CT& c) {
     using B = BProg<TIER>;
     int f = 0;
     Fetch<TIER> fe;

@@ -128,59 +128,50 @@ DFN_DEV void slab_advance(Stream& s, lds_char* ring, int wave, int lane) {
 
 // ---- GEMM pieces ------------------------------------------------------------------------------------------
 // Training-mode recorder: the forward pass leaves what the backward kernels need (all null otherwise).
-//   act_T : feature-major activations [rows][NP] (bf16 / f32 by tier): the inputs of every GEMM, read by the
-//           weight-gradient GEMMs (contraction over the NP sample points);
+//   act_T : feature-major activations per 32-point tile, [tile][rows][32] (bf16 / f32 by tier): the inputs of
+//           every GEMM, read by the weight-gradient GEMMs (contraction over the sample points);
 //   masks : ReLU masks as bits, [pass][dword][64 lanes], read by the dX chain.
 struct Rec {
-    void* act_T;
+    void* act_T;    // tile-major: [pass][rows][32 points]; every store of a pass is base + compile-time offset
     unsigned* masks;
-    long NP;        // sample points of this field in the launch
-    long p0;        // point index of lane n = 0 of this wave's tile
-    long pass;      // tile (pass) index of this field, for the mask array
+    int rows;       // rows per tile of act_T for this field
+    long pass;      // tile (pass) index of this field = point / 32
     int mask_dwords;
 };
 
-struct Ctx {                // per-wave constants threaded through the ops
+template <bool REC> struct CtxT {   // per-wave constants threaded through the ops; REC = training recorder on
+    static constexpr bool rec_on = REC;
     lds_char* ring;
     int wave, lane, half;
     Rec rec;
 };
+typedef CtxT<false> Ctx;
 
 template <int TIER> struct ActT;
 template <> struct ActT<TIER_BF16> { typedef __bf16 type; };
 template <> struct ActT<TIER_F32> { typedef float type; };
 
-// store a B-operand vector feature-major: element (row0 + feature, p0 + n) of a [rows][NP] array.
-// 32-bit element offsets (rows * NP < 2^32 is checked by the host) off a uniform base, four rows at a time
-// with a scheduling fence in between: 128 scattered 2/4-byte stores must not turn into 128 live addresses.
-template <int TIER, int NT>
-DFN_DEV void store_vec_T(void* arr, long NP, long p0, int row0, const Vec<TIER, NT>& v, const Ctx& c) {
+// store a B-operand vector feature-major into a tile-major array [tile][rows][32]: element (row0 + feature, n).
+// All offsets from the tile base are compile-time constants.
+template <int TIER, int NT, class CT>
+DFN_DEV void store_vec_T(void* arr, int rows, long tile, int row0, const Vec<TIER, NT>& v, const CT& c) {
     typedef typename ActT<TIER>::type T;
-    T* base = (T*)arr;
-    const unsigned np = (unsigned)NP;
-    const unsigned off = (unsigned)(row0 + 4 * c.half) * np + (unsigned)p0 + (unsigned)(c.lane & 31);
+    T* base = (T*)arr + ((tile * rows + row0 + 4 * c.half) * 32 + (c.lane & 31));
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const unsigned o = off + (unsigned)(32 * t + 8 * q) * np;       // rows 32t + 8q + {0,1,2,3} (+4 upper half)
-            base[o] = (T)v.get(16 * t + 4 * q + 0);
-            base[o + np] = (T)v.get(16 * t + 4 * q + 1);
-            base[o + 2 * np] = (T)v.get(16 * t + 4 * q + 2);
-            base[o + 3 * np] = (T)v.get(16 * t + 4 * q + 3);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    for (int L = 0; L < 16 * NT; ++L) {
+        const int f = 32 * (L >> 4) + tile_feat(0, L & 15);      // + 4 for the upper half (in base)
+        base[f * 32] = (T)v.get(L);
     }
 }
-template <int TIER, int NT>
-DFN_DEV void rec_vec(const Ctx& c, int row0, const Vec<TIER, NT>& v) {
-    if (!c.rec.act_T) return;
-    store_vec_T<TIER, NT>(c.rec.act_T, c.rec.NP, c.rec.p0, row0, v, c);
+template <int TIER, int NT, class CT>
+DFN_DEV void rec_vec(const CT& c, int row0, const Vec<TIER, NT>& v) {
+    if constexpr (!CT::rec_on) return;
+    else store_vec_T<TIER, NT>(c.rec.act_T, c.rec.rows, c.rec.pass, row0, v, c);
 }
 // ReLU mask bits of a vector (bit L of this lane's words = local slot L is positive)
-template <int TIER, int NT>
-DFN_DEV void rec_mask(const Ctx& c, int dword0, const Vec<TIER, NT>& v) {
-    if (!c.rec.masks) return;
+template <int TIER, int NT, class CT>
+DFN_DEV void rec_mask(const CT& c, int dword0, const Vec<TIER, NT>& v) {
+    if constexpr (CT::rec_on)
 #pragma unroll
     for (int w = 0; w < (NT + 1) / 2; ++w) {
         unsigned bits = 0;
@@ -200,12 +191,12 @@ DFN_DEV void rec_mask(const Ctx& c, int dword0, const Vec<TIER, NT>& v) {
 constexpr int PF_DEPTH = 4;
 template <int TIER> struct Fetch {
     u32x4 buf[PF_DEPTH];
-    DFN_DEV void load(int slot, int fp, Stream& s, const Ctx& c) {
+    template <class CT> DFN_DEV void load(int slot, int fp, Stream& s, const CT& c) {
         if (fp % SLAB_FRAGS == 0) slab_advance<TIER>(s, c.ring, c.wave, c.lane);
         buf[slot] = *(const lds_u32x4*)(c.ring + c.lane * 16 + s.rd_off + (fp % SLAB_FRAGS) * FRAG_BYTES);
     }
     // start of a pass: fragments 0..PF_DEPTH-1
-    DFN_DEV void prime(Stream& s, const Ctx& c) {
+    template <class CT> DFN_DEV void prime(Stream& s, const CT& c) {
 #pragma unroll
         for (int i = 0; i < PF_DEPTH; ++i) load(i, i, s, c);
     }
@@ -214,9 +205,9 @@ template <int TIER> struct Fetch {
 // One tile-group: acc[g] (g < G output tiles) += W x b over k-units [0, KU) of b.
 // Fragments are consumed in stream order [ku][g]; `f` is the running fragment index of the pass.
 // TAIL: number of fragments that follow this group in the pass (-1 = plenty): no prefetch past the end.
-template <int TIER, int G, int KU, int NTB, int TAIL = -1>
+template <int TIER, int G, int KU, int NTB, int TAIL = -1, class CT>
 DFN_DEV void gemm_group(f32x16 (&acc)[G], const Vec<TIER, NTB>& b, int& f, Fetch<TIER>& fe, Stream& s,
-                        const Ctx& c) {
+                        const CT& c) {
 #pragma unroll
     for (int ku = 0; ku < KU; ++ku) {
 #pragma unroll
@@ -282,37 +273,59 @@ DFN_DEV void acc_to_vec(const f32x16 (&acc)[G], Vec<TIER, NT>& v, int t0) {
         }
 }
 
+// training recorder, per tile pair, straight from the accumulators (post-activation values as the next layer
+// sees them): rows row0 + {0..63} of act_T, and one dword of ReLU bits
+template <int TIER, bool RELU, class CT>
+DFN_DEV void rec_pair(const CT& c, int row0, int mask_dword, const f32x16 (&acc)[2]) {
+    if constexpr (CT::rec_on) {
+        typedef typename ActT<TIER>::type T;
+        if (row0 >= 0) {
+            T* base = (T*)c.rec.act_T + ((c.rec.pass * c.rec.rows + row0 + 4 * c.half) * 32 + (c.lane & 31));
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float x = acc[g][r];
+                    base[(32 * g + tile_feat(0, r)) * 32] = (T)(RELU ? relu_(x) : x);
+                }
+        }
+        if (mask_dword >= 0) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int b = 0; b < 32; ++b) bits |= (acc[b >> 4][b & 15] > 0.f) ? (1u << b) : 0u;
+            c.rec.masks[((long)c.rec.pass * c.rec.mask_dwords + mask_dword) * 64 + c.lane] = bits;
+        }
+    }
+}
+
 // out[OT tiles] = act( bias + W x in ), tile pairs; KU = k-units of `in` used
-template <int TIER, int OT, int KU, int NTB, bool RELU>
+template <int TIER, int OT, int KU, int NTB, bool RELU, class CT>
 DFN_DEV void layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_f32* bias, int& f, Fetch<TIER>& fe,
-                   Stream& s, const Ctx& c) {
+                   Stream& s, const CT& c, int rec_row = -1, int rec_mask = -1) {
     static_assert(OT % 2 == 0, "tile pairs");
 #pragma unroll
     for (int tg = 0; tg < OT / 2; ++tg) {
         f32x16 acc[2];
         acc_init<2>(acc, bias + tg * 64, c.half);
         gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c);
+        rec_pair<TIER, RELU>(c, rec_row < 0 ? -1 : rec_row + 64 * tg, rec_mask < 0 ? -1 : rec_mask + tg, acc);
         acc_to_vec<TIER, 2, OT, RELU>(acc, out, 2 * tg);
     }
 }
 // out = relu(bias + W x in) + bias2 + W2 x in2      (no activation after the skip)
-template <int TIER, int OT, int KU, int NTB, int KU2, int NTB2>
+template <int TIER, int OT, int KU, int NTB, int KU2, int NTB2, class CT>
 DFN_DEV void layer_skip(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_f32* bias,
                         const Vec<TIER, NTB2>& in2, const lds_f32* bias2, int& f, Fetch<TIER>& fe,
-                        Stream& s, const Ctx& c, int mask_dword0 = -1) {
+                        Stream& s, const CT& c, int rec_row = -1, int mask_dword0 = -1) {
 #pragma unroll
     for (int tg = 0; tg < OT / 2; ++tg) {
         f32x16 acc[2];
         acc_init<2>(acc, bias + tg * 64, c.half);
         gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c);
-        if (mask_dword0 >= 0 && c.rec.masks) {      // ReLU mask of the pre-skip activation (one dword per pair)
-            unsigned bits = 0;
-#pragma unroll
-            for (int b = 0; b < 32; ++b) bits |= (acc[b >> 4][b & 15] > 0.f) ? (1u << b) : 0u;
-            c.rec.masks[((long)c.rec.pass * c.rec.mask_dwords + mask_dword0 + tg) * 64 + c.lane] = bits;
-        }
+        rec_pair<TIER, false>(c, -1, mask_dword0 < 0 ? -1 : mask_dword0 + tg, acc);    // ReLU bits of the pre-skip value
         acc_relu_add<2>(acc, bias2 + tg * 64, c.half);
         gemm_group<TIER, 2, KU2, NTB2>(acc, in2, f, fe, s, c);
+        rec_pair<TIER, false>(c, rec_row < 0 ? -1 : rec_row + 64 * tg, -1, acc);        // post-skip value (no ReLU)
         acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);
     }
 }
@@ -426,36 +439,31 @@ DFN_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // shared trunk: L1..L3, L4+skip, L5..L7, view layer, rgb head.  `act` holds relu(first layer) on entry;
 // f_l1 is the slab phase (fragment index mod 32) at L1.
-template <int TIER, int NTP, int KUP>
+template <int TIER, int NTP, int KUP, class CT>
 DFN_DEV MlpOut mlp_trunk(Vec<TIER, 8>& act, const Vec<TIER, NTP>& pvec, const DhatRef& dref,
                          const lds_f32* bias, int b_l1, int b_skip, int b_l5, int b_view, int b_out,
-                         int f_l1, Fetch<TIER>& fe, Stream& s, const Ctx& c, int r_trunk, int m_trunk) {
+                         int f_l1, Fetch<TIER>& fe, Stream& s, const CT& c, int r_trunk, int m_trunk) {
     using P = Prog<TIER>;
     Vec<TIER, 8> nxt;
-    rec_vec<TIER, 8>(c, r_trunk + RecMap::T_A0, act);
-    rec_mask<TIER, 8>(c, m_trunk + RecMap::TM_A0, act);
-    // blocks[0..2]
+    // blocks[0..2]  (a0 itself was recorded by the caller's first layer)
     for (int l = 0; l < 3; ++l) {
         int f = f_l1;                                       // same slab phase every iteration
-        layer<TIER, 8, P::KU_ACT, 8, true>(nxt, act, bias + b_l1 + 256 * l, f, fe, s, c);
+        layer<TIER, 8, P::KU_ACT, 8, true>(nxt, act, bias + b_l1 + 256 * l, f, fe, s, c,
+                                           r_trunk + RecMap::T_A0 + 256 * (l + 1), m_trunk + RecMap::TM_A0 + 4 * (l + 1));
         act = nxt;
-        rec_vec<TIER, 8>(c, r_trunk + RecMap::T_A0 + 256 * (l + 1), act);
-        rec_mask<TIER, 8>(c, m_trunk + RecMap::TM_A0 + 4 * (l + 1), act);
     }
     int f = f_l1;
     // blocks[3], then the skip: relu(.) + fc_z_skips(z) + fc_p_skips(p)   (decoder.py:316-325)
     layer_skip<TIER, 8, P::KU_ACT, 8, KUP, NTP>(nxt, act, bias + b_l1 + 256 * 3, pvec, bias + b_skip, f, fe, s, c,
-                                                m_trunk + RecMap::TM_A4R);
+                                                r_trunk + RecMap::T_A0 + 256 * 4, m_trunk + RecMap::TM_A4R);
     act = nxt;
-    rec_vec<TIER, 8>(c, r_trunk + RecMap::T_A0 + 256 * 4, act);
     const int f_l5 = f % SLAB_FRAGS;
     // blocks[4..6]
     for (int l = 0; l < 3; ++l) {
         f = f_l5;
-        layer<TIER, 8, P::KU_ACT, 8, true>(nxt, act, bias + b_l5 + 256 * l, f, fe, s, c);
+        layer<TIER, 8, P::KU_ACT, 8, true>(nxt, act, bias + b_l5 + 256 * l, f, fe, s, c,
+                                           r_trunk + RecMap::T_A0 + 256 * (5 + l), m_trunk + RecMap::TM_A5 + 4 * l);
         act = nxt;
-        rec_vec<TIER, 8>(c, r_trunk + RecMap::T_A0 + 256 * (5 + l), act);
-        rec_mask<TIER, 8>(c, m_trunk + RecMap::TM_A5 + 4 * l, act);
     }
     // feat_view (+ sigma_out as row 0 of a 9th tile) on [act ; view PE]   (decoder.py:329-340)
     MlpOut o;
@@ -471,6 +479,7 @@ DFN_DEV MlpOut mlp_trunk(Vec<TIER, 8>& act, const Vec<TIER, NTP>& pvec, const Dh
             acc_init<2>(acc, bias + b_view + tg * 64, c.half);
             gemm_group<TIER, 2, P::KU_ACT, 8>(acc, act, f, fe, s, c);
             gemm_group<TIER, 2, P::KU_VIEW, 1>(acc, vview, f, fe, s, c);
+            rec_pair<TIER, true>(c, r_trunk + RecMap::T_H + 64 * tg, m_trunk + RecMap::TM_H + tg, acc);
             acc_to_vec<TIER, 2, 8, true>(acc, nxt, 2 * tg);
         }
         f32x16 acc1[1];
@@ -478,8 +487,6 @@ DFN_DEV MlpOut mlp_trunk(Vec<TIER, 8>& act, const Vec<TIER, NTP>& pvec, const Dh
         gemm_group<TIER, 1, P::KU_ACT, 8>(acc1, act, f, fe, s, c);
         gemm_group<TIER, 1, P::KU_VIEW, 1>(acc1, vview, f, fe, s, c);
         o.sigma = acc1[0][0];
-        rec_vec<TIER, 8>(c, r_trunk + RecMap::T_H, nxt);
-        rec_mask<TIER, 8>(c, m_trunk + RecMap::TM_H, nxt);
     }
     // feat_out + sigmoid   (decoder.py:344-347)
     {
@@ -494,9 +501,9 @@ DFN_DEV MlpOut mlp_trunk(Vec<TIER, 8>& act, const Vec<TIER, NTP>& pvec, const Dh
 }
 
 // ---- head pass: decoder.py:291-349 with head_or_torso == 'head' ----------------------------------------------
-template <int TIER>
+template <int TIER, class CT>
 DFN_DEV MlpOut mlp_head(const float (&p)[3], const DhatRef& dhat, const lds_f32* bias, Stream& s,
-                        const Ctx& c) {
+                        const CT& c) {
     using P = Prog<TIER>;
     Vec<TIER, 2> pe;
     posenc<TIER, 2, NPE>(pe, p, c.half);
@@ -505,15 +512,16 @@ DFN_DEV MlpOut mlp_head(const float (&p)[3], const DhatRef& dhat, const lds_f32*
     int f = 0;
     Fetch<TIER> fe;
     fe.prime(s, c);
-    layer<TIER, 8, P::KU_PE, 2, true>(act, pe, bias + P::H_B_IN, f, fe, s, c);
+    layer<TIER, 8, P::KU_PE, 2, true>(act, pe, bias + P::H_B_IN, f, fe, s, c, RecMap::H_TRUNK + RecMap::T_A0,
+                                      RecMap::H_MTRUNK + RecMap::TM_A0);
     return mlp_trunk<TIER, 2, P::KU_PE>(act, pe, dhat, bias, P::H_B_L1, P::H_B_SKIP, P::H_B_L5, P::H_B_VIEW,
                                         P::H_B_OUT, f % SLAB_FRAGS, fe, s, c, RecMap::H_TRUNK, RecMap::H_MTRUNK);
 }
 
 // ---- torso pass: deformation field (decoder.py:109-134, 297-299) then the trunk ---------------------------
-template <int TIER>
+template <int TIER, class CT>
 DFN_DEV MlpOut mlp_torso(const float (&p)[3], const DhatRef& dhat, const lds_f32* bias, Stream& s,
-                         const Ctx& c) {
+                         const CT& c) {
     using P = Prog<TIER>;
     Vec<TIER, 2> pe;
     posenc<TIER, 2, NPE>(pe, p, c.half);
@@ -522,39 +530,31 @@ DFN_DEV MlpOut mlp_torso(const float (&p)[3], const DhatRef& dhat, const lds_f32
     int f = 0;
     Fetch<TIER> fe;
     fe.prime(s, c);
-    // record(k, v): deformation vector k (0: ve0, 1: vs0, 2: ve1, ...) as GEMM input and its ReLU mask
-#define DFN_REC_D(k, v)                                   \
-    rec_vec<TIER, 2>(c, RecMap::S_D0 + 64 * (k), v);       \
-    rec_mask<TIER, 2>(c, RecMap::S_MD0 + (k), v)
-    layer<TIER, 2, P::KU_PE, 2, true>(ve, pe, bias + P::T_B_E0, f, fe, s, c);  DFN_REC_D(0, ve);
-    layer<TIER, 2, P::KU_PE, 2, true>(vs, pe, bias + P::T_B_S0, f, fe, s, c);  DFN_REC_D(1, vs);
-    layer<TIER, 2, P::KU_D, 2, true>(vn, ve, bias + P::T_B_E1, f, fe, s, c);  ve = vn;  DFN_REC_D(2, ve);
-    layer<TIER, 2, P::KU_D, 2, true>(vn, vs, bias + P::T_B_S1, f, fe, s, c);  vs = vn;  DFN_REC_D(3, vs);
-    layer<TIER, 2, P::KU_D, 2, true>(vn, ve, bias + P::T_B_E2, f, fe, s, c);  ve = vn;  DFN_REC_D(4, ve);
-    layer<TIER, 2, P::KU_D, 2, true>(vn, vs, bias + P::T_B_S2, f, fe, s, c);  vs = vn;  DFN_REC_D(5, vs);
+    // deformation vector k (0: ve0, 1: vs0, 2: ve1, ...) is recorded as the next GEMM's input, with its ReLU bits
+#define DFN_RD(k) RecMap::S_D0 + 64 * (k), RecMap::S_MD0 + (k)
+    layer<TIER, 2, P::KU_PE, 2, true>(ve, pe, bias + P::T_B_E0, f, fe, s, c, DFN_RD(0));
+    layer<TIER, 2, P::KU_PE, 2, true>(vs, pe, bias + P::T_B_S0, f, fe, s, c, DFN_RD(1));
+    layer<TIER, 2, P::KU_D, 2, true>(vn, ve, bias + P::T_B_E1, f, fe, s, c, DFN_RD(2));  ve = vn;
+    layer<TIER, 2, P::KU_D, 2, true>(vn, vs, bias + P::T_B_S1, f, fe, s, c, DFN_RD(3));  vs = vn;
+    layer<TIER, 2, P::KU_D, 2, true>(vn, ve, bias + P::T_B_E2, f, fe, s, c, DFN_RD(4));  ve = vn;
+    layer<TIER, 2, P::KU_D, 2, true>(vn, vs, bias + P::T_B_S2, f, fe, s, c, DFN_RD(5));  vs = vn;
     // skips join after the ReLU of layer idx 3 (decoder.py:118-119, 128-129)
     layer_skip<TIER, 2, P::KU_D, 2, P::KU_PE, 2>(vn, ve, bias + P::T_B_E3, pe, bias + P::T_B_ESKIP, f, fe, s, c,
-                                                 RecMap::S_MD0 + 6);
+                                                 DFN_RD(6));
     ve = vn;
-    rec_vec<TIER, 2>(c, RecMap::S_D0 + 64 * 6, ve);
     {   // signal net: its skip input is the per-frame pose signal -> a constant added after the ReLU
         f32x16 acc[2];
         acc_init<2>(acc, bias + P::T_B_S3, c.half);
         gemm_group<TIER, 2, P::KU_D, 2>(acc, vs, f, fe, s, c);
-        if (c.rec.masks) {
-            unsigned bits = 0;
-#pragma unroll
-            for (int b = 0; b < 32; ++b) bits |= (acc[b >> 4][b & 15] > 0.f) ? (1u << b) : 0u;
-            c.rec.masks[((long)c.rec.pass * c.rec.mask_dwords + RecMap::S_MD0 + 7) * 64 + c.lane] = bits;
-        }
+        rec_pair<TIER, false>(c, -1, RecMap::S_MD0 + 7, acc);
         acc_relu_add<2>(acc, bias + P::T_B_SSKIP, c.half);
+        rec_pair<TIER, false>(c, RecMap::S_D0 + 64 * 7, -1, acc);
         acc_to_vec<TIER, 2, 2, false>(acc, vn, 0);
         vs = vn;
-        rec_vec<TIER, 2>(c, RecMap::S_D0 + 64 * 7, vs);
     }
-    layer<TIER, 2, P::KU_D, 2, true>(vn, ve, bias + P::T_B_E4, f, fe, s, c);  ve = vn;  DFN_REC_D(8, ve);
-    layer<TIER, 2, P::KU_D, 2, true>(vn, vs, bias + P::T_B_S4, f, fe, s, c);  vs = vn;  DFN_REC_D(9, vs);
-#undef DFN_REC_D
+    layer<TIER, 2, P::KU_D, 2, true>(vn, ve, bias + P::T_B_E4, f, fe, s, c, DFN_RD(8));  ve = vn;
+    layer<TIER, 2, P::KU_D, 2, true>(vn, vs, bias + P::T_B_S4, f, fe, s, c, DFN_RD(9));  vs = vn;
+#undef DFN_RD
     // p = deform(p) + p  (decoder.py:299): PE column j sits in the register where the GEMM leaves output
     // j (identity slot map); the signal half of the residual is folded into the SO bias by the fold kernel.
     Vec<TIER, 4> pd;      // tiles 0,1: deformed PE (60 valid); tiles 2,3: deformed pose signal (42 valid)
@@ -571,7 +571,8 @@ DFN_DEV MlpOut mlp_torso(const float (&p)[3], const DhatRef& dhat, const lds_f32
     }
     rec_vec<TIER, 4>(c, RecMap::S_PD, pd);
     Vec<TIER, 8> act;
-    layer<TIER, 8, P::KU_PD, 4, true>(act, pd, bias + P::T_B_IN, f, fe, s, c);
+    layer<TIER, 8, P::KU_PD, 4, true>(act, pd, bias + P::T_B_IN, f, fe, s, c, RecMap::S_TRUNK + RecMap::T_A0,
+                                      RecMap::S_MTRUNK + RecMap::TM_A0);
     return mlp_trunk<TIER, 4, P::KU_PD>(act, pd, dhat, bias, P::T_B_L1, P::T_B_SKIP, P::T_B_L5, P::T_B_VIEW,
                                         P::T_B_OUT, f % SLAB_FRAGS, fe, s, c, RecMap::S_TRUNK, RecMap::S_MTRUNK);
 }

@@ -116,7 +116,7 @@ template <int TIER> struct KernelLds {
 // ================================================================================================
 // Frame renderer
 // ================================================================================================
-template <int TIER, bool TWO>
+template <int TIER, bool TWO, bool TRAIN>
 __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 256) void render_kernel(
     const RenderArgs A) {
     using C = TierCfg<TIER>;
@@ -129,9 +129,7 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     const int n = lane & 31;
     const DfnFrame& F = A.frame;
     lds_char* lds = (lds_char*)smem;
-    Ctx ctx = {lds, wave, lane, lane >> 5, {}};
-    ctx.rec.act_T = nullptr;
-    ctx.rec.masks = nullptr;
+    CtxT<TRAIN> ctx = {lds, wave, lane, lane >> 5, {}};
 
     Stream s;
     s.base[0] = A.wblob[0];
@@ -218,28 +216,24 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
                 float p[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) p[k] = add_(st[RS_OH + k], mul_(st[RS_DH + k], z));
-                if (A.act_T[0] && valid && stage == 0) {
-                    ctx.rec = {A.act_T[0], A.masks[0], A.NP, (long)r_raw * 64 + tile * 32, (long)r_raw * 2 + tile,
-                               RecMap::H_MDWORDS};
+                if constexpr (TRAIN) {      // idle waves (ray >= ray_count) record into the last ray's slots: same values
+                    const long rr = valid ? r_raw : F.ray_count - 1;
+                    ctx.rec = {A.act_T[0], A.masks[0], RecMap::H_ROWS, rr * 2 + tile, RecMap::H_MDWORDS};
                 }
                 a = mlp_head<TIER>(p, dref_h, bias_h, s, ctx);
-                ctx.rec.act_T = nullptr;
-                ctx.rec.masks = nullptr;
             }
             if (two) {
                 const float z = ((volatile lds_f32*)zall)[si];
                 float p[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) p[k] = add_(st[RS_OT + k], mul_(st[RS_DT + k], z));
-                if (A.act_T[1] && valid && stage == 0) {
-                    ctx.rec = {A.act_T[1], A.masks[1], A.NP, (long)r_raw * 64 + tile * 32, (long)r_raw * 2 + tile,
-                               RecMap::S_MDWORDS};
+                if constexpr (TRAIN) {
+                    const long rr = valid ? r_raw : F.ray_count - 1;
+                    ctx.rec = {A.act_T[1], A.masks[1], RecMap::S_ROWS, rr * 2 + tile, RecMap::S_MDWORDS};
                 }
                 b = mlp_torso<TIER>(p, dref_t, bias_t, s, ctx);
-                ctx.rec.act_T = nullptr;
-                ctx.rec.masks = nullptr;
             }
-            if (A.samples_out && valid && stage == 0 && lane < 32) {
+            if (TRAIN && valid && lane < 32) {
                 float* so = A.samples_out + ((size_t)r_raw * 64 + si) * 8;
                 so[0] = a.sigma; so[1] = a.r; so[2] = a.g; so[3] = a.b;
                 so[4] = b.sigma; so[5] = b.r; so[6] = b.g; so[7] = b.b;
@@ -428,17 +422,17 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
 template <typename K> static hipError_t set_lds(K kernel, int lds) {
     return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
-template <int TIER, bool TWO> static hipError_t launch_render_t(const RenderArgs& A, hipStream_t st) {
+template <int TIER, bool TWO, bool TRAIN = false> static hipError_t launch_render_t(const RenderArgs& A, hipStream_t st) {
     using C = TierCfg<TIER>;
     const int lds = KernelLds<TIER>::TOTAL;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = set_lds(render_kernel<TIER, TWO>, lds);
+        hipError_t e = set_lds(render_kernel<TIER, TWO, TRAIN>, lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     const int blocks = (A.frame.ray_count + C::WAVES - 1) / C::WAVES;
-    hipLaunchKernelGGL((render_kernel<TIER, TWO>), dim3(blocks), dim3(C::THREADS), lds, st, A);
+    hipLaunchKernelGGL((render_kernel<TIER, TWO, TRAIN>), dim3(blocks), dim3(C::THREADS), lds, st, A);
     return hipGetLastError();
 }
 template <int TIER, bool TORSO> static hipError_t launch_decoder_t(const DecoderArgs& A, hipStream_t st) {
@@ -458,6 +452,10 @@ template <int TIER, bool TORSO> static hipError_t launch_decoder_t(const Decoder
 
 hipError_t launch_render(int tier, const RenderArgs& A, hipStream_t st) {
     const bool two = A.frame.fields == 2;
+    if (A.samples_out) {     // training step: two fields, coarse only, recorder on
+        return tier == TIER_BF16 ? launch_render_t<TIER_BF16, true, true>(A, st)
+                                 : launch_render_t<TIER_F32, true, true>(A, st);
+    }
     if (tier == TIER_BF16)
         return two ? launch_render_t<TIER_BF16, true>(A, st) : launch_render_t<TIER_BF16, false>(A, st);
     return two ? launch_render_t<TIER_F32, true>(A, st) : launch_render_t<TIER_F32, false>(A, st);

@@ -12,7 +12,7 @@ struct MlpBwdArgs {
     const float* samples;       // [NP][8] forward outputs (sigma_h, rgb_h, sigma_t, rgb_t)
     const float* dsamples;      // [NP][8] gradients w.r.t. them
     const unsigned* masks;      // forward ReLU bits of the field
-    void* dy_T;                 // out: [rows][NP] pre-activation gradients, feature-major
+    void* dy_T;                 // out: tile-major [NP/32][rows][32] pre-activation gradients
     long NP;
 };
 
@@ -34,10 +34,10 @@ struct WOp {                    // one weight-gradient GEMM: C[M x N] = dy_T[a_r
 hipError_t launch_mlp_bwd(int tier, int field, const MlpBwdArgs& A, hipStream_t st);
 void bwd_program_info(int tier, int field, ProgramInfo* out);
 hipError_t launch_composite_bwd(const CompositeBwdArgs& A, hipStream_t st);
-hipError_t launch_wgrad(int tier, const WOp* ops_dev, int n_ops, const int* prefix_dev, int total_items,
+hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, const int* prefix_dev, int total_items,
                         const void* dy_T, const void* act_T, long NP, int ksplit, float* C, hipStream_t st);
 hipError_t launch_scatter_add(const int* map, const float* dense, long n, float* grad_flat, hipStream_t st);
-hipError_t launch_bias_grad(int tier, const int* row_of, int n, const void* dy_T, long NP, float* dbias,
+hipError_t launch_bias_grad(int tier, int field, const int* row_of, int n, const void* dy_T, long NP, float* dbias,
                             hipStream_t st);
 
 }  // namespace dfn

@@ -23,9 +23,7 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     lds_char* lds = (lds_char*)smem;
-    Ctx ctx = {lds, wave, lane, lane >> 5, {}};
-    ctx.rec.act_T = nullptr;
-    ctx.rec.masks = nullptr;
+    const Ctx ctx = {lds, wave, lane, lane >> 5, {}};
     Stream s;
     s.base[0] = s.base[1] = A.wblob_T;
     s.nslab[0] = s.nslab[1] = A.nslab;
@@ -50,8 +48,7 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     BwdIO io;
     io.dy_T = A.dy_T;
     io.masks = A.masks;
-    io.NP = A.NP;
-    io.p0 = tile * 32;
+    io.rows = TORSO ? GradMap::S_ROWS : GradMap::H_ROWS;
     io.pass = tile;
     io.mask_dwords = TORSO ? RecMap::S_MDWORDS : RecMap::H_MDWORDS;
     __syncthreads();
@@ -243,7 +240,8 @@ hipError_t launch_composite_bwd(const CompositeBwdArgs& A, hipStream_t st) {
 // ================================================================================================
 template <int TIER>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, const int* work_prefix, const void* dy_T,
-                                                    const void* act_T, long NP, int ksplit, float* C) {
+                                                    const void* act_T, long n_tiles, int g_rows, int a_rows,
+                                                    int ksplit, float* C) {
     typedef typename ActT<TIER>::type T;
     const int lane = threadIdx.x & 63;
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -256,27 +254,33 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
     const int ks = (int)(loc % ksplit);
     loc /= ksplit;
     const int nt = (int)(loc % nt_n), mt = (int)(loc / nt_n);
-    const long per = NP / ksplit;
-    const long k0 = ks * per, k1 = k0 + per;
-    const T* a = (const T*)dy_T + (long)(o.a_row + 32 * mt + (lane & 31)) * NP;
-    const T* b = (const T*)act_T + (long)(o.b_row + 32 * nt + (lane & 31)) * NP;
+    const long per = (n_tiles + ksplit - 1) / ksplit;
+    const long t0 = ks * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
+    // tile-major operands: row r of tile t starts at (t * rows + r) * 32
+    const T* a = (const T*)dy_T + (long)(o.a_row + 32 * mt + (lane & 31)) * 32;
+    const T* b = (const T*)act_T + (long)(o.b_row + 32 * nt + (lane & 31)) * 32;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    if constexpr (TIER == TIER_BF16) {
-        const int ko = 8 * (lane >> 5);
-        for (long k = k0; k < k1; k += 16) {
-            const bf16x8 av = *(const bf16x8*)(a + k + ko);
-            const bf16x8 bv = *(const bf16x8*)(b + k + ko);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
-        }
-    } else {
-        const int h = lane >> 5;
-        for (long k = k0; k < k1; k += 4) {
-            const f32x4 av = *(const f32x4*)(a + k);
-            const f32x4 bv = *(const f32x4*)(b + k);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? av[1] : av[0], h ? bv[1] : bv[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? av[3] : av[2], h ? bv[3] : bv[2], acc, 0, 0, 0);
+    const int h = lane >> 5;
+    for (long t = t0; t < t1; ++t) {
+        const T* at = a + t * (long)g_rows * 32;
+        const T* bt = b + t * (long)a_rows * 32;
+        if constexpr (TIER == TIER_BF16) {
+#pragma unroll
+            for (int k = 0; k < 32; k += 16) {
+                const bf16x8 av = *(const bf16x8*)(at + k + 8 * h);
+                const bf16x8 bv = *(const bf16x8*)(bt + k + 8 * h);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 32; k += 4) {
+                const f32x4 av = *(const f32x4*)(at + k);
+                const f32x4 bv = *(const f32x4*)(bt + k);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? av[1] : av[0], h ? bv[1] : bv[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? av[3] : av[2], h ? bv[3] : bv[2], acc, 0, 0, 0);
+            }
         }
     }
     float* c = C + o.c_off;
@@ -286,15 +290,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
         atomicAdd(c + (long)row * o.N + col, acc[r]);
     }
 }
-hipError_t launch_wgrad(int tier, const WOp* ops_dev, int n_ops, const int* prefix_dev, int total_items,
+hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, const int* prefix_dev, int total_items,
                         const void* dy_T, const void* act_T, long NP, int ksplit, float* C, hipStream_t st) {
     const int blocks = (total_items + 3) / 4;
+    const bool torso = field == FIELD_TORSO;
+    const int g_rows = torso ? GradMap::S_ROWS : GradMap::H_ROWS, a_rows = torso ? RecMap::S_ROWS : RecMap::H_ROWS;
     if (tier == TIER_BF16)
         hipLaunchKernelGGL(wgrad_kernel<TIER_BF16>, dim3(blocks), dim3(256), 0, st, ops_dev, n_ops, prefix_dev, dy_T,
-                           act_T, NP, ksplit, C);
+                           act_T, NP / 32, g_rows, a_rows, ksplit, C);
     else
         hipLaunchKernelGGL(wgrad_kernel<TIER_F32>, dim3(blocks), dim3(256), 0, st, ops_dev, n_ops, prefix_dev, dy_T,
-                           act_T, NP, ksplit, C);
+                           act_T, NP / 32, g_rows, a_rows, ksplit, C);
     return hipGetLastError();
 }
 
@@ -310,28 +316,31 @@ hipError_t launch_scatter_add(const int* map, const float* dense, long n, float*
     return hipGetLastError();
 }
 
-// d(bias blob)[e] = sum over points of dy_T[row_of[e]][:]
+// d(bias blob)[e] = sum over points of dy_T[.., row_of[e], ..]   (tile-major array)
 template <typename T>
-__global__ void bias_grad_kernel(const int* row_of, const T* dy_T, long NP, float* dbias) {
+__global__ void bias_grad_kernel(const int* row_of, const T* dy_T, long n_tiles, int rows, float* dbias) {
     __shared__ float red[4];
     const int e = blockIdx.x;
     const int row = row_of[e];
     float acc = 0.f;
     if (row >= 0) {
-        const T* p = dy_T + (long)row * NP;
-        for (long k = threadIdx.x; k < NP; k += 256) acc += (float)p[k];
+        const int n = threadIdx.x & 31;
+        for (long t = threadIdx.x >> 5; t < n_tiles; t += 8) acc += (float)dy_T[(t * rows + row) * 32 + n];
     }
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) dbias[e] = red[0] + red[1] + red[2] + red[3];
 }
-hipError_t launch_bias_grad(int tier, const int* row_of, int n, const void* dy_T, long NP, float* dbias,
+hipError_t launch_bias_grad(int tier, int field, const int* row_of, int n, const void* dy_T, long NP, float* dbias,
                             hipStream_t st) {
+    const int rows = field == FIELD_TORSO ? GradMap::S_ROWS : GradMap::H_ROWS;
     if (tier == TIER_BF16)
-        hipLaunchKernelGGL(bias_grad_kernel<__bf16>, dim3(n), dim3(256), 0, st, row_of, (const __bf16*)dy_T, NP, dbias);
+        hipLaunchKernelGGL(bias_grad_kernel<__bf16>, dim3(n), dim3(256), 0, st, row_of, (const __bf16*)dy_T, NP / 32,
+                           rows, dbias);
     else
-        hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(n), dim3(256), 0, st, row_of, (const float*)dy_T, NP, dbias);
+        hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(n), dim3(256), 0, st, row_of, (const float*)dy_T, NP / 32, rows,
+                           dbias);
     return hipGetLastError();
 }
 
