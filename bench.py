@@ -39,6 +39,9 @@ WORKLOADS = {
     "c1": (0, 1, "Obama head NeRF, 450x450, coarse-only 64 samples/ray (configs[0] geometry, on GPU)"),
     "c2": (128, 1, "Obama head NeRF inference, 450x450, 64+128 hierarchical (configs[1])"),
     "c3": (128, 2, "Obama head+torso two-NeRF composite render, 450x450, 64+128 (configs[2])"),
+    # training step (configs[3]): reference semantics = coarse 64 samples, both fields, fwd+bwd, 5 gated Adams;
+    # data parallel: every rank draws its own frame + 2048 rays (weak scaling), one flat-bucket all_reduce
+    "c4": (0, 2, "Obama training step (fwd+bwd, Adam), N_rand=2048 per GPU, data-parallel RCCL grad all-reduce (configs[3])"),
 }
 
 
@@ -91,6 +94,88 @@ def cpu_baseline(args, sc, st, zs, za, n_fine, fields):
                       f"torch {torch.__version__} CPU, {cores} threads, {t_used:.1f} s"}
 
 
+def bench_training(args, world, rank, local, dev, desc):
+    """configs[3]: one optimisation step per `step`: signals -> fold -> fused HIP forward (recorder on) -> MSE
+    losses -> HIP backward (compositing, dX chain, weight-gradient GEMMs) -> flat-bucket all_reduce -> gated Adams."""
+    from dfanerf import nets, parallel, run_nerf, synth, training
+    from dfanerf.decoder import Decoder
+    N_RAND = 2048
+    sc = synth.bench_scene(0, n_frames=8)
+    st = synth.synth_all_states(0)
+    H, W = sc["H"], sc["W"]
+    t = lambda x: torch.from_numpy(np.asarray(x))
+    mods = {"decoder": Decoder(z_dim=256, hidden_size=256, dim_signal=96, use_deformation_field=True),
+            "AudNet": nets.AudioNet_W2L(), "ExpNet": nets.ExpressionEnc(), "AudAttNet": nets.AudioAttNet(96, 4),
+            "PoseAttNet": nets.AudioAttNet(42, 8)}
+    for k, m in mods.items():
+        m.load_state_dict({kk: t(v) for kk, v in st[k].items()})
+        m.to(dev)
+    a = run_nerf.config_parser().parse_args(
+        f"--expname b --concate_bg --N_rand={N_RAND} --sample_rate=0 --smo_size=4 --smo_torse_size 8 --use_et_embed "
+        "--dim_signal=96 --dim_aud=96 --n_object=1 --use_deformation_field --noexp_iters 400000".split())
+    ds = [{"auds": t(sc["aud"]).to(dev), "exp": t(sc["exp"]).to(dev), "poses": t(sc["poses"]).to(dev),
+           "bc_img": (t(sc["bg"]).float() / 255.0).to(dev), "hwfcxy": [H, W, sc["focal"], sc["cx"], sc["cy"]],
+           "near": sc["near"], "far": sc["far"]}]
+    zs, za = [t(v).to(dev) for v in synth.synth_latents(0)]
+    embed_fn, _ = nets.get_embedder(3, 0)
+    opts = {k: torch.optim.Adam(m.parameters(), lr=5e-4, betas=(0.9, 0.999)) for k, m in mods.items()}
+    buf = training.TrainBuffers(args.tier, N_RAND, dev)
+    bucket = parallel.FlatGradBucket(list(mods.values())) if world > 1 else None
+    rng = np.random.RandomState(100 + rank)
+    tgt_h = torch.rand(H, W, 3, device=dev)
+    tgt_c = torch.rand(H, W, 3, device=dev)
+    gstep = 300000                                   # all five optimizers' gates exercised except ExpNet
+
+    def step():
+        img_i = int(rng.randint(0, 8))
+        sel = run_nerf.select_coords(H, W, N_RAND, 0, None, rng)
+        ys, xs = t(sel[:, 0]).to(dev), t(sel[:, 1]).to(dev)
+        loss, *_ = run_nerf.train_step_loss_hip(mods, ds, 0, img_i, sel, tgt_h[ys, xs], tgt_c[ys, xs], zs, za, gstep, a,
+                                                8, embed_fn, ds[0]["poses"][0], buf)
+        for o in opts.values():
+            o.zero_grad()
+        loss.backward()
+        if bucket is not None:
+            bucket.all_reduce_()
+        run_nerf.optimizer_steps(opts, gstep, a)
+        run_nerf.update_lrate(opts, gstep, a)
+        return loss
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert torch.isfinite(loss)
+    if rank == 0:
+        flop_ray = 3 * 64 * (FLOP_PT_HEAD + FLOP_PT_TORSO)          # fwd + 2x bwd, SURVEY.md 8(d)
+        ach = flop_ray * N_RAND * world * args.steps / dt / 1e12
+        print(json.dumps({
+            "metric": "training rays/sec (whole node), N_rand=2048 per GPU, 64 coarse samples, 2 fields, fwd+bwd+Adam",
+            "value": N_RAND * world * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.tier, "data": "synthetic",
+            "config": {"workload": desc, "H": H, "W": W, "N_rand_per_gpu": N_RAND, "n_coarse": 64, "fields": 2,
+                       "parallelism": f"dp{world}, one flat-bucket all_reduce (1,138,656 floats)"},
+            "roofline": {"bound": "mfma", "kernel": "whole step (render_kernel<train> + mlp_bwd + wgrad)",
+                         "achieved": ach, "peak": PEAK_TFLOPS[args.tier] * world, "unit": "TFLOP/s",
+                         "frac": ach / (PEAK_TFLOPS[args.tier] * world), "traffic": None, "flop_per_ray": flop_ray}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     n_fine, fields, desc = WORKLOADS[args.workload]
@@ -104,6 +189,9 @@ def main():
         print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}; using {world}", file=sys.stderr)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+
+    if args.workload == "c4":
+        return bench_training(args, world, rank, local, dev, desc)
 
     from dfanerf import engine, nets, synth
     F = 8                                              # frames of the audio-driven sequence (configs[4] batch)
