@@ -74,21 +74,23 @@ struct Stream {
     unsigned pf_slot;        // ring slot the next prefetch lands in
     unsigned rd_off;         // LDS byte offset (within the ring) of the slab being consumed
     unsigned rd_slot;
+    int pf_owed;             // pieces of the slab two ahead still to be issued
+#ifdef DFN_TIMING
+    unsigned long long t_wait, t_bar, t_issue;
+#endif
 };
 
+// One LDS-DMA piece: this wave's k-th 1 KiB fragment of the slab the prefetch cursor points at.
 template <int TIER>
-DFN_DEV void stream_issue(Stream& s, lds_char* ring, int wave, int lane) {
+DFN_DEV void stream_issue_piece(const Stream& s, lds_char* ring, int wave, int lane, int k) {
     using C = TierCfg<TIER>;
-    const char* src = s.pf_ptr + (size_t)lane * 16;
-    lds_char* dst = ring + s.pf_slot * SLAB_BYTES;
-#pragma unroll
-    for (int k = 0; k < C::LOADS_PER_SLAB; ++k) {
-        const int f = k * C::WAVES + wave;
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(src + f * FRAG_BYTES),
-            (DFN_LDS void*)(dst + f * FRAG_BYTES), 16, 0, 0);
-    }
-    // advance the cursor (cyclic: running past the last pass just re-reads the first slabs)
+    const int f = k * C::WAVES + wave;
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(s.pf_ptr + (size_t)lane * 16 + f * FRAG_BYTES),
+        (DFN_LDS void*)(ring + s.pf_slot * SLAB_BYTES + f * FRAG_BYTES), 16, 0, 0);
+}
+// advance the prefetch cursor to the next slab (cyclic: running past the last pass just re-reads the first slabs)
+DFN_DEV void stream_cursor_next(Stream& s) {
     s.pf_slot = (s.pf_slot + 1 == RING_SLOTS) ? 0u : s.pf_slot + 1;
     s.pf_ptr += SLAB_BYTES;
     if (--s.pf_left == 0) {
@@ -96,6 +98,23 @@ DFN_DEV void stream_issue(Stream& s, lds_char* ring, int wave, int lane) {
         const int f = s.two_fields ? (s.pf_pass & 1) : 0;
         s.pf_ptr = s.base[f];
         s.pf_left = s.nslab[f];
+    }
+}
+template <int TIER>
+DFN_DEV void stream_issue(Stream& s, lds_char* ring, int wave, int lane) {
+#pragma unroll
+    for (int k = 0; k < TierCfg<TIER>::LOADS_PER_SLAB; ++k) stream_issue_piece<TIER>(s, ring, wave, lane, k);
+    stream_cursor_next(s);
+}
+// A pass whose last slab is partial stops reading fragments before every piece of the slab two ahead went out:
+// the next pass issues the rest before its first fragment (pass boundaries only).
+template <int TIER>
+DFN_DEV void stream_flush(Stream& s, lds_char* ring, int wave, int lane) {
+    constexpr int L = TierCfg<TIER>::LOADS_PER_SLAB;
+    if (s.pf_owed > 0) {
+        for (int k = L - s.pf_owed; k < L; ++k) stream_issue_piece<TIER>(s, ring, wave, lane, k);
+        stream_cursor_next(s);
+        s.pf_owed = 0;
     }
 }
 
@@ -107,23 +126,36 @@ DFN_DEV void stream_begin(Stream& s, lds_char* ring, int wave, int lane) {
     s.pf_slot = 0;
     s.rd_slot = RING_SLOTS - 1;     // the first slab_advance moves it to slot 0
     s.rd_off = 0;
+    s.pf_owed = 0;
     stream_issue<TIER>(s, ring, wave, lane);     // slab 0
     stream_issue<TIER>(s, ring, wave, lane);     // slab 1
 }
 
-// Called by every wave right before it reads the first fragment of the next slab.
+// Called by every wave right before it reads the first fragment of the next slab (slab g).  The DMA of slab g+2
+// (into the slot slab g-1 releases here) is NOT issued here: a burst of 32 loads per CU right behind the barrier
+// keeps the vector-memory issue path busy for ~500 cycles during which no wave can issue an MFMA (in-order
+// issue).  Its pieces are spread over the fragment reads of slab g instead (Fetch::load).
 template <int TIER>
 DFN_DEV void slab_advance(Stream& s, lds_char* ring, int wave, int lane) {
     using C = TierCfg<TIER>;
-    // my share of the slab about to be consumed has landed (only the next slab's loads are younger)
-    // ... and my fragment reads of the slab being released have returned (the DMA issued below reuses
-    // its slot; the compiler knows nothing about that hazard)
+    // my share of slab g has landed (only slab g+1's pieces are younger), and my fragment reads of slab g-1 have
+    // returned (its slot is refilled during slab g; the compiler knows nothing about that hazard)
+#ifdef DFN_TIMING
+    const unsigned long long t0 = __builtin_readcyclecounter();
+#endif
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::LOADS_PER_SLAB) : "memory");
-    __builtin_amdgcn_s_barrier();   // everyone's share landed; everyone is done with the previous slab
+#ifdef DFN_TIMING
+    const unsigned long long t1 = __builtin_readcyclecounter();
+#endif
+    __builtin_amdgcn_s_barrier();   // everyone's share landed; everyone is done with slab g-1
     asm volatile("" ::: "memory");
+#ifdef DFN_TIMING
+    const unsigned long long t2 = __builtin_readcyclecounter();
+    s.t_wait += t1 - t0; s.t_bar += t2 - t1;
+#endif
     s.rd_slot = (s.rd_slot + 1 == RING_SLOTS) ? 0u : s.rd_slot + 1;
     s.rd_off = s.rd_slot * SLAB_BYTES;
-    stream_issue<TIER>(s, ring, wave, lane);     // two slabs ahead, into the slot just released
+    s.pf_owed += C::LOADS_PER_SLAB;
 }
 
 // ---- GEMM pieces ------------------------------------------------------------------------------------------
@@ -192,11 +224,20 @@ constexpr int PF_DEPTH = 4;
 template <int TIER> struct Fetch {
     u32x4 buf[PF_DEPTH];
     template <class CT> DFN_DEV void load(int slot, int fp, Stream& s, const CT& c) {
+        using C = TierCfg<TIER>;
+        constexpr int GAP = SLAB_FRAGS / C::LOADS_PER_SLAB;       // fragment reads between two DMA pieces
         if (fp % SLAB_FRAGS == 0) slab_advance<TIER>(s, c.ring, c.wave, c.lane);
         buf[slot] = *(const lds_u32x4*)(c.ring + c.lane * 16 + s.rd_off + (fp % SLAB_FRAGS) * FRAG_BYTES);
+        if (fp % GAP == GAP / 2) {                                 // one piece of the slab two ahead
+            const int k = (fp % SLAB_FRAGS) / GAP;                 // compile-time
+            stream_issue_piece<TIER>(s, c.ring, c.wave, c.lane, k);
+            --s.pf_owed;
+            if (k == C::LOADS_PER_SLAB - 1) stream_cursor_next(s);
+        }
     }
     // start of a pass: fragments 0..PF_DEPTH-1
     template <class CT> DFN_DEV void prime(Stream& s, const CT& c) {
+        stream_flush<TIER>(s, c.ring, c.wave, c.lane);
 #pragma unroll
         for (int i = 0; i < PF_DEPTH; ++i) load(i, i, s, c);
     }

@@ -137,6 +137,12 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     s.nslab[0] = A.nslab[0];
     s.nslab[1] = A.nslab[1];
     s.two_fields = TWO;
+#ifdef DFN_TIMING
+    s.t_wait = s.t_bar = s.t_issue = 0;
+    unsigned long long T_mlp = 0, T_pdf = 0;
+    const unsigned long long T_start = __builtin_readcyclecounter();
+    const unsigned long long R_start = __builtin_amdgcn_s_memrealtime();
+#endif
     stream_begin<TIER>(s, lds, wave, lane);
     {
         lds_f32* bl = (lds_f32*)(lds + L::BIAS_H);
@@ -220,7 +226,13 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
                     const long rr = valid ? r_raw : F.ray_count - 1;
                     ctx.rec = {A.act_T[0], A.masks[0], RecMap::H_ROWS, rr * 2 + tile, RecMap::H_MDWORDS};
                 }
+#ifdef DFN_TIMING
+                const unsigned long long tm0 = __builtin_readcyclecounter();
+#endif
                 a = mlp_head<TIER>(p, dref_h, bias_h, s, ctx);
+#ifdef DFN_TIMING
+                T_mlp += __builtin_readcyclecounter() - tm0;
+#endif
             }
             if (two) {
                 const float z = ((volatile lds_f32*)zall)[si];
@@ -275,6 +287,9 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
             }
         }
 
+#ifdef DFN_TIMING
+        const unsigned long long tp0 = __builtin_readcyclecounter();
+#endif
         if (stage == 0 && F.n_fine > 0) {
             // ---- sample_pdf(z_mid, weights[1:-1], n_fine, det=True), run_nerf_helpers.py:537-581 ----
             wave_lds_fence();
@@ -349,7 +364,19 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
                 if (m < NF / 64) zall[rank_f[m]] = myf[m];
             wave_lds_fence();
         }
+#ifdef DFN_TIMING
+        T_pdf += __builtin_readcyclecounter() - tp0;
+#endif
     }
+#ifdef DFN_TIMING
+    if (valid && lane == 0 && A.z_out) {
+        const unsigned long long T_end = __builtin_readcyclecounter();
+        const unsigned long long R_end = __builtin_amdgcn_s_memrealtime();
+        float* o = A.z_out + (size_t)r_raw * (64 + F.n_fine) + 64;
+        o[0] = (float)(T_end - T_start); o[1] = (float)(R_end - R_start); o[2] = (float)T_mlp; o[3] = (float)T_pdf;
+        o[4] = (float)s.t_wait; o[5] = (float)s.t_bar; o[6] = (float)s.t_issue; o[7] = (float)wave;
+    }
+#endif
     if (valid && lane == 0) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {

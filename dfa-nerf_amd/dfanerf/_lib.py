@@ -8,7 +8,8 @@ import os
 import torch  # noqa: F401  (first: the library must bind to the HIP runtime torch has loaded, not a second copy)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdfanerf.so")
+# DFN_LIB: developer override (A/B builds of the kernels); the shipped path is the in-tree library
+LIB_PATH = os.environ.get("DFN_LIB") or os.path.join(_HERE, "libdfanerf.so")
 
 TIER_F32, TIER_BF16 = 0, 1
 FIELD_HEAD, FIELD_TORSO, FIELD_LISTENER = 0, 1, 2
