@@ -61,12 +61,12 @@ template <int NT> struct Vec<TIER_F32, NT> {
 };
 
 // ---- weight stream -------------------------------------------------------------------------------------
-// All state is wave-uniform.  The stream of one MLP pass is nslab[field] slabs; passes alternate
-// head/torso when two fields are rendered (pass p -> field p & 1), else always field 0.
+// All state is wave-uniform.  The stream of one MLP pass is nslab[field] slabs; pass p of a workgroup runs
+// field (sched >> p) & 1 (bit mask set by the kernel: 0 = always field 0).
 struct Stream {
     const char* base[2];     // packed blobs (global)
     int nslab[2];
-    int two_fields;
+    unsigned sched;          // field of pass p = bit p (passes beyond bit 31: field 0)
     // prefetch cursor
     const char* pf_ptr;
     int pf_left;             // slabs left in the pass the cursor is in
@@ -95,7 +95,7 @@ DFN_DEV void stream_cursor_next(Stream& s) {
     s.pf_ptr += SLAB_BYTES;
     if (--s.pf_left == 0) {
         s.pf_pass++;
-        const int f = s.two_fields ? (s.pf_pass & 1) : 0;
+        const int f = (s.pf_pass < 32) ? ((s.sched >> s.pf_pass) & 1u) : 0;
         s.pf_ptr = s.base[f];
         s.pf_left = s.nslab[f];
     }

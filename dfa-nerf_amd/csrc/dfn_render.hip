@@ -106,8 +106,14 @@ template <int TIER> struct KernelLds {
     static constexpr int BIAS_H = RING_BYTES;
     static constexpr int BIAS_T = BIAS_H + P::H_NBIAS * 4;
     static constexpr int SCRATCH = BIAS_T + P::T_NBIAS * 4;
-    // zall[192] zc[64] zf[128] cdf[64] tmp[64] state[32] dhat_lane[3*64]
-    static constexpr int SCRATCH_FLOATS = 192 + 64 + 128 + 64 + 64 + 32 + 192;
+    // per wave (floats): zall[192] | M[4][192] | rank8[128 bytes] | state[32]
+    //   zall   sample depths: the 64 coarse z, then the merged, sorted 64 + n_fine
+    //   M      per merged sample (sigma, r, g, b) of the field set being composited; while the coarse pass and
+    //          sample_pdf run its first 256 floats hold tmp[64] cdf[64] zf[128]
+    //   rank8  merged rank of fine sample j (u8)
+    // (decoder_kernel keeps its per-lane d/|d| [3][64] at float 544 of the same area)
+    static constexpr int Z_ALL = 0, M_OFF = 192, M_STRIDE = 192, RANK8 = 960, STATE = 992;
+    static constexpr int SCRATCH_FLOATS = 1024;
     static constexpr int SCRATCH_PER_WAVE = SCRATCH_FLOATS * 4;
     static constexpr int TOTAL = SCRATCH + TierCfg<TIER>::WAVES * SCRATCH_PER_WAVE;
     static_assert(TOTAL <= 160 * 1024, "LDS budget");
@@ -116,6 +122,12 @@ template <int TIER> struct KernelLds {
 // ================================================================================================
 // Frame renderer
 // ================================================================================================
+// Pass order of one ray (= one wave): coarse tiles 0,1 (head, then torso when two fields are rendered), the
+// fine sampler, then the decoder on the n_fine NEW points only - there is one network (SURVEY.md 8(a) row H,
+// step 4), so its outputs at the 64 coarse points are kept from the coarse pass instead of being evaluated a
+// second time: head on the fine tiles, compositing of the head image over the merged samples, torso on the fine
+// tiles, compositing of the two-field image.  Every sample's (sigma, rgb) is bit-identical to what a pass over
+// all 64 + n_fine merged points gives (an MFMA column depends on its own point only).
 template <int TIER, bool TWO, bool TRAIN>
 __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 256) void render_kernel(
     const RenderArgs A) {
@@ -130,13 +142,19 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     const DfnFrame& F = A.frame;
     lds_char* lds = (lds_char*)smem;
     CtxT<TRAIN> ctx = {lds, wave, lane, lane >> 5, {}};
+    constexpr bool two = TWO;
+    const int NF = TRAIN ? 0 : F.n_fine;          // the training forward is the reference's coarse renderer
+    const bool hier = NF > 0;
+    const int KF = NF / 32;                        // fine tiles
+    const int S = 64 + NF;
 
     Stream s;
     s.base[0] = A.wblob[0];
     s.base[1] = A.wblob[1];
     s.nslab[0] = A.nslab[0];
     s.nslab[1] = A.nslab[1];
-    s.two_fields = TWO;
+    // coarse: H T H T; fine: KF x H, then KF x T
+    s.sched = two ? (0xAu | (((1u << KF) - 1u) << (4 + KF))) : 0u;
 #ifdef DFN_TIMING
     s.t_wait = s.t_bar = s.t_issue = 0;
     unsigned long long T_mlp = 0, T_pdf = 0;
@@ -153,12 +171,14 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     const lds_f32* bias_t = (const lds_f32*)(lds + L::BIAS_T);
 
     lds_f32* scr = (lds_f32*)(lds + L::SCRATCH + wave * L::SCRATCH_PER_WAVE);
-    lds_f32* zall = scr;            // [192]
-    lds_f32* zc = scr + 192;        // [64]
-    lds_f32* zf = scr + 256;        // [128]
-    lds_f32* cdf = scr + 384;       // [64]
-    lds_f32* tmp = scr + 448;       // [64]  coarse weights, then pdf / bins
-    volatile lds_f32* st = scr + 512;
+    lds_f32* zall = scr + L::Z_ALL;      // [192]
+    lds_f32* zc = zall;                  // [64]  the coarse z (until the merge overwrites the area)
+    lds_f32* M = scr + L::M_OFF;         // [4][192]
+    lds_f32* tmp = M;                    // [64]  coarse weights, then pdf / bins
+    lds_f32* cdf = M + 64;               // [64]
+    lds_f32* zf = M + 128;               // [128]
+    DFN_LDS unsigned char* rank8 = (DFN_LDS unsigned char*)(scr + L::RANK8);
+    volatile lds_f32* st = scr + L::STATE;
 
     // ---- this wave's ray -----------------------------------------------------------------------
     const int r_raw = blockIdx.x * C::WAVES + wave;
@@ -191,109 +211,145 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
             }
             st[RS_NH] = nh;
             st[RS_NT] = nt;
-        }
-        // coarse z: near*(1-t) + far*t (run_nerf_com_trainExpLater.py:617-618)
-        const float t = linspace01(lane, 64);
-        const float z = add_(mul_(F.z_near, sub_(1.0f, t)), mul_(F.z_far, t));
-        zc[lane] = z;
-        zall[lane] = z;
-    }
-    __syncthreads();     // bias blob + ray state visible (also drains the first two slab loads)
-
-    constexpr bool two = TWO;
-    const bool cbg = F.concate_bg != 0;
-    const DhatRef dref_h = {st + RS_DHAT_H, 1}, dref_t = {st + RS_DHAT_T, 1};
-
-    for (int stage = 0; stage < 2; ++stage) {
-        const int S = (stage == 0) ? 64 : 64 + F.n_fine;
-        if (stage == 1 && F.n_fine == 0) break;
-        if (lane == 0) {
             st[RS_TH] = 1.0f;
             st[RS_TC] = 1.0f;
 #pragma unroll
             for (int k = 0; k < 3; ++k) st[RS_RGB_H + k] = st[RS_RGB_C + k] = 0.f;
         }
-        wave_lds_fence();
-        for (int tile = 0; tile < S / 32; ++tile) {
-            const int si = tile * 32 + n;
-            MlpOut a, b = {};
-            {
-                const float z = ((volatile lds_f32*)zall)[si];
-                float p[3];
+        // coarse z: near*(1-t) + far*t (run_nerf_com_trainExpLater.py:617-618)
+        const float t = linspace01(lane, 64);
+        zall[lane] = add_(mul_(F.z_near, sub_(1.0f, t)), mul_(F.z_far, t));
+    }
+    __syncthreads();     // bias blob + ray state visible (also drains the first two slab loads)
+
+    const bool cbg = F.concate_bg != 0;
+    const DhatRef dref_h = {st + RS_DHAT_H, 1}, dref_t = {st + RS_DHAT_T, 1};
+
+    // head-image inputs of one sample: background colour / sigma bump on the last sample (:669-671, :693)
+    auto head_inputs = [&](float sg_h, float (&fh)[3], bool last, float& s1) {
+        if (cbg && last) { fh[0] = st[RS_BG]; fh[1] = st[RS_BG + 1]; fh[2] = st[RS_BG + 2]; }
+        s1 = fmaxf(sg_h, 0.f);                     // head-only image: K = 1 (composite_function is a squeeze)
+        if (cbg && last) s1 = add_(s1, 1e-6f);
+    };
+    // composite_function over {head, torso} for one sample (:158-162, :678-679, :694); fh after head_inputs
+    auto combine = [&](float sg_h, const float (&fh)[3], float sg_t, const float (&ft)[3], bool last, float& ssum,
+                       float (&fm)[3]) {
+        if (cbg && last) sg_t = 0.f;
+        const float sh = fmaxf(sg_h, 0.f);
+        float stt = fmaxf(sg_t, 0.f);
+        if (cbg && last) stt = add_(stt, 1e-6f);   // last stacked field
+        ssum = add_(sh, stt);
+        const float den = (ssum == 0.f) ? 1e-4f : ssum;
+        const float wh = div_(sh, den), wt = div_(stt, den);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) p[k] = add_(st[RS_OH + k], mul_(st[RS_DH + k], z));
-                if constexpr (TRAIN) {      // idle waves (ray >= ray_count) record into the last ray's slots: same values
-                    const long rr = valid ? r_raw : F.ray_count - 1;
-                    ctx.rec = {A.act_T[0], A.masks[0], RecMap::H_ROWS, rr * 2 + tile, RecMap::H_MDWORDS};
-                }
-#ifdef DFN_TIMING
-                const unsigned long long tm0 = __builtin_readcyclecounter();
-#endif
-                a = mlp_head<TIER>(p, dref_h, bias_h, s, ctx);
-#ifdef DFN_TIMING
-                T_mlp += __builtin_readcyclecounter() - tm0;
-#endif
+        for (int k = 0; k < 3; ++k) fm[k] = add_(mul_(fh[k], wh), mul_(ft[k], wt));
+    };
+    // calc_volume_weights + colour sum over the S merged samples held in M (4 rows: sigma, r, g, b)
+    auto composite_merged = [&](bool head_image, float* w_out) {
+        for (int t = 0; t < S / 32; ++t) {
+            const int si = t * 32 + n;
+            const float z = ((volatile lds_f32*)zall)[si];
+            const bool last = (si == S - 1);
+            const float znext = ((volatile lds_f32*)zall)[last ? si : si + 1];
+            const float dz = last ? F.last_dist : sub_(znext, z);
+            const volatile lds_f32* Mv = M;
+            float sg = Mv[si], col[3] = {Mv[L::M_STRIDE + si], Mv[2 * L::M_STRIDE + si], Mv[3 * L::M_STRIDE + si]};
+            float w;
+            if (head_image) {
+                float s1;
+                head_inputs(sg, col, last, s1);
+                w = integrate_tile(st, RS_TH, RS_RGB_H, s1, mul_(dz, st[RS_NH]), col, n, lane);
+            } else {
+                w = integrate_tile(st, RS_TC, RS_RGB_C, sg, mul_(dz, st[RS_NT]), col, n, lane);
             }
-            if (two) {
-                const float z = ((volatile lds_f32*)zall)[si];
-                float p[3];
+            if (valid && lane < 32) {
+                if (w_out) w_out[(size_t)r_raw * S + si] = w;
+                if (head_image && A.z_out) A.z_out[(size_t)r_raw * S + si] = z;
+            }
+        }
+    };
+
+    // what the coarse pass leaves for the merged compositing: coarse sample `lane`'s head outputs and its
+    // two-field composite (ssum, fm)
+    float keep_h[4] = {0.f, 0.f, 0.f, 0.f}, keep_c[4] = {0.f, 0.f, 0.f, 0.f};
+    int rank_c = lane;
+
+    enum { PH_COARSE = 0, PH_FINE_H = 1, PH_FINE_T = 2 };
+    int phase = PH_COARSE, tile = 0;
+    // one call site per MLP: the loop is a small state machine around them
+    for (;;) {
+        const int idx = tile * 32 + n;
+        const int ri = (phase == PH_COARSE) ? idx : (int)rank8[idx];       // sample's index in zall
+        const float z = ((volatile lds_f32*)zall)[ri];
+        MlpOut a = {}, b = {};
+        if (phase != PH_FINE_T) {
+            float p[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) p[k] = add_(st[RS_OT + k], mul_(st[RS_DT + k], z));
-                if constexpr (TRAIN) {
-                    const long rr = valid ? r_raw : F.ray_count - 1;
-                    ctx.rec = {A.act_T[1], A.masks[1], RecMap::S_ROWS, rr * 2 + tile, RecMap::S_MDWORDS};
-                }
-                b = mlp_torso<TIER>(p, dref_t, bias_t, s, ctx);
+            for (int k = 0; k < 3; ++k) p[k] = add_(st[RS_OH + k], mul_(st[RS_DH + k], z));
+            if constexpr (TRAIN) {      // idle waves (ray >= ray_count) record into the last ray's slots: same values
+                const long rr = valid ? r_raw : F.ray_count - 1;
+                ctx.rec = {A.act_T[0], A.masks[0], RecMap::H_ROWS, rr * 2 + tile, RecMap::H_MDWORDS};
             }
+#ifdef DFN_TIMING
+            const unsigned long long tm0 = __builtin_readcyclecounter();
+#endif
+            a = mlp_head<TIER>(p, dref_h, bias_h, s, ctx);
+#ifdef DFN_TIMING
+            T_mlp += __builtin_readcyclecounter() - tm0;
+#endif
+        }
+        if (two && phase != PH_FINE_H) {
+            float p[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p[k] = add_(st[RS_OT + k], mul_(st[RS_DT + k], z));
+            if constexpr (TRAIN) {
+                const long rr = valid ? r_raw : F.ray_count - 1;
+                ctx.rec = {A.act_T[1], A.masks[1], RecMap::S_ROWS, rr * 2 + tile, RecMap::S_MDWORDS};
+            }
+            b = mlp_torso<TIER>(p, dref_t, bias_t, s, ctx);
+        }
+
+        if (phase == PH_COARSE) {
+            const int si = idx;
             if (TRAIN && valid && lane < 32) {
                 float* so = A.samples_out + ((size_t)r_raw * 64 + si) * 8;
                 so[0] = a.sigma; so[1] = a.r; so[2] = a.g; so[3] = a.b;
                 so[4] = b.sigma; so[5] = b.r; so[6] = b.g; so[7] = b.b;
             }
             // results live in lanes 0..31; mirror them so that both halves run the same arithmetic
-            const float z = ((volatile lds_f32*)zall)[si];
-            const bool last = (si == S - 1);
+            const bool last = (si == 63);
             const float znext = ((volatile lds_f32*)zall)[last ? si : si + 1];
             const float dz = last ? F.last_dist : sub_(znext, z);
-            float sg_h = __shfl(a.sigma, n), fh[3] = {__shfl(a.r, n), __shfl(a.g, n), __shfl(a.b, n)};
-            if (cbg && last) { fh[0] = st[RS_BG]; fh[1] = st[RS_BG + 1]; fh[2] = st[RS_BG + 2]; }   // :669-671
-            // head-only image: K = 1 (composite_function is a squeeze)
-            float s1 = fmaxf(sg_h, 0.f);
-            if (cbg && last) s1 = add_(s1, 1e-6f);                               // :693
+            const float sg_h = __shfl(a.sigma, n);
+            float fh[3] = {__shfl(a.r, n), __shfl(a.g, n), __shfl(a.b, n)};
+            const bool mine = (lane >> 5) == tile;          // this lane's coarse sample is in this tile
+            if (mine) { keep_h[0] = sg_h; keep_h[1] = fh[0]; keep_h[2] = fh[1]; keep_h[3] = fh[2]; }
+            float s1;
+            head_inputs(sg_h, fh, last, s1);
             const float w_h = integrate_tile(st, RS_TH, RS_RGB_H, s1, mul_(dz, st[RS_NH]), fh, n, lane);
             float w_c = 0.f;
             if (two) {
-                float sg_t = __shfl(b.sigma, n);
+                const float sg_t = __shfl(b.sigma, n);
                 const float ft[3] = {__shfl(b.r, n), __shfl(b.g, n), __shfl(b.b, n)};
-                if (cbg && last) sg_t = 0.f;                                     // :678-679
-                const float sh = fmaxf(sg_h, 0.f);
-                float stt = fmaxf(sg_t, 0.f);
-                if (cbg && last) stt = add_(stt, 1e-6f);                         // :694 (last stacked field)
-                // composite_function, :158-162
-                const float ssum = add_(sh, stt);
-                const float den = (ssum == 0.f) ? 1e-4f : ssum;
-                const float wh = div_(sh, den), wt = div_(stt, den);
-                float fm[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) fm[k] = add_(mul_(fh[k], wh), mul_(ft[k], wt));
+                float ssum, fm[3];
+                combine(sg_h, fh, sg_t, ft, last, ssum, fm);
+                if (mine) { keep_c[0] = ssum; keep_c[1] = fm[0]; keep_c[2] = fm[1]; keep_c[3] = fm[2]; }
                 w_c = integrate_tile(st, RS_TC, RS_RGB_C, ssum, mul_(dz, st[RS_NT]), fm, n, lane);
             }
-            if (stage == 0 && lane < 32) tmp[si] = two ? w_c : w_h;
-            const bool final_stage = (stage == 1) || (F.n_fine == 0);
-            if (final_stage && valid && lane < 32) {
-                if (A.w_head) A.w_head[(size_t)r_raw * S + si] = w_h;
-                if (A.w_com && two) A.w_com[(size_t)r_raw * S + si] = w_c;
-                if (A.z_out) A.z_out[(size_t)r_raw * S + si] = z;
+            if (hier) {
+                if (lane < 32) tmp[si] = two ? w_c : w_h;
+            } else if (valid && lane < 32) {
+                if (A.w_head) A.w_head[(size_t)r_raw * 64 + si] = w_h;
+                if (A.w_com && two) A.w_com[(size_t)r_raw * 64 + si] = w_c;
+                if (A.z_out) A.z_out[(size_t)r_raw * 64 + si] = z;
             }
-        }
-
+            if (++tile < 2) continue;
+            if (!hier) break;
 #ifdef DFN_TIMING
-        const unsigned long long tp0 = __builtin_readcyclecounter();
+            const unsigned long long tp0 = __builtin_readcyclecounter();
 #endif
-        if (stage == 0 && F.n_fine > 0) {
             // ---- sample_pdf(z_mid, weights[1:-1], n_fine, det=True), run_nerf_helpers.py:537-581 ----
             wave_lds_fence();
-            const int NF = F.n_fine;
             const float wp = (lane >= 1 && lane <= 62) ? add_(tmp[lane], 1e-5f) : 0.f;
             float Ssum = wp;
 #pragma unroll
@@ -303,12 +359,12 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
             wave_lds_fence();
             tmp[lane] = pdf;                 // pdf of weights index k lives at tmp[k]
             wave_lds_fence();
-            float c = 0.f, mine = 0.f;       // sequential cumsum like torch.cumsum
+            float c = 0.f, mine_c = 0.f;     // sequential cumsum like torch.cumsum
             for (int k = 0; k < 62; ++k) {
                 c = add_(c, tmp[k + 1]);
-                if (lane == k + 1) mine = c;
+                if (lane == k + 1) mine_c = c;
             }
-            cdf[lane] = (lane <= 62) ? mine : 3.0e38f;
+            cdf[lane] = (lane <= 62) ? mine_c : 3.0e38f;
             wave_lds_fence();
             tmp[lane] = zmid;                // bins
             wave_lds_fence();
@@ -332,7 +388,6 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
             wave_lds_fence();
             // ---- z_all = sort(cat(z, z_fine)): ranks by counting, no sortedness assumption on z_fine ----
             const float myc = zc[lane];
-            int rank_c = lane;
             int rank_f[3] = {0, 0, 0};
             float myf[3] = {0, 0, 0};
 #pragma unroll
@@ -357,22 +412,69 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
                     rank_f[m] += (v < myf[m] || (v == myf[m] && i < j)) ? 1 : 0;
                 }
             }
-            wave_lds_fence();
+            wave_lds_fence();                // every read of zc / zf / tmp / cdf is done: the areas are reused
             zall[rank_c] = myc;
 #pragma unroll
             for (int m = 0; m < 3; ++m)
-                if (m < NF / 64) zall[rank_f[m]] = myf[m];
+                if (m < NF / 64) {
+                    zall[rank_f[m]] = myf[m];
+                    rank8[lane + 64 * m] = (unsigned char)rank_f[m];
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) M[q * L::M_STRIDE + rank_c] = keep_h[q];
+            if (lane == 0) {                 // the merged compositing starts from scratch
+                st[RS_TH] = 1.0f;
+                st[RS_TC] = 1.0f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) st[RS_RGB_H + k] = st[RS_RGB_C + k] = 0.f;
+            }
             wave_lds_fence();
-        }
 #ifdef DFN_TIMING
-        T_pdf += __builtin_readcyclecounter() - tp0;
+            T_pdf += __builtin_readcyclecounter() - tp0;
 #endif
+            phase = PH_FINE_H;
+            tile = 0;
+        } else if (phase == PH_FINE_H) {
+            if (lane < 32) {
+                M[ri] = a.sigma;
+                M[L::M_STRIDE + ri] = a.r;
+                M[2 * L::M_STRIDE + ri] = a.g;
+                M[3 * L::M_STRIDE + ri] = a.b;
+            }
+            if (++tile < KF) continue;
+            wave_lds_fence();
+            composite_merged(true, A.w_head);
+            if (!two) break;
+            phase = PH_FINE_T;
+            tile = 0;
+        } else {
+            if (lane < 32) {                 // the sample's head outputs are in M: replace them by the two-field mix
+                const volatile lds_f32* Mv = M;
+                const float sg_h = Mv[ri];
+                float fh[3] = {Mv[L::M_STRIDE + ri], Mv[2 * L::M_STRIDE + ri], Mv[3 * L::M_STRIDE + ri]};
+                const bool last = (ri == S - 1);
+                float s1, ssum, fm[3];
+                head_inputs(sg_h, fh, last, s1);
+                const float ft[3] = {b.r, b.g, b.b};
+                combine(sg_h, fh, b.sigma, ft, last, ssum, fm);
+                M[ri] = ssum;
+                M[L::M_STRIDE + ri] = fm[0];
+                M[2 * L::M_STRIDE + ri] = fm[1];
+                M[3 * L::M_STRIDE + ri] = fm[2];
+            }
+            if (++tile < KF) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) M[q * L::M_STRIDE + rank_c] = keep_c[q];
+            wave_lds_fence();
+            composite_merged(false, A.w_com);
+            break;
+        }
     }
 #ifdef DFN_TIMING
     if (valid && lane == 0 && A.z_out) {
         const unsigned long long T_end = __builtin_readcyclecounter();
         const unsigned long long R_end = __builtin_amdgcn_s_memrealtime();
-        float* o = A.z_out + (size_t)r_raw * (64 + F.n_fine) + 64;
+        float* o = A.z_out + (size_t)r_raw * S + 64;
         o[0] = (float)(T_end - T_start); o[1] = (float)(R_end - R_start); o[2] = (float)T_mlp; o[3] = (float)T_pdf;
         o[4] = (float)s.t_wait; o[5] = (float)s.t_bar; o[6] = (float)s.t_issue; o[7] = (float)wave;
     }
@@ -384,7 +486,7 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
             if (two && A.rgb_com) A.rgb_com[(size_t)r_raw * 3 + k] = st[RS_RGB_C + k];
         }
     }
-    // drain the two prefetched slabs before the LDS allocation is released
+    // drain the prefetched slabs before the LDS allocation is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -409,7 +511,7 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     Stream s;
     s.base[0] = s.base[1] = A.wblob;
     s.nslab[0] = s.nslab[1] = A.nslab;
-    s.two_fields = 0;
+    s.sched = 0;
     stream_begin<TIER>(s, lds, wave, lane);
     constexpr bool torso = TORSO;
     lds_f32* bias_l = (lds_f32*)(lds + (torso ? L::BIAS_T : L::BIAS_H));

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     Stream s;
     s.base[0] = s.base[1] = A.wblob_T;
     s.nslab[0] = s.nslab[1] = A.nslab;
-    s.two_fields = 0;
+    s.sched = 0;
     stream_begin<TIER>(s, lds, wave, lane);
     const long n_tiles = A.NP / 32;
     const long tile_raw = (long)blockIdx.x * C::WAVES + wave;
