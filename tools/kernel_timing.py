@@ -32,7 +32,7 @@ torch.cuda.synchronize()
 z = out[-1].cpu().numpy()[:, 64:72].astype(np.float64)
 tot, real, mlp, pdf, wait, bar, issue, wave = z.T
 print(f"rays {len(tot)}  clock = {np.mean(tot / real) * 100:.0f} MHz (shader cycles per 100 MHz tick)")
-npass = 8 * fields
+npass = 6 * fields        # 2 coarse + 4 fine tiles per field
 print(f"per ray: total {tot.mean():.0f} cyc | mlp {mlp.mean():.0f} ({mlp.mean()/tot.mean():.1%}) = {mlp.mean()/npass:.0f} per pass"
       f" (ideal MFMA-only, 2 waves/SIMD: {2*32*(1138 if fields==1 else (1138+1302)/2):.0f}) | pdf+merge {pdf.mean():.0f} ({pdf.mean()/tot.mean():.1%})")
 print(f"slab hand-over per ray: waitcnt {wait.mean():.0f} ({wait.mean()/tot.mean():.1%})  barrier {bar.mean():.0f} ({bar.mean()/tot.mean():.1%})"
