@@ -269,16 +269,28 @@ def main():
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
-        # roofline.achieved follows SURVEY.md 8(d): ALGORITHMIC FLOPs of the workload as the reference composes it
-        # (coarse pass on 64 points + the one network again on all 64+n_fine merged points) / kernel time,
-        # "regardless of folding tricks the kernel uses".  The kernel keeps the coarse outputs instead of
-        # re-evaluating them (identical results), so it EXECUTES fewer decoder evaluations: both are reported.
+        # Algorithmic FLOPs of a ray = (decoder evaluations the workload NEEDS) x (2 MACs of the layers the reference
+        # evaluates per point).  Row H needs 64 + n_fine evaluations per field: there is one network,
+        # so the 64 coarse outputs are reused in the merged pass (identical results).  SURVEY.md 8(d) priced the
+        # composition as the NeRF lineage codes it (coarse points evaluated twice: 64 + 64 + n_fine); that figure is
+        # reported beside it as `reference_composition_*` - it would put the exact-f32 tier above 100 % of peak, so
+        # it is not what `achieved` / `frac` use.
         per_pt = FLOP_PT_HEAD + (FLOP_PT_TORSO if fields == 2 else 0.0)
-        evals_alg = 64 + ((64 + n_fine) if n_fine > 0 else 0)
-        evals_exec = 64 + n_fine
-        flop_ray = evals_alg * per_pt
+        evals = 64 + n_fine
+        evals_ref = 64 + ((64 + n_fine) if n_fine > 0 else 0)
+        flop_ray = evals * per_pt
         achieved = flop_ray * count / (kern_ms * 1e-3) / 1e12
-        executed = evals_exec * per_pt * count / (kern_ms * 1e-3) / 1e12
+        ref_comp = evals_ref * per_pt * count / (kern_ms * 1e-3) / 1e12
+        # HBM bytes per launch cannot be counted from inside this process: they come from the committed rocprofv3
+        # PMC passes of this same command (profiles/traffic.json, see profiles/README.md); null if none was taken
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                tr = json.load(f).get(f"{args.workload}_{args.tier}")
+            if tr:
+                traffic, traffic_src = tr["hbm_bytes_per_launch"], "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+        except OSError:
+            pass
         out = {
             "metric": "rays/sec (whole node) at 450x450, 64c+128f samples" if n_fine else
                       "rays/sec (whole node) at 450x450, 64 coarse samples",
@@ -291,9 +303,11 @@ def main():
                        else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "render_kernel", "achieved": achieved,
                          "peak": PEAK_TFLOPS[args.tier], "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.tier],
-                         "traffic": None, "kernel_ms": kern_ms, "flop_per_ray": flop_ray,
-                         "decoder_evals_per_ray_per_field": {"algorithmic": evals_alg, "executed": evals_exec},
-                         "executed_tflops": executed, "frac_executed": executed / PEAK_TFLOPS[args.tier],
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms,
+                         "flop_per_ray": flop_ray, "decoder_evals_per_ray_per_field": evals,
+                         "reference_composition": {"decoder_evals_per_ray_per_field": evals_ref,
+                                                   "flop_per_ray": evals_ref * per_pt, "tflops": ref_comp,
+                                                   "frac": ref_comp / PEAK_TFLOPS[args.tier]},
                          "rays_per_launch": count},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -89,16 +89,20 @@ DFN_DEV void stream_issue_piece(const Stream& s, lds_char* ring, int wave, int l
         (const __attribute__((address_space(1))) void*)(s.pf_ptr + (size_t)lane * 16 + f * FRAG_BYTES),
         (DFN_LDS void*)(ring + s.pf_slot * SLAB_BYTES + f * FRAG_BYTES), 16, 0, 0);
 }
-// advance the prefetch cursor to the next slab (cyclic: running past the last pass just re-reads the first slabs)
+// advance the prefetch cursor to the next slab (cyclic: running past the last pass just re-reads the first slabs).
+// Branch-free on purpose: a branch per slab cuts the MLP into 32-MFMA basic blocks, and the register allocator
+// then spills around every one of them (the two-field kernel wrote 21 GB of scratch per frame that way).
 DFN_DEV void stream_cursor_next(Stream& s) {
     s.pf_slot = (s.pf_slot + 1 == RING_SLOTS) ? 0u : s.pf_slot + 1;
-    s.pf_ptr += SLAB_BYTES;
-    if (--s.pf_left == 0) {
-        s.pf_pass++;
-        const int f = (s.pf_pass < 32) ? ((s.sched >> s.pf_pass) & 1u) : 0;
-        s.pf_ptr = s.base[f];
-        s.pf_left = s.nslab[f];
-    }
+    const int left = s.pf_left - 1;
+    const bool wrap = __builtin_unpredictable(left == 0);    // keep the selects below selects
+    const int np = s.pf_pass + 1;
+    const bool f1 = __builtin_unpredictable(((np < 32) & ((s.sched >> (np & 31)) & 1u)) != 0);   // field of the next pass
+    const char* nb = f1 ? s.base[1] : s.base[0];
+    const int nn = f1 ? s.nslab[1] : s.nslab[0];
+    s.pf_ptr = wrap ? nb : s.pf_ptr + SLAB_BYTES;
+    s.pf_left = wrap ? nn : left;
+    s.pf_pass = wrap ? np : s.pf_pass;
 }
 template <int TIER>
 DFN_DEV void stream_issue(Stream& s, lds_char* ring, int wave, int lane) {
@@ -302,16 +306,41 @@ DFN_DEV void acc_relu_add(f32x16 (&acc)[G], const lds_f32* bias_lds, int half) {
         }
     }
 }
-// accumulators of G tiles -> tiles [t0, t0+G) of the next layer's B operand
+// accumulators of G tiles -> tiles [t0, t0+G) of the next layer's B operand.
+// bf16 tier with ReLU: pack first (v_cvt_pk_bf16_f32), then ReLU on the packed pairs as a signed 16-bit max
+// (v_pk_max_i16: a negative bf16 is a negative int16; relu(round(x)) == round(relu(x))): 1 VALU per value pair
+// less than max-then-pack.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int TIER, int G, int NT, bool RELU>
 DFN_DEV void acc_to_vec(const f32x16 (&acc)[G], Vec<TIER, NT>& v, int t0) {
+    if constexpr (TIER == TIER_BF16 && RELU) {
 #pragma unroll
-    for (int g = 0; g < G; ++g)
+        for (int g = 0; g < G; ++g) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float x = RELU ? relu_(acc[g][r]) : acc[g][r];
-            v.set(16 * (t0 + g) + r, x);
+            for (int h = 0; h < 2; ++h) {
+                unsigned w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x2 x = {acc[g][8 * h + 2 * e], acc[g][8 * h + 2 * e + 1]};
+                    const bf16x2 pk = __builtin_convertvector(x, bf16x2);                        // v_cvt_pk_bf16_f32
+                    const s16x2 m = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk), (s16x2)(0));   // v_pk_max_i16
+                    w[e] = __builtin_bit_cast(unsigned, m);
+                }
+                const u32x4 q = {w[0], w[1], w[2], w[3]};
+                v.u[2 * (t0 + g) + h] = __builtin_bit_cast(bf16x8, q);
+            }
         }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = RELU ? relu_(acc[g][r]) : acc[g][r];
+                v.set(16 * (t0 + g) + r, x);
+            }
+    }
 }
 
 // training recorder, per tile pair, straight from the accumulators (post-activation values as the next layer
@@ -486,7 +515,9 @@ DFN_DEV MlpOut mlp_trunk(Vec<TIER, 8>& act, const Vec<TIER, NTP>& pvec, const Dh
                          int f_l1, Fetch<TIER>& fe, Stream& s, const CT& c, int r_trunk, int m_trunk) {
     using P = Prog<TIER>;
     Vec<TIER, 8> nxt;
-    // blocks[0..2]  (a0 itself was recorded by the caller's first layer)
+    // blocks[0..2]  (a0 itself was recorded by the caller's first layer).  Runtime loop on purpose: unrolling it
+    // (act/nxt ping-pong by register renaming instead of a 64-register copy per layer) measured 3 % SLOWER
+    // (code size).
     for (int l = 0; l < 3; ++l) {
         int f = f_l1;                                       // same slab phase every iteration
         layer<TIER, 8, P::KU_ACT, 8, true>(nxt, act, bias + b_l1 + 256 * l, f, fe, s, c,
