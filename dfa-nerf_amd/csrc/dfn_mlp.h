@@ -70,7 +70,9 @@ struct Stream {
     // prefetch cursor
     const char* pf_ptr;
     int pf_left;             // slabs left in the pass the cursor is in
-    int pf_pass;
+    int pass;                // index of the pass the consumer starts next
+    const char* next_ptr;    // stream of the pass after the one being consumed
+    int next_left;
     unsigned pf_slot;        // ring slot the next prefetch lands in
     unsigned rd_off;         // LDS byte offset (within the ring) of the slab being consumed
     unsigned rd_slot;
@@ -89,20 +91,25 @@ DFN_DEV void stream_issue_piece(const Stream& s, lds_char* ring, int wave, int l
         (const __attribute__((address_space(1))) void*)(s.pf_ptr + (size_t)lane * 16 + f * FRAG_BYTES),
         (DFN_LDS void*)(ring + s.pf_slot * SLAB_BYTES + f * FRAG_BYTES), 16, 0, 0);
 }
-// advance the prefetch cursor to the next slab (cyclic: running past the last pass just re-reads the first slabs).
-// Branch-free on purpose: a branch per slab cuts the MLP into 32-MFMA basic blocks, and the register allocator
-// then spills around every one of them (the two-field kernel wrote 21 GB of scratch per frame that way).
+// advance the prefetch cursor to the next slab; at the end of a pass it jumps to the stream of the next pass
+// (next_ptr / next_left, set when the CONSUMER starts a pass: the cursor is only two slabs ahead of it).
+// Two cheap selects on purpose: anything heavier is turned into a branch per slab, which cuts the MLP into
+// 32-MFMA basic blocks that the register allocator spills around (the two-field kernel wrote 21 GB of scratch
+// per frame that way).
 DFN_DEV void stream_cursor_next(Stream& s) {
     s.pf_slot = (s.pf_slot + 1 == RING_SLOTS) ? 0u : s.pf_slot + 1;
     const int left = s.pf_left - 1;
-    const bool wrap = __builtin_unpredictable(left == 0);    // keep the selects below selects
-    const int np = s.pf_pass + 1;
-    const bool f1 = __builtin_unpredictable(((np < 32) & ((s.sched >> (np & 31)) & 1u)) != 0);   // field of the next pass
-    const char* nb = f1 ? s.base[1] : s.base[0];
-    const int nn = f1 ? s.nslab[1] : s.nslab[0];
-    s.pf_ptr = wrap ? nb : s.pf_ptr + SLAB_BYTES;
-    s.pf_left = wrap ? nn : left;
-    s.pf_pass = wrap ? np : s.pf_pass;
+    const bool wrap = left == 0;
+    s.pf_ptr = wrap ? s.next_ptr : s.pf_ptr + SLAB_BYTES;
+    s.pf_left = wrap ? s.next_left : left;
+}
+// the consumer starts pass s.pass: publish where the cursor goes after the end of this pass
+DFN_DEV void stream_pass_begin(Stream& s) {
+    const int np = s.pass + 1;
+    const int f = (np < 32) ? ((s.sched >> np) & 1u) : 0;
+    s.next_ptr = s.base[f];
+    s.next_left = s.nslab[f];
+    s.pass = np;
 }
 template <int TIER>
 DFN_DEV void stream_issue(Stream& s, lds_char* ring, int wave, int lane) {
@@ -126,7 +133,9 @@ template <int TIER>
 DFN_DEV void stream_begin(Stream& s, lds_char* ring, int wave, int lane) {
     s.pf_ptr = s.base[0];
     s.pf_left = s.nslab[0];
-    s.pf_pass = 0;
+    s.pass = 0;
+    s.next_ptr = s.base[0];
+    s.next_left = s.nslab[0];
     s.pf_slot = 0;
     s.rd_slot = RING_SLOTS - 1;     // the first slab_advance moves it to slot 0
     s.rd_off = 0;
@@ -242,6 +251,7 @@ template <int TIER> struct Fetch {
     // start of a pass: fragments 0..PF_DEPTH-1
     template <class CT> DFN_DEV void prime(Stream& s, const CT& c) {
         stream_flush<TIER>(s, c.ring, c.wave, c.lane);
+        stream_pass_begin(s);
 #pragma unroll
         for (int i = 0; i < PF_DEPTH; ++i) load(i, i, s, c);
     }
