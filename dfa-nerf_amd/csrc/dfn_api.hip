@@ -157,6 +157,18 @@ int dfn_fold_bias(int tier, int field, const float* params, const float* signal,
     return DFN_OK;
 }
 
+int dfn_fold_bias_bwd(int tier, int field, const float* params, const float* signal, const float* z_shape,
+                      const float* z_app, const float* dbias, float* grad_flat, float* d_signal, void* stream) {
+    if (!tier_ok(tier) || !field_ok(field) || !params || !z_shape || !z_app || !dbias || !grad_flat)
+        return fail(DFN_E_ARG, "dfn_fold_bias_bwd: bad argument");
+    if (field != DFN_FIELD_LISTENER && !signal) return fail(DFN_E_ARG, "dfn_fold_bias_bwd: signal is NULL");
+    const int n = (int)dfn_bias_floats(tier, field);
+    hipError_t err = launch_fold_bwd(field, params, signal, z_shape, z_app, dbias, grad_flat, d_signal, n,
+                                     (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "fold_bwd_kernel");
+    return DFN_OK;
+}
+
 int dfn_render_fwd(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
                    const float* bias_head, const float* bias_torso, const float* bg_f32,
                    const uint8_t* bg_u8, const int32_t* pix_index, float* rgb_head, float* rgb_com,

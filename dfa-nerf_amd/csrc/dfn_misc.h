@@ -4,6 +4,8 @@
 
 namespace dfn {
 hipError_t launch_pack(const int* plan, const float* params, void* out, long n, int bf16, hipStream_t st);
+hipError_t launch_fold_bwd(int field, const float* params, const float* sig, const float* zs, const float* za,
+                           const float* dbias, float* grad_flat, float* dsig, int n, hipStream_t st);
 hipError_t launch_fold(int field, const float* params, const float* sig, const float* zs, const float* za,
                        float* out, int n, hipStream_t st);
 hipError_t launch_get_rays(int H, int W, float focal, float cx, float cy, const float* c2w_host, float* ro,

@@ -134,6 +134,94 @@ hipError_t launch_fold(int field, const float* params, const float* sig, const f
     return hipGetLastError();
 }
 
+// ---- fold backward: gradient of the bias blob -> decoder parameters and the conditioning signal ------------------
+// The fold is linear: bias[i] = sum of bias parameters + sum of rowdot(W[row, c0:c0+n], v).  One thread per bias
+// element applies, for its g = dbias[i]: dP[bias term] += g, dW[row, c0+k] += g v[k], dv[k] += g W[row, c0+k].
+// Inside one launch every parameter element is touched by exactly one thread (plain +=; launches on a stream
+// serialise); dv is shared by all rows -> atomics.  z_shape / z_app are constants upstream (never passed to an
+// optimizer, MAIN:522-547): no gradient is produced for them.
+struct FoldGrad {
+    const float* P; float* G; float* dsig; float g;
+    __device__ void b(int pid, int f) const { G[param_offset(pid) + f] += g; }
+    __device__ void w(int pid, int row, int c0, int n, const float* v, bool want_dv) const {
+        const long o = param_offset(pid) + (long)row * param_shape(pid).cols + c0;
+        for (int k = 0; k < n; ++k) {
+            G[o + k] += g * v[k];
+            if (want_dv && dsig) atomicAdd(dsig + k, g * P[o + k]);
+        }
+    }
+};
+__global__ void fold_bwd_kernel(int field, const float* __restrict__ P, const float* __restrict__ sig,
+                                const float* __restrict__ zs, const float* __restrict__ za,
+                                const float* __restrict__ dbias, float* G, float* dsig, int n) {
+    using PG = Prog<TIER_BF16>;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    auto feat_of = [](int e) { return 32 * (e >> 5) + tile_feat((e >> 4) & 1, e & 15); };
+    const FoldGrad q = {P, G, dsig, dbias[i]};
+    int base, f;
+    auto trunk_tail = [&](int i, int b_l1, int b_skip, int b_l5, int b_view, int b_out, int skb) {
+        // shared by head / listener / torso: everything after IN except the signal columns of SKIP
+        if (i < b_skip) {
+            base = i - b_l1; f = feat_of(base & 255); q.b(P_BLK0_B + 2 * (base >> 8), f);
+        } else if (i < b_l5) {
+            f = feat_of(i - b_skip); q.b(P_FCZSK_B, f); q.w(P_FCZSK_W, f, 0, ZDIM, zs, false); q.b(skb, f);
+        } else if (i < b_view) {
+            base = i - b_l5; f = feat_of(base & 255); q.b(P_BLK4_B + 2 * (base >> 8), f);
+        } else if (i < b_out) {
+            f = feat_of(i - b_view);
+            if (f < 256) { q.b(P_FEATV_B, f); q.b(P_FCZV_B, f); q.w(P_FCZV_W, f, 0, ZDIM, za, false); q.b(P_FCV_B, f); }
+            else if (f == 256) q.b(P_SIGMA_B, 0);
+        } else {
+            f = feat_of(i - b_out); if (f < 3) q.b(P_FEATO_B, f);
+        }
+    };
+    if (field != FIELD_TORSO) {
+        const bool lis = (field == 2);
+        const int in_w = lis ? P_FCINL_W : P_FCIN_W, in_b = lis ? P_FCINL_B : P_FCIN_B;
+        const int sk_w = lis ? P_FCPSKL_W : P_FCPSK_W, sk_b = lis ? P_FCPSKL_B : P_FCPSK_B;
+        if (i < PG::H_B_L1) {
+            f = feat_of(i); q.b(in_b, f); q.b(P_FCZ_B, f); q.w(P_FCZ_W, f, 0, ZDIM, zs, false);
+            if (!lis) q.w(in_w, f, NPE, NSIG, sig, true);
+        } else {
+            trunk_tail(i, PG::H_B_L1, PG::H_B_SKIP, PG::H_B_L5, PG::H_B_VIEW, PG::H_B_OUT, sk_b);
+            if (!lis && i >= PG::H_B_SKIP && i < PG::H_B_L5) q.w(sk_w, feat_of(i - PG::H_B_SKIP), NPE, NSIG, sig, true);
+        }
+    } else {
+        if (i < PG::T_B_IN) {
+            const int vec = i >> 6;
+            f = feat_of(i & 63);
+            switch (vec) {
+            case 0: q.b(P_DE0_B, f); q.w(P_DE0_W, f, NPE, NET, sig, true); break;
+            case 1: q.b(P_DS0_B, f); q.w(P_DS0_W, f, NPE, NET, sig, true); break;
+            case 2: q.b(P_DE1_B, f); break;
+            case 3: q.b(P_DS1_B, f); break;
+            case 4: q.b(P_DE2_B, f); break;
+            case 5: q.b(P_DS2_B, f); break;
+            case 6: q.b(P_DE3_B, f); break;
+            case 7: q.b(P_DESK_B, f); break;
+            case 8: q.b(P_DS3_B, f); break;
+            case 9: q.b(P_DSSK_B, f); q.w(P_DSSK_W, f, 0, NET, sig, true); break;
+            case 10: q.b(P_DE4_B, f); break;
+            case 11: q.b(P_DS4_B, f); break;
+            case 12: if (f < NPE) q.b(P_DEO_B, f); break;
+            default: if (f < NET) { q.b(P_DSO_B, f); if (dsig) atomicAdd(dsig + f, q.g); } break;
+            }
+        } else if (i < PG::T_B_L1) {
+            f = feat_of(i - PG::T_B_IN); q.b(P_FCINT_B, f); q.b(P_FCZ_B, f); q.w(P_FCZ_W, f, 0, ZDIM, zs, false);
+        } else {
+            trunk_tail(i, PG::T_B_L1, PG::T_B_SKIP, PG::T_B_L5, PG::T_B_VIEW, PG::T_B_OUT, P_FCPSKT_B);
+        }
+    }
+}
+hipError_t launch_fold_bwd(int field, const float* params, const float* sig, const float* zs, const float* za,
+                           const float* dbias, float* grad_flat, float* dsig, int n, hipStream_t st) {
+    hipLaunchKernelGGL(fold_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, st, field, params, sig, zs, za, dbias,
+                       grad_flat, dsig, n);
+    return hipGetLastError();
+}
+
+
 // ---- get_rays / ndc_rays ----------------------------------------------------------------------------------------
 struct Pose12 { float m[12]; };
 __global__ void get_rays_kernel(int H, int W, float focal, float cx, float cy, Pose12 c2w, float* ro, float* rd) {

@@ -43,6 +43,7 @@ def _load():
         "dfn_pack_plan": (lg, [i32, i32, ip, lg]),
         "dfn_bias_floats": (lg, [i32, i32]),
         "dfn_fold_bias": (i32, [i32, i32, fp, fp, fp, fp, fp, vp]),
+        "dfn_fold_bias_bwd": (i32, [i32, i32, fp, fp, fp, fp, fp, fp, fp, vp]),
         "dfn_render_fwd": (i32, [i32, C.POINTER(DfnFrame), vp, vp, fp, fp, fp, vp, ip, fp, fp, fp, fp, fp, vp]),
         "dfn_decoder_fwd": (i32, [i32, i32, vp, fp, fp, fp, lg, fp, fp, vp]),
         "dfn_get_rays": (i32, [i32, i32, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), fp, fp, vp]),

@@ -59,6 +59,8 @@ class TrainBuffers:
     """Device buffers of one training step, sized for `n_rays` (reused across steps)."""
 
     def __init__(self, tier, n_rays, device):
+        self.flat = None            # [955242] f32 copy of the decoder parameters (state_dict order), see bind()
+        self.flat_views = None
         self.tier = TIERS[tier]
         self.n_rays, self.NP = n_rays, n_rays * 64
         assert self.NP % 512 == 0, "N_rand must be a multiple of 8"
@@ -75,6 +77,26 @@ class TrainBuffers:
         self.packed_T = [torch.empty(check(lib.dfn_packed_bwd_bytes(self.tier, f), "packed_T"), dtype=torch.uint8,
                                      device=device) for f in (0, 1)]
         self.nb = [check(lib.dfn_bias_floats(self.tier, f), "bias") for f in (0, 1)]
+        self.bias = torch.empty(self.nb[0] + self.nb[1], dtype=torch.float32, device=device)
+
+    def bind(self, dec):
+        """Parameter list of `dec` in state_dict order and the matching views of one flat buffer: the kernels read
+        the flat copy (one multi-tensor copy per step) and write gradients into a flat buffer whose slices become
+        the parameters' .grad (no per-tensor copies)."""
+        if self.flat is None or getattr(self, "_dec", None) is not dec:
+            self.params = list(dec.state_dict(keep_vars=True).values())
+            n = sum(p.numel() for p in self.params)
+            dev = self.params[0].device
+            self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+            self.offsets, o = [], 0
+            for p in self.params:
+                self.offsets.append(o)
+                o += p.numel()
+            self.flat_views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
+            self._dec = dec
+        with torch.no_grad():
+            torch._foreach_copy_(self.flat_views, [p.detach() for p in self.params])
+        return self.flat
 
 
 class RenderTrainFn(torch.autograd.Function):
@@ -122,9 +144,91 @@ class RenderTrainFn(torch.autograd.Function):
         return g_flat, g_bias, None, None, None, None
 
 
-def render_train(dec, buf, frame, bg, pix_index, sig_head, sig_torso, z_shape, z_app):
+class FusedTrainFn(torch.autograd.Function):
+    """(sig_head [96], sig_torso [42]) -> rgb_head, rgb_com [n,3]: fold + fused forward in HIP; the backward runs
+    dfn_composite_bwd, dfn_mlp_bwd, dfn_weight_grad, dfn_bias_grad and dfn_fold_bias_bwd, returns the gradients of
+    the two signals to autograd (-> conditioning networks) and DEPOSITS the decoder gradients straight into the
+    parameters' .grad as slices of one flat buffer (side effect of backward(), like a DDP hook: ~10 launches instead
+    of the ~600 of the torch fold + cat/split autograd)."""
+
+    @staticmethod
+    def forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app):
+        t, st = buf.tier, _stream()
+        flat = buf.flat
+        dev = flat.device
+        sh = sig_head.detach().reshape(-1).float().contiguous()
+        stt = sig_torso.detach().reshape(-1).float().contiguous()
+        zs = z_shape.detach().reshape(2, 256).float().contiguous()
+        za = z_app.detach().reshape(2, 256).float().contiguous()
+        bias = buf.bias
+        bias_t = C.c_void_p(bias.data_ptr() + 4 * buf.nb[0])
+        check(lib.dfn_fold_bias(t, FIELD_HEAD, _ptr(flat), _ptr(sh), _ptr(zs[0]), _ptr(za[0]), _ptr(bias), st),
+              "dfn_fold_bias(head)")
+        check(lib.dfn_fold_bias(t, FIELD_TORSO, _ptr(flat), _ptr(stt), _ptr(zs[1]), _ptr(za[1]), bias_t, st),
+              "dfn_fold_bias(torso)")
+        for f in (0, 1):
+            check(lib.dfn_pack_weights(t, f, _ptr(flat), _ptr(buf.packed[f]), st), "dfn_pack_weights")
+            check(lib.dfn_pack_weights_bwd(t, f, _ptr(flat), _ptr(buf.packed_T[f]), st), "dfn_pack_weights_bwd")
+        n = frame.ray_count
+        rgb_h = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        rgb_c = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        bg_f32 = bg if bg.dtype == torch.float32 else None
+        bg_u8 = bg if bg.dtype == torch.uint8 else None
+        check(lib.dfn_train_fwd(t, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias), bias_t,
+                                _ptr(bg_f32), _ptr(bg_u8), _ptr(pix_index), _ptr(rgb_h), _ptr(rgb_c),
+                                _ptr(buf.samples), _ptr(buf.act[0]), _ptr(buf.masks[0]), _ptr(buf.act[1]),
+                                _ptr(buf.masks[1]), st), "dfn_train_fwd")
+        ctx.buf, ctx.frame, ctx.bg, ctx.pix = buf, frame, bg, pix_index
+        ctx.keep = (sh, stt, zs, za)
+        ctx.sig_shapes = (sig_head.shape, sig_torso.shape)
+        return rgb_h, rgb_c
+
+    @staticmethod
+    def backward(ctx, d_h, d_c):
+        buf, frame, bg, st = ctx.buf, ctx.frame, ctx.bg, _stream()
+        sh, stt, zs, za = ctx.keep
+        flat, dev = buf.flat, buf.flat.device
+        d_h = d_h.contiguous().float()
+        d_c = d_c.contiguous().float()
+        bg_f32 = bg if bg.dtype == torch.float32 else None
+        bg_u8 = bg if bg.dtype == torch.uint8 else None
+        check(lib.dfn_composite_bwd(C.byref(frame), _ptr(ctx.pix), _ptr(bg_f32), _ptr(bg_u8), _ptr(buf.samples),
+                                    _ptr(d_h), _ptr(d_c), _ptr(buf.dsamples), st), "dfn_composite_bwd")
+        g_flat = torch.zeros(flat.numel(), dtype=torch.float32, device=dev)
+        g_bias = torch.empty(buf.nb[0] + buf.nb[1], dtype=torch.float32, device=dev)
+        d_sig = torch.zeros(96 + 42, dtype=torch.float32, device=dev)
+        for f in (0, 1):
+            gb = C.c_void_p(g_bias.data_ptr() + (4 * buf.nb[0] if f else 0))
+            check(lib.dfn_mlp_bwd(buf.tier, f, _ptr(buf.packed_T[f]), _ptr(buf.samples), _ptr(buf.dsamples),
+                                  _ptr(buf.masks[f]), buf.NP, _ptr(buf.dy[f]), st), "dfn_mlp_bwd")
+            check(lib.dfn_weight_grad(buf.tier, f, _ptr(buf.dy[f]), _ptr(buf.act[f]), buf.NP, _ptr(buf.ws[f]),
+                                      _ptr(g_flat), st), "dfn_weight_grad")
+            check(lib.dfn_bias_grad(buf.tier, f, _ptr(buf.dy[f]), buf.NP, gb, st), "dfn_bias_grad")
+            check(lib.dfn_fold_bias_bwd(buf.tier, FIELD_TORSO if f else FIELD_HEAD, _ptr(flat), _ptr(stt if f else sh),
+                                        _ptr(zs[f]), _ptr(za[f]), gb, _ptr(g_flat),
+                                        C.c_void_p(d_sig.data_ptr() + (4 * 96 if f else 0)), st), "dfn_fold_bias_bwd")
+        for p, o in zip(buf.params, buf.offsets):
+            if not p.requires_grad:
+                continue
+            g = g_flat[o:o + p.numel()].view_as(p)
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+        return (d_sig[:96].reshape(ctx.sig_shapes[0]), d_sig[96:].reshape(ctx.sig_shapes[1]), None, None, None, None,
+                None, None)
+
+
+def render_train(dec, buf, frame, bg, pix_index, sig_head, sig_torso, z_shape, z_app, fused=True):
     """Differentiable (w.r.t. the decoder parameters and the two signals) coarse two-field render of the
-    pixels `pix_index` [n] (int32, y*W+x).  Returns rgb_head, rgb_com [n,3]."""
+    pixels `pix_index` [n] (int32, y*W+x).  Returns rgb_head, rgb_com [n,3].
+    fused=True: fold and its backward in HIP, decoder gradients deposited into .grad by the backward (FusedTrainFn);
+    fused=False: the fold as differentiable torch ops around RenderTrainFn (the twin the tests compare against)."""
+    if fused:
+        buf.bind(dec)
+        if not sig_head.requires_grad:      # keep the Function in the graph even when no conditioning net trains
+            sig_head = sig_head.detach().requires_grad_(True)
+        return FusedTrainFn.apply(sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app)
     flat = torch.cat([p.reshape(-1) for p in dec.state_dict(keep_vars=True).values()])
     bias = fold_bias_torch(dec, sig_head, sig_torso, z_shape, z_app)
     return RenderTrainFn.apply(flat, bias, buf, frame, bg, pix_index)

@@ -121,6 +121,12 @@ int dfn_mlp_bwd(int tier, int field, const void* packed_T, const float* samples,
 int dfn_weight_grad(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
                     float* grad_flat, void* stream);
 int dfn_bias_grad(int tier, int field, const void* dy_T, long NP, float* dbias, void* stream);
+/* Backward of dfn_fold_bias (the fold is linear; upstream it is the autograd of DEC:293-295, 311, 318, 332):
+ * dbias [dfn_bias_floats] -> grad_flat (+=, layout of `params`: fc_z / fc_z_skips / fc_z_view, the signal columns
+ * of fc_in / fc_p_skips / the deformation nets, every bias) and d_signal (+=, [96] head / [42] torso; may be NULL).
+ * z_shape / z_app get no gradient: they are constants upstream (never handed to an optimizer, MAIN:522-547). */
+int dfn_fold_bias_bwd(int tier, int field, const float* params, const float* signal, const float* z_shape,
+                      const float* z_app, const float* dbias, float* grad_flat, float* d_signal, void* stream);
 
 /* ---- Decoder.forward on explicit points: replaces DEC:277-349 -------------------------------------------
  * points, dirs [n,3]; feat [n,3] (after sigmoid), sigma [n] (raw). */

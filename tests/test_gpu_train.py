@@ -125,3 +125,40 @@ def test_training_step_hip_vs_golden(states, scene, latents, golden, tier, step)
                 np.testing.assert_allclose(samp, g[f"gsamp_{step}/{tag}/{k}"], rtol=2e-2,
                                            atol=1e-3 * ref / np.sqrt(gs.numel()) + 1e-9)
     print(f"{tier} step {step}: worst relative gradient-norm error {worst:.2e}")
+
+
+def test_fused_fold_backward_matches_torch_fold(states, scene, latents):
+    """FusedTrainFn (fold forward/backward in HIP, decoder gradients deposited as slices of one flat buffer) against
+    the same step with the fold as differentiable torch ops around RenderTrainFn: same loss, same gradients for the
+    decoder parameters and for the two conditioning signals."""
+    from dfanerf import engine, training
+    dev = torch.device("cuda")
+    H, W = scene["H"], scene["W"]
+    zs, za = [t(v).to(dev) for v in latents]
+    bg = (t(scene["bg"]).float() / 255.0).reshape(-1, 3).to(dev)
+    n = 256
+    pix = torch.arange(n, dtype=torch.int32, device=dev) * 701 % (H * W)
+    frame = engine.make_frame(H, W, scene["focal"], scene["cx"], scene["cy"], scene["poses"][1], scene["pose_body"], 0.3,
+                              0.9, 1e10, 0, n, 64, 0, 2, True)
+    tgt = torch.rand(n, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    res = {}
+    for fused in (True, False):
+        mods = _modules(states, dev)
+        dec = mods["decoder"]
+        sh = (t(synth.synth_tensor(0, "ff/sh", (1, 96), 0.3))).to(dev).requires_grad_(True)
+        st = (t(synth.synth_tensor(0, "ff/st", (42,), 0.3))).to(dev).requires_grad_(True)
+        buf = training.TrainBuffers("f32", n, dev)
+        rh, rc = training.render_train(dec, buf, frame, bg, pix, sh, st, zs[0, :2], za[0, :2], fused=fused)
+        loss = ((rh - tgt) ** 2).mean() + ((rc - tgt) ** 2).mean()
+        loss.backward()
+        res[fused] = (loss.item(), sh.grad.clone(), st.grad.clone(),
+                      {k: (None if p.grad is None else p.grad.clone()) for k, p in dec.named_parameters()})
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
+    for a, b in ((res[True][1], res[False][1]), (res[True][2], res[False][2])):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=1e-7 + 2e-5 * b.abs().max().item())
+    for k, gb in res[False][3].items():
+        ga = res[True][3][k]
+        if gb is None:
+            assert ga is None or ga.abs().max().item() == 0.0, k
+            continue
+        torch.testing.assert_close(ga, gb, rtol=2e-4, atol=1e-7 + 2e-5 * gb.abs().max().item(), msg=k)
