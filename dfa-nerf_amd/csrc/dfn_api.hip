@@ -61,10 +61,11 @@ struct WgradEntry {
     bool built = false;
     std::vector<WOpHost> ops;
     std::vector<int32_t> map, bias_rows;
-    std::vector<int> prefix;          // work items (32x32 tiles) prefix per op, without the k-split factor
+    std::vector<int> prefix;          // work items (WG_MT x WG_NT macro-tiles x k-splits) prefix per op
     WOp* ops_dev = nullptr;
     int32_t* map_dev = nullptr;
     int32_t* rows_dev = nullptr;
+    int32_t* eof_dev = nullptr;      // dy_T row -> bias element
     int* prefix_dev = nullptr;
     int ksplit_uploaded = 0;
 };
@@ -82,7 +83,9 @@ WgradEntry& wgrad_of(int field) {
     if (!w.built) {
         build_wgrad_plan(field, w.ops, w.map, w.bias_rows);
         w.prefix.assign(1, 0);
-        for (const WOpHost& o : w.ops) w.prefix.push_back(w.prefix.back() + (o.M / 32) * (o.N / 32) * WGRAD_KSPLIT);
+        for (const WOpHost& o : w.ops)
+            w.prefix.push_back(w.prefix.back() +
+                               ((o.M / 32 + WG_MT - 1) / WG_MT) * ((o.N / 32 + WG_NT - 1) / WG_NT) * WGRAD_KSPLIT);
         w.built = true;
     }
     return w;
@@ -379,15 +382,23 @@ int dfn_bias_grad(int tier, int field, const void* dy_T, long NP, float* dbias, 
     if (!tier_ok(tier) || (field != 0 && field != 1) || !dy_T || !dbias || NP <= 0)
         return fail(DFN_E_ARG, "dfn_bias_grad: bad argument");
     WgradEntry& w = wgrad_of(field);
+    if ((long)w.bias_rows.size() != dfn_bias_floats(tier, field)) return fail(DFN_E_ARG, "internal: bias row table size");
     {
         std::lock_guard<std::mutex> lk(g_plan_mu);
-        if (!w.rows_dev) {
-            hipError_t e = upload(&w.rows_dev, w.bias_rows.data(), w.bias_rows.size());
+        if (!w.eof_dev) {       // inverse table: dy_T row -> bias element (each row feeds at most one)
+            const int rows = (int)dfn_train_rows(field, 1);
+            std::vector<int32_t> e_of(rows, -1);
+            for (size_t e = 0; e < w.bias_rows.size(); ++e) {
+                const int r = w.bias_rows[e];
+                if (r < 0) continue;
+                if (r >= rows || e_of[r] >= 0) return fail(DFN_E_ARG, "internal: bias row table is not one-to-one");
+                e_of[r] = (int32_t)e;
+            }
+            hipError_t e = upload(&w.eof_dev, e_of.data(), e_of.size());
             if (e != hipSuccess) return hip_fail(e, "upload(bias rows)");
         }
     }
-    if ((long)w.bias_rows.size() != dfn_bias_floats(tier, field)) return fail(DFN_E_ARG, "internal: bias row table size");
-    hipError_t err = launch_bias_grad(tier, field, w.rows_dev, (int)w.bias_rows.size(), dy_T, NP, dbias, (hipStream_t)stream);
+    hipError_t err = launch_bias_grad(tier, field, w.eof_dev, (int)w.bias_rows.size(), dy_T, NP, dbias, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "bias_grad_kernel");
     return DFN_OK;
 }

@@ -72,7 +72,7 @@ enum ParamId : int {
 
 struct ParamShape { int rows, cols; };   // bias: rows = n, cols = 1
 
-DFN_HD ParamShape param_shape(int id) {
+DFN_HD constexpr ParamShape param_shape(int id) {
     switch (id) {
     case P_DE0_W: case P_DS0_W: return {DH, NPE + NET};
     case P_DE1_W: case P_DE2_W: case P_DE3_W: case P_DE4_W:
@@ -101,12 +101,25 @@ DFN_HD ParamShape param_shape(int id) {
     }
 }
 
-DFN_HD int param_numel(int id) { ParamShape s = param_shape(id); return s.rows * s.cols; }
-DFN_HD int param_offset(int id) {
+DFN_HD constexpr int param_numel(int id) { return param_shape(id).rows * param_shape(id).cols; }
+// offsets of the tensors in the flat parameter vector: a compile-time table (a runtime id costs one load, not a
+// 60-iteration loop over the shapes - the fold kernels index it with computed ids)
+struct ParamOffsets { int v[P_COUNT + 1]; };
+DFN_HD constexpr ParamOffsets make_param_offsets() {
+    ParamOffsets t = {};
     int off = 0;
-    for (int i = 0; i < id; ++i) off += param_numel(i);
-    return off;
+    for (int i = 0; i < P_COUNT; ++i) {
+        t.v[i] = off;
+        off += param_numel(i);
+    }
+    t.v[P_COUNT] = off;
+    return t;
 }
+DFN_HD constexpr int param_offset(int id) {
+    constexpr ParamOffsets T = make_param_offsets();
+    return T.v[id];
+}
+static_assert(make_param_offsets().v[P_COUNT] == 955242, "flat decoder parameter count");
 constexpr int N_DECODER_PARAMS = 955242;     // checked against param_offset(P_COUNT) at load time
 
 // ---- input-vector slot maps -------------------------------------------------------------------------

@@ -140,37 +140,33 @@ hipError_t launch_fold(int field, const float* params, const float* sig, const f
 // Inside one launch every parameter element is touched by exactly one thread (plain +=; launches on a stream
 // serialise); dv is shared by all rows -> atomics.  z_shape / z_app are constants upstream (never passed to an
 // optimizer, MAIN:522-547): no gradient is produced for them.
-struct FoldGrad {
-    const float* P; float* G; float* dsig; float g;
-    __device__ void b(int pid, int f) const { G[param_offset(pid) + f] += g; }
-    __device__ void w(int pid, int row, int c0, int n, const float* v, bool want_dv) const {
+struct FoldGrad {      // one WAVE per bias element: lane 0 owns the bias terms, the lanes stride over a row's columns
+    float* G; float g; int lane;
+    __device__ void b(int pid, int f) const { if (lane == 0) G[param_offset(pid) + f] += g; }
+    __device__ void w(int pid, int row, int c0, int n, const float* v) const {
         const long o = param_offset(pid) + (long)row * param_shape(pid).cols + c0;
-        for (int k = 0; k < n; ++k) {
-            G[o + k] += g * v[k];
-            if (want_dv && dsig) atomicAdd(dsig + k, g * P[o + k]);
-        }
+        for (int k = lane; k < n; k += 64) G[o + k] += g * v[k];
     }
 };
-__global__ void fold_bwd_kernel(int field, const float* __restrict__ P, const float* __restrict__ sig,
-                                const float* __restrict__ zs, const float* __restrict__ za,
-                                const float* __restrict__ dbias, float* G, float* dsig, int n) {
+__global__ void fold_bwd_kernel(int field, const float* __restrict__ sig, const float* __restrict__ zs,
+                                const float* __restrict__ za, const float* __restrict__ dbias, float* G, int n) {
     using PG = Prog<TIER_BF16>;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n) return;
     auto feat_of = [](int e) { return 32 * (e >> 5) + tile_feat((e >> 4) & 1, e & 15); };
-    const FoldGrad q = {P, G, dsig, dbias[i]};
+    const FoldGrad q = {G, dbias[i], (int)(threadIdx.x & 63)};
     int base, f;
     auto trunk_tail = [&](int i, int b_l1, int b_skip, int b_l5, int b_view, int b_out, int skb) {
         // shared by head / listener / torso: everything after IN except the signal columns of SKIP
         if (i < b_skip) {
             base = i - b_l1; f = feat_of(base & 255); q.b(P_BLK0_B + 2 * (base >> 8), f);
         } else if (i < b_l5) {
-            f = feat_of(i - b_skip); q.b(P_FCZSK_B, f); q.w(P_FCZSK_W, f, 0, ZDIM, zs, false); q.b(skb, f);
+            f = feat_of(i - b_skip); q.b(P_FCZSK_B, f); q.w(P_FCZSK_W, f, 0, ZDIM, zs); q.b(skb, f);
         } else if (i < b_view) {
             base = i - b_l5; f = feat_of(base & 255); q.b(P_BLK4_B + 2 * (base >> 8), f);
         } else if (i < b_out) {
             f = feat_of(i - b_view);
-            if (f < 256) { q.b(P_FEATV_B, f); q.b(P_FCZV_B, f); q.w(P_FCZV_W, f, 0, ZDIM, za, false); q.b(P_FCV_B, f); }
+            if (f < 256) { q.b(P_FEATV_B, f); q.b(P_FCZV_B, f); q.w(P_FCZV_W, f, 0, ZDIM, za); q.b(P_FCV_B, f); }
             else if (f == 256) q.b(P_SIGMA_B, 0);
         } else {
             f = feat_of(i - b_out); if (f < 3) q.b(P_FEATO_B, f);
@@ -181,19 +177,19 @@ __global__ void fold_bwd_kernel(int field, const float* __restrict__ P, const fl
         const int in_w = lis ? P_FCINL_W : P_FCIN_W, in_b = lis ? P_FCINL_B : P_FCIN_B;
         const int sk_w = lis ? P_FCPSKL_W : P_FCPSK_W, sk_b = lis ? P_FCPSKL_B : P_FCPSK_B;
         if (i < PG::H_B_L1) {
-            f = feat_of(i); q.b(in_b, f); q.b(P_FCZ_B, f); q.w(P_FCZ_W, f, 0, ZDIM, zs, false);
-            if (!lis) q.w(in_w, f, NPE, NSIG, sig, true);
+            f = feat_of(i); q.b(in_b, f); q.b(P_FCZ_B, f); q.w(P_FCZ_W, f, 0, ZDIM, zs);
+            if (!lis) q.w(in_w, f, NPE, NSIG, sig);
         } else {
             trunk_tail(i, PG::H_B_L1, PG::H_B_SKIP, PG::H_B_L5, PG::H_B_VIEW, PG::H_B_OUT, sk_b);
-            if (!lis && i >= PG::H_B_SKIP && i < PG::H_B_L5) q.w(sk_w, feat_of(i - PG::H_B_SKIP), NPE, NSIG, sig, true);
+            if (!lis && i >= PG::H_B_SKIP && i < PG::H_B_L5) q.w(sk_w, feat_of(i - PG::H_B_SKIP), NPE, NSIG, sig);
         }
     } else {
         if (i < PG::T_B_IN) {
             const int vec = i >> 6;
             f = feat_of(i & 63);
             switch (vec) {
-            case 0: q.b(P_DE0_B, f); q.w(P_DE0_W, f, NPE, NET, sig, true); break;
-            case 1: q.b(P_DS0_B, f); q.w(P_DS0_W, f, NPE, NET, sig, true); break;
+            case 0: q.b(P_DE0_B, f); q.w(P_DE0_W, f, NPE, NET, sig); break;
+            case 1: q.b(P_DS0_B, f); q.w(P_DS0_W, f, NPE, NET, sig); break;
             case 2: q.b(P_DE1_B, f); break;
             case 3: q.b(P_DS1_B, f); break;
             case 4: q.b(P_DE2_B, f); break;
@@ -201,23 +197,47 @@ __global__ void fold_bwd_kernel(int field, const float* __restrict__ P, const fl
             case 6: q.b(P_DE3_B, f); break;
             case 7: q.b(P_DESK_B, f); break;
             case 8: q.b(P_DS3_B, f); break;
-            case 9: q.b(P_DSSK_B, f); q.w(P_DSSK_W, f, 0, NET, sig, true); break;
+            case 9: q.b(P_DSSK_B, f); q.w(P_DSSK_W, f, 0, NET, sig); break;
             case 10: q.b(P_DE4_B, f); break;
             case 11: q.b(P_DS4_B, f); break;
             case 12: if (f < NPE) q.b(P_DEO_B, f); break;
-            default: if (f < NET) { q.b(P_DSO_B, f); if (dsig) atomicAdd(dsig + f, q.g); } break;
+            default: if (f < NET) q.b(P_DSO_B, f); break;
             }
         } else if (i < PG::T_B_L1) {
-            f = feat_of(i - PG::T_B_IN); q.b(P_FCINT_B, f); q.b(P_FCZ_B, f); q.w(P_FCZ_W, f, 0, ZDIM, zs, false);
+            f = feat_of(i - PG::T_B_IN); q.b(P_FCINT_B, f); q.b(P_FCZ_B, f); q.w(P_FCZ_W, f, 0, ZDIM, zs);
         } else {
             trunk_tail(i, PG::T_B_L1, PG::T_B_SKIP, PG::T_B_L5, PG::T_B_VIEW, PG::T_B_OUT, P_FCPSKT_B);
         }
     }
 }
+// d(signal)[k] = sum over the bias elements whose fold has a W[., c0 + k] * signal[k] term (+ the identity term of
+// the torso's SO vector).  One wave per k, lanes stride over the elements: no atomics, one writer per output.
+struct SigTerm { int base, len, pid, c0; };
+__global__ void fold_bwd_sig_kernel(int field, const float* __restrict__ P, const float* __restrict__ dbias, float* dsig) {
+    using PG = Prog<TIER_BF16>;
+    const int k = blockIdx.x, lane = threadIdx.x;
+    auto feat_of = [](int e) { return 32 * (e >> 5) + tile_feat((e >> 4) & 1, e & 15); };
+    const SigTerm head[2] = {{PG::H_B_IN, 256, P_FCIN_W, NPE}, {PG::H_B_SKIP, 256, P_FCPSK_W, NPE}};
+    const SigTerm torso[3] = {{PG::T_B_E0, 64, P_DE0_W, NPE}, {PG::T_B_S0, 64, P_DS0_W, NPE}, {PG::T_B_SSKIP, 64, P_DSSK_W, 0}};
+    const bool t = field == FIELD_TORSO;
+    float acc = 0.f;
+    for (int q = 0; q < (t ? 3 : 2); ++q) {
+        const SigTerm m = t ? torso[q] : head[q];
+        const long o = param_offset(m.pid) + m.c0 + k;
+        const int cols = param_shape(m.pid).cols;
+        for (int e = lane; e < m.len; e += 64) acc += dbias[m.base + e] * P[o + (long)feat_of(e) * cols];
+    }
+    if (t)      // SO: bias = out_signal.bias + signal  (identity)
+        for (int e = lane; e < 64; e += 64) if (feat_of(e) == k) acc += dbias[PG::T_B_SO + e];
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0) dsig[k] += acc;
+}
 hipError_t launch_fold_bwd(int field, const float* params, const float* sig, const float* zs, const float* za,
                            const float* dbias, float* grad_flat, float* dsig, int n, hipStream_t st) {
-    hipLaunchKernelGGL(fold_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, st, field, params, sig, zs, za, dbias,
-                       grad_flat, dsig, n);
+    hipLaunchKernelGGL(fold_bwd_kernel, dim3((n + 3) / 4), dim3(256), 0, st, field, sig, zs, za, dbias, grad_flat, n);
+    if (dsig && field != 2)
+        hipLaunchKernelGGL(fold_bwd_sig_kernel, dim3(field == FIELD_TORSO ? NET : NSIG), dim3(64), 0, st, field, params,
+                           dbias, dsig);
     return hipGetLastError();
 }
 

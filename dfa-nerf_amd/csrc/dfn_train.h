@@ -37,6 +37,8 @@ hipError_t launch_composite_bwd(const CompositeBwdArgs& A, hipStream_t st);
 hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, const int* prefix_dev, int total_items,
                         const void* dy_T, const void* act_T, long NP, int ksplit, float* C, hipStream_t st);
 hipError_t launch_scatter_add(const int* map, const float* dense, long n, float* grad_flat, hipStream_t st);
+// macro-tile of one wgrad wave, in 32x32 output tiles (dfn_api.hip sizes the work list with the same numbers)
+constexpr int WG_MT = 2, WG_NT = 4;
 hipError_t launch_bias_grad(int tier, int field, const int* row_of, int n, const void* dy_T, long NP, float* dbias,
                             hipStream_t st);
 

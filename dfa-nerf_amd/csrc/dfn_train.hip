@@ -238,6 +238,9 @@ hipError_t launch_composite_bwd(const CompositeBwdArgs& A, hipStream_t st) {
 // ================================================================================================
 // weight gradients: C[M x N] += A[M x NP] * B[N x NP]^T, contraction over the sample points, split-K + atomics
 // ================================================================================================
+// One wave = one macro-tile of up to WG_MT x WG_NT 32x32 output tiles over a slice of the sample points: per
+// 32-point step it loads WG_MT A tiles + WG_NT B tiles (1 KiB each) for WG_MT*WG_NT tile products - 2.7x less
+// operand traffic than one tile per wave (the kernel is bound by operand reads out of L2/HBM, not by the MFMAs).
 template <int TIER>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, const int* work_prefix, const void* dy_T,
                                                     const void* act_T, long n_tiles, int g_rows, int a_rows,
@@ -250,45 +253,94 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
     while (item >= work_prefix[op + 1]) ++op;
     const WOp o = ops[op];
     long loc = item - work_prefix[op];
-    const int nt_n = o.N / 32;
+    const int mts = o.M / 32, nts = o.N / 32;
+    const int nb_n = (nts + WG_NT - 1) / WG_NT;
     const int ks = (int)(loc % ksplit);
     loc /= ksplit;
-    const int nt = (int)(loc % nt_n), mt = (int)(loc / nt_n);
+    const int nb = (int)(loc % nb_n), mb = (int)(loc / nb_n);
+    const int mt_n = min(WG_MT, mts - WG_MT * mb), nt_n = min(WG_NT, nts - WG_NT * nb);     // wave-uniform
     const long per = (n_tiles + ksplit - 1) / ksplit;
     const long t0 = ks * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
     // tile-major operands: row r of tile t starts at (t * rows + r) * 32
-    const T* a = (const T*)dy_T + (long)(o.a_row + 32 * mt + (lane & 31)) * 32;
-    const T* b = (const T*)act_T + (long)(o.b_row + 32 * nt + (lane & 31)) * 32;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int h = lane >> 5;
-    for (long t = t0; t < t1; ++t) {
-        const T* at = a + t * (long)g_rows * 32;
-        const T* bt = b + t * (long)a_rows * 32;
-        if constexpr (TIER == TIER_BF16) {
+    constexpr int KOFF = (TIER == TIER_BF16) ? 8 : 0;
+    const T* a = (const T*)dy_T + (long)(o.a_row + 32 * WG_MT * mb + (lane & 31)) * 32 + KOFF * h;
+    const T* b = (const T*)act_T + (long)(o.b_row + 32 * WG_NT * nb + (lane & 31)) * 32 + KOFF * h;
+    f32x16 acc[WG_MT][WG_NT];
 #pragma unroll
-            for (int k = 0; k < 32; k += 16) {
-                const bf16x8 av = *(const bf16x8*)(at + k + 8 * h);
-                const bf16x8 bv = *(const bf16x8*)(bt + k + 8 * h);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
-            }
-        } else {
+    for (int i = 0; i < WG_MT; ++i)
+#pragma unroll
+        for (int j = 0; j < WG_NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if constexpr (TIER == TIER_BF16) {
+        // register double buffer: the operands of step t+1 are in flight while the 16 MFMAs of step t run
+        bf16x8 av[2][WG_MT][2], bv[2][WG_NT][2];
+        auto load = [&](int s, long t) {
+            const T* at = a + t * (long)g_rows * 32;
+            const T* bt = b + t * (long)a_rows * 32;
+#pragma unroll
+            for (int i = 0; i < WG_MT; ++i)
+                if (i < mt_n) { av[s][i][0] = *(const bf16x8*)(at + i * 1024); av[s][i][1] = *(const bf16x8*)(at + i * 1024 + 16); }
+#pragma unroll
+            for (int j = 0; j < WG_NT; ++j)
+                if (j < nt_n) { bv[s][j][0] = *(const bf16x8*)(bt + j * 1024); bv[s][j][1] = *(const bf16x8*)(bt + j * 1024 + 16); }
+        };
+        auto mac = [&](int s) {
+#pragma unroll
+            for (int i = 0; i < WG_MT; ++i)
+#pragma unroll
+                for (int j = 0; j < WG_NT; ++j)
+                    if (i < mt_n && j < nt_n) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][i][0], bv[s][j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][i][1], bv[s][j][1], acc[i][j], 0, 0, 0);
+                    }
+        };
+        if (t0 < t1) load(0, t0);
+        long t = t0;
+        for (; t + 1 < t1; t += 2) {
+            load(1, t + 1);
+            mac(0);
+            if (t + 2 < t1) load(0, t + 2);
+            mac(1);
+        }
+        if (t < t1) mac(0);
+    } else {
+        for (long t = t0; t < t1; ++t) {
+            const T* at = a + t * (long)g_rows * 32;
+            const T* bt = b + t * (long)a_rows * 32;
 #pragma unroll
             for (int k = 0; k < 32; k += 4) {
-                const f32x4 av = *(const f32x4*)(at + k);
-                const f32x4 bv = *(const f32x4*)(bt + k);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? av[1] : av[0], h ? bv[1] : bv[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? av[3] : av[2], h ? bv[3] : bv[2], acc, 0, 0, 0);
+                f32x4 av[WG_MT], bv[WG_NT];
+#pragma unroll
+                for (int i = 0; i < WG_MT; ++i) if (i < mt_n) av[i] = *(const f32x4*)(at + i * 1024 + k);
+#pragma unroll
+                for (int j = 0; j < WG_NT; ++j) if (j < nt_n) bv[j] = *(const f32x4*)(bt + j * 1024 + k);
+#pragma unroll
+                for (int i = 0; i < WG_MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < WG_NT; ++j)
+                        if (i < mt_n && j < nt_n) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? av[i][1] : av[i][0], h ? bv[j][1] : bv[j][0],
+                                                                             acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? av[i][3] : av[i][2], h ? bv[j][3] : bv[j][2],
+                                                                             acc[i][j], 0, 0, 0);
+                        }
             }
         }
     }
     float* c = C + o.c_off;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = 32 * mt + tile_feat(lane >> 5, r), col = 32 * nt + (lane & 31);
-        atomicAdd(c + (long)row * o.N + col, acc[r]);
-    }
+    for (int i = 0; i < WG_MT; ++i)
+#pragma unroll
+        for (int j = 0; j < WG_NT; ++j)
+            if (i < mt_n && j < nt_n) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * (WG_MT * mb + i) + tile_feat(lane >> 5, r), col = 32 * (WG_NT * nb + j) + (lane & 31);
+                    atomicAdd(c + (long)row * o.N + col, acc[i][j][r]);
+                }
+            }
 }
 hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, const int* prefix_dev, int total_items,
                         const void* dy_T, const void* act_T, long NP, int ksplit, float* C, hipStream_t st) {
@@ -316,31 +368,51 @@ hipError_t launch_scatter_add(const int* map, const float* dense, long n, float*
     return hipGetLastError();
 }
 
-// d(bias blob)[e] = sum over points of dy_T[.., row_of[e], ..]   (tile-major array)
+// d(bias blob)[e] = sum over points of dy_T[.., row_of[e], ..]   (tile-major array [tile][rows][32]).
+// Streaming row sums: thread = one row, block = 256 consecutive rows, blockIdx.y = a slice of the tiles; a wave
+// reads 64 rows x 32 points = one contiguous 4 KiB (bf16) / 8 KiB (f32) run per tile.  Partial sums are added
+// atomically to the (zeroed) blob through e_of[row] (bias element of a row, -1 = none).
 template <typename T>
-__global__ void bias_grad_kernel(const int* row_of, const T* dy_T, long n_tiles, int rows, float* dbias) {
-    __shared__ float red[4];
-    const int e = blockIdx.x;
-    const int row = row_of[e];
+__global__ void bias_grad_kernel(const int* e_of, const T* dy_T, long n_tiles, int rows, float* dbias) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const int e = e_of[row];
+    if (e < 0) return;
+    const long per = (n_tiles + gridDim.y - 1) / gridDim.y;
+    const long t0 = blockIdx.y * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
     float acc = 0.f;
-    if (row >= 0) {
-        const int n = threadIdx.x & 31;
-        for (long t = threadIdx.x >> 5; t < n_tiles; t += 8) acc += (float)dy_T[(t * rows + row) * 32 + n];
+    for (long t = t0; t < t1; ++t) {
+        const uint4* p = (const uint4*)(dy_T + (t * rows + row) * 32);
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 v = p[q];
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)      // bf16 pair -> two f32
+                    acc += __uint_as_float(w[k] << 16) + __uint_as_float(w[k] & 0xffff0000u);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint4 v = p[q];
+                acc += (__uint_as_float(v.x) + __uint_as_float(v.y)) + (__uint_as_float(v.z) + __uint_as_float(v.w));
+            }
+        }
     }
-    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) dbias[e] = red[0] + red[1] + red[2] + red[3];
+    atomicAdd(dbias + e, acc);
 }
-hipError_t launch_bias_grad(int tier, int field, const int* row_of, int n, const void* dy_T, long NP, float* dbias,
+hipError_t launch_bias_grad(int tier, int field, const int* e_of, int n_bias, const void* dy_T, long NP, float* dbias,
                             hipStream_t st) {
     const int rows = field == FIELD_TORSO ? GradMap::S_ROWS : GradMap::H_ROWS;
+    hipError_t err = hipMemsetAsync(dbias, 0, (size_t)n_bias * sizeof(float), st);
+    if (err != hipSuccess) return err;
+    const dim3 grid((rows + 255) / 256, 128);
     if (tier == TIER_BF16)
-        hipLaunchKernelGGL(bias_grad_kernel<__bf16>, dim3(n), dim3(256), 0, st, row_of, (const __bf16*)dy_T, NP / 32,
-                           rows, dbias);
-    else
-        hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(n), dim3(256), 0, st, row_of, (const float*)dy_T, NP / 32, rows,
+        hipLaunchKernelGGL(bias_grad_kernel<__bf16>, grid, dim3(256), 0, st, e_of, (const __bf16*)dy_T, NP / 32, rows,
                            dbias);
+    else
+        hipLaunchKernelGGL(bias_grad_kernel<float>, grid, dim3(256), 0, st, e_of, (const float*)dy_T, NP / 32, rows, dbias);
     return hipGetLastError();
 }
 
