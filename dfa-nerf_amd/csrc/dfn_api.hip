@@ -172,10 +172,10 @@ int dfn_fold_bias_bwd(int tier, int field, const float* params, const float* sig
     return DFN_OK;
 }
 
-int dfn_render_fwd(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
-                   const float* bias_head, const float* bias_torso, const float* bg_f32,
-                   const uint8_t* bg_u8, const int32_t* pix_index, float* rgb_head, float* rgb_com,
-                   float* weights_head, float* weights_com, float* z_vals, void* stream) {
+static int render_fwd_impl(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
+                           const float* bias_head, const float* bias_torso, const float* bg_f32,
+                           const uint8_t* bg_u8, const int32_t* pix_index, float* rgb_head, float* rgb_com,
+                           float* weights_head, float* weights_com, float* z_vals, int out_u8, void* stream) {
     if (!tier_ok(tier) || !frame || !packed_head || !bias_head || !rgb_head)
         return fail(DFN_E_ARG, "dfn_render_fwd: bad argument");
     const DfnFrame& F = *frame;
@@ -210,6 +210,7 @@ int dfn_render_fwd(int tier, const DfnFrame* frame, const void* packed_head, con
     A.w_head = weights_head;
     A.w_com = weights_com;
     A.z_out = z_vals;
+    A.out_u8 = out_u8;
     A.samples_out = nullptr;
     A.act_T[0] = A.act_T[1] = nullptr;
     A.masks[0] = A.masks[1] = nullptr;
@@ -217,6 +218,21 @@ int dfn_render_fwd(int tier, const DfnFrame* frame, const void* packed_head, con
     hipError_t err = launch_render(tier, A, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "render_kernel");
     return DFN_OK;
+}
+
+int dfn_render_fwd(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
+                   const float* bias_head, const float* bias_torso, const float* bg_f32,
+                   const uint8_t* bg_u8, const int32_t* pix_index, float* rgb_head, float* rgb_com,
+                   float* weights_head, float* weights_com, float* z_vals, void* stream) {
+    return render_fwd_impl(tier, frame, packed_head, packed_torso, bias_head, bias_torso, bg_f32, bg_u8, pix_index,
+                           rgb_head, rgb_com, weights_head, weights_com, z_vals, 0, stream);
+}
+
+int dfn_render_fwd_u8(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
+                      const float* bias_head, const float* bias_torso, const float* bg_f32, const uint8_t* bg_u8,
+                      const int32_t* pix_index, uint8_t* rgb8_head, uint8_t* rgb8_com, void* stream) {
+    return render_fwd_impl(tier, frame, packed_head, packed_torso, bias_head, bias_torso, bg_f32, bg_u8, pix_index,
+                           (float*)rgb8_head, (float*)rgb8_com, nullptr, nullptr, nullptr, 1, stream);
 }
 
 // ---- training ---------------------------------------------------------------------------------------------------
@@ -285,6 +301,7 @@ int dfn_train_fwd(int tier, const DfnFrame* frame, const void* packed_head, cons
         return fail(DFN_E_ARG, "dfn_train_fwd: bias_torso must directly follow bias_head in memory");
     RenderArgs A;
     A.frame = F;
+    A.out_u8 = 0;
     A.wblob[0] = (const char*)packed_head;
     A.wblob[1] = (const char*)packed_torso;
     A.nslab[0] = ph.n_slabs;

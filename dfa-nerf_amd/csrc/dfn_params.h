@@ -19,6 +19,7 @@ struct RenderArgs {
     float* w_head;
     float* w_com;
     float* z_out;
+    int out_u8;                 // rgb_head / rgb_com point at uint8 [ray_count,3]: to8b in the epilogue (HELP:17)
     // training recorder (all null for inference): per-sample raw outputs and per-field activations / ReLU masks
     float* samples_out;         // [ray_count][n_coarse][8]
     void* act_T[2];

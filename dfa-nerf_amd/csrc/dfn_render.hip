@@ -480,10 +480,21 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     }
 #endif
     if (valid && lane == 0) {
+        if (A.out_u8) {      // to8b (run_nerf_helpers.py:17): (255 * clip(x, 0, 1)) truncated, straight from the epilogue
+            unsigned char* o8h = (unsigned char*)A.rgb_head;
+            unsigned char* o8c = (unsigned char*)A.rgb_com;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            A.rgb_head[(size_t)r_raw * 3 + k] = st[RS_RGB_H + k];
-            if (two && A.rgb_com) A.rgb_com[(size_t)r_raw * 3 + k] = st[RS_RGB_C + k];
+            for (int k = 0; k < 3; ++k) {
+                o8h[(size_t)r_raw * 3 + k] = (unsigned char)(int)mul_(255.0f, fminf(fmaxf(st[RS_RGB_H + k], 0.f), 1.f));
+                if (two && o8c)
+                    o8c[(size_t)r_raw * 3 + k] = (unsigned char)(int)mul_(255.0f, fminf(fmaxf(st[RS_RGB_C + k], 0.f), 1.f));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                A.rgb_head[(size_t)r_raw * 3 + k] = st[RS_RGB_H + k];
+                if (two && A.rgb_com) A.rgb_com[(size_t)r_raw * 3 + k] = st[RS_RGB_C + k];
+            }
         }
     }
     // drain the prefetched slabs before the LDS allocation is released

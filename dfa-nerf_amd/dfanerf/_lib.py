@@ -45,6 +45,7 @@ def _load():
         "dfn_fold_bias": (i32, [i32, i32, fp, fp, fp, fp, fp, vp]),
         "dfn_fold_bias_bwd": (i32, [i32, i32, fp, fp, fp, fp, fp, fp, fp, vp]),
         "dfn_render_fwd": (i32, [i32, C.POINTER(DfnFrame), vp, vp, fp, fp, fp, vp, ip, fp, fp, fp, fp, fp, vp]),
+        "dfn_render_fwd_u8": (i32, [i32, C.POINTER(DfnFrame), vp, vp, fp, fp, fp, vp, ip, vp, vp, vp]),
         "dfn_decoder_fwd": (i32, [i32, i32, vp, fp, fp, fp, lg, fp, fp, vp]),
         "dfn_get_rays": (i32, [i32, i32, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), fp, fp, vp]),
         "dfn_ndc_rays": (i32, [i32, i32, C.c_float, C.c_float, fp, fp, lg, fp, fp, vp]),

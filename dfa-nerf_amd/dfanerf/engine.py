@@ -147,6 +147,28 @@ def render(packed, bias, frame, bg, pix_index=None, want_weights=False, out_head
     return out
 
 
+def render_u8(packed, bias, frame, bg, pix_index=None):
+    """dfn_render_fwd_u8: the same launch with to8b fused into the epilogue -> uint8 [n,3] images (head, composite)."""
+    dev = packed.device
+    n = frame.ray_count
+    two = frame.fields == 2
+    out_h = torch.empty(n, 3, dtype=torch.uint8, device=dev)
+    out_c = torch.empty(n, 3, dtype=torch.uint8, device=dev) if two else None
+    bg_f32 = bg if bg.dtype == torch.float32 else None
+    bg_u8 = bg if bg.dtype == torch.uint8 else None
+    if bg_f32 is None and bg_u8 is None:
+        raise TypeError("bg must be float32 or uint8")
+    nh = packed.bias_floats(FIELD_HEAD)
+    bias_t = C.c_void_p(bias.data_ptr() + 4 * nh) if two else None
+    if pix_index is not None:
+        pix_index = pix_index.to(device=dev, dtype=torch.int32).contiguous()
+    check(lib.dfn_render_fwd_u8(packed.tier, C.byref(frame), _ptr(packed.packed[FIELD_HEAD]),
+                                _ptr(packed.packed.get(FIELD_TORSO)) if two else None, _ptr(bias), bias_t,
+                                _ptr(bg_f32), _ptr(bg_u8), _ptr(pix_index), _ptr(out_h), _ptr(out_c), _stream()),
+          "dfn_render_fwd_u8")
+    return out_h, out_c
+
+
 def decoder_forward(packed, field, bias, points, dirs):
     """dfn_decoder_fwd: points/dirs [N,3] -> feat [N,3], sigma [N]."""
     dev = packed.device

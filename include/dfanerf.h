@@ -94,6 +94,12 @@ int dfn_render_fwd(int tier, const DfnFrame* frame, const void* packed_head, con
                    const uint8_t* bg_u8, const int32_t* pix_index, float* rgb_head, float* rgb_com,
                    float* weights_head, float* weights_com, float* z_vals, void* stream);
 
+/* Same launch with the output stage fused: rgb8_* [ray_count,3] uint8 =
+ * to8b(rgb) = (255 * clip(x, 0, 1)) truncated (HELP:17, MAIN:712-732), written from the kernel epilogue. */
+int dfn_render_fwd_u8(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
+                      const float* bias_head, const float* bias_torso, const float* bg_f32, const uint8_t* bg_u8,
+                      const int32_t* pix_index, uint8_t* rgb8_head, uint8_t* rgb8_com, void* stream);
+
 /* ---- training step: replaces loss.backward() through MAIN:855-899 + DEC:277-349 (torch autograd upstream) ------
  * One step = dfn_train_fwd (the fused renderer with its recorder on: coarse samples, both fields) ->
  * [caller: loss and d loss / d rgb] -> dfn_composite_bwd -> per field: dfn_mlp_bwd (dX chain on transposed weight

@@ -337,3 +337,35 @@ def test_fold_bias_matches_numpy(eng, packed, golden, latents, states):
     b_v = P["feat_view.bias"] + P["fc_z_view.weight"] @ za[0, 0] + P["fc_z_view.bias"] + P["fc_view.bias"]
     np.testing.assert_allclose(view[:256], b_v, atol=2e-5, rtol=1e-5)
     assert view[256] == np.float32(P["sigma_out.bias"][0]) and (view[257:] == 0).all()
+
+
+@pytest.mark.parametrize("tier,n_fine,fields", [("f32", 0, 2), ("bf16", 128, 2), ("bf16", 64, 1)])
+def test_render_u8_epilogue_equals_to8b_of_float_render(eng, packed, scene, latents, golden, tier, n_fine, fields):
+    """dfn_render_fwd_u8 (to8b fused into the kernel epilogue) == to8b(dfn_render_fwd), byte for
+    byte, on ragged ray counts; and against the reference's uint8 golden image (G7) for the coarse f32 case."""
+    g = golden("g7_frame_coarse")
+    zs, za = latents
+    pk = packed[tier]
+    bias = pk.fold(g["signal"][0], g["signal_torso"].reshape(-1) if fields == 2 else None, zs[0], za[0])
+    bg = (t(scene["bg"]).float() / 255.0).reshape(-1, 3).cuda()
+    for begin, count in ((0, 1003), (101250, 517)):
+        fr = eng.make_frame(scene["H"], scene["W"], scene["focal"], scene["cx"], scene["cy"], scene["poses"][2],
+                            scene["pose_body"], scene["near"], scene["far"], ray_begin=begin, ray_count=count,
+                            n_fine=n_fine, fields=fields)
+        f_h, f_c = eng.render(pk, bias, fr, bg)[:2]
+        u_h, u_c = eng.render_u8(pk, bias, fr, bg)
+        assert u_h.dtype == torch.uint8 and tuple(u_h.shape) == (count, 3)
+        assert torch.equal(u_h, eng.to8b(f_h))
+        if fields == 2:
+            assert torch.equal(u_c, eng.to8b(f_c))
+        else:
+            assert u_c is None
+    if tier == "f32" and n_fine == 0:
+        idx = t(np.asarray(g["ray_idx"], np.int32)).cuda()
+        fr = eng.make_frame(scene["H"], scene["W"], scene["focal"], scene["cx"], scene["cy"], scene["poses"][2],
+                            scene["pose_body"], scene["near"], scene["far"], ray_count=len(g["ray_idx"]), n_fine=0,
+                            fields=2)
+        u_h, u_c = eng.render_u8(pk, bias, fr, bg, pix_index=idx)
+        for got, ref in ((u_h, g["rgb8_head"]), (u_c, g["rgb8_com"])):
+            d = np.abs(got.cpu().numpy().astype(np.int32) - ref.astype(np.int32))
+            assert d.max() <= 1 and (d > 0).mean() <= 2e-3      # SURVEY 8(c): identical up to +-1 LSB on <= 0.1-0.2 %
