@@ -220,8 +220,10 @@ def main():
     per = (R + world - 1) // world                       # rank r renders [r*per, min(R,(r+1)*per))
     begin = rank * per
     count = max(0, min(R, begin + per) - begin)
-    shard = torch.zeros(per, 3, dtype=torch.float32, device=dev)
-    gathered = torch.empty(world * per, 3, dtype=torch.float32, device=dev) if world > 1 else None
+    # one [per, 3] shard per image the workload produces (head; head + two-field composite for c3), gathered together
+    n_img = 2 if fields == 2 else 1
+    shard = torch.zeros(n_img, per, 3, dtype=torch.float32, device=dev)
+    gathered = torch.empty(world, n_img, per, 3, dtype=torch.float32, device=dev) if world > 1 else None
     bias_buf = None
     ev = []
 
@@ -237,13 +239,13 @@ def main():
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        engine.render(pk, bias_buf, fr, bg, out_head=shard[:count], out_com=None)
+        engine.render(pk, bias_buf, fr, bg, out_head=shard[0, :count], out_com=shard[1, :count] if fields == 2 else None)
         if timed:
             e1.record()
             ev.append((e0, e1))
         if world > 1:
             dist.all_gather_into_tensor(gathered, shard)
-            return gathered[:R]
+            return gathered
         return shard
 
     for i in range(args.warmup):

@@ -201,7 +201,7 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_gloo_world2_gather_and_grad_bucket():
+def _run_world2():
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -213,10 +213,22 @@ def test_gloo_world2_gather_and_grad_bucket():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
+    try:
+        res = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
+    except Exception:
+        res = None
     for p in procs:
         p.join(60)
-        assert p.exitcode == 0
+        if p.is_alive():
+            p.kill()
+    if res is None or any(p.exitcode != 0 for p in procs):
+        return None
+    return res
+
+
+def test_gloo_world2_gather_and_grad_bucket():
+    res = _run_world2() or _run_world2()       # one retry: the free port found above can be taken in between
+    assert res is not None
     assert all(r[1] for r in res) and res[0][2] == 5 * 3 + 3 + 3 * 2 + 2
     for k in range(4):
         a, b = res[0][3][k], res[1][3][k]
