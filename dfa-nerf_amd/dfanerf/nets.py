@@ -138,3 +138,44 @@ def encode_signal_torso(dataset, itr_obj, img_i, PoseAttNet, global_step, args, 
         return PoseAttNet(emb)
     et = pose_to_euler_trans(poses[img_i].unsqueeze(0))
     return torch.cat((embed_fn(et[:, :3]), embed_fn(et[:, 3:])), 1)
+
+
+def _att_batch(att, windows):
+    """AudioAttNet on a batch of windows [B, S, D] -> [B, D] (same arithmetic as AudioAttNet.forward per window)."""
+    B, S, D = windows.shape
+    y = att.attentionConvNet(windows[..., :att.dim_aud].permute(0, 2, 1))           # [B,1,S]
+    a = att.attentionNet(y.reshape(B, S))                                          # [B,S], softmax over the window
+    return torch.sum(a.unsqueeze(-1) * windows, dim=1)
+
+
+def encode_signals_batch(dataset, itr_obj, frame_ids, AudNet, ExpNet, AudAttNet, PoseAttNet, global_step, args,
+                         length, embed_fn):
+    """encode_signal + encode_signal_torso (MAIN:28-111) for a LIST of frames of object 0 in one pass (SURVEY.md
+    8(f) rank 3): every network runs once on all rows instead of once per frame.  Returns (sig [B,96], sig_torso
+    [B,42]); row b equals encode_signal(...)[0][0] / encode_signal_torso(...).reshape(-1) of frame_ids[b] up to
+    the rounding of batched vs single-row GEMMs."""
+    d = dataset[itr_obj]
+    auds, exps, poses = d['auds'], d['exp'], d['poses']
+    idx = torch.as_tensor(list(frame_ids), dtype=torch.long, device=auds.device)
+    et = pose_to_euler_trans(poses[:length])
+    if global_step >= args.nosmo_iters:
+        def windows(x, half):                      # zero-padded rows at both ends, like _window
+            z = x.new_zeros(half, x.shape[1])
+            xp = torch.cat((z, x[:length], z), 0)
+            return xp.unfold(0, 2 * half, 1)[idx].permute(0, 2, 1)                 # [B, 2*half, D]
+        h = int(args.smo_size / 2)
+        wa, we = windows(auds, h), windows(exps, h)
+        B, S = wa.shape[0], wa.shape[1]
+        feat = torch.cat((AudNet(wa.reshape(B * S, -1)), ExpNet(we.reshape(B * S, -1))), 1).reshape(B, S, -1)
+        sig = _att_batch(AudAttNet, feat)
+        ht = int(args.smo_torse_size / 2)
+        wt = windows(et, ht)
+        Bt, St = wt.shape[0], wt.shape[1]
+        flat = wt.reshape(Bt * St, 6)
+        emb = torch.cat((embed_fn(flat[:, :3]), embed_fn(flat[:, 3:])), 1).reshape(Bt, St, -1)
+        sigt = _att_batch(PoseAttNet, emb)
+    else:
+        sig = torch.cat((AudNet(auds[idx]), ExpNet(exps[idx])), 1)
+        e = et[idx]
+        sigt = torch.cat((embed_fn(e[:, :3]), embed_fn(e[:, 3:])), 1)
+    return sig, sigt

@@ -256,3 +256,26 @@ def test_dropin_modules_importable():
         sys.path.remove(d)
         for m in ("run_nerf_com_trainExpLater", "run_nerf_helpers", "decoder", "load_audface", "_bootstrap"):
             sys.modules.pop(m, None)
+
+
+@pytest.mark.parametrize("step", [0, 300000])
+def test_encode_signals_batch_matches_per_frame(states, scene, step):
+    """Batched signal encoders == the per-frame encode_signal / encode_signal_torso, including
+    the zero-padded windows at both ends of the sequence."""
+    mods = _modules(states)
+    n = scene["aud"].shape[0]
+    ds = [{"auds": t(scene["aud"]), "exp": t(scene["exp"]), "poses": t(scene["poses"])}]
+    embed_fn, _ = nets.get_embedder(3, 0)
+
+    class A:
+        nosmo_iters, smo_size, smo_torse_size = 300000, 4, 8
+    ids = [0, 1, n // 2, n - 2, n - 1]
+    with torch.no_grad():
+        sb, stb = nets.encode_signals_batch(ds, 0, ids, mods["AudNet"], mods["ExpNet"], mods["AudAttNet"],
+                                            mods["PoseAttNet"], step, A, n, embed_fn)
+        for b, i in enumerate(ids):
+            s1 = nets.encode_signal(ds, 0, i, 96, mods["AudNet"], mods["ExpNet"], mods["AudAttNet"], step, A, n,
+                                    embed_fn=embed_fn)[0]
+            t1 = nets.encode_signal_torso(ds, 0, i, mods["PoseAttNet"], step, A, n, embed_fn=embed_fn)
+            torch.testing.assert_close(sb[b], s1.reshape(-1), rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(stb[b], t1.reshape(-1), rtol=1e-4, atol=1e-5)
