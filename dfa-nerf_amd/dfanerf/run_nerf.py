@@ -373,21 +373,43 @@ def _mimwrite(path, frames, fps=25):
         return False
 
 
+def _choice_distinct(rng, n, k):
+    """k distinct indices of range(n), uniform over the k-subsets, in random order - what
+    np.random.choice(n, k, replace=False) gives upstream (MAIN:818-820), but O(k) instead of a permutation of all n
+    (2.9 ms per step for n = 202,500: it was the longest host-side item of the training step)."""
+    if k * 4 >= n:
+        return rng.choice(n, size=[k], replace=False)
+    got = np.unique(rng.randint(0, n, size=k + k // 4 + 16))
+    while got.shape[0] < k:
+        got = np.unique(np.concatenate([got, rng.randint(0, n, size=k)]))
+    return got[rng.permutation(got.shape[0])[:k]]
+
+
 def select_coords(H, W, N_rand, sample_rate, rect, rng=np.random):
     """Pixel sampling of MAIN:786-820 on the host (np.random as upstream); returns int64 [N_rand, 2] (y, x)."""
     if sample_rate > 0:
-        ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
-        ys, xs = ys.reshape(-1), xs.reshape(-1)
-        in_rect = (ys >= rect[0]) & (ys <= rect[0] + rect[2]) & (xs >= rect[1]) & (xs <= rect[1] + rect[3])
-        in_torso = (ys >= H / 2) & (ys <= H) & (xs >= 0) & (xs <= W)
-        m = in_rect | in_torso
+        # rect_num pixels from (face rect | lower half), the rest from outside (MAIN:786-817): rejection sampling on
+        # uniform distinct candidates, classified arithmetically (no H*W meshgrid / nonzero per step)
+        def inside(p):
+            y, x = p // W, p % W
+            in_rect = (y >= rect[0]) & (y <= rect[0] + rect[2]) & (x >= rect[1]) & (x <= rect[1] + rect[3])
+            return in_rect | (y >= H / 2)
         rect_num = int(N_rand * sample_rate)
-        idx_in, idx_out = np.nonzero(m)[0], np.nonzero(~m)[0]
-        a = rng.choice(idx_in.shape[0], size=[rect_num], replace=False)
-        b = rng.choice(idx_out.shape[0], size=[N_rand - rect_num], replace=False)
-        sel = np.concatenate([idx_in[a], idx_out[b]])
+        need = {True: rect_num, False: N_rand - rect_num}
+        have = {True: np.empty(0, np.int64), False: np.empty(0, np.int64)}
+        tries = 0
+        while any(have[c].shape[0] < need[c] for c in (True, False)):
+            cand = _choice_distinct(rng, H * W, min(H * W, 4 * N_rand << min(tries, 4)))
+            m = inside(cand)
+            for c in (True, False):
+                if have[c].shape[0] < need[c]:
+                    have[c] = np.unique(np.concatenate([have[c], cand[m == c]]))
+            tries += 1
+            if tries > 64:
+                raise ValueError("select_coords: not enough pixels inside / outside the sampling region")
+        sel = np.concatenate([have[c][rng.permutation(have[c].shape[0])[:need[c]]] for c in (True, False)])
     else:
-        sel = rng.choice(H * W, size=[N_rand], replace=False)
+        sel = _choice_distinct(rng, H * W, N_rand)
     return np.stack([sel // W, sel % W], 1).astype(np.int64)
 
 
