@@ -5,8 +5,8 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A "step" = one 450x450 audio-driven frame through the hot path: conditioning signals (encoded for the whole
-8-frame batch every 8 steps) -> per-frame bias fold -> fused render (rays -> 64 coarse -> sample_pdf -> 64+128 merged samples -> decoder MLP ->
+A "step" = one 450x450 audio-driven frame through the hot path: per-frame conditioning signals (HIP encoders)
+-> bias fold -> fused render (rays -> 64 coarse -> sample_pdf -> 64+128 merged samples -> decoder MLP ->
 compositing) -> (N > 1) RCCL all-gather of the RGB shards.  Weights, background and the audio/expression/
 pose features are resident in HBM before the timed region.  For N > 1 the rays of every frame are sharded
 across the ranks (strong scaling: total work per step is fixed), the partition SURVEY.md 8(e) names.
@@ -227,18 +227,15 @@ def main():
     bias_buf = None
     ev = []
 
-    sig_cache = {}
+    # conditioning networks in HIP (dfn_encode_signal / dfn_encode_signal_torso)
+    enc = engine.SignalEncoder(aud_net, exp_net, att, patt, ds[0]["auds"], ds[0]["exp"], ds[0]["poses"])
+    fid = [torch.tensor([f], dtype=torch.int32, device=dev) for f in range(F)]
 
     def step(i, timed):
         nonlocal bias_buf
         f = i % F
-        if f == 0 or not sig_cache:
-            # conditioning signals of the whole F-frame batch in ONE pass of the encoders (configs[4], SURVEY.md 8(f)
-            # rank 3), every F steps, inside the timed region; the per-frame work is fold + render
-            with torch.no_grad():
-                sig_cache["h"], sig_cache["t"] = nets.encode_signals_batch(ds, 0, range(F), aud_net, exp_net, att, patt,
-                                                                           300000, A, F, embed_fn)
-        sig, sigt = sig_cache["h"][f], (sig_cache["t"][f] if fields == 2 else None)
+        s2, t2 = enc.encode(fid[f], A.smo_size, A.smo_torse_size)           # 2 launches: [1,96], [1,42]
+        sig, sigt = s2[0], (t2[0] if fields == 2 else None)
         bias_buf = pk.fold(sig, sigt, zs_d, za_d, out=bias_buf)
         fr = engine.make_frame(H, W, sc["focal"], sc["cx"], sc["cy"], sc["poses"][f], sc["pose_body"], sc["near"],
                                sc["far"], ray_begin=begin, ray_count=count, n_fine=n_fine, fields=fields)

@@ -12,6 +12,7 @@
 #include "dfn_misc.h"
 #include "dfn_params.h"
 #include "dfn_plan.h"
+#include "dfn_signal.h"
 #include "dfn_train.h"
 
 using namespace dfn;
@@ -417,6 +418,34 @@ int dfn_bias_grad(int tier, int field, const void* dy_T, long NP, float* dbias, 
     }
     hipError_t err = launch_bias_grad(tier, field, w.eof_dev, (int)w.bias_rows.size(), dy_T, NP, dbias, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "bias_grad_kernel");
+    return DFN_OK;
+}
+
+int dfn_encode_signal(const float* aud_params, const float* exp_params, const float* att_params, const float* auds,
+                      const float* exps, int n_total, const int32_t* frame_ids, int n_frames, int smo_size, float* out,
+                      void* stream) {
+    if (!aud_params || !exp_params || !auds || !exps || !frame_ids || !out || n_total <= 0 || n_frames < 0)
+        return fail(DFN_E_ARG, "dfn_encode_signal: bad argument");
+    if (smo_size < 0 || smo_size > 8 || (smo_size & 1)) return fail(DFN_E_ARG, "dfn_encode_signal: smo_size must be 0, 2, 4, 6 or 8");
+    if (smo_size > 0 && !att_params) return fail(DFN_E_ARG, "dfn_encode_signal: attention parameters missing");
+    if (n_frames == 0) return DFN_OK;
+    hipError_t err = launch_encode_signal(aud_params, exp_params, att_params, auds, exps, n_total, frame_ids, n_frames,
+                                          smo_size, out, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "encode_signal_kernel");
+    return DFN_OK;
+}
+
+int dfn_encode_signal_torso(const float* att_params, const float* poses, int pose_stride, int n_total,
+                            const int32_t* frame_ids, int n_frames, int smo_size, float* out, void* stream) {
+    if (!poses || !frame_ids || !out || n_total <= 0 || n_frames < 0 || (pose_stride != 12 && pose_stride != 16))
+        return fail(DFN_E_ARG, "dfn_encode_signal_torso: bad argument");
+    if (smo_size < 0 || smo_size > 8 || (smo_size & 1))
+        return fail(DFN_E_ARG, "dfn_encode_signal_torso: smo_size must be 0, 2, 4, 6 or 8");
+    if (smo_size > 0 && !att_params) return fail(DFN_E_ARG, "dfn_encode_signal_torso: attention parameters missing");
+    if (n_frames == 0) return DFN_OK;
+    hipError_t err = launch_encode_signal_torso(att_params, poses, pose_stride, n_total, frame_ids, n_frames, smo_size, out,
+                                                (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "encode_signal_torso_kernel");
     return DFN_OK;
 }
 

@@ -98,6 +98,45 @@ class PackedDecoder:
         return out
 
 
+class SignalEncoder:
+    """dfn_encode_signal / dfn_encode_signal_torso: the conditioning networks' forward in HIP (inference).  Holds flat
+    f32 copies of the four networks' parameters (state_dict order); call refresh() after they change."""
+
+    def __init__(self, aud_net, exp_net, att_net, pose_att_net, auds, exps, poses):
+        require_gpu()
+        self.nets = (aud_net, exp_net, att_net, pose_att_net)
+        dev = auds.device
+        self.auds, self.exps = _f32c(auds, dev), _f32c(exps, dev)
+        self.poses = _f32c(poses, dev)
+        self.n = int(self.auds.shape[0])
+        self.pose_stride = int(self.poses[0].numel())
+        self.device = dev
+        self.refresh()
+
+    def refresh(self):
+        flat = lambda m: None if m is None else torch.cat(
+            [v.detach().reshape(-1).to(self.device, torch.float32) for v in m.state_dict().values()]).contiguous()
+        self.p_aud, self.p_exp, self.p_att, self.p_patt = [flat(m) for m in self.nets]
+
+    def encode(self, frame_ids, smo_size, smo_torso_size, length=None):
+        """-> sig [B,96], sig_torso [B,42] for the frames `frame_ids`; smo_* = 0 selects the unsmoothed branch;
+        `length` = number of leading frames that form the sequence (zero padding beyond it), default all."""
+        if isinstance(frame_ids, torch.Tensor):
+            ids = frame_ids.to(device=self.device, dtype=torch.int32).reshape(-1)
+        else:
+            ids = torch.as_tensor(list(frame_ids), dtype=torch.int32, device=self.device)
+        n_total = self.n if length is None else int(length)
+        B = ids.numel()
+        sig = torch.empty(B, 96, dtype=torch.float32, device=self.device)
+        sigt = torch.empty(B, 42, dtype=torch.float32, device=self.device)
+        check(lib.dfn_encode_signal(_ptr(self.p_aud), _ptr(self.p_exp), _ptr(self.p_att), _ptr(self.auds),
+                                    _ptr(self.exps), n_total, _ptr(ids), B, int(smo_size), _ptr(sig), _stream()),
+              "dfn_encode_signal")
+        check(lib.dfn_encode_signal_torso(_ptr(self.p_patt), _ptr(self.poses), self.pose_stride, n_total, _ptr(ids), B,
+                                          int(smo_torso_size), _ptr(sigt), _stream()), "dfn_encode_signal_torso")
+        return sig, sigt
+
+
 def make_frame(H, W, focal, cx, cy, pose, pose_body, near, far, last_dist=1e10, ray_begin=0, ray_count=None,
                n_coarse=64, n_fine=0, fields=2, concate_bg=True):
     fr = DfnFrame()

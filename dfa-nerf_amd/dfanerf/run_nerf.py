@@ -576,12 +576,25 @@ def train():
         rgbs = []
         writer = _FrameWriter(H, W, 2)
         body_host = _host(pose_body_t)
+        # conditioning signals through the HIP encoders (dfn_encode_signal*, rows A7 / A8) when the whole path is on
+        # the GPU with the reference's configuration (pose attention on); otherwise the torch modules
+        enc = None
+        if dev.type == 'cuda' and "PoseAttNet" in nets and args.dim_aud == 96 and embed_fn is not None:
+            from . import engine
+            enc = engine.SignalEncoder(nets["AudNet"], nets["ExpNet"], nets["AudAttNet"], nets["PoseAttNet"],
+                                       ds['auds'], ds['exp'], ds['poses'])
+        smoothed = global_step >= args.nosmo_iters
         for img_i in frame_ids:
             with torch.no_grad():
-                signal = encode_signal(datasets, itr_obj, img_i, args.dim_aud, nets["AudNet"], nets["ExpNet"],
-                                       nets["AudAttNet"], global_step, args, len_sig, embed_fn=embed_fn)
-                signal_torso = encode_signal_torso(datasets, itr_obj, img_i, nets.get("PoseAttNet"), global_step,
-                                                   args, len_sig, embed_fn=embed_fn)
+                if enc is not None:
+                    s2, t2 = enc.encode([img_i], args.smo_size if smoothed else 0,
+                                        args.smo_torse_size if smoothed else 0, length=len_sig)
+                    signal, signal_torso = [s2, None], t2[0]
+                else:
+                    signal = encode_signal(datasets, itr_obj, img_i, args.dim_aud, nets["AudNet"], nets["ExpNet"],
+                                           nets["AudAttNet"], global_step, args, len_sig, embed_fn=embed_fn)
+                    signal_torso = encode_signal_torso(datasets, itr_obj, img_i, nets.get("PoseAttNet"), global_step,
+                                                       args, len_sig, embed_fn=embed_fn)
                 # uint8 straight from the kernel epilogue (to8b fused), gathered as uint8 across the ranks
                 rgb8_head, rgb8 = renderer.render_image(poses_host[img_i], body_host, signal, signal_torso, out_u8=True)
             if rank == 0:

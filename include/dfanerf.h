@@ -81,6 +81,21 @@ long dfn_bias_floats(int tier, int field);
 int dfn_fold_bias(int tier, int field, const float* params, const float* signal, const float* z_shape,
                   const float* z_app, float* bias, void* stream);
 
+/* ---- per-frame conditioning signals (forward; training differentiates the torch twins) ---------------------------
+ * encode_signal, MAIN:28-75 (object 0): AudioNet_W2L (HELP:165-178) and ExpressionEnc (HELP:182-193) on the window
+ * [i - smo/2, i + smo/2) of audio [n_total,512] / expression [n_total,64] features, rows outside the sequence are
+ * ZERO INPUT rows (MAIN:36-57), then AudioAttNet(96, smo) (HELP:210-240) -> out [n_frames,96].  smo_size == 0 is the
+ * branch before --nosmo_iters: cat(AudNet(aud[i]), ExpNet(exp[i])).  *_params: each network's state_dict()
+ * flattened in registration order (172,480 / 3,136 / 5,169 floats for smo 4).  frame_ids: device int32. */
+int dfn_encode_signal(const float* aud_params, const float* exp_params, const float* att_params, const float* auds,
+                      const float* exps, int n_total, const int32_t* frame_ids, int n_frames, int smo_size, float* out,
+                      void* stream);
+/* encode_signal_torso, MAIN:78-111: rot_to_euler + translation (MAIN:182-204) of the window of poses
+ * ([n_total] matrices of pose_stride = 16 (4x4) or 12 (3x4) floats), zero rows outside, get_embedder(3,0)
+ * (HELP:21-70) on each half -> 42, AudioAttNet(42, smo) -> out [n_frames,42]; smo_size == 0: the single frame. */
+int dfn_encode_signal_torso(const float* att_params, const float* poses, int pose_stride, int n_total,
+                            const int32_t* frame_ids, int n_frames, int smo_size, float* out, void* stream);
+
 /* ---- the fused renderer: replaces the frame loop MAIN:611-713 (and its training twin MAIN:829-899) --
  * packed_head/packed_torso, bias_head/bias_torso: from the calls above (torso ones may be NULL when
  * frame.fields == 1).  bg: background as f32 [H*W,3] in [0,1] (MAIN:477) or u8 [H*W,3]; give one.

@@ -369,3 +369,44 @@ def test_render_u8_epilogue_equals_to8b_of_float_render(eng, packed, scene, late
         for got, ref in ((u_h, g["rgb8_head"]), (u_c, g["rgb8_com"])):
             d = np.abs(got.cpu().numpy().astype(np.int32) - ref.astype(np.int32))
             assert d.max() <= 1 and (d > 0).mean() <= 2e-3      # identical up to +-1 LSB on <= 0.1-0.2 %
+
+
+def test_signal_encoders_hip_vs_reference_golden(eng, states, scene, golden):
+    """dfn_encode_signal / dfn_encode_signal_torso against golden G6 (the reference's
+    encode_signal / encode_signal_torso: both branches, zero-padded windows at both ends, the shortened sequence) and
+    against the torch twins on every frame."""
+    from dfanerf import nets
+    g = golden("g6_signals")
+    dev = torch.device("cuda")
+    mods = {"AudNet": nets.AudioNet_W2L(), "ExpNet": nets.ExpressionEnc(), "AudAttNet": nets.AudioAttNet(96, 4),
+            "PoseAttNet": nets.AudioAttNet(42, 8)}
+    for k, m in mods.items():
+        m.load_state_dict({kk: t(v) for kk, v in states[k].items()})
+        m.to(dev)
+    auds, exps, poses = [t(scene[k]).to(dev) for k in ("aud", "exp", "poses")]
+    n = auds.shape[0]
+    enc = eng.SignalEncoder(mods["AudNet"], mods["ExpNet"], mods["AudAttNet"], mods["PoseAttNet"], auds, exps, poses)
+    ids = [0, 1, 4, n - 1]
+    for tag, smo, smo_t in (("raw", 0, 0), ("smo", 4, 8)):
+        sig, sigt = enc.encode(ids, smo, smo_t)
+        for b, i in enumerate(ids):
+            np.testing.assert_allclose(sig[b].cpu().numpy(), g[f"aud_{tag}_{i}"].reshape(-1), rtol=2e-5, atol=2e-6)
+            np.testing.assert_allclose(sigt[b].cpu().numpy(), g[f"torso_{tag}_{i}"].reshape(-1), rtol=2e-5, atol=2e-6)
+    sig, _ = enc.encode([5], 4, 8, length=6)
+    np.testing.assert_allclose(sig[0].cpu().numpy(), g["aud_smo_5_len6"].reshape(-1), rtol=2e-5, atol=2e-6)
+    # every frame against the torch modules (batched twin)
+    ds = [{"auds": auds, "exp": exps, "poses": poses}]
+    embed_fn, _ = nets.get_embedder(3, 0)
+
+    class A:
+        nosmo_iters, smo_size, smo_torse_size = 300000, 4, 8
+    for step, smo, smo_t in ((0, 0, 0), (300000, 4, 8)):
+        with torch.no_grad():
+            rs, rt = nets.encode_signals_batch(ds, 0, range(n), mods["AudNet"], mods["ExpNet"], mods["AudAttNet"],
+                                               mods["PoseAttNet"], step, A, n, embed_fn)
+        sig, sigt = enc.encode(range(n), smo, smo_t)
+        torch.testing.assert_close(sig, rs, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(sigt, rt, rtol=1e-4, atol=1e-5)
+    # error paths
+    with pytest.raises(Exception):
+        enc.encode([0], 3, 8)

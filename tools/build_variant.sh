@@ -10,7 +10,7 @@ OBJ="$ROOT/exp_libs/obj_$NAME"
 mkdir -p "$OBJ"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I$SRC -I$ROOT/include $*"
 pids=()
-for f in dfn_render dfn_misc dfn_api dfn_train; do
+for f in dfn_render dfn_misc dfn_api dfn_train dfn_signal; do
   ( hipcc $FLAGS -c "$SRC/$f.hip" -o "$OBJ/$f.o" 2>"$OBJ/$f.log" ) &
   pids+=($!)
 done
