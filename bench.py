@@ -118,7 +118,7 @@ def bench_training(args, world, rank, local, dev, desc):
            "near": sc["near"], "far": sc["far"]}]
     zs, za = [t(v).to(dev) for v in synth.synth_latents(0)]
     embed_fn, _ = nets.get_embedder(3, 0)
-    opts = {k: torch.optim.Adam(m.parameters(), lr=5e-4, betas=(0.9, 0.999)) for k, m in mods.items()}
+    opts = {k: run_nerf.make_adam(m.parameters(), 5e-4) for k, m in mods.items()}
     buf = training.TrainBuffers(args.tier, N_RAND, dev)
     bucket = parallel.FlatGradBucket(list(mods.values())) if world > 1 else None
     rng = np.random.RandomState(100 + rank)

@@ -304,6 +304,18 @@ def run_network(inputs, viewdirs, decoder, z_shape, z_app, signal, head_or_torso
     return feat.reshape(*inputs.shape[:-1], 3), sigma.reshape(inputs.shape[:-1])
 
 
+def make_adam(params, lr):
+    """torch.optim.Adam(lr, betas=(0.9, 0.999)) as upstream (MAIN:522-547); on the GPU the fused implementation (one
+    multi-tensor kernel per step instead of ~8 foreach kernels: the five optimizers cost 1 ms of host time per step
+    otherwise).  Same update rule, same state_dict layout."""
+    params = list(params)
+    fused = bool(params) and all(p.is_cuda for p in params)
+    try:
+        return torch.optim.Adam(params=params, lr=lr, betas=(0.9, 0.999), fused=fused)
+    except (RuntimeError, TypeError):          # a build without the fused kernels
+        return torch.optim.Adam(params=params, lr=lr, betas=(0.9, 0.999))
+
+
 def create_nerf(args, dev=None):
     """North-star shim: build the networks and optimizers exactly as train() does (MAIN:512-547)."""
     dev = dev or device
@@ -318,8 +330,7 @@ def create_nerf(args, dev=None):
             "AudAttNet": AudioAttNet(dim_aud=args.dim_aud, seq_len=args.smo_size).to(dev)}
     if args.use_et_embed:
         nets["PoseAttNet"] = AudioAttNet(dim_aud=dim_torso_signal, seq_len=args.smo_torse_size).to(dev)
-    opts = {k: torch.optim.Adam(params=list(m.parameters()), lr=args.lrate, betas=(0.9, 0.999))
-            for k, m in nets.items()}
+    opts = {k: make_adam(m.parameters(), args.lrate) for k, m in nets.items()}
     return nets, opts, embed_fn
 
 

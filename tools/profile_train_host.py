@@ -1,14 +1,23 @@
 #!/usr/bin/env python3
-"""Developer tool: host-side (Python) profile of the training step of bench.py c4."""
+"""Developer tool: host-side (Python) profile of the TIMED training steps of bench.py c4 (warm-up excluded: the
+profiler is switched on at the synchronize() that opens the timed region and off at the one that closes it)."""
 import cProfile, pstats, sys, os, io
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.argv = ["bench.py", "--workload", "c4", "--steps", "40", "--warmup", "8", "--no-cpu-baseline"]
+sys.argv = ["bench.py", "--workload", "c4", "--steps", "40", "--warmup", "10", "--no-cpu-baseline"]
+import torch
 import bench
 pr = cProfile.Profile()
-pr.enable()
+real_sync = torch.cuda.synchronize
+state = {"n": 0}
+def sync(*a, **k):
+    r = real_sync(*a, **k)
+    state["n"] += 1
+    if state["n"] == 2: pr.enable()
+    if state["n"] == 3: pr.disable()
+    return r
+torch.cuda.synchronize = sync
 bench.main()
-pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
-print(s.getvalue()[:9000])
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(35)
+print(s.getvalue()[:7000])
