@@ -486,8 +486,17 @@ def train_step_loss_hip(nets, dataset, itr_obj, img_i, sel_yx, target_head, targ
     signal_torso = encode_signal_torso(dataset, itr_obj, img_i, nets.get("PoseAttNet"), global_step, args, len_train,
                                        embed_fn=embed_fn)
     pix = torch.as_tensor(sel_yx[:, 0] * W + sel_yx[:, 1], dtype=torch.int32, device=dev)
-    frame = engine.make_frame(H, W, focal, cx, cy, poses[img_i].detach().cpu().numpy(),
-                              pose_torso.detach().cpu().numpy(), dataset[itr_obj]['near'], dataset[itr_obj]['far'],
+    # the frame geometry travels in the kernel arguments: keep host copies of the poses (a .cpu() per step would
+    # synchronise the stream and serialise the host with the previous step's kernels)
+    d = dataset[itr_obj]
+    if d.get('_poses_host_of') is not poses:
+        d['_poses_host'], d['_poses_host_of'] = poses.detach().cpu().numpy(), poses
+    if isinstance(pose_torso, torch.Tensor):
+        key = (pose_torso.data_ptr(), pose_torso._version)
+        if d.get('_pose_torso_key') != key:
+            d['_pose_torso_host'], d['_pose_torso_key'] = pose_torso.detach().cpu().numpy(), key
+        pose_torso = d['_pose_torso_host']
+    frame = engine.make_frame(H, W, focal, cx, cy, d['_poses_host'][img_i], pose_torso, d['near'], d['far'],
                               args.last_dist, 0, pix.numel(), args.N_samples, 0, 2, args.concate_bg)
     bg = dataset[itr_obj]['bc_img'].reshape(-1, 3)
     zs = z_shape[0, itr_obj * 2:itr_obj * 2 + 2]
