@@ -120,6 +120,8 @@ def bench_training(args, world, rank, local, dev, desc):
     embed_fn, _ = nets.get_embedder(3, 0)
     opts = {k: run_nerf.make_adam(m.parameters(), 5e-4) for k, m in mods.items()}
     buf = training.TrainBuffers(args.tier, N_RAND, dev)
+    buf.signal_trainer = training.SignalTrainer(mods["AudNet"], mods["ExpNet"], mods["AudAttNet"], mods["PoseAttNet"],
+                                                ds[0]["auds"], ds[0]["exp"], ds[0]["poses"])
     bucket = parallel.FlatGradBucket(list(mods.values())) if world > 1 else None
     rng = np.random.RandomState(100 + rank)
     tgt_h = torch.rand(H, W, 3, device=dev)

@@ -17,38 +17,52 @@
 namespace dfn {
 
 constexpr int SIG_MAX_WIN = 8;       // largest attention window (smo_size / smo_torse_size)
-constexpr int SIG_THREADS = 256;
+constexpr int SIG_THREADS = 1024;     // 16 waves: the kernels are latency-bound chains of small layers
 
 __device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : 0.02f * x; }
 
-// y[t][o] = act(b[o] + sum_k W[o][k] x[t][k]),  x: LDS [S][K], y: LDS [S][M]
-__device__ void linear_rows(const float* __restrict__ W, const float* __restrict__ b, int M, int K, const float* x,
-                            float* y, int S, bool act) {
+// y[t][o] = act(b[o] + sum_k W[o][k] x[t][k]),  x: LDS [S][K], y: LDS [S][M].  A wave owns output rows; all of a row's
+// weights are requested before the first FMA (K/64 <= 8 independent loads in flight: the layer is latency-bound).
+template <int K>
+__device__ void linear_rows(const float* __restrict__ W, const float* __restrict__ b, int M, const float* x, float* y,
+                            int S, bool act) {
+    constexpr int KU = (K + 63) / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int o = wave; o < M; o += nw) {
-        float acc[SIG_MAX_WIN];
-#pragma unroll
-        for (int t = 0; t < SIG_MAX_WIN; ++t) acc[t] = 0.f;
         const float* w = W + (long)o * K;
-        for (int k = lane; k < K; k += 64) {
-            const float wv = w[k];
+        float wv[KU];
 #pragma unroll
-            for (int t = 0; t < SIG_MAX_WIN; ++t)
-                if (t < S) acc[t] = fmaf(wv, x[t * K + k], acc[t]);
-        }
+        for (int u = 0; u < KU; ++u) wv[u] = (lane + 64 * u < K) ? w[lane + 64 * u] : 0.f;
+        const float bo = b[o];
 #pragma unroll
         for (int t = 0; t < SIG_MAX_WIN; ++t) {
             if (t < S) {
-                float a = acc[t];
+                float a = 0.f;
+#pragma unroll
+                for (int u = 0; u < KU; ++u)
+                    if (lane + 64 * u < K) a = fmaf(wv[u], x[t * K + lane + 64 * u], a);
                 for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
                 if (lane == 0) {
-                    a += b[o];
+                    a += bo;
                     y[t * M + o] = act ? leaky(a) : a;
                 }
             }
         }
     }
     __syncthreads();
+}
+
+// number of parameters of AudioAttNet(D, S): convs D->16->8->4->2->1 (k3) + Linear(S,S)
+__device__ __host__ constexpr int att_param_count(int D, int S) {
+    return 16 * D * 3 + 16 + 8 * 16 * 3 + 8 + 4 * 8 * 3 + 4 + 2 * 4 * 3 + 2 + 1 * 2 * 3 + 1 + S * S + S;
+}
+constexpr int ATT_PARAMS_MAX = att_param_count(96, SIG_MAX_WIN);
+// the attention net's few thousand parameters are read many times by few threads: stage them in LDS
+__device__ const float* stage_att(const float* __restrict__ P, float* dst, int D, int S) {
+    const int n = att_param_count(D, S);
+    for (int e = threadIdx.x; e < n; e += blockDim.x) dst[e] = P[e];
+    __syncthreads();
+    return dst;
 }
 
 // AudioAttNet on the window feat [S][D] (LDS): conv stack D->16->8->4->2->1 (k3, p1, LeakyReLU .02 after every conv),
@@ -124,6 +138,7 @@ __global__ __launch_bounds__(SIG_THREADS) void encode_signal_kernel(const float*
     float* b1 = b0 + SIG_MAX_WIN * 16;     // [S][16]
     float* a64 = b1 + SIG_MAX_WIN * 16;    // [S][64]
     float* e32 = a64 + SIG_MAX_WIN * 64;   // [S][32]
+    float* ps = e32 + SIG_MAX_WIN * 32;    // attention parameters
     const int f = frame_ids[blockIdx.x];
     for (int e = threadIdx.x; e < S * 512; e += blockDim.x) {
         const int t = e >> 9, k = e & 511, src = smo > 0 ? f - half + t : f;
@@ -135,19 +150,19 @@ __global__ __launch_bounds__(SIG_THREADS) void encode_signal_kernel(const float*
     }
     __syncthreads();
     // AudioNet_W2L: 512 -> 256 -> 128 -> 64
-    linear_rows(PA, PA + 131072, 256, 512, xa, h1, S, true);
-    linear_rows(PA + 131328, PA + 131328 + 32768, 128, 256, h1, h2, S, true);
-    linear_rows(PA + 164224, PA + 164224 + 8192, 64, 128, h2, a64, S, false);
+    linear_rows<512>(PA, PA + 131072, 256, xa, h1, S, true);
+    linear_rows<256>(PA + 131328, PA + 131328 + 32768, 128, h1, h2, S, true);
+    linear_rows<128>(PA + 164224, PA + 164224 + 8192, 64, h2, a64, S, false);
     // ExpressionEnc: 64 -> 32 -> 32
-    linear_rows(PE, PE + 2048, 32, 64, xe, e1, S, true);
-    linear_rows(PE + 2080, PE + 2080 + 1024, 32, 32, e1, e32, S, false);
+    linear_rows<64>(PE, PE + 2048, 32, xe, e1, S, true);
+    linear_rows<32>(PE + 2080, PE + 2080 + 1024, 32, e1, e32, S, false);
     for (int e = threadIdx.x; e < S * 96; e += blockDim.x) {
         const int t = e / 96, d = e - t * 96;
         ft[t * 96 + d] = d < 64 ? a64[t * 64 + d] : e32[t * 32 + d - 64];
     }
     __syncthreads();
     float* o = out + (long)blockIdx.x * 96;
-    if (smo > 0) attention(PT, 96, S, ft, b0, b1, o);
+    if (smo > 0) attention(stage_att(PT, ps, 96, S), 96, S, ft, b0, b1, o);
     else
         for (int d = threadIdx.x; d < 96; d += blockDim.x) o[d] = ft[d];
 }
@@ -157,7 +172,7 @@ __global__ __launch_bounds__(SIG_THREADS) void encode_signal_torso_kernel(const 
                                                                           const float* __restrict__ poses, int pose_stride,
                                                                           int N, const int* __restrict__ frame_ids, int smo,
                                                                           float* out) {
-    __shared__ float emb[SIG_MAX_WIN * 42], b0[SIG_MAX_WIN * 16], b1[SIG_MAX_WIN * 16];
+    __shared__ float emb[SIG_MAX_WIN * 42], b0[SIG_MAX_WIN * 16], b1[SIG_MAX_WIN * 16], ps[att_param_count(42, SIG_MAX_WIN)];
     const int S = smo > 0 ? smo : 1, half = smo / 2;
     const int f = frame_ids[blockIdx.x];
     for (int e = threadIdx.x; e < S * 6; e += blockDim.x) {
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(SIG_THREADS) void encode_signal_torso_kernel(const 
     }
     __syncthreads();
     float* o = out + (long)blockIdx.x * 42;
-    if (smo > 0) attention(PT, 42, S, emb, b0, b1, o);
+    if (smo > 0) attention(stage_att(PT, ps, 42, S), 42, S, emb, b0, b1, o);
     else
         for (int d = threadIdx.x; d < 42; d += blockDim.x) o[d] = emb[d];
 }
@@ -188,7 +203,7 @@ __global__ __launch_bounds__(SIG_THREADS) void encode_signal_torso_kernel(const 
 hipError_t launch_encode_signal(const float* aud_params, const float* exp_params, const float* att_params,
                                 const float* auds, const float* exps, int N, const int* frame_ids, int n_frames, int smo,
                                 float* out, hipStream_t st) {
-    const size_t lds = sizeof(float) * SIG_MAX_WIN * (512 + 256 + 128 + 64 + 32 + 96 + 16 + 16 + 64 + 32);
+    const size_t lds = sizeof(float) * (SIG_MAX_WIN * (512 + 256 + 128 + 64 + 32 + 96 + 16 + 16 + 64 + 32) + ATT_PARAMS_MAX);
     static bool done = false;
     if (!done) {
         hipError_t e = hipFuncSetAttribute((const void*)encode_signal_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -204,6 +219,335 @@ hipError_t launch_encode_signal_torso(const float* att_params, const float* pose
                                       const int* frame_ids, int n_frames, int smo, float* out, hipStream_t st) {
     hipLaunchKernelGGL(encode_signal_torso_kernel, dim3(n_frames), dim3(SIG_THREADS), 0, st, att_params, poses,
                        pose_stride, N, frame_ids, smo, out);
+    return hipGetLastError();
+}
+
+}  // namespace dfn
+
+// ==========================================================================================================================
+// Backward (training, one frame per step as upstream: MAIN:737-941).  Each kernel recomputes its forward into LDS, then
+// back-propagates d(out) into the parameter gradients (+= into flat buffers laid out like the parameters).  The inputs
+// (audio / expression features, poses) are data: no gradient is produced for them.
+// ==========================================================================================================================
+namespace dfn {
+
+__device__ __forceinline__ float dleaky(float post) { return post > 0.f ? 1.0f : 0.02f; }   // slope > 0: sign(pre) = sign(post)
+
+// gradients of y = act(b + W x) over the S rows:  GW[o][k] += sum_t dy[t][o] x[t][k];  Gb[o] += sum_t dy[t][o]
+// (dy already multiplied by act'), and optionally dx[t][k] = sum_o W[o][k] dy[t][o].
+template <int K>
+__device__ void linear_rows_bwd(const float* __restrict__ W, float* GW, float* Gb, int M, const float* x, const float* dy,
+                                float* dx, int S) {
+    constexpr int KU = (K + 63) / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int o = wave; o < M; o += nw) {
+        float* g = GW + (long)o * K;
+        float old[KU];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) old[u] = (lane + 64 * u < K) ? g[lane + 64 * u] : 0.f;      // all loads first
+        float sb = 0.f;
+#pragma unroll
+        for (int t = 0; t < SIG_MAX_WIN; ++t) {
+            if (t < S) {
+                const float d = dy[t * M + o];
+                sb += d;
+#pragma unroll
+                for (int u = 0; u < KU; ++u)
+                    if (lane + 64 * u < K) old[u] = fmaf(d, x[t * K + lane + 64 * u], old[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u)
+            if (lane + 64 * u < K) g[lane + 64 * u] = old[u];
+        if (lane == 0) Gb[o] += sb;
+    }
+    if (dx) {
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            float a[SIG_MAX_WIN];
+#pragma unroll
+            for (int t = 0; t < SIG_MAX_WIN; ++t) a[t] = 0.f;
+            for (int o0 = 0; o0 < M; o0 += 8) {
+                float w[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) w[q] = W[(long)(o0 + q) * K + k];           // M is a multiple of 8
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int t = 0; t < SIG_MAX_WIN; ++t)
+                        if (t < S) a[t] = fmaf(w[q], dy[t * M + o0 + q], a[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < SIG_MAX_WIN; ++t)
+                if (t < S) dx[t * K + k] = a[t];
+        }
+    }
+    __syncthreads();
+}
+
+// Forward of AudioAttNet keeping every activation: acts[l] = output of conv l (post-LeakyReLU), [S][chans[l+1]];
+// returns att[S] in LDS.  Then the backward: d_out[D] -> G (+=, layout of P) and d_feat[S][D] (+= the direct path).
+struct AttWork {
+    float* act[5];      // LDS: [S][16], [S][8], [S][4], [S][2], [S][1]
+    float* dact[2];     // LDS ping-pong for the gradients, [S][D] each (largest layer input)
+    float* att;         // [S]
+    float* dz;          // [S]
+};
+__device__ void attention_fwd_keep(const float* __restrict__ P, int D, int S, const float* feat, const AttWork& w) {
+    const int chans[6] = {D, 16, 8, 4, 2, 1};
+    const float* cur = feat;
+    int cs = D;
+    long off = 0;
+    for (int l = 0; l < 5; ++l) {
+        const int ci = chans[l], co = chans[l + 1];
+        const float* W = P + off;
+        const float* B = W + (long)co * ci * 3;
+        for (int e = threadIdx.x; e < co * S; e += blockDim.x) {
+            const int o = e / S, t = e - o * S;
+            float a = B[o];
+            for (int c = 0; c < ci; ++c) {
+                const float* wv = W + ((long)o * ci + c) * 3;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int tt = t + j - 1;
+                    if (tt >= 0 && tt < S) a = fmaf(wv[j], cur[tt * cs + c], a);
+                }
+            }
+            w.act[l][t * co + o] = leaky(a);
+        }
+        __syncthreads();
+        off += (long)co * ci * 3 + co;
+        cur = w.act[l];
+        cs = co;
+    }
+    const float* LW = P + off;
+    const float* LB = LW + S * S;
+    if (threadIdx.x == 0) {
+        float z[SIG_MAX_WIN], m = -3.0e38f;
+        for (int i = 0; i < S; ++i) {
+            float a = LB[i];
+            for (int j = 0; j < S; ++j) a = fmaf(LW[i * S + j], cur[j], a);
+            z[i] = a;
+            m = fmaxf(m, a);
+        }
+        float sum = 0.f;
+        for (int i = 0; i < S; ++i) { z[i] = expf(z[i] - m); sum += z[i]; }
+        for (int i = 0; i < S; ++i) w.att[i] = z[i] / sum;
+    }
+    __syncthreads();
+}
+__device__ void attention_bwd(const float* __restrict__ P, float* G, int D, int S, const float* feat, const float* d_out,
+                              const AttWork& w, float* d_feat /* [S][D], overwritten */) {
+    const int chans[6] = {D, 16, 8, 4, 2, 1};
+    long offs[6];
+    offs[0] = 0;
+    for (int l = 0; l < 5; ++l) offs[l + 1] = offs[l] + (long)chans[l + 1] * chans[l] * 3 + chans[l + 1];
+    // out[d] = sum_t att[t] feat[t][d]
+    if (threadIdx.x < S) {
+        float a = 0.f;
+        for (int d = 0; d < D; ++d) a = fmaf(d_out[d], feat[threadIdx.x * D + d], a);
+        w.dz[threadIdx.x] = a;                       // d att[t] for now
+    }
+    for (int e = threadIdx.x; e < S * D; e += blockDim.x) d_feat[e] = w.att[e / D] * d_out[e % D];
+    __syncthreads();
+    // softmax, then Linear(S,S): z = LW c5 + LB
+    const float* LW = P + offs[5];
+    float* GLW = G + offs[5];
+    float* GLB = GLW + S * S;
+    const float* c5 = w.act[4];                      // [S][1]
+    float* dcur = w.dact[0];                         // gradient w.r.t. the current layer's OUTPUT (post-activation)
+    if (threadIdx.x == 0) {
+        float dot = 0.f, dz[SIG_MAX_WIN];
+        for (int j = 0; j < S; ++j) dot = fmaf(w.att[j], w.dz[j], dot);
+        for (int i = 0; i < S; ++i) dz[i] = w.att[i] * (w.dz[i] - dot);
+        for (int i = 0; i < S; ++i) {
+            GLB[i] += dz[i];
+            for (int j = 0; j < S; ++j) GLW[i * S + j] += dz[i] * c5[j];
+        }
+        for (int j = 0; j < S; ++j) {
+            float a = 0.f;
+            for (int i = 0; i < S; ++i) a = fmaf(LW[i * S + j], dz[i], a);
+            dcur[j] = a;                             // d c5[j]  ([S][1])
+        }
+    }
+    __syncthreads();
+    // conv stack backwards
+    for (int l = 4; l >= 0; --l) {
+        const int ci = chans[l], co = chans[l + 1];
+        const float* W = P + offs[l];
+        float* GW = G + offs[l];
+        float* GB = GW + (long)co * ci * 3;
+        const float* x = l == 0 ? feat : w.act[l - 1];
+        const int xs = l == 0 ? D : ci;
+        const float* y = w.act[l];
+        // d pre = d y * leaky'(y)   (in place)
+        for (int e = threadIdx.x; e < S * co; e += blockDim.x) dcur[e] *= dleaky(y[e]);
+        __syncthreads();
+        for (int e = threadIdx.x; e < co * ci * 3; e += blockDim.x) {
+            const int o = e / (ci * 3), r = e - o * ci * 3, c = r / 3, j = r - 3 * c;
+            float a = 0.f;
+            for (int t = 0; t < S; ++t) {
+                const int tt = t + j - 1;
+                if (tt >= 0 && tt < S) a = fmaf(dcur[t * co + o], x[tt * xs + c], a);
+            }
+            GW[e] += a;
+        }
+        for (int o = threadIdx.x; o < co; o += blockDim.x) {
+            float a = 0.f;
+            for (int t = 0; t < S; ++t) a += dcur[t * co + o];
+            GB[o] += a;
+        }
+        float* dnext = (l == 0) ? nullptr : ((dcur == w.dact[0]) ? w.dact[1] : w.dact[0]);
+        for (int e = threadIdx.x; e < S * ci; e += blockDim.x) {
+            const int tt = e / ci, c = e - tt * ci;
+            float a = 0.f;
+            for (int o = 0; o < co; ++o) {
+                const float* wv = W + ((long)o * ci + c) * 3;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int t = tt - j + 1;
+                    if (t >= 0 && t < S) a = fmaf(wv[j], dcur[t * co + o], a);
+                }
+            }
+            if (l == 0) d_feat[tt * D + c] += a;     // the conv stack reads feat[..., :D]
+            else dnext[e] = a;
+        }
+        __syncthreads();
+        if (l > 0) dcur = dnext;
+    }
+}
+
+__global__ __launch_bounds__(SIG_THREADS) void encode_signal_bwd_kernel(
+    const float* __restrict__ PA, const float* __restrict__ PE, const float* __restrict__ PT, const float* __restrict__ auds,
+    const float* __restrict__ exps, int N, int f, int smo, const float* __restrict__ d_out, float* GA, float* GE, float* GT) {
+    extern __shared__ float lds[];
+    const int S = smo > 0 ? smo : 1, half = smo / 2;
+    float* xa = lds;                       // [S][512]
+    float* h1 = xa + SIG_MAX_WIN * 512;    // [S][256]
+    float* h2 = h1 + SIG_MAX_WIN * 256;    // [S][128]
+    float* xe = h2 + SIG_MAX_WIN * 128;    // [S][64]
+    float* e1 = xe + SIG_MAX_WIN * 64;     // [S][32]
+    float* ft = e1 + SIG_MAX_WIN * 32;     // [S][96]
+    float* a64 = ft + SIG_MAX_WIN * 96;    // [S][64]
+    float* e32 = a64 + SIG_MAX_WIN * 64;   // [S][32]
+    float* dft = e32 + SIG_MAX_WIN * 32;   // [S][96]
+    float* g0 = dft + SIG_MAX_WIN * 96;    // [S][256] gradient scratch
+    float* g1 = g0 + SIG_MAX_WIN * 256;    // [S][256]
+    float* aw = g1 + SIG_MAX_WIN * 256;    // attention work: 5 activations + att + dz
+    float* ps = aw + SIG_MAX_WIN * 33;     // attention parameters
+    AttWork w;
+    w.act[0] = aw; w.act[1] = w.act[0] + SIG_MAX_WIN * 16; w.act[2] = w.act[1] + SIG_MAX_WIN * 8;
+    w.act[3] = w.act[2] + SIG_MAX_WIN * 4; w.act[4] = w.act[3] + SIG_MAX_WIN * 2;
+    w.att = w.act[4] + SIG_MAX_WIN; w.dz = w.att + SIG_MAX_WIN;
+    w.dact[0] = g0; w.dact[1] = g1;
+    __shared__ float dout_s[96];
+    for (int e = threadIdx.x; e < S * 512; e += blockDim.x) {
+        const int t = e >> 9, k = e & 511, src = smo > 0 ? f - half + t : f;
+        xa[t * 512 + k] = (src >= 0 && src < N) ? auds[(long)src * 512 + k] : 0.f;
+    }
+    for (int e = threadIdx.x; e < S * 64; e += blockDim.x) {
+        const int t = e >> 6, k = e & 63, src = smo > 0 ? f - half + t : f;
+        xe[t * 64 + k] = (src >= 0 && src < N) ? exps[(long)src * 64 + k] : 0.f;
+    }
+    for (int d = threadIdx.x; d < 96; d += blockDim.x) dout_s[d] = d_out[d];
+    __syncthreads();
+    // ---- forward, every activation kept ----
+    linear_rows<512>(PA, PA + 131072, 256, xa, h1, S, true);
+    linear_rows<256>(PA + 131328, PA + 131328 + 32768, 128, h1, h2, S, true);
+    linear_rows<128>(PA + 164224, PA + 164224 + 8192, 64, h2, a64, S, false);
+    linear_rows<64>(PE, PE + 2048, 32, xe, e1, S, true);
+    linear_rows<32>(PE + 2080, PE + 2080 + 1024, 32, e1, e32, S, false);
+    for (int e = threadIdx.x; e < S * 96; e += blockDim.x) {
+        const int t = e / 96, d = e - t * 96;
+        ft[t * 96 + d] = d < 64 ? a64[t * 64 + d] : e32[t * 32 + d - 64];
+    }
+    __syncthreads();
+    // ---- backward ----
+    if (smo > 0) {
+        const float* Pl = stage_att(PT, ps, 96, S);
+        attention_fwd_keep(Pl, 96, S, ft, w);
+        attention_bwd(Pl, GT, 96, S, ft, dout_s, w, dft);
+    } else {
+        for (int d = threadIdx.x; d < 96; d += blockDim.x) dft[d] = dout_s[d];
+        __syncthreads();
+    }
+    // split d feat -> d a64 (g0 as [S][64]) and d e32 (g1 as [S][32])
+    for (int e = threadIdx.x; e < S * 96; e += blockDim.x) {
+        const int t = e / 96, d = e - t * 96;
+        if (d < 64) g0[t * 64 + d] = dft[e];
+        else g1[t * 32 + d - 64] = dft[e];
+    }
+    __syncthreads();
+    // ExpressionEnc: e32 = W2 e1 + b2 ; e1 = leaky(W1 xe + b1)      (g1 = d e32; dft reused as d e1)
+    linear_rows_bwd<32>(PE + 2080, GE + 2080, GE + 2080 + 1024, 32, e1, g1, dft, S);
+    for (int e = threadIdx.x; e < S * 32; e += blockDim.x) dft[e] *= dleaky(e1[e]);
+    __syncthreads();
+    linear_rows_bwd<64>(PE, GE, GE + 2048, 32, xe, dft, nullptr, S);
+    // AudioNet_W2L: a64 = W3 h2 + b3 ; h2 = leaky(W2 h1 + b2) ; h1 = leaky(W1 xa + b1)      (g0 = d a64)
+    linear_rows_bwd<128>(PA + 164224, GA + 164224, GA + 164224 + 8192, 64, h2, g0, g1, S);       // g1 = d h2
+    for (int e = threadIdx.x; e < S * 128; e += blockDim.x) g1[e] *= dleaky(h2[e]);
+    __syncthreads();
+    linear_rows_bwd<256>(PA + 131328, GA + 131328, GA + 131328 + 32768, 128, h1, g1, g0, S);     // g0 = d h1
+    for (int e = threadIdx.x; e < S * 256; e += blockDim.x) g0[e] *= dleaky(h1[e]);
+    __syncthreads();
+    linear_rows_bwd<512>(PA, GA, GA + 131072, 256, xa, g0, nullptr, S);
+}
+
+__global__ __launch_bounds__(SIG_THREADS) void encode_signal_torso_bwd_kernel(const float* __restrict__ PT,
+                                                                              const float* __restrict__ poses, int pose_stride,
+                                                                              int N, int f, int smo,
+                                                                              const float* __restrict__ d_out, float* GT) {
+    __shared__ float emb[SIG_MAX_WIN * 42], demb[SIG_MAX_WIN * 42], g0[SIG_MAX_WIN * 42], g1[SIG_MAX_WIN * 42];
+    __shared__ float aw[SIG_MAX_WIN * 33], dout_s[42], ps[att_param_count(42, SIG_MAX_WIN)];
+    if (smo <= 0) return;                      // before --nosmo_iters no parameter takes part in the torso signal
+    const int S = smo, half = smo / 2;
+    for (int e = threadIdx.x; e < S * 6; e += blockDim.x) {
+        const int t = e / 6, c = e - t * 6, src = f - half + t;
+        float v = 0.f;
+        if (src >= 0 && src < N) {
+            const float* R = poses + (long)src * pose_stride;
+            if (c == 0) v = atan2f(R[2 * 4 + 2], R[1 * 4 + 2]);
+            else if (c == 1) v = asinf(-R[0 * 4 + 2]);
+            else if (c == 2) v = atan2f(R[0 * 4 + 0], -R[0 * 4 + 1]);
+            else v = R[(c - 3) * 4 + 3];
+        }
+        const int g = c / 3, a = c - 3 * g;
+        float* o = emb + t * 42 + g * 21;
+        o[a] = v;
+        o[3 + a] = sinf(v);          o[6 + a] = cosf(v);
+        o[9 + a] = sinf(v * 2.0f);   o[12 + a] = cosf(v * 2.0f);
+        o[15 + a] = sinf(v * 4.0f);  o[18 + a] = cosf(v * 4.0f);
+    }
+    for (int d = threadIdx.x; d < 42; d += blockDim.x) dout_s[d] = d_out[d];
+    __syncthreads();
+    AttWork w;
+    w.act[0] = aw; w.act[1] = w.act[0] + SIG_MAX_WIN * 16; w.act[2] = w.act[1] + SIG_MAX_WIN * 8;
+    w.act[3] = w.act[2] + SIG_MAX_WIN * 4; w.act[4] = w.act[3] + SIG_MAX_WIN * 2;
+    w.att = w.act[4] + SIG_MAX_WIN; w.dz = w.att + SIG_MAX_WIN;
+    w.dact[0] = g0; w.dact[1] = g1;
+    const float* Pl = stage_att(PT, ps, 42, S);
+    attention_fwd_keep(Pl, 42, S, emb, w);
+    attention_bwd(Pl, GT, 42, S, emb, dout_s, w, demb);
+}
+
+hipError_t launch_encode_signal_bwd(const float* aud_params, const float* exp_params, const float* att_params,
+                                    const float* auds, const float* exps, int N, int frame, int smo, const float* d_out,
+                                    float* g_aud, float* g_exp, float* g_att, hipStream_t st) {
+    const size_t lds = sizeof(float) * (SIG_MAX_WIN * (512 + 256 + 128 + 64 + 32 + 96 + 64 + 32 + 96 + 256 + 256 + 33) + ATT_PARAMS_MAX);
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void*)encode_signal_bwd_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    hipLaunchKernelGGL(encode_signal_bwd_kernel, dim3(1), dim3(SIG_THREADS), lds, st, aud_params, exp_params, att_params,
+                       auds, exps, N, frame, smo, d_out, g_aud, g_exp, g_att);
+    return hipGetLastError();
+}
+hipError_t launch_encode_signal_torso_bwd(const float* att_params, const float* poses, int pose_stride, int N, int frame,
+                                          int smo, const float* d_out, float* g_att, hipStream_t st) {
+    hipLaunchKernelGGL(encode_signal_torso_bwd_kernel, dim3(1), dim3(SIG_THREADS), 0, st, att_params, poses, pose_stride, N,
+                       frame, smo, d_out, g_att);
     return hipGetLastError();
 }
 

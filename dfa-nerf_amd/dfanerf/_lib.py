@@ -44,6 +44,8 @@ def _load():
         "dfn_bias_floats": (lg, [i32, i32]),
         "dfn_encode_signal": (i32, [fp, fp, fp, fp, fp, i32, ip, i32, i32, fp, vp]),
         "dfn_encode_signal_torso": (i32, [fp, fp, i32, i32, ip, i32, i32, fp, vp]),
+        "dfn_encode_signal_bwd": (i32, [fp, fp, fp, fp, fp, i32, i32, i32, fp, fp, fp, fp, vp]),
+        "dfn_encode_signal_torso_bwd": (i32, [fp, fp, i32, i32, i32, i32, fp, fp, vp]),
         "dfn_fold_bias": (i32, [i32, i32, fp, fp, fp, fp, fp, vp]),
         "dfn_fold_bias_bwd": (i32, [i32, i32, fp, fp, fp, fp, fp, fp, fp, vp]),
         "dfn_render_fwd": (i32, [i32, C.POINTER(DfnFrame), vp, vp, fp, fp, fp, vp, ip, fp, fp, fp, fp, fp, vp]),

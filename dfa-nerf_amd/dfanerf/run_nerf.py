@@ -481,10 +481,17 @@ def train_step_loss_hip(nets, dataset, itr_obj, img_i, sel_yx, target_head, targ
     poses = dataset[itr_obj]['poses']
     H, W, focal, cx, cy = dataset[itr_obj]['hwfcxy']
     H, W = int(H), int(W)
-    signal = encode_signal(dataset, itr_obj, img_i, args.dim_aud, nets["AudNet"], nets["ExpNet"], nets["AudAttNet"],
-                           global_step, args, len_train, embed_fn=embed_fn)
-    signal_torso = encode_signal_torso(dataset, itr_obj, img_i, nets.get("PoseAttNet"), global_step, args, len_train,
-                                       embed_fn=embed_fn)
+    sig_tr = getattr(buf, "signal_trainer", None)
+    if sig_tr is not None and itr_obj == 0:
+        # rows A7 / A8 forward + backward in HIP (training.SignalTrainer): 4 launches instead of ~200
+        smoothed = global_step >= args.nosmo_iters
+        s2, t2 = sig_tr.encode(img_i, args.smo_size if smoothed else 0, args.smo_torse_size if smoothed else 0, len_train)
+        signal, signal_torso = [s2, None], (t2[0] if smoothed else t2)
+    else:
+        signal = encode_signal(dataset, itr_obj, img_i, args.dim_aud, nets["AudNet"], nets["ExpNet"], nets["AudAttNet"],
+                               global_step, args, len_train, embed_fn=embed_fn)
+        signal_torso = encode_signal_torso(dataset, itr_obj, img_i, nets.get("PoseAttNet"), global_step, args,
+                                           len_train, embed_fn=embed_fn)
     pix = torch.as_tensor(sel_yx[:, 0] * W + sel_yx[:, 1], dtype=torch.int32, device=dev)
     # the frame geometry travels in the kernel arguments: keep host copies of the poses (a .cpu() per step would
     # synchronise the stream and serialise the host with the previous step's kernels)
@@ -641,6 +648,9 @@ def train():
 
     from . import training
     train_buf = training.TrainBuffers(getattr(args, "hip_tier", "f32"), args.N_rand, dev)
+    if dev.type == 'cuda' and "PoseAttNet" in nets and args.dim_aud == 96 and not getattr(args, "train_aten", False):
+        train_buf.signal_trainer = training.SignalTrainer(nets["AudNet"], nets["ExpNet"], nets["AudAttNet"],
+                                                          nets["PoseAttNet"], ds['auds'], ds['exp'], ds['poses'])
     bucket = parallel.FlatGradBucket(list(nets.values())) if world > 1 else None
     rng = np.random.RandomState(1234 + rank) if world > 1 else np.random
     i_train = ds['i_train']

@@ -219,6 +219,93 @@ class FusedTrainFn(torch.autograd.Function):
                 None, None)
 
 
+class _FlatNet:
+    """Flat f32 copy of one small network's parameters (state_dict order) + the matching gradient buffer."""
+
+    def __init__(self, module):
+        self.module = module
+        self.params = list(module.state_dict(keep_vars=True).values())
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.offsets, o = [], 0
+        for p in self.params:
+            self.offsets.append(o)
+            o += p.numel()
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
+
+    def refresh(self):
+        with torch.no_grad():
+            torch._foreach_copy_(self.views, [p.detach() for p in self.params])
+
+    def deposit(self, grad_flat):
+        for p, o in zip(self.params, self.offsets):
+            if not p.requires_grad:
+                continue
+            g = grad_flat[o:o + p.numel()].view_as(p)
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+
+
+class SignalTrainer:
+    """Rows A7 / A8 of the training step in HIP: dfn_encode_signal* forward and dfn_encode_signal*_bwd backward for the
+    frame being trained (4 launches instead of the ~200 of the torch modules + autograd).  The returned signals carry
+    an autograd node whose backward deposits the four networks' gradients into their parameters' .grad."""
+
+    def __init__(self, aud_net, exp_net, att_net, pose_att_net, auds, exps, poses):
+        engine.require_gpu()
+        self.nets = [_FlatNet(m) for m in (aud_net, exp_net, att_net, pose_att_net)]
+        dev = auds.device
+        self.auds, self.exps = auds.detach().float().contiguous(), exps.detach().float().contiguous()
+        self.poses = poses.detach().float().contiguous()
+        self.pose_stride = int(self.poses[0].numel())
+        self.device = dev
+
+    def encode(self, frame, smo_size, smo_torso_size, length):
+        for n in self.nets:
+            n.refresh()
+        anchor = torch.zeros(1, device=self.device, requires_grad=True)       # keeps the node in the graph
+        return _SignalFn.apply(anchor, self, int(frame), int(smo_size), int(smo_torso_size), int(length))
+
+
+class _SignalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, tr, frame, smo, smo_t, length):
+        dev, st = tr.device, _stream()
+        ids = torch.tensor([frame], dtype=torch.int32, device=dev)
+        sig = torch.empty(1, 96, dtype=torch.float32, device=dev)
+        sigt = torch.empty(1, 42, dtype=torch.float32, device=dev)
+        a, e, t, p = [n.flat for n in tr.nets]
+        check(lib.dfn_encode_signal(_ptr(a), _ptr(e), _ptr(t), _ptr(tr.auds), _ptr(tr.exps), length, _ptr(ids), 1, smo,
+                                    _ptr(sig), st), "dfn_encode_signal")
+        check(lib.dfn_encode_signal_torso(_ptr(p), _ptr(tr.poses), tr.pose_stride, length, _ptr(ids), 1, smo_t,
+                                          _ptr(sigt), st), "dfn_encode_signal_torso")
+        ctx.tr, ctx.args = tr, (frame, smo, smo_t, length)
+        return sig, sigt
+
+    @staticmethod
+    def backward(ctx, d_sig, d_sigt):
+        tr, (frame, smo, smo_t, length) = ctx.tr, ctx.args
+        st = _stream()
+        a, e, t, p = [n.flat for n in tr.nets]
+        g = [torch.zeros_like(n.flat) for n in tr.nets]
+        d_sig = d_sig.contiguous().float()
+        d_sigt = d_sigt.contiguous().float()
+        check(lib.dfn_encode_signal_bwd(_ptr(a), _ptr(e), _ptr(t), _ptr(tr.auds), _ptr(tr.exps), length, frame, smo,
+                                        _ptr(d_sig), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), st), "dfn_encode_signal_bwd")
+        check(lib.dfn_encode_signal_torso_bwd(_ptr(p), _ptr(tr.poses), tr.pose_stride, length, frame, smo_t, _ptr(d_sigt),
+                                              _ptr(g[3]), st), "dfn_encode_signal_torso_bwd")
+        tr.nets[0].deposit(g[0])
+        tr.nets[1].deposit(g[1])
+        if smo > 0:
+            tr.nets[2].deposit(g[2])
+        if smo_t > 0:
+            tr.nets[3].deposit(g[3])
+        return None, None, None, None, None, None
+
+
 def render_train(dec, buf, frame, bg, pix_index, sig_head, sig_torso, z_shape, z_app, fused=True):
     """Differentiable (w.r.t. the decoder parameters and the two signals) coarse two-field render of the
     pixels `pix_index` [n] (int32, y*W+x).  Returns rgb_head, rgb_com [n,3].

@@ -96,6 +96,15 @@ int dfn_encode_signal(const float* aud_params, const float* exp_params, const fl
 int dfn_encode_signal_torso(const float* att_params, const float* poses, int pose_stride, int n_total,
                             const int32_t* frame_ids, int n_frames, int smo_size, float* out, void* stream);
 
+/* Backward of the two encoders for ONE frame (upstream trains one frame per step, MAIN:737-941; there it is torch
+ * autograd): d_out [96] / [42] -> parameter gradients, ADDED into g_* (flat, laid out like the *_params).  The inputs
+ * (features, poses) are data and get no gradient.  smo_size == 0: g_att untouched (the attention net is unused). */
+int dfn_encode_signal_bwd(const float* aud_params, const float* exp_params, const float* att_params, const float* auds,
+                          const float* exps, int n_total, int frame, int smo_size, const float* d_out, float* g_aud,
+                          float* g_exp, float* g_att, void* stream);
+int dfn_encode_signal_torso_bwd(const float* att_params, const float* poses, int pose_stride, int n_total, int frame,
+                                int smo_size, const float* d_out, float* g_att, void* stream);
+
 /* ---- the fused renderer: replaces the frame loop MAIN:611-713 (and its training twin MAIN:829-899) --
  * packed_head/packed_torso, bias_head/bias_torso: from the calls above (torso ones may be NULL when
  * frame.fields == 1).  bg: background as f32 [H*W,3] in [0,1] (MAIN:477) or u8 [H*W,3]; give one.

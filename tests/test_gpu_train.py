@@ -81,8 +81,9 @@ def test_composite_backward_vs_autograd(states, scene, latents, golden):
     np.testing.assert_allclose(got, ref, atol=2e-5 * scale, rtol=2e-4)
 
 
-@pytest.mark.parametrize("tier,step", [("f32", 0), ("f32", 300000), ("bf16", 0)])
-def test_training_step_hip_vs_golden(states, scene, latents, golden, tier, step):
+@pytest.mark.parametrize("tier,step,hip_signals", [("f32", 0, False), ("f32", 300000, False), ("bf16", 0, False),
+                                                   ("f32", 0, True), ("f32", 300000, True), ("f32", 400000, True)])
+def test_training_step_hip_vs_golden(states, scene, latents, golden, tier, step, hip_signals):
     """One training step through the HIP forward+backward against golden G8 (loss, per-tensor gradient norms and
     sampled entries of every parameter of all five networks; produced by the reference's modules + torch autograd)."""
     from dfanerf import nets, run_nerf, training
@@ -102,6 +103,9 @@ def test_training_step_hip_vs_golden(states, scene, latents, golden, tier, step)
     zs, za = [t(v).to(dev) for v in latents]
     embed_fn, _ = nets.get_embedder(3, 0)
     buf = training.TrainBuffers(tier, sel.shape[0], dev)
+    if hip_signals:      # rows A7 / A8 (conditioning networks) forward + backward in HIP as well
+        buf.signal_trainer = training.SignalTrainer(mods["AudNet"], mods["ExpNet"], mods["AudAttNet"], mods["PoseAttNet"],
+                                                    ds[0]["auds"], ds[0]["exp"], ds[0]["poses"])
     ys, xs = t(sel[:, 0]).to(dev), t(sel[:, 1]).to(dev)
     loss, lh, lc, _, _ = run_nerf.train_step_loss_hip(mods, ds, 0, 3, sel, tgt_h[ys, xs], tgt_c[ys, xs], zs, za, step,
                                                       args, scene["aud"].shape[0], embed_fn, ds[0]["poses"][0], buf)
