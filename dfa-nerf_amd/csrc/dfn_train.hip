@@ -306,28 +306,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
         }
         if (t < t1) mac(0);
     } else {
-        for (long t = t0; t < t1; ++t) {
-            const T* at = a + t * (long)g_rows * 32;
-            const T* bt = b + t * (long)a_rows * 32;
+        // f32: v_mfma_f32_32x32x2_f32 takes A[row][k = half].  The contraction order is free, so MFMA m of a group of
+        // four pairs k = m (lower half of the wave) with k = m + 4 (upper half): each lane then needs 4 CONSECUTIVE
+        // points - one 16-byte load, nothing fetched twice, no selects - and a group covers 8 points.  Steps of 8
+        // points are double-buffered in registers like the bf16 path.
+        f32x4 av[2][WG_MT], bv[2][WG_NT];
+        const long n_steps = (t1 - t0) * 4;                    // 4 groups of 8 points per 32-point tile
+        auto load = [&](int s, long q) {
+            const long t = t0 + (q >> 2);
+            const int k8 = (int)(q & 3) * 8 + 4 * h;
+            const T* at = a + t * (long)g_rows * 32 + k8;
+            const T* bt = b + t * (long)a_rows * 32 + k8;
 #pragma unroll
-            for (int k = 0; k < 32; k += 4) {
-                f32x4 av[WG_MT], bv[WG_NT];
+            for (int i = 0; i < WG_MT; ++i) if (i < mt_n) av[s][i] = *(const f32x4*)(at + i * 1024);
 #pragma unroll
-                for (int i = 0; i < WG_MT; ++i) if (i < mt_n) av[i] = *(const f32x4*)(at + i * 1024 + k);
+            for (int j = 0; j < WG_NT; ++j) if (j < nt_n) bv[s][j] = *(const f32x4*)(bt + j * 1024);
+        };
+        auto mac = [&](int s) {
 #pragma unroll
-                for (int j = 0; j < WG_NT; ++j) if (j < nt_n) bv[j] = *(const f32x4*)(bt + j * 1024 + k);
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int i = 0; i < WG_MT; ++i)
 #pragma unroll
                     for (int j = 0; j < WG_NT; ++j)
-                        if (i < mt_n && j < nt_n) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? av[i][1] : av[i][0], h ? bv[j][1] : bv[j][0],
-                                                                             acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? av[i][3] : av[i][2], h ? bv[j][3] : bv[j][2],
-                                                                             acc[i][j], 0, 0, 0);
-                        }
-            }
+                        if (i < mt_n && j < nt_n)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i][m], bv[s][j][m], acc[i][j], 0, 0, 0);
+        };
+        if (n_steps > 0) load(0, 0);
+        long q = 0;
+        for (; q + 1 < n_steps; q += 2) {
+            load(1, q + 1);
+            mac(0);
+            if (q + 2 < n_steps) load(0, q + 2);
+            mac(1);
         }
+        if (q < n_steps) mac(0);
     }
     float* c = C + o.c_off;
 #pragma unroll
