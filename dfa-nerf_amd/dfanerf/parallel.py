@@ -58,25 +58,22 @@ class FlatGradBucket:
         self.numel = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
 
     def all_reduce_(self, group=None):
-        """Average the gradients over the ranks in place (missing grads count as zero)."""
+        """Average the gradients over the ranks in place (missing grads count as zero).  Two multi-tensor copies and
+        one collective per step: afterwards every parameter's .grad IS its slice of the bucket (no copy back)."""
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
             return
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
+        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
+        if len(have) < len(self.params):
+            self.flat.zero_()
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         self.flat.mul_(1.0 / dist.get_world_size(group))
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                p.grad = torch.empty_like(p)
-            p.grad.copy_(self.flat[off:off + n].view_as(p))
-            off += n
+        for p, v in zip(self.params, self.views):
+            p.grad = v
