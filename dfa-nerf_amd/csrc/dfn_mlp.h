@@ -241,6 +241,12 @@ template <int TIER> struct Fetch {
         constexpr int GAP = SLAB_FRAGS / C::LOADS_PER_SLAB;       // fragment reads between two DMA pieces
         if (fp % SLAB_FRAGS == 0) slab_advance<TIER>(s, c.ring, c.wave, c.lane);
         buf[slot] = *(const lds_u32x4*)(c.ring + c.lane * 16 + s.rd_off + (fp % SLAB_FRAGS) * FRAG_BYTES);
+#ifdef DFN_EXP_DBLLDS       // experiment: what does the LDS fragment traffic cost?  read every fragment a second time
+        {                   // (same results, +100 % fragment reads; the neighbouring fragment so that the data differ)
+            const u32x4 dup = *(const volatile lds_u32x4*)(c.ring + c.lane * 16 + s.rd_off + ((fp + 1) % SLAB_FRAGS) * FRAG_BYTES);
+            asm volatile("" ::"v"(dup));
+        }
+#endif
         if (fp % GAP == GAP / 2) {                                 // one piece of the slab two ahead
             const int k = (fp % SLAB_FRAGS) / GAP;                 // compile-time
             stream_issue_piece<TIER>(s, c.ring, c.wave, c.lane, k);
