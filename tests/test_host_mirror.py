@@ -279,3 +279,55 @@ def test_encode_signals_batch_matches_per_frame(states, scene, step):
             t1 = nets.encode_signal_torso(ds, 0, i, mods["PoseAttNet"], step, A, n, embed_fn=embed_fn)
             torch.testing.assert_close(sb[b], s1.reshape(-1), rtol=1e-4, atol=1e-5)
             torch.testing.assert_close(stb[b], t1.reshape(-1), rtol=1e-4, atol=1e-5)
+
+
+def test_select_coords_distinct_and_region_counts():
+    """Pixel sampling of MAIN:786-820: distinct pixels, the requested share inside (face rect | lower half)."""
+    rng = np.random.RandomState(7)
+    H = W = 450
+    for _ in range(3):
+        sel = run_nerf.select_coords(H, W, 2048, 0, None, rng)
+        assert sel.shape == (2048, 2) and sel.dtype == np.int64
+        assert len({(int(y), int(x)) for y, x in sel}) == 2048
+        assert sel.min() >= 0 and sel[:, 0].max() < H and sel[:, 1].max() < W
+    rect = (100, 120, 150, 160)
+    sel = run_nerf.select_coords(H, W, 2048, 0.95, rect, rng)
+    y, x = sel[:, 0], sel[:, 1]
+    inside = ((y >= rect[0]) & (y <= rect[0] + rect[2]) & (x >= rect[1]) & (x <= rect[1] + rect[3])) | (y >= H / 2)
+    assert len({(int(a), int(b)) for a, b in sel}) == 2048 and int(inside.sum()) == int(2048 * 0.95)
+    # dense request (more than a quarter of the population) still works
+    s = run_nerf._choice_distinct(rng, 1000, 900)
+    assert len(set(s.tolist())) == 900 and s.min() >= 0 and s.max() < 1000
+    # roughly uniform: mean index of many draws is near the middle
+    m = np.mean([run_nerf._choice_distinct(rng, 202500, 2048).mean() for _ in range(20)])
+    assert abs(m - 101250) < 2500
+
+
+def test_frame_writer_pipeline(tmp_path):
+    """Output stage: images go through the pinned-buffer ring and the encoder thread in order, files are written."""
+    from PIL import Image
+    H, W = 24, 32
+    w = run_nerf._FrameWriter(H, W, 2, depth=2)
+    kept, imgs = [], []
+    for i in range(5):
+        a = torch.full((H, W, 3), 10 * i, dtype=torch.uint8)
+        b = torch.full((H, W, 3), 10 * i + 1, dtype=torch.uint8)
+        imgs.append(a.numpy().copy())
+        w.submit([a, b], [str(tmp_path / f"com_{i}.jpg"), str(tmp_path / f"head_{i}.jpg") if i % 2 == 0 else None],
+                 keep=kept)
+    w.drain()
+    assert len(kept) == 5 and all(np.array_equal(k, im) for k, im in zip(kept, imgs))
+    for i in range(5):
+        im = np.asarray(Image.open(tmp_path / f"com_{i}.jpg"))
+        assert im.shape == (H, W, 3) and abs(int(im.mean()) - 10 * i) <= 2
+        assert (tmp_path / f"head_{i}.jpg").exists() == (i % 2 == 0)
+
+
+def test_make_adam_cpu_fallback_and_state_layout():
+    lin = torch.nn.Linear(3, 2)
+    opt = run_nerf.make_adam(lin.parameters(), 5e-4)
+    lin(torch.ones(1, 3)).sum().backward()
+    opt.step()
+    sd = opt.state_dict()
+    assert sd["param_groups"][0]["lr"] == 5e-4 and sd["param_groups"][0]["betas"] == (0.9, 0.999)
+    assert set(sd["state"][0].keys()) >= {"step", "exp_avg", "exp_avg_sq"}
