@@ -39,6 +39,7 @@ hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, cons
 hipError_t launch_scatter_add(const int* map, const float* dense, long n, float* grad_flat, hipStream_t st);
 // macro-tile of one wgrad wave, in 32x32 output tiles (dfn_api.hip sizes the work list with the same numbers)
 constexpr int WG_MT = 2, WG_NT = 4;
+constexpr int WG_PF = 4;      // register prefetch depth of wgrad_kernel, in 32-point (bf16) / 8-point (f32) steps
 hipError_t launch_bias_grad(int tier, int field, const int* row_of, int n, const void* dy_T, long NP, float* dbias,
                             hipStream_t st);
 

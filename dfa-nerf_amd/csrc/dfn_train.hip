@@ -254,10 +254,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
     const WOp o = ops[op];
     long loc = item - work_prefix[op];
     const int mts = o.M / 32, nts = o.N / 32;
-    const int nb_n = (nts + WG_NT - 1) / WG_NT;
-    const int ks = (int)(loc % ksplit);
-    loc /= ksplit;
-    const int nb = (int)(loc % nb_n), mb = (int)(loc / nb_n);
+    const int nb_n = (nts + WG_NT - 1) / WG_NT, mb_n = (mts + WG_MT - 1) / WG_MT;
+    // row block fastest: the 4 waves of a workgroup then share the column block and the slice of points, i.e. they
+    // request the SAME B tiles at about the same time (one trip to L2 instead of four)
+    const int mb = (int)(loc % mb_n);
+    loc /= mb_n;
+    const int nb = (int)(loc % nb_n), ks = (int)(loc / nb_n);
     const int mt_n = min(WG_MT, mts - WG_MT * mb), nt_n = min(WG_NT, nts - WG_NT * nb);     // wave-uniform
     const long per = (n_tiles + ksplit - 1) / ksplit;
     const long t0 = ks * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
@@ -274,8 +276,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     if constexpr (TIER == TIER_BF16) {
-        // register double buffer: the operands of step t+1 are in flight while the 16 MFMAs of step t run
-        bf16x8 av[2][WG_MT][2], bv[2][WG_NT][2];
+        // register ring, WG_PF steps deep: a step's 16 MFMAs take ~500 cycles, an operand load ~2-4 k cycles, and the
+        // 400+ registers leave one wave per SIMD - so the loads of step t + WG_PF - 1 go out before the MFMAs of step t
+        bf16x8 av[WG_PF][WG_MT][2], bv[WG_PF][WG_NT][2];
         auto load = [&](int s, long t) {
             const T* at = a + t * (long)g_rows * 32;
             const T* bt = b + t * (long)a_rows * 32;
@@ -296,21 +299,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][i][1], bv[s][j][1], acc[i][j], 0, 0, 0);
                     }
         };
-        if (t0 < t1) load(0, t0);
-        long t = t0;
-        for (; t + 1 < t1; t += 2) {
-            load(1, t + 1);
-            mac(0);
-            if (t + 2 < t1) load(0, t + 2);
-            mac(1);
+#pragma unroll
+        for (int s = 0; s < WG_PF - 1; ++s)
+            if (t0 + s < t1) load(s, t0 + s);
+        for (long t = t0; t < t1; t += WG_PF) {
+#pragma unroll
+            for (int s = 0; s < WG_PF; ++s) {
+                const long tt = t + s;
+                if (tt + WG_PF - 1 < t1) load((s + WG_PF - 1) % WG_PF, tt + WG_PF - 1);
+                if (tt < t1) mac(s);
+            }
         }
-        if (t < t1) mac(0);
     } else {
         // f32: v_mfma_f32_32x32x2_f32 takes A[row][k = half].  The contraction order is free, so MFMA m of a group of
         // four pairs k = m (lower half of the wave) with k = m + 4 (upper half): each lane then needs 4 CONSECUTIVE
         // points - one 16-byte load, nothing fetched twice, no selects - and a group covers 8 points.  Steps of 8
         // points are double-buffered in registers like the bf16 path.
-        f32x4 av[2][WG_MT], bv[2][WG_NT];
+        f32x4 av[WG_PF][WG_MT], bv[WG_PF][WG_NT];
         const long n_steps = (t1 - t0) * 4;                    // 4 groups of 8 points per 32-point tile
         auto load = [&](int s, long q) {
             const long t = t0 + (q >> 2);
@@ -332,15 +337,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
                         if (i < mt_n && j < nt_n)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i][m], bv[s][j][m], acc[i][j], 0, 0, 0);
         };
-        if (n_steps > 0) load(0, 0);
-        long q = 0;
-        for (; q + 1 < n_steps; q += 2) {
-            load(1, q + 1);
-            mac(0);
-            if (q + 2 < n_steps) load(0, q + 2);
-            mac(1);
+#pragma unroll
+        for (int s = 0; s < WG_PF - 1; ++s)
+            if (s < n_steps) load(s, s);
+        for (long q = 0; q < n_steps; q += WG_PF) {
+#pragma unroll
+            for (int s = 0; s < WG_PF; ++s) {
+                const long qq = q + s;
+                if (qq + WG_PF - 1 < n_steps) load((s + WG_PF - 1) % WG_PF, qq + WG_PF - 1);
+                if (qq < n_steps) mac(s);
+            }
         }
-        if (q < n_steps) mac(0);
     }
     float* c = C + o.c_off;
 #pragma unroll
