@@ -45,6 +45,28 @@ def test_error_paths_without_gpu():
     assert _lib.lib.dfn_pack_plan(1, 0, small.ctypes.data, 4) == -3      # DFN_E_SIZE
     with pytest.raises(_lib.DfnError):
         _lib.check(_lib.lib.dfn_pack_weights(1, 0, None, None, None), "pack")
+    # argument validation of every launch entry point happens before any HIP call: checkable without a GPU
+    L, N = _lib.lib, None
+    fr = _lib.DfnFrame()
+    fr.n_coarse, fr.n_fine, fr.fields, fr.ray_count, fr.H, fr.W = 64, 128, 1, 8, 4, 4
+    one = 4096      # any non-null address: the calls below must fail before they would use it
+    assert L.dfn_render_fwd(1, None, one, N, one, N, one, N, N, one, N, N, N, N, N) == -1
+    assert L.dfn_render_fwd(1, _lib.C.byref(fr), N, N, one, N, one, N, N, one, N, N, N, N, N) == -1      # no weights
+    fr.n_fine = 96
+    assert L.dfn_render_fwd(1, _lib.C.byref(fr), one, N, one, N, one, N, N, one, N, N, N, N, N) == -1
+    assert b"n_fine" in L.dfn_last_error()
+    fr.n_fine, fr.fields = 128, 2
+    assert L.dfn_render_fwd_u8(1, _lib.C.byref(fr), one, N, one, N, one, N, N, one, N, N) == -1          # torso inputs missing
+    assert L.dfn_fold_bias(1, 0, one, N, one, one, one, N) == -1 and b"signal" in L.dfn_last_error()
+    assert L.dfn_fold_bias_bwd(1, 0, one, one, one, one, N, one, N, N) == -1
+    assert L.dfn_encode_signal(one, one, one, one, one, 8, one, 1, 3, one, N) == -1 and b"smo_size" in L.dfn_last_error()
+    assert L.dfn_encode_signal(one, one, N, one, one, 8, one, 1, 4, one, N) == -1                         # attention missing
+    assert L.dfn_encode_signal_torso(one, one, 10, 8, one, 1, 8, one, N) == -1                            # pose stride
+    assert L.dfn_encode_signal_bwd(one, one, one, one, one, 8, 0, 4, N, one, one, one, N) == -1
+    assert L.dfn_encode_signal_torso_bwd(one, one, 16, 8, 0, 0, one, N, N) == 0                           # smo 0: nothing to do
+    assert L.dfn_bias_grad(1, 0, N, 64, one, N) == -1 and L.dfn_weight_grad(1, 5, one, one, 64, one, one, N) == -1
+    assert L.dfn_decoder_fwd(1, 0, one, one, N, one, 4, one, one, N) == -1
+    assert L.dfn_sample_pdf(one, one, 4, 300, 8, N, one, N) == -1                                         # nb <= 256
 
 
 class Reader:
