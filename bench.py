@@ -164,6 +164,17 @@ def bench_training(args, world, rank, local, dev, desc):
     if rank == 0:
         flop_ray = 3 * 64 * (FLOP_PT_HEAD + FLOP_PT_TORSO)          # fwd + 2x bwd, SURVEY.md 8(d)
         ach = flop_ray * N_RAND * world * args.steps / dt / 1e12
+        # The step is bound by the traffic of what the forward records for the backward, not by the MFMAs.  Algorithmic
+        # bytes per step and GPU (every array touched once per use, no re-reads): the forward writes the GEMM inputs
+        # act_T, the dX chain writes the pre-activation gradients dy_T, the weight-gradient GEMMs read both, the bias
+        # gradient reads dy_T again; rows from dfn_train_rows, NP = 64 * N_rand points, element = the tier's type.
+        from dfanerf._lib import lib as _l
+        esz = 2 if args.tier == "bf16" else 4
+        NP = 64 * N_RAND
+        act_b = sum(_l.dfn_train_rows(f, 0) for f in (0, 1)) * NP * esz
+        dy_b = sum(_l.dfn_train_rows(f, 1) for f in (0, 1)) * NP * esz
+        step_bytes = 2 * act_b + 3 * dy_b
+        gbs = step_bytes * world * args.steps / dt / 1e9
         print(json.dumps({
             "metric": "training rays/sec (whole node), N_rand=2048 per GPU, 64 coarse samples, 2 fields, fwd+bwd+Adam",
             "value": N_RAND * world * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
@@ -171,9 +182,11 @@ def bench_training(args, world, rank, local, dev, desc):
             "vs_baseline": None, "dtype": args.tier, "data": "synthetic",
             "config": {"workload": desc, "H": H, "W": W, "N_rand_per_gpu": N_RAND, "n_coarse": 64, "fields": 2,
                        "parallelism": f"dp{world}, one flat-bucket all_reduce (1,138,656 floats)"},
-            "roofline": {"bound": "mfma", "kernel": "whole step (render_kernel<train> + mlp_bwd + wgrad)",
-                         "achieved": ach, "peak": PEAK_TFLOPS[args.tier] * world, "unit": "TFLOP/s",
-                         "frac": ach / (PEAK_TFLOPS[args.tier] * world), "traffic": None, "flop_per_ray": flop_ray}}))
+            "roofline": {"bound": "hbm", "kernel": "whole step (render_kernel<train>, mlp_bwd, wgrad, bias_grad)",
+                         "achieved": gbs, "peak": 8000.0 * world, "unit": "GB/s", "frac": gbs / (8000.0 * world),
+                         "traffic": None, "bytes_per_step_per_gpu": step_bytes,
+                         "mfma": {"achieved_tflops": ach, "peak_tflops": PEAK_TFLOPS[args.tier] * world,
+                                  "frac": ach / (PEAK_TFLOPS[args.tier] * world), "flop_per_ray": flop_ray}}}))
     if world > 1:
         dist.destroy_process_group()
 
