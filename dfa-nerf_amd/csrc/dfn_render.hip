@@ -101,7 +101,7 @@ DFN_DEV float integrate_tile(volatile lds_f32* st, int rs_T, int rs_rgb, float s
     return w;
 }
 
-template <int TIER> struct KernelLds {
+template <int TIER, bool TWO = false> struct KernelLds {
     using P = Prog<TIER>;
     static constexpr int BIAS_H = RING_BYTES;
     static constexpr int BIAS_T = BIAS_H + P::H_NBIAS * 4;
@@ -112,8 +112,10 @@ template <int TIER> struct KernelLds {
     //          sample_pdf run its first 256 floats hold tmp[64] cdf[64] zf[128]
     //   rank8  merged rank of fine sample j (u8)
     // (decoder_kernel keeps its per-lane d/|d| [3][64] at float 544 of the same area)
-    static constexpr int Z_ALL = 0, M_OFF = 192, M_STRIDE = 192, RANK8 = 960, STATE = 992;
-    static constexpr int SCRATCH_FLOATS = 1024;
+    //   keepc  (two-field kernel only) the coarse samples' two-field mix (ssum, fm) [4][64]
+    static constexpr int Z_ALL = 0, M_OFF = 192, M_STRIDE = 192, RANK8 = 960, STATE = 992, KEEPC = 1024;
+    static constexpr int PARK_H = 256;       // inside M: the coarse samples' head outputs [4][64] until the merge
+    static constexpr int SCRATCH_FLOATS = TWO ? 1280 : 1024;
     static constexpr int SCRATCH_PER_WAVE = SCRATCH_FLOATS * 4;
     static constexpr int TOTAL = SCRATCH + TierCfg<TIER>::WAVES * SCRATCH_PER_WAVE;
     static_assert(TOTAL <= 160 * 1024, "LDS budget");
@@ -132,7 +134,7 @@ template <int TIER, bool TWO, bool TRAIN>
 __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 256) void render_kernel(
     const RenderArgs A) {
     using C = TierCfg<TIER>;
-    using L = KernelLds<TIER>;
+    using L = KernelLds<TIER, TWO>;
     using P = Prog<TIER>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -269,9 +271,11 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
         }
     };
 
-    // what the coarse pass leaves for the merged compositing: coarse sample `lane`'s head outputs and its
-    // two-field composite (ssum, fm)
-    float keep_h[4] = {0.f, 0.f, 0.f, 0.f}, keep_c[4] = {0.f, 0.f, 0.f, 0.f};
+    // what the coarse pass leaves for the merged compositing, parked in LDS so that nothing of it is live in
+    // registers across the MLP passes: the coarse samples' head outputs (inside M until the merge scatters them to
+    // their ranks) and, with two fields, their mix (ssum, fm)
+    lds_f32* park_h = M + L::PARK_H;          // [4][64]
+    lds_f32* keepc = scr + L::KEEPC;          // [4][64]  (allocated for the two-field kernel only)
     int rank_c = lane;
 
     enum { PH_COARSE = 0, PH_FINE_H = 1, PH_FINE_T = 2 };
@@ -322,8 +326,9 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
             const float dz = last ? F.last_dist : sub_(znext, z);
             const float sg_h = __shfl(a.sigma, n);
             float fh[3] = {__shfl(a.r, n), __shfl(a.g, n), __shfl(a.b, n)};
-            const bool mine = (lane >> 5) == tile;          // this lane's coarse sample is in this tile
-            if (mine) { keep_h[0] = sg_h; keep_h[1] = fh[0]; keep_h[2] = fh[1]; keep_h[3] = fh[2]; }
+            if (hier && lane < 32) {
+                park_h[si] = sg_h; park_h[64 + si] = fh[0]; park_h[128 + si] = fh[1]; park_h[192 + si] = fh[2];
+            }
             float s1;
             head_inputs(sg_h, fh, last, s1);
             const float w_h = integrate_tile(st, RS_TH, RS_RGB_H, s1, mul_(dz, st[RS_NH]), fh, n, lane);
@@ -333,7 +338,9 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
                 const float ft[3] = {__shfl(b.r, n), __shfl(b.g, n), __shfl(b.b, n)};
                 float ssum, fm[3];
                 combine(sg_h, fh, sg_t, ft, last, ssum, fm);
-                if (mine) { keep_c[0] = ssum; keep_c[1] = fm[0]; keep_c[2] = fm[1]; keep_c[3] = fm[2]; }
+                if (hier && lane < 32) {
+                    keepc[si] = ssum; keepc[64 + si] = fm[0]; keepc[128 + si] = fm[1]; keepc[192 + si] = fm[2];
+                }
                 w_c = integrate_tile(st, RS_TC, RS_RGB_C, ssum, mul_(dz, st[RS_NT]), fm, n, lane);
             }
             if (hier) {
@@ -412,7 +419,10 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
                     rank_f[m] += (v < myf[m] || (v == myf[m] && i < j)) ? 1 : 0;
                 }
             }
-            wave_lds_fence();                // every read of zc / zf / tmp / cdf is done: the areas are reused
+            float keep_h[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) keep_h[q] = park_h[q * 64 + lane];
+            wave_lds_fence();                // every read of zc / zf / tmp / cdf / park_h is done: the areas are reused
             zall[rank_c] = myc;
 #pragma unroll
             for (int m = 0; m < 3; ++m)
@@ -464,7 +474,7 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
             }
             if (++tile < KF) continue;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) M[q * L::M_STRIDE + rank_c] = keep_c[q];
+            for (int q = 0; q < 4; ++q) M[q * L::M_STRIDE + rank_c] = keepc[q * 64 + lane];
             wave_lds_fence();
             composite_merged(false, A.w_com);
             break;
@@ -564,7 +574,7 @@ template <typename K> static hipError_t set_lds(K kernel, int lds) {
 }
 template <int TIER, bool TWO, bool TRAIN = false> static hipError_t launch_render_t(const RenderArgs& A, hipStream_t st) {
     using C = TierCfg<TIER>;
-    const int lds = KernelLds<TIER>::TOTAL;
+    const int lds = KernelLds<TIER, TWO>::TOTAL;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = set_lds(render_kernel<TIER, TWO, TRAIN>, lds);
