@@ -42,6 +42,8 @@ WORKLOADS = {
     # training step (configs[3]): reference semantics = coarse 64 samples, both fields, fwd+bwd, 5 gated Adams;
     # data parallel: every rank draws its own frame + 2048 rays (weak scaling), one flat-bucket all_reduce
     "c4": (0, 2, "Obama training step (fwd+bwd, Adam), N_rand=2048 per GPU, data-parallel RCCL grad all-reduce (configs[3])"),
+    # the strong-scaling variant SURVEY.md 8(e) asks to report as well: the reference's 2048 rays split over the ranks
+    "c4s": (0, 2, "Obama training step (fwd+bwd, Adam), N_rand=2048 GLOBAL (2048/N per GPU), RCCL grad all-reduce"),
 }
 
 
@@ -99,7 +101,9 @@ def bench_training(args, world, rank, local, dev, desc):
     losses -> HIP backward (compositing, dX chain, weight-gradient GEMMs) -> flat-bucket all_reduce -> gated Adams."""
     from dfanerf import nets, parallel, run_nerf, synth, training
     from dfanerf.decoder import Decoder
-    N_RAND = 2048
+    strong = args.workload == "c4s"
+    N_RAND = 2048 // world if strong else 2048
+    assert N_RAND % 8 == 0
     sc = synth.bench_scene(0, n_frames=8)
     st = synth.synth_all_states(0)
     H, W = sc["H"], sc["W"]
@@ -124,12 +128,13 @@ def bench_training(args, world, rank, local, dev, desc):
                                                 ds[0]["auds"], ds[0]["exp"], ds[0]["poses"])
     bucket = parallel.FlatGradBucket(list(mods.values())) if world > 1 else None
     rng = np.random.RandomState(100 + rank)
+    rng_frame = np.random.RandomState(100) if strong else rng      # strong: ONE frame per step on all ranks (MAIN:779)
     tgt_h = torch.rand(H, W, 3, device=dev)
     tgt_c = torch.rand(H, W, 3, device=dev)
     gstep = 300000                                   # all five optimizers' gates exercised except ExpNet
 
     def step():
-        img_i = int(rng.randint(0, 8))
+        img_i = int(rng_frame.randint(0, 8))
         sel = run_nerf.select_coords(H, W, N_RAND, 0, None, rng)
         ys, xs = t(sel[:, 0]).to(dev), t(sel[:, 1]).to(dev)
         loss, *_ = run_nerf.train_step_loss_hip(mods, ds, 0, img_i, sel, tgt_h[ys, xs], tgt_c[ys, xs], zs, za, gstep, a,
@@ -176,9 +181,10 @@ def bench_training(args, world, rank, local, dev, desc):
         step_bytes = 2 * act_b + 3 * dy_b
         gbs = step_bytes * world * args.steps / dt / 1e9
         print(json.dumps({
-            "metric": "training rays/sec (whole node), N_rand=2048 per GPU, 64 coarse samples, 2 fields, fwd+bwd+Adam",
+            "metric": f"training rays/sec (whole node), N_rand={N_RAND} per GPU, 64 coarse samples, 2 fields, fwd+bwd+Adam",
             "value": N_RAND * world * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": args.tier, "data": "synthetic",
             "config": {"workload": desc, "H": H, "W": W, "N_rand_per_gpu": N_RAND, "n_coarse": 64, "fields": 2,
                        "parallelism": f"dp{world}, one flat-bucket all_reduce (1,138,656 floats)"},
@@ -205,7 +211,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    if args.workload == "c4":
+    if args.workload in ("c4", "c4s"):
         return bench_training(args, world, rank, local, dev, desc)
 
     from dfanerf import engine, nets, synth
