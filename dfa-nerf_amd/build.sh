@@ -6,15 +6,19 @@ SRC="$HERE/csrc"
 OUT="$HERE/dfanerf/libdfanerf.so"
 OBJ="$HERE/build"
 mkdir -p "$OBJ"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I$SRC -I$HERE/../include"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -I$SRC -I$HERE/../include"
 pids=()
 for f in dfn_render dfn_misc dfn_api dfn_train dfn_signal; do
   ( if [ ! -f "$OBJ/$f.o" ] || [ -n "$(find "$SRC" "$HERE/../include" -newer "$OBJ/$f.o" \( -name '*.h' -o -name "$f.hip" \) -print -quit)" ]; then
-      hipcc $FLAGS -c "$SRC/$f.hip" -o "$OBJ/$f.o"
+      EXTRA=""; [ "$f" = dfn_render ] && EXTRA="--save-temps=obj"     # keep the ISA of the render kernels for the check below
+      hipcc $FLAGS $EXTRA -c "$SRC/$f.hip" -o "$OBJ/$f.o"
     fi ) &
   pids+=($!)
 done
 g++ -O2 -std=c++17 -fPIC -I"$SRC" -I"$HERE/../include" -c "$SRC/dfn_plan.cpp" -o "$OBJ/dfn_plan.o"
 for p in "${pids[@]}"; do wait $p; done
+# the asm fragment fetch (DFN_ASM_FETCH) is only safe if nothing touches an in-flight destination register
+ISA="$OBJ/dfn_render-hip-amdgcn-amd-amdhsa-gfx950.s"
+if [ -f "$ISA" ]; then python3 "$HERE/../tools/check_inflight.py" "$ISA" || { echo "build.sh: in-flight register hazard in the render kernels" >&2; exit 1; }; fi
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/dfn_render.o "$OBJ"/dfn_misc.o "$OBJ"/dfn_api.o "$OBJ"/dfn_train.o "$OBJ"/dfn_signal.o "$OBJ"/dfn_plan.o
 echo "built $OUT"

@@ -27,6 +27,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define DFN_DEV __device__ __forceinline__
+// 1: in the bf16 inference render kernels the fragment reads and the LDS-DMA are inline asm with counted lgkmcnt waits
+// (-2.2 % on C2).  The build checks the generated ISA with tools/check_inflight.py: no instruction may
+// touch an asm read's destination before the wait that retires it.  0 = everything through the compiler.
+#ifndef DFN_ASM_FETCH
+#define DFN_ASM_FETCH 1
+#endif
 // explicit LDS address space: every LDS access must be a ds_* instruction (a flat access would wait on
 // vmcnt and drain the weight prefetch)
 #define DFN_LDS __attribute__((address_space(3)))
@@ -76,6 +82,7 @@ struct Stream {
     unsigned pf_slot;        // ring slot the next prefetch lands in
     unsigned rd_off;         // LDS byte offset (within the ring) of the slab being consumed
     unsigned rd_slot;
+    unsigned rd_vaddr;       // per lane: LDS address of this lane's 16 bytes of fragment 0 of the slab being consumed
     int pf_owed;             // pieces of the slab two ahead still to be issued
 #ifdef DFN_TIMING
     unsigned long long t_wait, t_bar, t_issue;
@@ -83,13 +90,22 @@ struct Stream {
 };
 
 // One LDS-DMA piece: this wave's k-th 1 KiB fragment of the slab the prefetch cursor points at.
-template <int TIER>
+template <int TIER, bool ASM = false>
 DFN_DEV void stream_issue_piece(const Stream& s, lds_char* ring, int wave, int lane, int k) {
     using C = TierCfg<TIER>;
     const int f = k * C::WAVES + wave;
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(s.pf_ptr + (size_t)lane * 16 + f * FRAG_BYTES),
-        (DFN_LDS void*)(ring + s.pf_slot * SLAB_BYTES + f * FRAG_BYTES), 16, 0, 0);
+    if constexpr (ASM) {
+        // asm on purpose: with the builtin ("LDS DMA" to the compiler) in the function, hipcc treats lgkmcnt as out of
+        // order and puts s_waitcnt lgkmcnt(0) in front of every MFMA whose operands came from LDS
+        const char* src = s.pf_ptr + (size_t)lane * 16 + f * FRAG_BYTES;
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)ring + s.pf_slot * SLAB_BYTES +
+                                                            (unsigned)f * FRAG_BYTES);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+    } else {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(s.pf_ptr + (size_t)lane * 16 + f * FRAG_BYTES),
+            (DFN_LDS void*)(ring + s.pf_slot * SLAB_BYTES + f * FRAG_BYTES), 16, 0, 0);
+    }
 }
 // advance the prefetch cursor to the next slab; at the end of a pass it jumps to the stream of the next pass
 // (next_ptr / next_left, set when the CONSUMER starts a pass: the cursor is only two slabs ahead of it).
@@ -111,25 +127,25 @@ DFN_DEV void stream_pass_begin(Stream& s) {
     s.next_left = s.nslab[f];
     s.pass = np;
 }
-template <int TIER>
+template <int TIER, bool ASM = false>
 DFN_DEV void stream_issue(Stream& s, lds_char* ring, int wave, int lane) {
 #pragma unroll
-    for (int k = 0; k < TierCfg<TIER>::LOADS_PER_SLAB; ++k) stream_issue_piece<TIER>(s, ring, wave, lane, k);
+    for (int k = 0; k < TierCfg<TIER>::LOADS_PER_SLAB; ++k) stream_issue_piece<TIER, ASM>(s, ring, wave, lane, k);
     stream_cursor_next(s);
 }
 // A pass whose last slab is partial stops reading fragments before every piece of the slab two ahead went out:
 // the next pass issues the rest before its first fragment (pass boundaries only).
-template <int TIER>
+template <int TIER, bool ASM = false>
 DFN_DEV void stream_flush(Stream& s, lds_char* ring, int wave, int lane) {
     constexpr int L = TierCfg<TIER>::LOADS_PER_SLAB;
     if (s.pf_owed > 0) {
-        for (int k = L - s.pf_owed; k < L; ++k) stream_issue_piece<TIER>(s, ring, wave, lane, k);
+        for (int k = L - s.pf_owed; k < L; ++k) stream_issue_piece<TIER, ASM>(s, ring, wave, lane, k);
         stream_cursor_next(s);
         s.pf_owed = 0;
     }
 }
 
-template <int TIER>
+template <int TIER, bool ASM = false>
 DFN_DEV void stream_begin(Stream& s, lds_char* ring, int wave, int lane) {
     s.pf_ptr = s.base[0];
     s.pf_left = s.nslab[0];
@@ -139,9 +155,10 @@ DFN_DEV void stream_begin(Stream& s, lds_char* ring, int wave, int lane) {
     s.pf_slot = 0;
     s.rd_slot = RING_SLOTS - 1;     // the first slab_advance moves it to slot 0
     s.rd_off = 0;
+    s.rd_vaddr = 0;
     s.pf_owed = 0;
-    stream_issue<TIER>(s, ring, wave, lane);     // slab 0
-    stream_issue<TIER>(s, ring, wave, lane);     // slab 1
+    stream_issue<TIER, ASM>(s, ring, wave, lane);     // slab 0
+    stream_issue<TIER, ASM>(s, ring, wave, lane);     // slab 1
 }
 
 // Called by every wave right before it reads the first fragment of the next slab (slab g).  The DMA of slab g+2
@@ -168,6 +185,7 @@ DFN_DEV void slab_advance(Stream& s, lds_char* ring, int wave, int lane) {
 #endif
     s.rd_slot = (s.rd_slot + 1 == RING_SLOTS) ? 0u : s.rd_slot + 1;
     s.rd_off = s.rd_slot * SLAB_BYTES;
+    s.rd_vaddr = (unsigned)(unsigned long)ring + (unsigned)lane * 16u + s.rd_off;
     s.pf_owed += C::LOADS_PER_SLAB;
 }
 
@@ -184,8 +202,11 @@ struct Rec {
     int mask_dwords;
 };
 
-template <bool REC> struct CtxT {   // per-wave constants threaded through the ops; REC = training recorder on
+// per-wave constants threaded through the ops; REC = training recorder on; ASMF = fragment reads / LDS-DMA as inline asm
+// with counted waits (only kernels whose registers do not spill: an in-flight asm destination must never be copied)
+template <bool REC, bool ASMF = false> struct CtxT {
     static constexpr bool rec_on = REC;
+    static constexpr bool asm_fetch = ASMF && !REC && (DFN_ASM_FETCH != 0);
     lds_char* ring;
     int wave, lane, half;
     Rec rec;
@@ -234,13 +255,43 @@ DFN_DEV void rec_mask(const CT& c, int dword0, const Vec<TIER, NT>& v) {
 // PREFETCH; both indices are compile-time after inlining/unrolling (in the runtime layer loops only their
 // slab phase matters, and one 256x256 layer is a whole number of slabs and of ring turns).
 constexpr int PF_DEPTH = 4;
+template <int TIER, class CT> constexpr bool use_asm_fetch() { return TIER == TIER_BF16 && CT::asm_fetch; }
+
+#define DFN_FRAG_CASE(K)                                                                                      \
+    case K:                                                                                                   \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(vaddr), "n"((K) * FRAG_BYTES) : "memory"); \
+        break;
+DFN_DEV void frag_read(u32x4& dst, unsigned vaddr, int pos) {      // pos = fragment index within the slab (constant)
+    switch (pos) {
+        DFN_FRAG_CASE(0) DFN_FRAG_CASE(1) DFN_FRAG_CASE(2) DFN_FRAG_CASE(3) DFN_FRAG_CASE(4) DFN_FRAG_CASE(5)
+        DFN_FRAG_CASE(6) DFN_FRAG_CASE(7) DFN_FRAG_CASE(8) DFN_FRAG_CASE(9) DFN_FRAG_CASE(10) DFN_FRAG_CASE(11)
+        DFN_FRAG_CASE(12) DFN_FRAG_CASE(13) DFN_FRAG_CASE(14) DFN_FRAG_CASE(15) DFN_FRAG_CASE(16) DFN_FRAG_CASE(17)
+        DFN_FRAG_CASE(18) DFN_FRAG_CASE(19) DFN_FRAG_CASE(20) DFN_FRAG_CASE(21) DFN_FRAG_CASE(22) DFN_FRAG_CASE(23)
+        DFN_FRAG_CASE(24) DFN_FRAG_CASE(25) DFN_FRAG_CASE(26) DFN_FRAG_CASE(27) DFN_FRAG_CASE(28) DFN_FRAG_CASE(29)
+        DFN_FRAG_CASE(30) DFN_FRAG_CASE(31)
+        default: __builtin_unreachable();
+    }
+}
+#undef DFN_FRAG_CASE
+// wait until at most `younger` LDS operations issued after the read of `r` are outstanding (they return in order); the
+// "+v" ties the wait to the register so that the MFMA consuming it cannot be scheduled above it
+DFN_DEV void frag_wait(u32x4& r, int younger) {
+    switch (younger) {
+        case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r)); break;
+        case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(r)); break;
+        case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r)); break;
+        default: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(r)); break;
+    }
+}
+
 template <int TIER> struct Fetch {
     u32x4 buf[PF_DEPTH];
     template <class CT> DFN_DEV void load(int slot, int fp, Stream& s, const CT& c) {
         using C = TierCfg<TIER>;
         constexpr int GAP = SLAB_FRAGS / C::LOADS_PER_SLAB;       // fragment reads between two DMA pieces
         if (fp % SLAB_FRAGS == 0) slab_advance<TIER>(s, c.ring, c.wave, c.lane);
-        buf[slot] = *(const lds_u32x4*)(c.ring + c.lane * 16 + s.rd_off + (fp % SLAB_FRAGS) * FRAG_BYTES);
+        if constexpr (use_asm_fetch<TIER, CT>()) frag_read(buf[slot], s.rd_vaddr, fp % SLAB_FRAGS);
+        else buf[slot] = *(const lds_u32x4*)(c.ring + c.lane * 16 + s.rd_off + (fp % SLAB_FRAGS) * FRAG_BYTES);
 #ifdef DFN_EXP_DBLLDS       // experiment: what does the LDS fragment traffic cost?  read every fragment a second time
         {                   // (same results, +100 % fragment reads; the neighbouring fragment so that the data differ)
             const u32x4 dup = *(const volatile lds_u32x4*)(c.ring + c.lane * 16 + s.rd_off + ((fp + 1) % SLAB_FRAGS) * FRAG_BYTES);
@@ -249,14 +300,14 @@ template <int TIER> struct Fetch {
 #endif
         if (fp % GAP == GAP / 2) {                                 // one piece of the slab two ahead
             const int k = (fp % SLAB_FRAGS) / GAP;                 // compile-time
-            stream_issue_piece<TIER>(s, c.ring, c.wave, c.lane, k);
+            stream_issue_piece<TIER, use_asm_fetch<TIER, CT>()>(s, c.ring, c.wave, c.lane, k);
             --s.pf_owed;
             if (k == C::LOADS_PER_SLAB - 1) stream_cursor_next(s);
         }
     }
     // start of a pass: fragments 0..PF_DEPTH-1
     template <class CT> DFN_DEV void prime(Stream& s, const CT& c) {
-        stream_flush<TIER>(s, c.ring, c.wave, c.lane);
+        stream_flush<TIER, use_asm_fetch<TIER, CT>()>(s, c.ring, c.wave, c.lane);
         stream_pass_begin(s);
 #pragma unroll
         for (int i = 0; i < PF_DEPTH; ++i) load(i, i, s, c);
@@ -273,10 +324,16 @@ DFN_DEV void gemm_group(f32x16 (&acc)[G], const Vec<TIER, NTB>& b, int& f, Fetch
     for (int ku = 0; ku < KU; ++ku) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const u32x4 a = fe.buf[f % PF_DEPTH];
             const int left = (KU - ku) * G - g - 1;           // fragments after this one in the group
-            if (TAIL < 0 || left + TAIL >= PF_DEPTH) fe.load(f % PF_DEPTH, f + PF_DEPTH, s, c);
-            ++f;
+            constexpr bool ASM = use_asm_fetch<TIER, CT>();
+            if constexpr (ASM) {
+                const int after = (TAIL < 0) ? PF_DEPTH : left + TAIL;             // ... in the pass
+                frag_wait(fe.buf[f % PF_DEPTH], after < PF_DEPTH - 1 ? after : PF_DEPTH - 1);     // fragment f has landed
+            }
+            const u32x4 a = fe.buf[f % PF_DEPTH];
+            if constexpr (!ASM) {
+                if (TAIL < 0 || left + TAIL >= PF_DEPTH) fe.load(f % PF_DEPTH, f + PF_DEPTH, s, c);
+            }
             if constexpr (TIER == TIER_BF16) {
                 acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), b.u[ku],
                                                                  acc[g], 0, 0, 0);
@@ -286,6 +343,10 @@ DFN_DEV void gemm_group(f32x16 (&acc)[G], const Vec<TIER, NTB>& b, int& f, Fetch
                 for (int e = 0; e < 4; ++e)
                     acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], b.v[4 * ku + e], acc[g], 0, 0, 0);
             }
+            if constexpr (ASM) {      // refill the slot just consumed (the MFMA has read its operands when it issued)
+                if (TAIL < 0 || left + TAIL >= PF_DEPTH) fe.load(f % PF_DEPTH, f + PF_DEPTH, s, c);
+            }
+            ++f;
         }
     }
 }

@@ -8,7 +8,7 @@ NAME="$1"; shift
 SRC="$ROOT/dfa-nerf_amd/csrc"
 OBJ="$ROOT/exp_libs/obj_$NAME"
 mkdir -p "$OBJ"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I$SRC -I$ROOT/include $*"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -I$SRC -I$ROOT/include $*"
 pids=()
 for f in dfn_render dfn_misc dfn_api dfn_train dfn_signal; do
   ( hipcc $FLAGS -c "$SRC/$f.hip" -o "$OBJ/$f.o" 2>"$OBJ/$f.log" ) &
