@@ -254,7 +254,10 @@ DFN_DEV void rec_mask(const CT& c, int dword0, const Vec<TIER, NT>& v) {
 // layers: LDS latency hides behind the MFMAs of earlier fragments.  `fp` = index of the next fragment to
 // PREFETCH; both indices are compile-time after inlining/unrolling (in the runtime layer loops only their
 // slab phase matters, and one 256x256 layer is a whole number of slabs and of ring turns).
-constexpr int PF_DEPTH = 4;
+#ifndef DFN_PF_DEPTH
+#define DFN_PF_DEPTH 4
+#endif
+constexpr int PF_DEPTH = DFN_PF_DEPTH;
 template <int TIER, class CT> constexpr bool use_asm_fetch() { return TIER == TIER_BF16 && CT::asm_fetch; }
 
 #define DFN_FRAG_CASE(K)                                                                                      \
@@ -280,9 +283,17 @@ DFN_DEV void frag_wait(u32x4& r, int younger) {
         case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r)); break;
         case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(r)); break;
         case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r)); break;
-        default: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(r)); break;
+        case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(r)); break;
+        case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(r)); break;
+        case 5: asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(r)); break;
+        case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(r)); break;
+        default: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(r)); break;
     }
 }
+static_assert(PF_DEPTH >= 1 && PF_DEPTH <= 8, "frag_wait covers up to 7 younger reads");
+// the runtime layer loops restart the fragment index at the same value every iteration: the register ring index
+// f % PF_DEPTH only stays consistent if a layer (128 fragments) is a whole number of ring turns (depth 6 renders garbage)
+static_assert((PF_DEPTH & (PF_DEPTH - 1)) == 0, "PF_DEPTH must be a power of two");
 
 template <int TIER> struct Fetch {
     u32x4 buf[PF_DEPTH];
