@@ -1,5 +1,6 @@
 // dfn_api.hip - the C ABI of libdfanerf.so (declared in include/dfanerf.h).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include <cstdio>
 #include <cstring>
@@ -86,7 +87,7 @@ WgradEntry& wgrad_of(int field) {
         w.prefix.assign(1, 0);
         for (const WOpHost& o : w.ops)
             w.prefix.push_back(w.prefix.back() +
-                               ((o.M / 32 + WG_MT - 1) / WG_MT) * ((o.N / 32 + WG_NT - 1) / WG_NT) * WGRAD_KSPLIT);
+                               ((o.M / 32 + WG_MT - 1) / WG_MT) * std::max(1, (o.N / 32 + WG_NT - 1) / WG_NT) * WGRAD_KSPLIT);
         w.built = true;
     }
     return w;
@@ -366,11 +367,30 @@ int dfn_mlp_bwd(int tier, int field, const void* packed_T, const float* samples,
     return DFN_OK;
 }
 
-int dfn_weight_grad(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
-                    float* grad_flat, void* stream) {
+// inverse of the bias row table: dy_T row -> bias element (each row feeds at most one)
+static int ensure_eof(WgradEntry& w, int tier, int field) {
+    if ((long)w.bias_rows.size() != dfn_bias_floats(tier, field)) return fail(DFN_E_ARG, "internal: bias row table size");
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    if (!w.eof_dev) {
+        const int rows = (int)dfn_train_rows(field, 1);
+        std::vector<int32_t> e_of(rows, -1);
+        for (size_t e = 0; e < w.bias_rows.size(); ++e) {
+            const int r = w.bias_rows[e];
+            if (r < 0) continue;
+            if (r >= rows || e_of[r] >= 0) return fail(DFN_E_ARG, "internal: bias row table is not one-to-one");
+            e_of[r] = (int32_t)e;
+        }
+        hipError_t e = upload(&w.eof_dev, e_of.data(), e_of.size());
+        if (e != hipSuccess) return hip_fail(e, "upload(bias rows)");
+    }
+    return DFN_OK;
+}
+
+static int weight_grad_impl(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
+                            float* grad_flat, float* dbias, void* stream, const char* who) {
     if (!tier_ok(tier) || (field != 0 && field != 1) || !dy_T || !act_T || !workspace || !grad_flat || NP <= 0 ||
         NP % 32)
-        return fail(DFN_E_ARG, "dfn_weight_grad: bad argument (NP must be a multiple of 32)");
+        return fail(DFN_E_ARG, std::string(who) + ": bad argument (NP must be a multiple of 32)");
     WgradEntry& w = wgrad_of(field);
     hipStream_t st = (hipStream_t)stream;
     {
@@ -378,7 +398,7 @@ int dfn_weight_grad(int tier, int field, const void* dy_T, const void* act_T, lo
         if (!w.ops_dev) {
             std::vector<WOp> ops(w.ops.size());
             for (size_t i = 0; i < ops.size(); ++i)
-                ops[i] = WOp{w.ops[i].a_row, w.ops[i].M, w.ops[i].b_row, w.ops[i].N, w.ops[i].c_off};
+                ops[i] = WOp{w.ops[i].a_row, w.ops[i].M, w.ops[i].b_row, w.ops[i].N, w.ops[i].c_off, w.ops[i].bias_owner};
             hipError_t e = upload(&w.ops_dev, ops.data(), ops.size());
             if (e == hipSuccess) e = upload(&w.map_dev, w.map.data(), w.map.size());
             if (e == hipSuccess) e = upload(&w.prefix_dev, w.prefix.data(), w.prefix.size());
@@ -388,33 +408,38 @@ int dfn_weight_grad(int tier, int field, const void* dy_T, const void* act_T, lo
     }
     hipError_t err = hipMemsetAsync(workspace, 0, w.map.size() * sizeof(float), st);
     if (err != hipSuccess) return hip_fail(err, "memset(workspace)");
+    if (dbias) {
+        const int rc = ensure_eof(w, tier, field);
+        if (rc != DFN_OK) return rc;
+        err = hipMemsetAsync(dbias, 0, w.bias_rows.size() * sizeof(float), st);
+        if (err != hipSuccess) return hip_fail(err, "memset(dbias)");
+    }
     err = launch_wgrad(tier, field, w.ops_dev, (int)w.ops.size(), w.prefix_dev, w.prefix.back(), dy_T, act_T, NP,
-                       WGRAD_KSPLIT, workspace, st);
+                       WGRAD_KSPLIT, workspace, dbias ? w.eof_dev : nullptr, dbias, st);
     if (err != hipSuccess) return hip_fail(err, "wgrad_kernel");
     err = launch_scatter_add(w.map_dev, workspace, (long)w.map.size(), grad_flat, st);
     if (err != hipSuccess) return hip_fail(err, "scatter_add_kernel");
     return DFN_OK;
 }
 
+int dfn_weight_grad(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
+                    float* grad_flat, void* stream) {
+    return weight_grad_impl(tier, field, dy_T, act_T, NP, workspace, grad_flat, nullptr, stream, "dfn_weight_grad");
+}
+
+int dfn_weight_bias_grad(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
+                         float* grad_flat, float* dbias, void* stream) {
+    if (!dbias) return fail(DFN_E_ARG, "dfn_weight_bias_grad: dbias is NULL");
+    return weight_grad_impl(tier, field, dy_T, act_T, NP, workspace, grad_flat, dbias, stream, "dfn_weight_bias_grad");
+}
+
 int dfn_bias_grad(int tier, int field, const void* dy_T, long NP, float* dbias, void* stream) {
     if (!tier_ok(tier) || (field != 0 && field != 1) || !dy_T || !dbias || NP <= 0)
         return fail(DFN_E_ARG, "dfn_bias_grad: bad argument");
     WgradEntry& w = wgrad_of(field);
-    if ((long)w.bias_rows.size() != dfn_bias_floats(tier, field)) return fail(DFN_E_ARG, "internal: bias row table size");
     {
-        std::lock_guard<std::mutex> lk(g_plan_mu);
-        if (!w.eof_dev) {       // inverse table: dy_T row -> bias element (each row feeds at most one)
-            const int rows = (int)dfn_train_rows(field, 1);
-            std::vector<int32_t> e_of(rows, -1);
-            for (size_t e = 0; e < w.bias_rows.size(); ++e) {
-                const int r = w.bias_rows[e];
-                if (r < 0) continue;
-                if (r >= rows || e_of[r] >= 0) return fail(DFN_E_ARG, "internal: bias row table is not one-to-one");
-                e_of[r] = (int32_t)e;
-            }
-            hipError_t e = upload(&w.eof_dev, e_of.data(), e_of.size());
-            if (e != hipSuccess) return hip_fail(e, "upload(bias rows)");
-        }
+        const int rc = ensure_eof(w, tier, field);
+        if (rc != DFN_OK) return rc;
     }
     hipError_t err = launch_bias_grad(tier, field, w.eof_dev, (int)w.bias_rows.size(), dy_T, NP, dbias, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "bias_grad_kernel");

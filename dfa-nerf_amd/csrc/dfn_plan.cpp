@@ -187,7 +187,10 @@ void build_wgrad_plan(int field, std::vector<WOpHost>& ops, std::vector<int32_t>
         return -1;
     };
     auto add = [&](int a_row, int M, int b_row, int N, const RowFn& rows, const ColFn& cols) {
-        WOpHost o{a_row, M, b_row, N, (int)map.size()};
+        int owner = 1;      // dy_T row ranges are either identical or disjoint between GEMMs
+        for (const WOpHost& q : ops)
+            if (q.a_row == a_row) owner = 0;
+        WOpHost o{a_row, M, b_row, N, (int)map.size(), owner};
         ops.push_back(o);
         for (int m = 0; m < M; ++m) {
             const Src src = rows(m);
@@ -238,6 +241,12 @@ void build_wgrad_plan(int field, std::vector<WOpHost>& ops, std::vector<int32_t>
     auto feat_of = [](int e) { return 32 * (e >> 5) + tile_feat((e >> 4) & 1, e & 15); };
     auto vec = [&](int row0, int n) {
         for (int e = 0; e < n; ++e) bias_rows.push_back(row0 + feat_of(e));
+        // the fused weight+bias gradient pass produces a row block's sums in the GEMM that reads it; a block that no
+        // GEMM reads (its layer multiplies a per-frame constant only, e.g. fc_signal_skips) gets a GEMM with N = 0
+        bool read = false;
+        for (const WOpHost& q : ops)
+            if (q.a_row <= row0 && row0 + n <= q.a_row + q.M) read = true;
+        if (!read) ops.push_back(WOpHost{row0, n, 0, 0, (int)map.size(), 1});
     };
     if (torso) {
         const int seq[14] = {GM::S_DE0, GM::S_DS0, GM::S_DE1, GM::S_DS1, GM::S_DE2, GM::S_DS2, GM::S_DE3, GM::S_GE3,

@@ -9,6 +9,7 @@ namespace dfn {
 long build_pack_plan(int tier, int field, std::vector<int32_t>& plan);
 struct WOpHost {
     int a_row, M, b_row, N, c_off;
+    int bias_owner;      // 1: the first GEMM that reads dy_T rows [a_row, a_row + M): it also produces their row sums
 };
 // Weight-gradient GEMM list of a field, the map dense-C element -> flat parameter index (or -1), and for every
 // element of the field's bias blob the row of dy_T whose sum over the sample points is its gradient.

@@ -29,13 +29,15 @@ struct CompositeBwdArgs {
 
 struct WOp {                    // one weight-gradient GEMM: C[M x N] = dy_T[a_row.., :] * act_T[b_row.., :]^T
     int a_row, M, b_row, N, c_off;
+    int bias_owner;             // this GEMM also accumulates the row sums of its dy_T rows (bias gradients)
 };
 
 hipError_t launch_mlp_bwd(int tier, int field, const MlpBwdArgs& A, hipStream_t st);
 void bwd_program_info(int tier, int field, ProgramInfo* out);
 hipError_t launch_composite_bwd(const CompositeBwdArgs& A, hipStream_t st);
 hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, const int* prefix_dev, int total_items,
-                        const void* dy_T, const void* act_T, long NP, int ksplit, float* C, hipStream_t st);
+                        const void* dy_T, const void* act_T, long NP, int ksplit, float* C, const int* e_of, float* dbias,
+                        hipStream_t st);
 hipError_t launch_scatter_add(const int* map, const float* dense, long n, float* grad_flat, hipStream_t st);
 // macro-tile of one wgrad wave, in 32x32 output tiles (dfn_api.hip sizes the work list with the same numbers)
 constexpr int WG_MT = 2, WG_NT = 4;

@@ -244,7 +244,7 @@ hipError_t launch_composite_bwd(const CompositeBwdArgs& A, hipStream_t st) {
 template <int TIER>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, const int* work_prefix, const void* dy_T,
                                                     const void* act_T, long n_tiles, int g_rows, int a_rows,
-                                                    int ksplit, float* C) {
+                                                    int ksplit, float* C, const int* e_of, float* dbias) {
     typedef typename ActT<TIER>::type T;
     const int lane = threadIdx.x & 63;
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
     const WOp o = ops[op];
     long loc = item - work_prefix[op];
     const int mts = o.M / 32, nts = o.N / 32;
-    const int nb_n = (nts + WG_NT - 1) / WG_NT, mb_n = (mts + WG_MT - 1) / WG_MT;
+    const int nb_n = max(1, (nts + WG_NT - 1) / WG_NT), mb_n = (mts + WG_MT - 1) / WG_MT;     // N = 0: row sums only
     // row block fastest: the 4 waves of a workgroup then share the column block and the slice of points, i.e. they
     // request the SAME B tiles at about the same time (one trip to L2 instead of four)
     const int mb = (int)(loc % mb_n);
@@ -268,6 +268,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
     constexpr int KOFF = (TIER == TIER_BF16) ? 8 : 0;
     const T* a = (const T*)dy_T + (long)(o.a_row + 32 * WG_MT * mb + (lane & 31)) * 32 + KOFF * h;
     const T* b = (const T*)act_T + (long)(o.b_row + 32 * WG_NT * nb + (lane & 31)) * 32 + KOFF * h;
+    // bias gradients for free: the first column block of the GEMM that owns these dy_T rows multiplies them by a tile of
+    // ones as well (2 more MFMAs per step, no extra memory traffic) -> row sums over the points
+    const bool do_bias = dbias && o.bias_owner && nb == 0;          // wave-uniform
+    f32x16 accb[WG_MT];
+#pragma unroll
+    for (int i = 0; i < WG_MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
     f32x16 acc[WG_MT][WG_NT];
 #pragma unroll
     for (int i = 0; i < WG_MT; ++i)
@@ -298,6 +306,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][i][0], bv[s][j][0], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][i][1], bv[s][j][1], acc[i][j], 0, 0, 0);
                     }
+            if (do_bias) {
+                bf16x8 ones;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+#pragma unroll
+                for (int i = 0; i < WG_MT; ++i)
+                    if (i < mt_n) {
+                        accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][i][0], ones, accb[i], 0, 0, 0);
+                        accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][i][1], ones, accb[i], 0, 0, 0);
+                    }
+            }
         };
 #pragma unroll
         for (int s = 0; s < WG_PF - 1; ++s)
@@ -336,6 +355,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
                     for (int j = 0; j < WG_NT; ++j)
                         if (i < mt_n && j < nt_n)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i][m], bv[s][j][m], acc[i][j], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int i = 0; i < WG_MT; ++i)
+                        if (i < mt_n) accb[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i][m], 1.0f, accb[i], 0, 0, 0);
+            }
         };
 #pragma unroll
         for (int s = 0; s < WG_PF - 1; ++s)
@@ -348,6 +374,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
                 if (qq < n_steps) mac(s);
             }
         }
+    }
+    if (do_bias && (lane & 31) == 0) {          // every column of accb holds the row sums: take column 0
+#pragma unroll
+        for (int i = 0; i < WG_MT; ++i)
+            if (i < mt_n) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int e = e_of[o.a_row + 32 * (WG_MT * mb + i) + tile_feat(lane >> 5, r)];
+                    if (e >= 0) atomicAdd(dbias + e, accb[i][r]);
+                }
+            }
     }
     float* c = C + o.c_off;
 #pragma unroll
@@ -363,16 +400,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
             }
 }
 hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, const int* prefix_dev, int total_items,
-                        const void* dy_T, const void* act_T, long NP, int ksplit, float* C, hipStream_t st) {
+                        const void* dy_T, const void* act_T, long NP, int ksplit, float* C, const int* e_of, float* dbias,
+                        hipStream_t st) {
     const int blocks = (total_items + 3) / 4;
     const bool torso = field == FIELD_TORSO;
     const int g_rows = torso ? GradMap::S_ROWS : GradMap::H_ROWS, a_rows = torso ? RecMap::S_ROWS : RecMap::H_ROWS;
     if (tier == TIER_BF16)
         hipLaunchKernelGGL(wgrad_kernel<TIER_BF16>, dim3(blocks), dim3(256), 0, st, ops_dev, n_ops, prefix_dev, dy_T,
-                           act_T, NP / 32, g_rows, a_rows, ksplit, C);
+                           act_T, NP / 32, g_rows, a_rows, ksplit, C, e_of, dbias);
     else
         hipLaunchKernelGGL(wgrad_kernel<TIER_F32>, dim3(blocks), dim3(256), 0, st, ops_dev, n_ops, prefix_dev, dy_T,
-                           act_T, NP / 32, g_rows, a_rows, ksplit, C);
+                           act_T, NP / 32, g_rows, a_rows, ksplit, C, e_of, dbias);
     return hipGetLastError();
 }
 

@@ -201,9 +201,8 @@ class FusedTrainFn(torch.autograd.Function):
             gb = C.c_void_p(g_bias.data_ptr() + (4 * buf.nb[0] if f else 0))
             check(lib.dfn_mlp_bwd(buf.tier, f, _ptr(buf.packed_T[f]), _ptr(buf.samples), _ptr(buf.dsamples),
                                   _ptr(buf.masks[f]), buf.NP, _ptr(buf.dy[f]), st), "dfn_mlp_bwd")
-            check(lib.dfn_weight_grad(buf.tier, f, _ptr(buf.dy[f]), _ptr(buf.act[f]), buf.NP, _ptr(buf.ws[f]),
-                                      _ptr(g_flat), st), "dfn_weight_grad")
-            check(lib.dfn_bias_grad(buf.tier, f, _ptr(buf.dy[f]), buf.NP, gb, st), "dfn_bias_grad")
+            check(lib.dfn_weight_bias_grad(buf.tier, f, _ptr(buf.dy[f]), _ptr(buf.act[f]), buf.NP, _ptr(buf.ws[f]),
+                                           _ptr(g_flat), gb, st), "dfn_weight_bias_grad")
             check(lib.dfn_fold_bias_bwd(buf.tier, FIELD_TORSO if f else FIELD_HEAD, _ptr(flat), _ptr(stt if f else sh),
                                         _ptr(zs[f]), _ptr(za[f]), gb, _ptr(g_flat),
                                         C.c_void_p(d_sig.data_ptr() + (4 * 96 if f else 0)), st), "dfn_fold_bias_bwd")

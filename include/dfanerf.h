@@ -151,6 +151,10 @@ int dfn_mlp_bwd(int tier, int field, const void* packed_T, const float* samples,
 int dfn_weight_grad(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
                     float* grad_flat, void* stream);
 int dfn_bias_grad(int tier, int field, const void* dy_T, long NP, float* dbias, void* stream);
+/* dfn_weight_grad and dfn_bias_grad in ONE pass over dy_T (the GEMM that owns a block of dy_T rows multiplies it by a
+ * tile of ones as well): same outputs, the gradient array is read once less. */
+int dfn_weight_bias_grad(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
+                         float* grad_flat, float* dbias, void* stream);
 /* Backward of dfn_fold_bias (the fold is linear; upstream it is the autograd of DEC:293-295, 311, 318, 332):
  * dbias [dfn_bias_floats] -> grad_flat (+=, layout of `params`: fc_z / fc_z_skips / fc_z_view, the signal columns
  * of fc_in / fc_p_skips / the deformation nets, every bias) and d_signal (+=, [96] head / [42] torso; may be NULL).
