@@ -414,9 +414,16 @@ static int weight_grad_impl(int tier, int field, const void* dy_T, const void* a
         err = hipMemsetAsync(dbias, 0, w.bias_rows.size() * sizeof(float), st);
         if (err != hipSuccess) return hip_fail(err, "memset(dbias)");
     }
+    // bf16 tier: the row sums ride along in the GEMMs (two cheap MFMAs per step).  f32 tier: an f32 MFMA costs 16x
+    // more, the streaming row-sum kernel is cheaper there (measured).
+    const bool fuse = dbias && tier == DFN_TIER_BF16;
     err = launch_wgrad(tier, field, w.ops_dev, (int)w.ops.size(), w.prefix_dev, w.prefix.back(), dy_T, act_T, NP,
-                       WGRAD_KSPLIT, workspace, dbias ? w.eof_dev : nullptr, dbias, st);
+                       WGRAD_KSPLIT, workspace, fuse ? w.eof_dev : nullptr, fuse ? dbias : nullptr, st);
     if (err != hipSuccess) return hip_fail(err, "wgrad_kernel");
+    if (dbias && !fuse) {
+        err = launch_bias_grad(tier, field, w.eof_dev, (int)w.bias_rows.size(), dy_T, NP, dbias, st);
+        if (err != hipSuccess) return hip_fail(err, "bias_grad_kernel");
+    }
     err = launch_scatter_add(w.map_dev, workspace, (long)w.map.size(), grad_flat, st);
     if (err != hipSuccess) return hip_fail(err, "scatter_add_kernel");
     return DFN_OK;
