@@ -410,3 +410,35 @@ def test_signal_encoders_hip_vs_reference_golden(eng, states, scene, golden):
     # error paths
     with pytest.raises(Exception):
         enc.encode([0], 3, 8)
+
+
+@pytest.mark.parametrize("fields", [1, 2])
+def test_render_hierarchical_64_fine_vs_oracle(eng, packed, scene, latents, golden, states, fields):
+    """Row H with n_fine = 64 (the other size the boundary accepts), f32 tier: the merged depths against the oracle's
+    own sampler (within one coarse bin, sorted, end points), weights summing to one, and decoder + compositing at the
+    kernel's depths against the oracle at those depths (stage (3) of the 64+128 test)."""
+    gc = golden("g7_frame_coarse")
+    idx = np.arange(5, scene["H"] * scene["W"], 1571)[:96]
+    out = _render_subset(eng, packed, scene, latents, gc["signal"][0], gc["signal_torso"].reshape(-1), idx, "f32", 64,
+                         fields, want_weights=True, want_z=True)
+    rh, rc, wh, wc, z = [None if o is None else o.cpu().numpy() for o in out]
+    assert z.shape == (96, 128) and (np.diff(z, axis=1) >= 0).all()
+    assert np.allclose(z[:, 0], 0.3) and np.allclose(z[:, -1], 0.9)
+    np.testing.assert_allclose(wh.sum(1), 1.0, atol=2e-6)
+    P = O.params_to_torch(states["decoder"])
+    zs, za = [t(v) for v in latents]
+    H, W = scene["H"], scene["W"]
+    o_h, d_h = O.get_rays(H, W, scene["focal"], scene["poses"][2][:3, :4], scene["cx"], scene["cy"])
+    o_t, d_t = O.get_rays(H, W, scene["focal"], scene["pose_body"][:3, :4], scene["cx"], scene["cy"])
+    rays = [x.reshape(-1, 3)[idx] for x in (o_h, d_h, o_t, d_t)]
+    bg = (t(scene["bg"]).float() / 255.0).reshape(-1, 3)[idx]
+    sig, sigt = [t(gc["signal"]), None], t(gc["signal_torso"])
+    with torch.no_grad():
+        _, _, aux = O.render_rays_chunk(P, *rays, bg, scene["near"], scene["far"], zs, za, sig, sigt, 64, 64, fields,
+                                        return_aux=True)
+        assert float((t(z) - aux["z_all"]).abs().max()) <= (0.6 / 63) * 1.001
+        oh, oc = O.render_fixed_samples(P, *rays, bg, t(z), zs, za, sig, sigt, fields)
+    np.testing.assert_allclose(rh, oh.numpy(), atol=5e-5, rtol=0)
+    if fields == 2:
+        np.testing.assert_allclose(wc.sum(1), 1.0, atol=2e-6)
+        np.testing.assert_allclose(rc, oc.numpy(), atol=5e-5, rtol=0)
