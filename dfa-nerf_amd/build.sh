@@ -20,5 +20,6 @@ for p in "${pids[@]}"; do wait $p; done
 # the asm fragment fetch (DFN_ASM_FETCH) is only safe if nothing touches an in-flight destination register
 ISA="$OBJ/dfn_render-hip-amdgcn-amd-amdhsa-gfx950.s"
 if [ -f "$ISA" ]; then python3 "$HERE/../tools/check_inflight.py" "$ISA" || { echo "build.sh: in-flight register hazard in the render kernels" >&2; exit 1; }; fi
+rm -f "$OBJ"/*.hipi "$OBJ"/*.bc "$OBJ"/*.out "$OBJ"/*.resolution.txt "$OBJ"/*.hipfb "$OBJ"/*-host-*.s      # --save-temps leftovers (the device ISA stays)
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/dfn_render.o "$OBJ"/dfn_misc.o "$OBJ"/dfn_api.o "$OBJ"/dfn_train.o "$OBJ"/dfn_signal.o "$OBJ"/dfn_plan.o
 echo "built $OUT"
