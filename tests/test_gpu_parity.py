@@ -442,3 +442,52 @@ def test_render_hierarchical_64_fine_vs_oracle(eng, packed, scene, latents, gold
     if fields == 2:
         np.testing.assert_allclose(wc.sum(1), 1.0, atol=2e-6)
         np.testing.assert_allclose(rc, oc.numpy(), atol=5e-5, rtol=0)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_render_coarse_f32_random_geometry_vs_oracle(eng, packed, states, latents, seed):
+    """The live renderer (coarse, both fields) on random geometry the fixed scene does not cover: non-square images,
+    other focal lengths / principal points, near / far like the dataset config files (0.4 / 1.0), random poses, a uint8
+    background, last_dist and concate_bg variations - against the oracle on the same rays (f32 tier, 2e-5)."""
+    rng = np.random.RandomState(seed)
+    H, W = [(48, 64), (97, 51), (450, 450)][seed - 1]
+    focal = float(rng.uniform(300, 1500))
+    cx, cy = float(W / 2 + rng.uniform(-5, 5)), float(H / 2 + rng.uniform(-5, 5))
+    near, far = [(0.4, 1.0), (0.25, 0.8), (0.3, 0.9)][seed - 1]
+
+    def pose():
+        a = rng.uniform(-0.2, 0.2, 3)
+        Rx = np.array([[1, 0, 0], [0, np.cos(a[0]), -np.sin(a[0])], [0, np.sin(a[0]), np.cos(a[0])]])
+        Ry = np.array([[np.cos(a[1]), 0, np.sin(a[1])], [0, 1, 0], [-np.sin(a[1]), 0, np.cos(a[1])]])
+        Rz = np.array([[np.cos(a[2]), -np.sin(a[2]), 0], [np.sin(a[2]), np.cos(a[2]), 0], [0, 0, 1]])
+        P = np.eye(4, dtype=np.float32)
+        P[:3, :3] = (Rz @ Ry @ Rx).astype(np.float32)
+        P[:3, 3] = np.array([rng.uniform(-.05, .05), rng.uniform(-.05, .05), rng.uniform(0.5, 0.7)], np.float32)
+        return P
+    pose_h, pose_b = pose(), pose()
+    bg_u8 = rng.randint(0, 256, size=(H * W, 3)).astype(np.uint8)
+    sig = (rng.randn(96) * 0.5).astype(np.float32)
+    sigt = (rng.randn(42) * 0.5).astype(np.float32)
+    last_dist = [1e10, 0.05, 1e10][seed - 1]
+    cbg = seed != 2
+    n = min(H * W, 257)
+    idx = np.sort(rng.choice(H * W, n, replace=False)).astype(np.int32)
+    zs, za = latents
+    pk = packed["f32"]
+    bias = pk.fold(sig, sigt, zs[0], za[0])
+    fr = eng.make_frame(H, W, focal, cx, cy, pose_h, pose_b, near, far, last_dist=last_dist, ray_count=n, n_fine=0,
+                        fields=2, concate_bg=cbg)
+    rh, rc, wh, wc = eng.render(pk, bias, fr, t(bg_u8).cuda(), pix_index=t(idx).cuda(), want_weights=True)
+    P = O.params_to_torch(states["decoder"])
+    o_h, d_h = O.get_rays(H, W, focal, pose_h[:3, :4], cx, cy)
+    o_t, d_t = O.get_rays(H, W, focal, pose_b[:3, :4], cx, cy)
+    rays = [x.reshape(-1, 3)[idx] for x in (o_h, d_h, o_t, d_t)]
+    bg = t(bg_u8).float() / 255.0
+    with torch.no_grad():
+        z = O.coarse_z(near, far, 64)[None, :].expand(n, 64)
+        s_h, f_h, s_t, f_t = O._eval_fields(P, *rays, z, t(zs), t(za), [t(sig)[None], None], t(sigt)[None], 2)
+        oh, owh, oc, owc = O.integrate_fields(z, rays[1], rays[3], s_h, f_h, s_t, f_t, bg[idx], last_dist, cbg)
+    np.testing.assert_allclose(rh.cpu().numpy(), oh.numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(rc.cpu().numpy(), oc.numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(wh.cpu().numpy(), owh.numpy(), atol=2e-6, rtol=0)
+    np.testing.assert_allclose(wc.cpu().numpy(), owc.numpy(), atol=2e-6, rtol=0)
