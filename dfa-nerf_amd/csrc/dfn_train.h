@@ -33,6 +33,7 @@ struct WOp {                    // one weight-gradient GEMM: C[M x N] = dy_T[a_r
 };
 
 hipError_t launch_mlp_bwd(int tier, int field, const MlpBwdArgs& A, hipStream_t st);
+hipError_t launch_mlp_bwd_bf16(bool torso, const MlpBwdArgs& A, hipStream_t st);     // dfn_bwd_bf16.hip
 void bwd_program_info(int tier, int field, ProgramInfo* out);
 hipError_t launch_composite_bwd(const CompositeBwdArgs& A, hipStream_t st);
 hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, const int* prefix_dev, int total_items,

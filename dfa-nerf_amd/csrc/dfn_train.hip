@@ -5,77 +5,13 @@
 // Differentiates run_nerf_com_trainExpLater.py:855-907 (two fields, coarse samples, composite, weights,
 // weighted colour sums) and decoder.py:277-349 / 109-134.
 #include <hip/hip_runtime.h>
-#include "dfn_bwd.h"
-#include "dfn_layout.h"
-#include "dfn_mlp.h"
-#include "dfn_train.h"
+#include "dfn_bwd_kernel.h"
 
 namespace dfn {
 
-// ================================================================================================
-// MLP backward: one wave = one 32-point tile, one pass of the transposed weight stream
-// ================================================================================================
-template <int TIER, bool TORSO>
-__global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 256) void mlp_bwd_kernel(
-    const MlpBwdArgs A) {
-    using C = TierCfg<TIER>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    lds_char* lds = (lds_char*)smem;
-    const Ctx ctx = {lds, wave, lane, lane >> 5, {}};
-    Stream s;
-    s.base[0] = s.base[1] = A.wblob_T;
-    s.nslab[0] = s.nslab[1] = A.nslab;
-    s.sched = 0;
-    stream_begin<TIER>(s, lds, wave, lane);
-    const long n_tiles = A.NP / 32;
-    const long tile_raw = (long)blockIdx.x * C::WAVES + wave;
-    const long tile = tile_raw < n_tiles ? tile_raw : n_tiles - 1;     // idle waves redo the last tile (same values)
-    const long p = tile * 32 + (lane & 31);
-    BwdIn in;
-    {
-        const int o = TORSO ? 4 : 0;
-        const float* ds = A.dsamples + p * 8 + o;
-        const float* sm = A.samples + p * 8 + o;
-        in.dsigma = ds[0];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float y = sm[1 + k];
-            in.dpre[k] = ds[1 + k] * (y * (1.0f - y));                 // sigmoid'
-        }
-    }
-    BwdIO io;
-    io.dy_T = A.dy_T;
-    io.masks = A.masks;
-    io.rows = TORSO ? GradMap::S_ROWS : GradMap::H_ROWS;
-    io.pass = tile;
-    io.mask_dwords = TORSO ? RecMap::S_MDWORDS : RecMap::H_MDWORDS;
-    __syncthreads();
-    if constexpr (TORSO) bwd_torso<TIER>(in, io, s, ctx);
-    else bwd_head<TIER>(in, io, s, ctx);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-template <int TIER, bool TORSO> static hipError_t launch_mlp_bwd_t(const MlpBwdArgs& A, hipStream_t st) {
-    using C = TierCfg<TIER>;
-    const int lds = RING_BYTES;
-    static bool done = false;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute((const void*)mlp_bwd_kernel<TIER, TORSO>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        done = true;
-    }
-    const long n_tiles = A.NP / 32;
-    const int blocks = (int)((n_tiles + C::WAVES - 1) / C::WAVES);
-    hipLaunchKernelGGL((mlp_bwd_kernel<TIER, TORSO>), dim3(blocks), dim3(C::THREADS), lds, st, A);
-    return hipGetLastError();
-}
 hipError_t launch_mlp_bwd(int tier, int field, const MlpBwdArgs& A, hipStream_t st) {
     const bool torso = field == FIELD_TORSO;
-    if (tier == TIER_BF16)
-        return torso ? launch_mlp_bwd_t<TIER_BF16, true>(A, st) : launch_mlp_bwd_t<TIER_BF16, false>(A, st);
+    if (tier == TIER_BF16) return launch_mlp_bwd_bf16(torso, A, st);      // dfn_bwd_bf16.hip
     return torso ? launch_mlp_bwd_t<TIER_F32, true>(A, st) : launch_mlp_bwd_t<TIER_F32, false>(A, st);
 }
 void bwd_program_info(int tier, int field, ProgramInfo* out) {

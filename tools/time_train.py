@@ -19,7 +19,7 @@ ds = [{"auds": t(sc["aud"]).to(dev), "exp": t(sc["exp"]).to(dev), "poses": t(sc[
 zs, za = [t(v).to(dev) for v in synth.synth_latents(0)]
 embed_fn, _ = nets.get_embedder(3, 0)
 tgt = torch.rand(2048, 3, device=dev)
-for tier in ("bf16", "f32", "aten"):
+for tier in (sys.argv[1:] or ("bf16", "f32", "aten")):
     mods = {"decoder": Decoder(z_dim=256, hidden_size=256, dim_signal=96, use_deformation_field=True),
             "AudNet": nets.AudioNet_W2L(), "ExpNet": nets.ExpressionEnc(), "AudAttNet": nets.AudioAttNet(96, 4),
             "PoseAttNet": nets.AudioAttNet(42, 8)}
