@@ -178,7 +178,7 @@ def bench_training(args, world, rank, local, dev, desc):
         NP = 64 * N_RAND
         act_b = sum(_l.dfn_train_rows(f, 0) for f in (0, 1)) * NP * esz
         dy_b = sum(_l.dfn_train_rows(f, 1) for f in (0, 1)) * NP * esz
-        step_bytes = 2 * act_b + 3 * dy_b
+        step_bytes = 2 * (act_b + dy_b)          # recorded activations and pre-activation gradients: written once, read once (wgrad)
         gbs = step_bytes * world * args.steps / dt / 1e9
         print(json.dumps({
             "metric": f"training rays/sec (whole node), N_rand={N_RAND} per GPU, 64 coarse samples, 2 fields, fwd+bwd+Adam",
@@ -188,7 +188,7 @@ def bench_training(args, world, rank, local, dev, desc):
             "vs_baseline": None, "dtype": args.tier, "data": "synthetic",
             "config": {"workload": desc, "H": H, "W": W, "N_rand_per_gpu": N_RAND, "n_coarse": 64, "fields": 2,
                        "parallelism": f"dp{world}, one flat-bucket all_reduce (1,138,656 floats)"},
-            "roofline": {"bound": "hbm", "kernel": "whole step (render_kernel<train>, mlp_bwd, wgrad, bias_grad)",
+            "roofline": {"bound": "hbm", "kernel": "whole step (render_kernel<train>, mlp_bwd, wgrad_lds)",
                          "achieved": gbs, "peak": 8000.0 * world, "unit": "GB/s", "frac": gbs / (8000.0 * world),
                          "traffic": None, "bytes_per_step_per_gpu": step_bytes,
                          "mfma": {"achieved_tflops": ach, "peak_tflops": PEAK_TFLOPS[args.tier] * world,

@@ -8,7 +8,7 @@ OBJ="$HERE/build"
 mkdir -p "$OBJ"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -I$SRC -I$HERE/../include"
 pids=()
-for f in dfn_render dfn_misc dfn_api dfn_train dfn_bwd_bf16 dfn_signal; do
+for f in dfn_render dfn_misc dfn_api dfn_train dfn_bwd_bf16 dfn_wgrad_bf16 dfn_signal; do
   ( if [ ! -f "$OBJ/$f.o" ] || [ -n "$(find "$SRC" "$HERE/../include" -newer "$OBJ/$f.o" \( -name '*.h' -o -name "$f.hip" \) -print -quit)" ]; then
       EXTRA=""; [ "$f" = dfn_render ] && EXTRA="--save-temps=obj"     # keep the ISA of the render kernels for the check below
       if [ "$f" = dfn_bwd_bf16 ]; then
@@ -30,5 +30,5 @@ for p in "${pids[@]}"; do wait $p; done
 ISA="$OBJ/dfn_render-hip-amdgcn-amd-amdhsa-gfx950.s"
 if [ -f "$ISA" ]; then python3 "$HERE/../tools/check_inflight.py" "$ISA" || { echo "build.sh: in-flight register hazard in the render kernels" >&2; exit 1; }; fi
 rm -f "$OBJ"/*.hipi "$OBJ"/*.bc "$OBJ"/*.out "$OBJ"/*.resolution.txt "$OBJ"/*.hipfb "$OBJ"/*-host-*.s      # --save-temps leftovers (the device ISA stays)
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/dfn_render.o "$OBJ"/dfn_misc.o "$OBJ"/dfn_api.o "$OBJ"/dfn_train.o "$OBJ"/dfn_bwd_bf16.o "$OBJ"/dfn_signal.o "$OBJ"/dfn_plan.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/dfn_render.o "$OBJ"/dfn_misc.o "$OBJ"/dfn_api.o "$OBJ"/dfn_train.o "$OBJ"/dfn_bwd_bf16.o "$OBJ"/dfn_wgrad_bf16.o "$OBJ"/dfn_signal.o "$OBJ"/dfn_plan.o
 echo "built $OUT"

@@ -3,6 +3,7 @@
 #include <algorithm>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -69,10 +70,15 @@ struct WgradEntry {
     int32_t* rows_dev = nullptr;
     int32_t* eof_dev = nullptr;      // dy_T row -> bias element
     int* prefix_dev = nullptr;
+    int* order_dev = nullptr;        // GEMMs by decreasing operand rows (bf16 tier: one workgroup per GEMM and k-split)
     int ksplit_uploaded = 0;
 };
 WgradEntry g_wgrad[2];
 constexpr int WGRAD_KSPLIT = 32;
+int wgrad_ksplit_bf16() {              // slices of the points per GEMM, bf16 tier (DFN_WGRAD_KSPLIT: developer override)
+    static const int v = [] { const char* e = getenv("DFN_WGRAD_KSPLIT"); const int k = e ? atoi(e) : 0; return k > 0 ? k : 24; }();
+    return v;
+}
 
 template <typename T> hipError_t upload(T** dev, const T* host, size_t n) {
     hipError_t e = hipMalloc((void**)dev, n * sizeof(T));
@@ -403,6 +409,11 @@ static int weight_grad_impl(int tier, int field, const void* dy_T, const void* a
             if (e == hipSuccess) e = upload(&w.map_dev, w.map.data(), w.map.size());
             if (e == hipSuccess) e = upload(&w.prefix_dev, w.prefix.data(), w.prefix.size());
             if (e == hipSuccess) e = upload(&w.rows_dev, w.bias_rows.data(), w.bias_rows.size());
+            std::vector<int> order(ops.size());
+            for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+            std::stable_sort(order.begin(), order.end(),
+                             [&](int a, int b) { return ops[a].M + ops[a].N > ops[b].M + ops[b].N; });
+            if (e == hipSuccess) e = upload(&w.order_dev, order.data(), order.size());
             if (e != hipSuccess) return hip_fail(e, "upload(wgrad plan)");
         }
     }
@@ -417,8 +428,12 @@ static int weight_grad_impl(int tier, int field, const void* dy_T, const void* a
     // bf16 tier: the row sums ride along in the GEMMs (two cheap MFMAs per step).  f32 tier: an f32 MFMA costs 16x
     // more, the streaming row-sum kernel is cheaper there (measured).
     const bool fuse = dbias && tier == DFN_TIER_BF16;
-    err = launch_wgrad(tier, field, w.ops_dev, (int)w.ops.size(), w.prefix_dev, w.prefix.back(), dy_T, act_T, NP,
-                       WGRAD_KSPLIT, workspace, fuse ? w.eof_dev : nullptr, fuse ? dbias : nullptr, st);
+    if (tier == DFN_TIER_BF16)
+        err = launch_wgrad_bf16(field, w.ops_dev, w.order_dev, (int)w.ops.size(), dy_T, act_T, NP, wgrad_ksplit_bf16(),
+                                workspace, fuse ? w.eof_dev : nullptr, fuse ? dbias : nullptr, st);
+    else
+        err = launch_wgrad(tier, field, w.ops_dev, (int)w.ops.size(), w.prefix_dev, w.prefix.back(), dy_T, act_T, NP,
+                           WGRAD_KSPLIT, workspace, fuse ? w.eof_dev : nullptr, fuse ? dbias : nullptr, st);
     if (err != hipSuccess) return hip_fail(err, "wgrad_kernel");
     if (dbias && !fuse) {
         err = launch_bias_grad(tier, field, w.eof_dev, (int)w.bias_rows.size(), dy_T, NP, dbias, st);

@@ -39,10 +39,15 @@ hipError_t launch_composite_bwd(const CompositeBwdArgs& A, hipStream_t st);
 hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, const int* prefix_dev, int total_items,
                         const void* dy_T, const void* act_T, long NP, int ksplit, float* C, const int* e_of, float* dbias,
                         hipStream_t st);
+// bf16 tier: one workgroup per (GEMM, slice of the points), operands through LDS (dfn_wgrad_bf16.hip); order = GEMMs by
+// decreasing size
+hipError_t launch_wgrad_bf16(int field, const WOp* ops_dev, const int* order_dev, int n_ops, const void* dy_T,
+                             const void* act_T, long NP, int ksplit, float* C, const int* e_of, float* dbias,
+                             hipStream_t st);
 hipError_t launch_scatter_add(const int* map, const float* dense, long n, float* grad_flat, hipStream_t st);
 // macro-tile of one wgrad wave, in 32x32 output tiles (dfn_api.hip sizes the work list with the same numbers)
 constexpr int WG_MT = 2, WG_NT = 4;
-constexpr int WG_PF = 4;      // register prefetch depth of wgrad_kernel, in 32-point (bf16) / 8-point (f32) steps
+constexpr int WG_PF = 4;      // register prefetch depth of wgrad_kernel (f32 tier), in 8-point steps
 hipError_t launch_bias_grad(int tier, int field, const int* row_of, int n, const void* dy_T, long NP, float* dbias,
                             hipStream_t st);
 

@@ -177,11 +177,11 @@ hipError_t launch_composite_bwd(const CompositeBwdArgs& A, hipStream_t st) {
 // One wave = one macro-tile of up to WG_MT x WG_NT 32x32 output tiles over a slice of the sample points: per
 // 32-point step it loads WG_MT A tiles + WG_NT B tiles (1 KiB each) for WG_MT*WG_NT tile products - 2.7x less
 // operand traffic than one tile per wave (the kernel is bound by operand reads out of L2/HBM, not by the MFMAs).
-template <int TIER>
+// f32 tier only: the bf16 tier shares the operands of a whole GEMM through LDS (dfn_wgrad_bf16.hip).
 __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, const int* work_prefix, const void* dy_T,
                                                     const void* act_T, long n_tiles, int g_rows, int a_rows,
                                                     int ksplit, float* C, const int* e_of, float* dbias) {
-    typedef typename ActT<TIER>::type T;
+    typedef float T;
     const int lane = threadIdx.x & 63;
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= work_prefix[n_ops]) return;
@@ -201,9 +201,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
     const long t0 = ks * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
     // tile-major operands: row r of tile t starts at (t * rows + r) * 32
     const int h = lane >> 5;
-    constexpr int KOFF = (TIER == TIER_BF16) ? 8 : 0;
-    const T* a = (const T*)dy_T + (long)(o.a_row + 32 * WG_MT * mb + (lane & 31)) * 32 + KOFF * h;
-    const T* b = (const T*)act_T + (long)(o.b_row + 32 * WG_NT * nb + (lane & 31)) * 32 + KOFF * h;
+    const T* a = (const T*)dy_T + (long)(o.a_row + 32 * WG_MT * mb + (lane & 31)) * 32;
+    const T* b = (const T*)act_T + (long)(o.b_row + 32 * WG_NT * nb + (lane & 31)) * 32;
     // bias gradients for free: the first column block of the GEMM that owns these dy_T rows multiplies them by a tile of
     // ones as well (2 more MFMAs per step, no extra memory traffic) -> row sums over the points
     const bool do_bias = dbias && o.bias_owner && nb == 0;          // wave-uniform
@@ -219,53 +218,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
         for (int j = 0; j < WG_NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if constexpr (TIER == TIER_BF16) {
-        // register ring, WG_PF steps deep: a step's 16 MFMAs take ~500 cycles, an operand load ~2-4 k cycles, and the
-        // 400+ registers leave one wave per SIMD - so the loads of step t + WG_PF - 1 go out before the MFMAs of step t
-        bf16x8 av[WG_PF][WG_MT][2], bv[WG_PF][WG_NT][2];
-        auto load = [&](int s, long t) {
-            const T* at = a + t * (long)g_rows * 32;
-            const T* bt = b + t * (long)a_rows * 32;
-#pragma unroll
-            for (int i = 0; i < WG_MT; ++i)
-                if (i < mt_n) { av[s][i][0] = *(const bf16x8*)(at + i * 1024); av[s][i][1] = *(const bf16x8*)(at + i * 1024 + 16); }
-#pragma unroll
-            for (int j = 0; j < WG_NT; ++j)
-                if (j < nt_n) { bv[s][j][0] = *(const bf16x8*)(bt + j * 1024); bv[s][j][1] = *(const bf16x8*)(bt + j * 1024 + 16); }
-        };
-        auto mac = [&](int s) {
-#pragma unroll
-            for (int i = 0; i < WG_MT; ++i)
-#pragma unroll
-                for (int j = 0; j < WG_NT; ++j)
-                    if (i < mt_n && j < nt_n) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][i][0], bv[s][j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][i][1], bv[s][j][1], acc[i][j], 0, 0, 0);
-                    }
-            if (do_bias) {
-                bf16x8 ones;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
-#pragma unroll
-                for (int i = 0; i < WG_MT; ++i)
-                    if (i < mt_n) {
-                        accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][i][0], ones, accb[i], 0, 0, 0);
-                        accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][i][1], ones, accb[i], 0, 0, 0);
-                    }
-            }
-        };
-#pragma unroll
-        for (int s = 0; s < WG_PF - 1; ++s)
-            if (t0 + s < t1) load(s, t0 + s);
-        for (long t = t0; t < t1; t += WG_PF) {
-#pragma unroll
-            for (int s = 0; s < WG_PF; ++s) {
-                const long tt = t + s;
-                if (tt + WG_PF - 1 < t1) load((s + WG_PF - 1) % WG_PF, tt + WG_PF - 1);
-                if (tt < t1) mac(s);
-            }
-        }
-    } else {
+    {
         // f32: v_mfma_f32_32x32x2_f32 takes A[row][k = half].  The contraction order is free, so MFMA m of a group of
         // four pairs k = m (lower half of the wave) with k = m + 4 (upper half): each lane then needs 4 CONSECUTIVE
         // points - one 16-byte load, nothing fetched twice, no selects - and a group covers 8 points.  Steps of 8
@@ -341,12 +294,9 @@ hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, cons
     const int blocks = (total_items + 3) / 4;
     const bool torso = field == FIELD_TORSO;
     const int g_rows = torso ? GradMap::S_ROWS : GradMap::H_ROWS, a_rows = torso ? RecMap::S_ROWS : RecMap::H_ROWS;
-    if (tier == TIER_BF16)
-        hipLaunchKernelGGL(wgrad_kernel<TIER_BF16>, dim3(blocks), dim3(256), 0, st, ops_dev, n_ops, prefix_dev, dy_T,
-                           act_T, NP / 32, g_rows, a_rows, ksplit, C, e_of, dbias);
-    else
-        hipLaunchKernelGGL(wgrad_kernel<TIER_F32>, dim3(blocks), dim3(256), 0, st, ops_dev, n_ops, prefix_dev, dy_T,
-                           act_T, NP / 32, g_rows, a_rows, ksplit, C, e_of, dbias);
+    if (tier != TIER_F32) return hipErrorInvalidValue;          // bf16: launch_wgrad_bf16
+    hipLaunchKernelGGL(wgrad_kernel, dim3(blocks), dim3(256), 0, st, ops_dev, n_ops, prefix_dev, dy_T, act_T, NP / 32,
+                       g_rows, a_rows, ksplit, C, e_of, dbias);
     return hipGetLastError();
 }
 
