@@ -11,16 +11,7 @@ pids=()
 for f in dfn_render dfn_misc dfn_api dfn_train dfn_bwd_bf16 dfn_wgrad_bf16 dfn_signal; do
   ( if [ ! -f "$OBJ/$f.o" ] || [ -n "$(find "$SRC" "$HERE/../include" -newer "$OBJ/$f.o" \( -name '*.h' -o -name "$f.hip" \) -print -quit)" ]; then
       EXTRA=""; [ "$f" = dfn_render ] && EXTRA="--save-temps=obj"     # keep the ISA of the render kernels for the check below
-      if [ "$f" = dfn_bwd_bf16 ]; then
-        # the bf16 backward chain kernels spill ~200 registers under the default scheduler and 17-89 under the
-        # minimum-register one (measured: training step 3.25 -> 3.04 ms; the f32 tier and wgrad prefer the default).
-        # -mllvm reaches the host pass too, where this scheduler crashes, so the device code is compiled on its own
-        # and handed to the host pass as the GPU binary.
-        hipcc $FLAGS --cuda-device-only -mllvm -misched=gcn-iterative-minreg -c "$SRC/$f.hip" -o "$OBJ/$f.hipfb"
-        hipcc $FLAGS --cuda-host-only -Xclang -fcuda-include-gpubinary -Xclang "$OBJ/$f.hipfb" -c "$SRC/$f.hip" -o "$OBJ/$f.o"
-      else
-        hipcc $FLAGS $EXTRA -c "$SRC/$f.hip" -o "$OBJ/$f.o"
-      fi
+      hipcc $FLAGS $EXTRA -c "$SRC/$f.hip" -o "$OBJ/$f.o"
     fi ) &
   pids+=($!)
 done

@@ -37,8 +37,11 @@ struct BwdIO {
 DFN_DEV void apply_mask(f32x16 (&acc)[2], unsigned bits) {
 #ifndef DFN_NOMASK
 #pragma unroll
-    for (int b = 0; b < 32; ++b)
-        if (!((bits >> b) & 1u)) acc[b >> 4][b & 15] = 0.f;
+    for (int b = 0; b < 32; ++b) {      // bit b sign-extended to a word (v_bfe_i32), ANDed onto the value: 2 ops per value
+        const unsigned keep = (unsigned)__builtin_amdgcn_sbfe((int)bits, b, 1);
+        const float x = acc[b >> 4][b & 15];          // a scalar copy: __builtin_bit_cast of a vector ELEMENT miscompiles
+        acc[b >> 4][b & 15] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & keep);
+    }
 #endif
 }
 DFN_DEV unsigned mask_word(const BwdIO& io, int dword, int lane) {

@@ -1,7 +1,8 @@
 // dfn_bwd_bf16.hip - bf16 instantiation of the MLP backward kernel (dfn_bwd_kernel.h).
-// A translation unit of its own so build.sh can give it the minimum-register instruction scheduler: under the
-// default one these two kernels spill 184-213 registers, under that one 17-89 (measured 447 -> 362 us and
-// 391 -> 260 us per training step); the f32 tier and the weight-gradient kernels are faster with the default.
+// A translation unit of its own: the two kernels are the longest compile of the library.  (For a while this unit was
+// built with LLVM's minimum-register scheduler, which cut their spills from ~200 to 17-89 registers; since the
+// operand vectors are converted in register pairs and the ReLU bits applied with bfe + and (dfn_mlp.h: acc_to_vec,
+// dfn_bwd.h: apply_mask) the default scheduler needs no spill at all and is 8 % faster than that build.)
 #include "dfn_bwd_kernel.h"
 
 namespace dfn {

@@ -1,6 +1,5 @@
 // dfn_bwd_kernel.h - the MLP backward (dX chain) kernel and its launcher, as templates over the tier.
-// Instantiated in two translation units because the tiers want different instruction schedulers:
-// dfn_bwd_bf16.hip (built with the minimum-register scheduler, see build.sh) and dfn_train.hip (f32 tier).
+// Instantiated in two translation units (compile time): dfn_bwd_bf16.hip and dfn_train.hip (f32 tier).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "dfn_bwd.h"

@@ -219,15 +219,42 @@ template <> struct ActT<TIER_F32> { typedef float type; };
 
 // store a B-operand vector feature-major into a tile-major array [tile][rows][32]: element (row0 + feature, n).
 // All offsets from the tile base are compile-time constants.
+// tiles [t0, t0 + n) of v -> rows row0 + 32 (t - t0) ...
 template <int TIER, int NT, class CT>
-DFN_DEV void store_vec_T(void* arr, int rows, long tile, int row0, const Vec<TIER, NT>& v, const CT& c) {
+DFN_DEV void store_tiles_T(void* arr, int rows, long tile, int row0, const Vec<TIER, NT>& v, int t0, int n, const CT& c) {
     typedef typename ActT<TIER>::type T;
     T* base = (T*)arr + ((tile * rows + row0 + 4 * c.half) * 32 + (c.lane & 31));
+    if constexpr (TIER == TIER_BF16) {
+        // straight from the packed operand words: register pair (r, r + 1) = features (f, f + 1) = one 32-bit word,
+        // stored as its low and its high half (global_store_short / _d16_hi) - no conversion, no extraction
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        unsigned short* b16 = (unsigned short*)base;
 #pragma unroll
-    for (int L = 0; L < 16 * NT; ++L) {
-        const int f = 32 * (L >> 4) + tile_feat(0, L & 15);      // + 4 for the upper half (in base)
-        base[f * 32] = (T)v.get(L);
+        for (int t = 0; t < NT; ++t)
+            if (t >= t0 && t < t0 + n)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bf16x8 uu = v.u[2 * t + h];
+                    const u32x4_ q = __builtin_bit_cast(u32x4_, uu);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int f = 32 * (t - t0) + tile_feat(0, 8 * h + 2 * e);      // + 4 for the upper half (in base)
+                        b16[f * 32] = (unsigned short)q[e];
+                        b16[(f + 1) * 32] = (unsigned short)(q[e] >> 16);
+                    }
+                }
+    } else {
+#pragma unroll
+        for (int L = 0; L < 16 * NT; ++L)
+            if ((L >> 4) >= t0 && (L >> 4) < t0 + n) {
+                const int f = 32 * ((L >> 4) - t0) + tile_feat(0, L & 15);
+                base[f * 32] = (T)v.get(L);
+            }
     }
+}
+template <int TIER, int NT, class CT>
+DFN_DEV void store_vec_T(void* arr, int rows, long tile, int row0, const Vec<TIER, NT>& v, const CT& c) {
+    store_tiles_T<TIER, NT>(arr, rows, tile, row0, v, 0, NT, c);
 }
 template <int TIER, int NT, class CT>
 DFN_DEV void rec_vec(const CT& c, int row0, const Vec<TIER, NT>& v) {
@@ -403,7 +430,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int TIER, int G, int NT, bool RELU>
 DFN_DEV void acc_to_vec(const f32x16 (&acc)[G], Vec<TIER, NT>& v, int t0) {
-    if constexpr (TIER == TIER_BF16 && RELU) {
+    if constexpr (TIER == TIER_BF16) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
 #pragma unroll
@@ -413,8 +440,12 @@ DFN_DEV void acc_to_vec(const f32x16 (&acc)[G], Vec<TIER, NT>& v, int t0) {
                 for (int e = 0; e < 4; ++e) {
                     const f32x2 x = {acc[g][8 * h + 2 * e], acc[g][8 * h + 2 * e + 1]};
                     const bf16x2 pk = __builtin_convertvector(x, bf16x2);                        // v_cvt_pk_bf16_f32
-                    const s16x2 m = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk), (s16x2)(0));   // v_pk_max_i16
-                    w[e] = __builtin_bit_cast(unsigned, m);
+                    if constexpr (RELU) {
+                        const s16x2 m = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk), (s16x2)(0));   // v_pk_max_i16
+                        w[e] = __builtin_bit_cast(unsigned, m);
+                    } else {
+                        w[e] = __builtin_bit_cast(unsigned, pk);
+                    }
                 }
                 const u32x4 q = {w[0], w[1], w[2], w[3]};
                 v.u[2 * (t0 + g) + h] = __builtin_bit_cast(bf16x8, q);
@@ -431,22 +462,24 @@ DFN_DEV void acc_to_vec(const f32x16 (&acc)[G], Vec<TIER, NT>& v, int t0) {
     }
 }
 
-// training recorder, per tile pair, straight from the accumulators (post-activation values as the next layer
-// sees them): rows row0 + {0..63} of act_T, and one dword of ReLU bits
-template <int TIER, bool RELU, class CT>
-DFN_DEV void rec_pair(const CT& c, int row0, int mask_dword, const f32x16 (&acc)[2]) {
+// training recorder, per tile pair.  Values (post-activation, as the next layer sees them): rows row0 + {0..63} of
+// act_T - bf16 tier: the packed operand words acc_to_vec just made (tiles t0, t0 + 1 of `out`), f32 tier: the
+// accumulators.  ReLU bits: one dword per lane from the accumulators.
+template <int TIER, bool RELU, int NT, class CT>
+DFN_DEV void rec_pair(const CT& c, int row0, int mask_dword, const f32x16 (&acc)[2], const Vec<TIER, NT>& out, int t0) {
     if constexpr (CT::rec_on) {
-        typedef typename ActT<TIER>::type T;
-        if (row0 >= 0) {
-            T* base = (T*)c.rec.act_T + ((c.rec.pass * c.rec.rows + row0 + 4 * c.half) * 32 + (c.lane & 31));
+        if (row0 >= 0) store_tiles_T<TIER, NT>(c.rec.act_T, c.rec.rows, c.rec.pass, row0, out, t0, 2, c);
+        if (mask_dword >= 0) {
+            unsigned bits = 0;
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float x = acc[g][r];
-                    base[(32 * g + tile_feat(0, r)) * 32] = (T)(RELU ? relu_(x) : x);
-                }
+            for (int b = 0; b < 32; ++b) bits |= (acc[b >> 4][b & 15] > 0.f) ? (1u << b) : 0u;
+            c.rec.masks[((long)c.rec.pass * c.rec.mask_dwords + mask_dword) * 64 + c.lane] = bits;
         }
+    }
+}
+template <class CT>
+DFN_DEV void rec_mask_pair(const CT& c, int mask_dword, const f32x16 (&acc)[2]) {
+    if constexpr (CT::rec_on) {
         if (mask_dword >= 0) {
             unsigned bits = 0;
 #pragma unroll
@@ -466,8 +499,8 @@ DFN_DEV void layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_f32* 
         f32x16 acc[2];
         acc_init<2>(acc, bias + tg * 64, c.half);
         gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c);
-        rec_pair<TIER, RELU>(c, rec_row < 0 ? -1 : rec_row + 64 * tg, rec_mask < 0 ? -1 : rec_mask + tg, acc);
         acc_to_vec<TIER, 2, OT, RELU>(acc, out, 2 * tg);
+        rec_pair<TIER, RELU>(c, rec_row < 0 ? -1 : rec_row + 64 * tg, rec_mask < 0 ? -1 : rec_mask + tg, acc, out, 2 * tg);
     }
 }
 // out = relu(bias + W x in) + bias2 + W2 x in2      (no activation after the skip)
@@ -480,11 +513,11 @@ DFN_DEV void layer_skip(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_
         f32x16 acc[2];
         acc_init<2>(acc, bias + tg * 64, c.half);
         gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c);
-        rec_pair<TIER, false>(c, -1, mask_dword0 < 0 ? -1 : mask_dword0 + tg, acc);    // ReLU bits of the pre-skip value
+        rec_mask_pair(c, mask_dword0 < 0 ? -1 : mask_dword0 + tg, acc);                 // ReLU bits of the pre-skip value
         acc_relu_add<2>(acc, bias2 + tg * 64, c.half);
         gemm_group<TIER, 2, KU2, NTB2>(acc, in2, f, fe, s, c);
-        rec_pair<TIER, false>(c, rec_row < 0 ? -1 : rec_row + 64 * tg, -1, acc);        // post-skip value (no ReLU)
         acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);
+        rec_pair<TIER, false>(c, rec_row < 0 ? -1 : rec_row + 64 * tg, -1, acc, out, 2 * tg);     // post-skip value (no ReLU)
     }
 }
 
@@ -639,8 +672,8 @@ DFN_DEV MlpOut mlp_trunk(Vec<TIER, 8>& act, const Vec<TIER, NTP>& pvec, const Dh
             acc_init<2>(acc, bias + b_view + tg * 64, c.half);
             gemm_group<TIER, 2, P::KU_ACT, 8>(acc, act, f, fe, s, c);
             gemm_group<TIER, 2, P::KU_VIEW, 1>(acc, vview, f, fe, s, c);
-            rec_pair<TIER, true>(c, r_trunk + RecMap::T_H + 64 * tg, m_trunk + RecMap::TM_H + tg, acc);
             acc_to_vec<TIER, 2, 8, true>(acc, nxt, 2 * tg);
+            rec_pair<TIER, true>(c, r_trunk + RecMap::T_H + 64 * tg, m_trunk + RecMap::TM_H + tg, acc, nxt, 2 * tg);
         }
         f32x16 acc1[1];
         acc_init<1>(acc1, bias + b_view + 256, c.half);
@@ -706,10 +739,10 @@ DFN_DEV MlpOut mlp_torso(const float (&p)[3], const DhatRef& dhat, const lds_f32
         f32x16 acc[2];
         acc_init<2>(acc, bias + P::T_B_S3, c.half);
         gemm_group<TIER, 2, P::KU_D, 2>(acc, vs, f, fe, s, c);
-        rec_pair<TIER, false>(c, -1, RecMap::S_MD0 + 7, acc);
+        rec_mask_pair(c, RecMap::S_MD0 + 7, acc);
         acc_relu_add<2>(acc, bias + P::T_B_SSKIP, c.half);
-        rec_pair<TIER, false>(c, RecMap::S_D0 + 64 * 7, -1, acc);
         acc_to_vec<TIER, 2, 2, false>(acc, vn, 0);
+        rec_pair<TIER, false>(c, RecMap::S_D0 + 64 * 7, -1, acc, vn, 0);
         vs = vn;
     }
     layer<TIER, 2, P::KU_D, 2, true>(vn, ve, bias + P::T_B_E4, f, fe, s, c, DFN_RD(8));  ve = vn;

@@ -11,10 +11,7 @@ mkdir -p "$OBJ"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -I$SRC -I$ROOT/include $*"
 pids=()
 for f in dfn_render dfn_misc dfn_api dfn_train dfn_bwd_bf16 dfn_wgrad_bf16 dfn_signal; do
-  ( if [ "$f" = dfn_bwd_bf16 ] && [ -z "$DFN_TRAIN_DEFAULT_SCHED" ]; then     # as build.sh: minimum-register scheduler for the backward kernels
-      hipcc $FLAGS --cuda-device-only -mllvm -misched=gcn-iterative-minreg -c "$SRC/$f.hip" -o "$OBJ/$f.hipfb" 2>"$OBJ/$f.log" &&
-      hipcc $FLAGS --cuda-host-only -Xclang -fcuda-include-gpubinary -Xclang "$OBJ/$f.hipfb" -c "$SRC/$f.hip" -o "$OBJ/$f.o" 2>>"$OBJ/$f.log"
-    else hipcc $FLAGS -c "$SRC/$f.hip" -o "$OBJ/$f.o" 2>"$OBJ/$f.log"; fi ) &
+  ( hipcc $FLAGS -c "$SRC/$f.hip" -o "$OBJ/$f.o" 2>"$OBJ/$f.log" ) &
   pids+=($!)
 done
 g++ -O2 -std=c++17 -fPIC -I"$SRC" -I"$ROOT/include" -c "$SRC/dfn_plan.cpp" -o "$OBJ/dfn_plan.o"
