@@ -45,7 +45,8 @@ DFN_DEV void apply_mask(f32x16 (&acc)[2], unsigned bits) {
 #endif
 }
 DFN_DEV unsigned mask_word(const BwdIO& io, int dword, int lane) {
-    return io.masks[((long)io.pass * io.mask_dwords + dword) * 64 + lane];
+    const gchar* mb = uniform_ptr(io.masks + ((long)io.pass * io.mask_dwords + dword) * 64);
+    return *(const __attribute__((address_space(1))) unsigned*)(mb + (unsigned)lane * 4u);
 }
 
 // out[OT tiles] = (W^T x in) [* mask]; mask_dword0 < 0: no mask

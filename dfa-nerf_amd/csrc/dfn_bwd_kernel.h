@@ -20,12 +20,13 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     lds_char* lds = (lds_char*)smem;
-    const Ctx ctx = {lds, wave, lane, lane >> 5, {}};
+    typedef CtxT<false, false, true> CtxB;      // LDS-DMA as asm: the ReLU mask loads must not drain the dY stores
+    const CtxB ctx = {lds, wave, lane, lane >> 5, {}};
     Stream s;
     s.base[0] = s.base[1] = A.wblob_T;
     s.nslab[0] = s.nslab[1] = A.nslab;
     s.sched = 0;
-    stream_begin<TIER>(s, lds, wave, lane);
+    stream_begin<TIER, use_asm_dma<TIER, CtxB>()>(s, lds, wave, lane);
     const long n_tiles = A.NP / 32;
     const long tile_raw = (long)blockIdx.x * C::WAVES + wave;
     const long tile = tile_raw < n_tiles ? tile_raw : n_tiles - 1;     // idle waves redo the last tile (same values)

@@ -204,9 +204,13 @@ struct Rec {
 
 // per-wave constants threaded through the ops; REC = training recorder on; ASMF = fragment reads / LDS-DMA as inline asm
 // with counted waits (only kernels whose registers do not spill: an in-flight asm destination must never be copied)
-template <bool REC, bool ASMF = false> struct CtxT {
+// ASMD = only the LDS-DMA as inline asm (fragment reads stay with the compiler): for the kernels that also STORE a lot
+// (recorder, dX chain).  With the builtin in the function hipcc drains the whole vector-memory queue - every store
+// still in flight - at each use of an ordinary load (a ReLU mask word, a spill reload); without it the waits are counted.
+template <bool REC, bool ASMF = false, bool ASMD = false> struct CtxT {
     static constexpr bool rec_on = REC;
     static constexpr bool asm_fetch = ASMF && !REC && (DFN_ASM_FETCH != 0);
+    static constexpr bool asm_dma = asm_fetch || ASMD;
     lds_char* ring;
     int wave, lane, half;
     Rec rec;
@@ -219,16 +223,31 @@ template <> struct ActT<TIER_F32> { typedef float type; };
 
 // store a B-operand vector feature-major into a tile-major array [tile][rows][32]: element (row0 + feature, n).
 // All offsets from the tile base are compile-time constants.
+// a pointer the caller knows to be wave-uniform, pinned to an SGPR pair
+// (returned as a GLOBAL address-space pointer: through an integer the compiler would fall back to flat_store)
+typedef __attribute__((address_space(1))) char gchar;
+DFN_DEV gchar* uniform_ptr(const void* p) {
+    const unsigned long v = (unsigned long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (gchar*)(((unsigned long)hi << 32) | lo);
+}
 // tiles [t0, t0 + n) of v -> rows row0 + 32 (t - t0) ...
 template <int TIER, int NT, class CT>
 DFN_DEV void store_tiles_T(void* arr, int rows, long tile, int row0, const Vec<TIER, NT>& v, int t0, int n, const CT& c) {
     typedef typename ActT<TIER>::type T;
-    T* base = (T*)arr + ((tile * rows + row0 + 4 * c.half) * 32 + (c.lane & 31));
+    // address = wave-uniform base (SGPR pair) + 32-bit per-lane offset + immediate: the "saddr" form of global_store.
+    // A per-lane 64-bit pointer per row block cost a v_lshl_add_u64 per store (the row offsets exceed the 4 KiB
+    // immediate) and the register allocator spilled those pointers around the MFMA loops.
+    gchar* ubase = uniform_ptr((T*)arr + (tile * rows + row0) * 32);
     if constexpr (TIER == TIER_BF16) {
-        // straight from the packed operand words: register pair (r, r + 1) = features (f, f + 1) = one 32-bit word,
-        // stored as its low and its high half (global_store_short / _d16_hi) - no conversion, no extraction
+        // straight from the packed operand words: register pair (r, r + 1) = features (f, f + 1) = one 32-bit word.
+        // Neighbouring lanes (points n, n ^ 1) swap halves first (one DPP move + one v_perm_b32), so that the even lane
+        // holds feature f of both points and the odd lane feature f + 1: one 4-byte store per word instead of two
+        // 2-byte stores, and every store instruction writes four 64-byte row segments instead of two.
         typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-        unsigned short* b16 = (unsigned short*)base;
+        const int odd = c.lane & 1;
+        const unsigned voff = (unsigned)((4 * c.half + odd) * 32 + (c.lane & 31) - odd) * 2u;     // odd lane: next row, one point back
+        const unsigned sel = odd ? 0x07060302u : 0x01000504u;             // v_perm bytes: 0-3 = neighbour's word, 4-7 = own
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (t >= t0 && t < t0 + n)
@@ -239,8 +258,9 @@ DFN_DEV void store_tiles_T(void* arr, int rows, long tile, int row0, const Vec<T
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int f = 32 * (t - t0) + tile_feat(0, 8 * h + 2 * e);      // + 4 for the upper half (in base)
-                        b16[f * 32] = (unsigned short)q[e];
-                        b16[(f + 1) * 32] = (unsigned short)(q[e] >> 16);
+                        const unsigned own = q[e];
+                        const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+                        *(__attribute__((address_space(1))) unsigned*)(ubase + f * 64 + voff) = __builtin_amdgcn_perm(own, nbr, sel);
                     }
                 }
     } else {
@@ -248,7 +268,8 @@ DFN_DEV void store_tiles_T(void* arr, int rows, long tile, int row0, const Vec<T
         for (int L = 0; L < 16 * NT; ++L)
             if ((L >> 4) >= t0 && (L >> 4) < t0 + n) {
                 const int f = 32 * ((L >> 4) - t0) + tile_feat(0, L & 15);
-                base[f * 32] = (T)v.get(L);
+                const unsigned voff = (unsigned)(4 * c.half * 32 + (c.lane & 31)) * (unsigned)sizeof(T);
+                *(__attribute__((address_space(1))) T*)(ubase + f * 32 * (int)sizeof(T) + voff) = (T)v.get(L);
             }
     }
 }
@@ -271,7 +292,8 @@ DFN_DEV void rec_mask(const CT& c, int dword0, const Vec<TIER, NT>& v) {
 #pragma unroll
         for (int b = 0; b < 32; ++b)
             if (32 * w + b < 16 * NT) bits |= (v.get(32 * w + b) > 0.f) ? (1u << b) : 0u;
-        c.rec.masks[((long)c.rec.pass * c.rec.mask_dwords + dword0 + w) * 64 + c.lane] = bits;
+        gchar* mb = uniform_ptr(c.rec.masks + ((long)c.rec.pass * c.rec.mask_dwords + dword0 + w) * 64);
+        *(__attribute__((address_space(1))) unsigned*)(mb + (unsigned)c.lane * 4u) = bits;
     }
 }
 
@@ -286,6 +308,7 @@ DFN_DEV void rec_mask(const CT& c, int dword0, const Vec<TIER, NT>& v) {
 #endif
 constexpr int PF_DEPTH = DFN_PF_DEPTH;
 template <int TIER, class CT> constexpr bool use_asm_fetch() { return TIER == TIER_BF16 && CT::asm_fetch; }
+template <int TIER, class CT> constexpr bool use_asm_dma() { return TIER == TIER_BF16 && CT::asm_dma; }
 
 #define DFN_FRAG_CASE(K)                                                                                      \
     case K:                                                                                                   \
@@ -338,14 +361,14 @@ template <int TIER> struct Fetch {
 #endif
         if (fp % GAP == GAP / 2) {                                 // one piece of the slab two ahead
             const int k = (fp % SLAB_FRAGS) / GAP;                 // compile-time
-            stream_issue_piece<TIER, use_asm_fetch<TIER, CT>()>(s, c.ring, c.wave, c.lane, k);
+            stream_issue_piece<TIER, use_asm_dma<TIER, CT>()>(s, c.ring, c.wave, c.lane, k);
             --s.pf_owed;
             if (k == C::LOADS_PER_SLAB - 1) stream_cursor_next(s);
         }
     }
     // start of a pass: fragments 0..PF_DEPTH-1
     template <class CT> DFN_DEV void prime(Stream& s, const CT& c) {
-        stream_flush<TIER, use_asm_fetch<TIER, CT>()>(s, c.ring, c.wave, c.lane);
+        stream_flush<TIER, use_asm_dma<TIER, CT>()>(s, c.ring, c.wave, c.lane);
         stream_pass_begin(s);
 #pragma unroll
         for (int i = 0; i < PF_DEPTH; ++i) load(i, i, s, c);
@@ -473,7 +496,8 @@ DFN_DEV void rec_pair(const CT& c, int row0, int mask_dword, const f32x16 (&acc)
             unsigned bits = 0;
 #pragma unroll
             for (int b = 0; b < 32; ++b) bits |= (acc[b >> 4][b & 15] > 0.f) ? (1u << b) : 0u;
-            c.rec.masks[((long)c.rec.pass * c.rec.mask_dwords + mask_dword) * 64 + c.lane] = bits;
+            gchar* mb = uniform_ptr(c.rec.masks + ((long)c.rec.pass * c.rec.mask_dwords + mask_dword) * 64);
+            *(__attribute__((address_space(1))) unsigned*)(mb + (unsigned)c.lane * 4u) = bits;
         }
     }
 }
@@ -484,7 +508,8 @@ DFN_DEV void rec_mask_pair(const CT& c, int mask_dword, const f32x16 (&acc)[2]) 
             unsigned bits = 0;
 #pragma unroll
             for (int b = 0; b < 32; ++b) bits |= (acc[b >> 4][b & 15] > 0.f) ? (1u << b) : 0u;
-            c.rec.masks[((long)c.rec.pass * c.rec.mask_dwords + mask_dword) * 64 + c.lane] = bits;
+            gchar* mb = uniform_ptr(c.rec.masks + ((long)c.rec.pass * c.rec.mask_dwords + mask_dword) * 64);
+            *(__attribute__((address_space(1))) unsigned*)(mb + (unsigned)c.lane * 4u) = bits;
         }
     }
 }

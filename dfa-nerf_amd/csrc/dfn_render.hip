@@ -143,7 +143,7 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     const int n = lane & 31;
     const DfnFrame& F = A.frame;
     lds_char* lds = (lds_char*)smem;
-    typedef CtxT<TRAIN, !TRAIN> CtxK;        // inference kernels: asm fragment fetch (DFN_ASM_FETCH)
+    typedef CtxT<TRAIN, !TRAIN, TRAIN> CtxK;     // inference: asm fragment fetch (DFN_ASM_FETCH); training: asm LDS-DMA only
     CtxK ctx = {lds, wave, lane, lane >> 5, {}};
     constexpr bool two = TWO;
     const int NF = TRAIN ? 0 : F.n_fine;          // the training forward is the reference's coarse renderer
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     const unsigned long long T_start = __builtin_readcyclecounter();
     const unsigned long long R_start = __builtin_amdgcn_s_memrealtime();
 #endif
-    stream_begin<TIER, use_asm_fetch<TIER, CtxK>()>(s, lds, wave, lane);
+    stream_begin<TIER, use_asm_dma<TIER, CtxK>()>(s, lds, wave, lane);
     {
         lds_f32* bl = (lds_f32*)(lds + L::BIAS_H);
         const int nb = P::H_NBIAS + (TWO ? P::T_NBIAS : 0);
