@@ -345,12 +345,23 @@ static_assert(PF_DEPTH >= 1 && PF_DEPTH <= 8, "frag_wait covers up to 7 younger 
 // f % PF_DEPTH only stays consistent if a layer (128 fragments) is a whole number of ring turns (depth 6 renders garbage)
 static_assert((PF_DEPTH & (PF_DEPTH - 1)) == 0, "PF_DEPTH must be a power of two");
 
+// Hook of the slab hand-over.  The kernels that store a lot (recorder, dX chain) issue the stores of a finished tile
+// pair HERE, right behind the wait of slab_advance, not where the pair finishes: vmcnt counts loads and stores in one
+// in-order queue, so the next hand-over (which must see this wave's LDS-DMA pieces landed) also waits for every store
+// issued before those pieces - behind the hand-over a store burst has a whole slab period to drain while the MFMAs
+// run; at the end of a pair it had none (measured: stores cost their full HBM time ON TOP of the compute).
+struct NoHook { DFN_DEV void operator()() const {} };
+
 template <int TIER> struct Fetch {
     u32x4 buf[PF_DEPTH];
-    template <class CT> DFN_DEV void load(int slot, int fp, Stream& s, const CT& c) {
+    template <class CT> DFN_DEV void load(int slot, int fp, Stream& s, const CT& c) { load(slot, fp, s, c, NoHook{}); }
+    template <class CT, class H> DFN_DEV void load(int slot, int fp, Stream& s, const CT& c, H&& hook) {
         using C = TierCfg<TIER>;
         constexpr int GAP = SLAB_FRAGS / C::LOADS_PER_SLAB;       // fragment reads between two DMA pieces
-        if (fp % SLAB_FRAGS == 0) slab_advance<TIER>(s, c.ring, c.wave, c.lane);
+        if (fp % SLAB_FRAGS == 0) {
+            slab_advance<TIER>(s, c.ring, c.wave, c.lane);
+            hook();
+        }
         if constexpr (use_asm_fetch<TIER, CT>()) frag_read(buf[slot], s.rd_vaddr, fp % SLAB_FRAGS);
         else buf[slot] = *(const lds_u32x4*)(c.ring + c.lane * 16 + s.rd_off + (fp % SLAB_FRAGS) * FRAG_BYTES);
 #ifdef DFN_EXP_DBLLDS       // experiment: what does the LDS fragment traffic cost?  read every fragment a second time
@@ -378,9 +389,9 @@ template <int TIER> struct Fetch {
 // One tile-group: acc[g] (g < G output tiles) += W x b over k-units [0, KU) of b.
 // Fragments are consumed in stream order [ku][g]; `f` is the running fragment index of the pass.
 // TAIL: number of fragments that follow this group in the pass (-1 = plenty): no prefetch past the end.
-template <int TIER, int G, int KU, int NTB, int TAIL = -1, class CT>
+template <int TIER, int G, int KU, int NTB, int TAIL = -1, class CT, class H = NoHook>
 DFN_DEV void gemm_group(f32x16 (&acc)[G], const Vec<TIER, NTB>& b, int& f, Fetch<TIER>& fe, Stream& s,
-                        const CT& c) {
+                        const CT& c, H&& hook = H{}) {
 #pragma unroll
     for (int ku = 0; ku < KU; ++ku) {
 #pragma unroll
@@ -393,7 +404,7 @@ DFN_DEV void gemm_group(f32x16 (&acc)[G], const Vec<TIER, NTB>& b, int& f, Fetch
             }
             const u32x4 a = fe.buf[f % PF_DEPTH];
             if constexpr (!ASM) {
-                if (TAIL < 0 || left + TAIL >= PF_DEPTH) fe.load(f % PF_DEPTH, f + PF_DEPTH, s, c);
+                if (TAIL < 0 || left + TAIL >= PF_DEPTH) fe.load(f % PF_DEPTH, f + PF_DEPTH, s, c, hook);
             }
             if constexpr (TIER == TIER_BF16) {
                 acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), b.u[ku],
@@ -405,7 +416,7 @@ DFN_DEV void gemm_group(f32x16 (&acc)[G], const Vec<TIER, NTB>& b, int& f, Fetch
                     acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], b.v[4 * ku + e], acc[g], 0, 0, 0);
             }
             if constexpr (ASM) {      // refill the slot just consumed (the MFMA has read its operands when it issued)
-                if (TAIL < 0 || left + TAIL >= PF_DEPTH) fe.load(f % PF_DEPTH, f + PF_DEPTH, s, c);
+                if (TAIL < 0 || left + TAIL >= PF_DEPTH) fe.load(f % PF_DEPTH, f + PF_DEPTH, s, c, hook);
             }
             ++f;
         }
@@ -486,20 +497,12 @@ DFN_DEV void acc_to_vec(const f32x16 (&acc)[G], Vec<TIER, NT>& v, int t0) {
 }
 
 // training recorder, per tile pair.  Values (post-activation, as the next layer sees them): rows row0 + {0..63} of
-// act_T - bf16 tier: the packed operand words acc_to_vec just made (tiles t0, t0 + 1 of `out`), f32 tier: the
-// accumulators.  ReLU bits: one dword per lane from the accumulators.
-template <int TIER, bool RELU, int NT, class CT>
-DFN_DEV void rec_pair(const CT& c, int row0, int mask_dword, const f32x16 (&acc)[2], const Vec<TIER, NT>& out, int t0) {
-    if constexpr (CT::rec_on) {
+// act_T - bf16 tier: the packed operand words acc_to_vec made (tiles t0, t0 + 1 of `out`); issued at the next slab
+// hand-over (NoHook above).  ReLU bits: one dword per lane from the accumulators, stored at once (rec_mask_pair).
+template <int TIER, int NT, class CT>
+DFN_DEV void rec_vals(const CT& c, int row0, const Vec<TIER, NT>& out, int t0) {
+    if constexpr (CT::rec_on)
         if (row0 >= 0) store_tiles_T<TIER, NT>(c.rec.act_T, c.rec.rows, c.rec.pass, row0, out, t0, 2, c);
-        if (mask_dword >= 0) {
-            unsigned bits = 0;
-#pragma unroll
-            for (int b = 0; b < 32; ++b) bits |= (acc[b >> 4][b & 15] > 0.f) ? (1u << b) : 0u;
-            gchar* mb = uniform_ptr(c.rec.masks + ((long)c.rec.pass * c.rec.mask_dwords + mask_dword) * 64);
-            *(__attribute__((address_space(1))) unsigned*)(mb + (unsigned)c.lane * 4u) = bits;
-        }
-    }
 }
 template <class CT>
 DFN_DEV void rec_mask_pair(const CT& c, int mask_dword, const f32x16 (&acc)[2]) {
@@ -519,31 +522,46 @@ template <int TIER, int OT, int KU, int NTB, bool RELU, class CT>
 DFN_DEV void layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_f32* bias, int& f, Fetch<TIER>& fe,
                    Stream& s, const CT& c, int rec_row = -1, int rec_mask = -1) {
     static_assert(OT % 2 == 0, "tile pairs");
+    bool pend = false;          // the values of pair tg - 1 wait for the next slab hand-over
 #pragma unroll
     for (int tg = 0; tg < OT / 2; ++tg) {
         f32x16 acc[2];
         acc_init<2>(acc, bias + tg * 64, c.half);
-        gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c);
+        auto flush = [&] {
+            if (pend) rec_vals<TIER>(c, rec_row + 64 * (tg - 1), out, 2 * (tg - 1));
+            pend = false;
+        };
+        gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c, flush);
+        flush();                // no hand-over inside this group
         acc_to_vec<TIER, 2, OT, RELU>(acc, out, 2 * tg);
-        rec_pair<TIER, RELU>(c, rec_row < 0 ? -1 : rec_row + 64 * tg, rec_mask < 0 ? -1 : rec_mask + tg, acc, out, 2 * tg);
+        rec_mask_pair(c, rec_mask < 0 ? -1 : rec_mask + tg, acc);
+        pend = CT::rec_on && rec_row >= 0;
     }
+    if (pend) rec_vals<TIER>(c, rec_row + 64 * (OT / 2 - 1), out, OT - 2);
 }
 // out = relu(bias + W x in) + bias2 + W2 x in2      (no activation after the skip)
 template <int TIER, int OT, int KU, int NTB, int KU2, int NTB2, class CT>
 DFN_DEV void layer_skip(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_f32* bias,
                         const Vec<TIER, NTB2>& in2, const lds_f32* bias2, int& f, Fetch<TIER>& fe,
                         Stream& s, const CT& c, int rec_row = -1, int mask_dword0 = -1) {
+    bool pend = false;
 #pragma unroll
     for (int tg = 0; tg < OT / 2; ++tg) {
         f32x16 acc[2];
         acc_init<2>(acc, bias + tg * 64, c.half);
-        gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c);
+        auto flush = [&] {
+            if (pend) rec_vals<TIER>(c, rec_row + 64 * (tg - 1), out, 2 * (tg - 1));
+            pend = false;
+        };
+        gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c, flush);
         rec_mask_pair(c, mask_dword0 < 0 ? -1 : mask_dword0 + tg, acc);                 // ReLU bits of the pre-skip value
         acc_relu_add<2>(acc, bias2 + tg * 64, c.half);
-        gemm_group<TIER, 2, KU2, NTB2>(acc, in2, f, fe, s, c);
-        acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);
-        rec_pair<TIER, false>(c, rec_row < 0 ? -1 : rec_row + 64 * tg, -1, acc, out, 2 * tg);     // post-skip value (no ReLU)
+        gemm_group<TIER, 2, KU2, NTB2>(acc, in2, f, fe, s, c, flush);
+        flush();
+        acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);                               // post-skip value (no ReLU)
+        pend = CT::rec_on && rec_row >= 0;
     }
+    if (pend) rec_vals<TIER>(c, rec_row + 64 * (OT / 2 - 1), out, OT - 2);
 }
 
 // ---- positional encodings ----------------------------------------------------------------------------------
@@ -691,19 +709,29 @@ DFN_DEV MlpOut mlp_trunk(Vec<TIER, 8>& act, const Vec<TIER, NTP>& pvec, const Dh
         dref.load(dhat);
         posenc<TIER, 1, NPEV>(vview, dhat, c.half);
         rec_vec<TIER, 1>(c, r_trunk + RecMap::T_VIEW, vview);
+        bool pend = false;      // recorder values of pair tg - 1, issued at the next slab hand-over (NoHook)
+        int ptg = 0;
+        auto flush = [&] {
+            if (pend) rec_vals<TIER>(c, r_trunk + RecMap::T_H + 64 * ptg, nxt, 2 * ptg);
+            pend = false;
+        };
 #pragma unroll
         for (int tg = 0; tg < 4; ++tg) {
             f32x16 acc[2];
             acc_init<2>(acc, bias + b_view + tg * 64, c.half);
-            gemm_group<TIER, 2, P::KU_ACT, 8>(acc, act, f, fe, s, c);
-            gemm_group<TIER, 2, P::KU_VIEW, 1>(acc, vview, f, fe, s, c);
+            gemm_group<TIER, 2, P::KU_ACT, 8>(acc, act, f, fe, s, c, flush);
+            gemm_group<TIER, 2, P::KU_VIEW, 1>(acc, vview, f, fe, s, c, flush);
+            flush();
             acc_to_vec<TIER, 2, 8, true>(acc, nxt, 2 * tg);
-            rec_pair<TIER, true>(c, r_trunk + RecMap::T_H + 64 * tg, m_trunk + RecMap::TM_H + tg, acc, nxt, 2 * tg);
+            rec_mask_pair(c, m_trunk + RecMap::TM_H + tg, acc);
+            pend = CT::rec_on;
+            ptg = tg;
         }
         f32x16 acc1[1];
         acc_init<1>(acc1, bias + b_view + 256, c.half);
-        gemm_group<TIER, 1, P::KU_ACT, 8>(acc1, act, f, fe, s, c);
-        gemm_group<TIER, 1, P::KU_VIEW, 1>(acc1, vview, f, fe, s, c);
+        gemm_group<TIER, 1, P::KU_ACT, 8>(acc1, act, f, fe, s, c, flush);
+        gemm_group<TIER, 1, P::KU_VIEW, 1>(acc1, vview, f, fe, s, c, flush);
+        flush();
         o.sigma = acc1[0][0];
     }
     // feat_out + sigmoid   (decoder.py:344-347)
@@ -767,7 +795,7 @@ DFN_DEV MlpOut mlp_torso(const float (&p)[3], const DhatRef& dhat, const lds_f32
         rec_mask_pair(c, RecMap::S_MD0 + 7, acc);
         acc_relu_add<2>(acc, bias + P::T_B_SSKIP, c.half);
         acc_to_vec<TIER, 2, 2, false>(acc, vn, 0);
-        rec_pair<TIER, false>(c, RecMap::S_D0 + 64 * 7, -1, acc, vn, 0);
+        rec_vals<TIER>(c, RecMap::S_D0 + 64 * 7, vn, 0);
         vs = vn;
     }
     layer<TIER, 2, P::KU_D, 2, true>(vn, ve, bias + P::T_B_E4, f, fe, s, c, DFN_RD(8));  ve = vn;
