@@ -180,6 +180,16 @@ int dfn_fold_bias_bwd(int tier, int field, const float* params, const float* sig
     return DFN_OK;
 }
 
+int dfn_adam_multi(const DfnAdamItem* items_dev, const int32_t* chunks_dev, int n_chunks, float lr, double beta1,
+                   double beta2, float eps, float bias_c1, float bias_c2_sqrt, void* stream) {
+    if (n_chunks < 0 || (n_chunks > 0 && (!items_dev || !chunks_dev)) || !(bias_c1 > 0.f) || !(bias_c2_sqrt > 0.f))
+        return fail(DFN_E_ARG, "dfn_adam_multi: bad argument");
+    hipError_t err = launch_adam_multi(items_dev, chunks_dev, n_chunks, lr, beta1, beta2, eps, bias_c1, bias_c2_sqrt,
+                                       (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "adam_multi_kernel");
+    return DFN_OK;
+}
+
 static int render_fwd_impl(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
                            const float* bias_head, const float* bias_torso, const float* bg_f32,
                            const uint8_t* bg_u8, const int32_t* pix_index, float* rgb_head, float* rgb_com,

@@ -1,6 +1,7 @@
 // dfn_misc.h - launchers of the small kernels (dfn_misc.hip)
 #pragma once
 #include <hip/hip_runtime.h>
+#include "dfanerf.h"
 
 namespace dfn {
 hipError_t launch_pack(const int* plan, const float* params, void* out, long n, int bf16, hipStream_t st);
@@ -20,4 +21,6 @@ hipError_t launch_volume_weights(const float* z, const float* ray, const float* 
                                  float last_dist, float* w, hipStream_t st);
 hipError_t launch_to8b(const float* x, long n, unsigned char* out, hipStream_t st);
 hipError_t launch_mfma_probe(float* out, hipStream_t st);
+hipError_t launch_adam_multi(const DfnAdamItem* items, const void* chunks, int n_chunks, float lr, double beta1, double beta2,
+                             float eps, float bias_c1, float bias_c2_sqrt, hipStream_t st);
 }  // namespace dfn

@@ -48,6 +48,7 @@ def _load():
         "dfn_encode_signal_torso_bwd": (i32, [fp, fp, i32, i32, i32, i32, fp, fp, vp]),
         "dfn_fold_bias": (i32, [i32, i32, fp, fp, fp, fp, fp, vp]),
         "dfn_fold_bias_bwd": (i32, [i32, i32, fp, fp, fp, fp, fp, fp, fp, vp]),
+        "dfn_adam_multi": (i32, [vp, vp, i32, C.c_float, C.c_double, C.c_double, C.c_float, C.c_float, C.c_float, vp]),
         "dfn_render_fwd": (i32, [i32, C.POINTER(DfnFrame), vp, vp, fp, fp, fp, vp, ip, fp, fp, fp, fp, fp, vp]),
         "dfn_render_fwd_u8": (i32, [i32, C.POINTER(DfnFrame), vp, vp, fp, fp, fp, vp, ip, vp, vp, vp]),
         "dfn_decoder_fwd": (i32, [i32, i32, vp, fp, fp, fp, lg, fp, fp, vp]),

@@ -1,0 +1,113 @@
+"""HipAdam: torch.optim.Adam (run_nerf_com_trainExpLater.py:522-547, betas (0.9, 0.999)) whose step() is ONE
+dfn_adam_multi launch per parameter group.
+
+torch's fused multi-tensor kernel gives a block a 64 K-element chunk: the decoder's 68 tensors become ~80 blocks and
+its step takes 104 us on an MI355X, the five optimizers of a training step 250 us; dfn_adam_multi cuts tensors into
+2048-element chunks and is bound by the bytes it moves.  Same update rule and the same state / state_dict layout as
+torch.optim.Adam(fused=True) (state[p] = {"step": 0-dim f32 device tensor, "exp_avg", "exp_avg_sq"}), so checkpoints
+move freely between the two; anything this class does not cover (weight decay, amsgrad, maximize, non-f32 or
+non-contiguous tensors, parameters of one group at different step counts) goes through torch's own step()."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from ._lib import lib, check
+
+ADAM_CHUNK = 2048          # DFN_ADAM_CHUNK in include/dfanerf.h
+
+
+class HipAdam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, fused=True)
+        self._cache = {}           # group index -> {"pkey", "gkey", "ps", "items", "chunks", "n_chunks", "t"}
+
+    # ---- state bookkeeping: torch keeps a step counter per parameter, the launch needs one per group -------------
+    def _sync_steps(self):
+        for c in self._cache.values():
+            if c.get("t") is not None:
+                torch._foreach_zero_([self.state[p]["step"] for p in c["ps"]])
+                torch._foreach_add_([self.state[p]["step"] for p in c["ps"]], float(c["t"]))
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._cache.clear()
+
+    def _torch_step(self, closure):
+        self._sync_steps()
+        self._cache.clear()
+        return super().step(closure)
+
+    def _build(self, gi, ps, pkey, gkey):
+        old = self._cache.get(gi)
+        if old is not None and old["pkey"] == pkey:
+            t = old["t"]                       # same parameters, new gradient buffers: the count carries on
+        else:
+            if old is not None:
+                self._sync_steps()
+            for p in ps:
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            steps = torch.stack([self.state[p]["step"].reshape(()).to(ps[0].device) for p in ps]).cpu()
+            if not bool((steps == steps[0]).all()):
+                return None
+            t = int(steps[0].item())
+        items = np.zeros((len(ps), 5), dtype=np.int64)
+        chunks = []
+        for i, p in enumerate(ps):
+            st = self.state[p]
+            m, v = st["exp_avg"], st["exp_avg_sq"]
+            if not (m.is_contiguous() and v.is_contiguous() and m.dtype == torch.float32 and v.dtype == torch.float32):
+                return None
+            items[i] = (p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
+            chunks.extend((i, k) for k in range((p.numel() + ADAM_CHUNK - 1) // ADAM_CHUNK))
+        dev = ps[0].device
+        c = {"pkey": pkey, "gkey": gkey, "ps": ps, "t": t, "n_chunks": len(chunks),
+             "items": torch.from_numpy(items).to(dev),
+             "chunks": torch.from_numpy(np.asarray(chunks, dtype=np.int32).reshape(-1, 2)).to(dev)}
+        self._cache[gi] = c
+        return c
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        plans = []
+        for gi, group in enumerate(self.param_groups):
+            if group.get("weight_decay", 0) or group.get("amsgrad") or group.get("maximize") or \
+                    not isinstance(group["lr"], (int, float)):
+                return self._torch_step(None) or loss
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            for p in ps:
+                g = p.grad
+                if not (p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32 and p.is_contiguous()
+                        and g.is_contiguous() and g.device == p.device and not g.is_sparse):
+                    return self._torch_step(None) or loss
+            pkey = tuple(p.data_ptr() for p in ps)
+            gkey = tuple(p.grad.data_ptr() for p in ps)
+            c = self._cache.get(gi)
+            if c is None or c["pkey"] != pkey or c["gkey"] != gkey:
+                c = self._build(gi, ps, pkey, gkey)
+                if c is None:
+                    return self._torch_step(None) or loss
+            plans.append((group, c))
+        for group, c in plans:
+            c["t"] += 1
+            t, (b1, b2) = c["t"], group["betas"]
+            st = C.c_void_p(torch.cuda.current_stream(c["ps"][0].device).cuda_stream)
+            check(lib.dfn_adam_multi(C.c_void_p(c["items"].data_ptr()), C.c_void_p(c["chunks"].data_ptr()), c["n_chunks"],
+                                     float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                     float(1.0 - b1 ** t), float(math.sqrt(1.0 - b2 ** t)), st), "dfn_adam_multi")
+        return loss

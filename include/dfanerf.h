@@ -162,6 +162,23 @@ int dfn_weight_bias_grad(int tier, int field, const void* dy_T, const void* act_
 int dfn_fold_bias_bwd(int tier, int field, const float* params, const float* signal, const float* z_shape,
                       const float* z_app, const float* dbias, float* grad_flat, float* d_signal, void* stream);
 
+/* ---- optimizer step: replaces torch.optim.Adam.step() of MAIN:522-547 / 924-931 (betas (0.9, 0.999), no weight
+ * decay, no amsgrad) for a list of tensors in ONE launch.  items [n_items] and chunks [n_chunks] live in DEVICE memory;
+ * chunk c = {item index, chunk index within the item} covers elements [chunk * DFN_ADAM_CHUNK, ...) of that item.
+ *   exp_avg    = lerp(exp_avg, grad, 1 - beta1);   exp_avg_sq = beta2 exp_avg_sq + (1 - beta2) grad^2
+ *   param     -= (lr / bias_c1) * exp_avg / (sqrt(exp_avg_sq) / bias_c2_sqrt + eps)
+ * with bias_c1 = 1 - beta1^t, bias_c2_sqrt = sqrt(1 - beta2^t) computed by the caller (t = step count from 1). */
+#define DFN_ADAM_CHUNK 2048
+typedef struct DfnAdamItem {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    long n;
+} DfnAdamItem;
+int dfn_adam_multi(const DfnAdamItem* items_dev, const int32_t* chunks_dev, int n_chunks, float lr, double beta1,
+                   double beta2, float eps, float bias_c1, float bias_c2_sqrt, void* stream);
+
 /* ---- Decoder.forward on explicit points: replaces DEC:277-349 -------------------------------------------
  * points, dirs [n,3]; feat [n,3] (after sigmoid), sigma [n] (raw). */
 int dfn_decoder_fwd(int tier, int field, const void* packed, const float* bias, const float* points,

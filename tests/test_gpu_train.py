@@ -166,3 +166,87 @@ def test_fused_fold_backward_matches_torch_fold(states, scene, latents):
             assert ga is None or ga.abs().max().item() == 0.0, k
             continue
         torch.testing.assert_close(ga, gb, rtol=2e-4, atol=1e-7 + 2e-5 * gb.abs().max().item(), msg=k)
+
+
+def _adam_pair(seed, shapes):
+    g = torch.Generator().manual_seed(seed)
+    ps = [torch.randn(*s, generator=g) for s in shapes]
+    a = [torch.nn.Parameter(p.clone().cuda()) for p in ps]
+    b = [torch.nn.Parameter(p.clone().cuda()) for p in ps]
+    return a, b
+
+
+def test_hip_adam_matches_torch_adam():
+    """optim.HipAdam (one dfn_adam_multi launch per step) against torch.optim.Adam (MAIN:522-547 / 924-931) on ragged
+    tensors: parameters and moments after several steps with a changing learning rate (MAIN:1081-1094), a step in which
+    one tensor has no gradient (torch's own step takes over: per-parameter step counts), and a state_dict round trip
+    in both directions."""
+    from dfanerf.optim import HipAdam
+    shapes = [(256, 351), (256,), (3, 7, 5), (1,), (4099,), (64, 64)]
+    a, b = _adam_pair(0, shapes)
+    oa, ob = HipAdam(a, lr=5e-4, betas=(0.9, 0.999)), torch.optim.Adam(b, lr=5e-4, betas=(0.9, 0.999))
+    gen = torch.Generator(device="cuda").manual_seed(1)
+
+    def run(n, skip=None, fresh=False):
+        for it in range(n):
+            for k, (p, q) in enumerate(zip(a, b)):
+                if k == skip:
+                    p.grad = q.grad = None
+                    continue
+                gr = torch.randn(p.shape, device="cuda", generator=gen) * (0.1 + it)
+                if p.grad is None or fresh:
+                    p.grad, q.grad = gr.clone(), gr.clone()
+                else:
+                    p.grad.copy_(gr); q.grad.copy_(gr)                  # same buffers: the cached table is reused
+            for o in (oa, ob):
+                o.param_groups[0]["lr"] = 5e-4 * 0.9 ** it
+                o.step()
+
+    def same(tol=1e-5):
+        # a step moves a parameter by ~lr = 5e-4; the two implementations differ by rounding (1-2 ulp of the moments)
+        for p, q in zip(a, b):
+            assert torch.allclose(p, q, rtol=tol, atol=1e-6), (p - q).abs().max().item()
+            sa, sb = oa.state[p], ob.state[q]
+            if len(sb):
+                for k in ("exp_avg", "exp_avg_sq"):          # a few ulp of the largest entry (lerp cancels for small ones)
+                    assert torch.allclose(sa[k], sb[k], rtol=tol, atol=1e-6 * float(sb[k].abs().max())), k
+
+    run(5); same()
+    run(2, fresh=True); same()                   # new gradient tensors every step
+    run(2, skip=2); same()                       # a tensor without gradient
+    run(3); same()                               # ... and with all of them again (step counts now differ: torch path)
+    sd = oa.state_dict()
+    assert float(sd["state"][0]["step"]) == 12.0 and float(sd["state"][2]["step"]) == 10.0
+    # checkpoints travel both ways
+    a2, b2 = _adam_pair(0, shapes)
+    o2 = torch.optim.Adam(b2, lr=1e-3, betas=(0.9, 0.999), fused=True)
+    o2.load_state_dict(sd)
+    o3 = HipAdam(a2, lr=1e-3, betas=(0.9, 0.999))
+    o3.load_state_dict(ob.state_dict())
+    assert o3.param_groups[0]["lr"] == ob.param_groups[0]["lr"]
+    with torch.no_grad():
+        for p, q in zip(a2, a):
+            p.copy_(q)
+    for p in a2:
+        p.grad = torch.ones_like(p)
+    for p in a:
+        p.grad = torch.ones_like(p)
+    o3.step(); oa.step()
+    for p, q in zip(a2, a):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-6)
+
+
+def test_hip_adam_fresh_optimizer_many_steps():
+    """All tensors stepping together from step 0 (the training loop's case): 50 steps stay on the HIP path."""
+    from dfanerf.optim import HipAdam
+    a, b = _adam_pair(3, [(300, 17), (5,), (2048,), (2049,)])
+    oa, ob = HipAdam(a, lr=5e-4), torch.optim.Adam(b, lr=5e-4)
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    for it in range(50):
+        for p, q in zip(a, b):
+            gr = torch.randn(p.shape, device="cuda", generator=gen)
+            p.grad, q.grad = gr, gr.clone()
+        oa.step(); ob.step()
+    assert oa._cache and oa._cache[0]["t"] == 50
+    for p, q in zip(a, b):
+        assert torch.allclose(p, q, rtol=1e-5, atol=2e-6), (p - q).abs().max().item()
