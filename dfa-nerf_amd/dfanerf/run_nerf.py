@@ -492,7 +492,12 @@ def train_step_loss_hip(nets, dataset, itr_obj, img_i, sel_yx, target_head, targ
                                global_step, args, len_train, embed_fn=embed_fn)
         signal_torso = encode_signal_torso(dataset, itr_obj, img_i, nets.get("PoseAttNet"), global_step, args,
                                            len_train, embed_fn=embed_fn)
-    pix = torch.as_tensor(sel_yx[:, 0] * W + sel_yx[:, 1], dtype=torch.int32, device=dev)
+    if isinstance(sel_yx, torch.Tensor):
+        pix = (sel_yx[:, 0] * W + sel_yx[:, 1]).to(device=dev, dtype=torch.int32)
+    else:
+        if getattr(buf, "upload", None) is None:
+            buf.upload = training.PinnedUpload()
+        pix = buf.upload(np.asarray(sel_yx[:, 0] * W + sel_yx[:, 1], dtype=np.int32), torch.int32, dev)
     # the frame geometry travels in the kernel arguments: keep host copies of the poses (a .cpu() per step would
     # synchronise the stream and serialise the host with the previous step's kernels)
     d = dataset[itr_obj]

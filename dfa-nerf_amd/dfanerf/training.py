@@ -9,6 +9,7 @@ the tiny per-frame pieces that surround it: the bias fold (fc_z, fc_z_skips, fc_
 conditioning networks (AudioNet_W2L, ExpressionEnc, AudioAttNet) that produce the 96 + 42 signal floats."""
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import engine
@@ -53,6 +54,30 @@ def fold_bias_torch(dec, sig_head, sig_torso, z_shape, z_app):
                       [trunk(zs1, za1, dec.fc_in_torso.bias + dec.fc_z(zs1),
                              dec.fc_z_skips[0](zs1) + dec.fc_p_skips_torso[0].bias)])
     return torch.cat([head, torso])
+
+
+class PinnedUpload:
+    """numpy -> device through a small ring of pinned staging buffers, asynchronously.  torch.as_tensor(ndarray,
+    device=...) copies from pageable memory, which blocks the host until the stream has drained - once per training
+    step that serialises the host with the GPU."""
+
+    def __init__(self, slots=8):
+        self.bufs, self.events, self.i = [None] * slots, [None] * slots, 0
+
+    def __call__(self, arr, dtype, device):
+        arr = np.ascontiguousarray(arr)
+        k, self.i = self.i, (self.i + 1) % len(self.bufs)
+        b = self.bufs[k]
+        if b is None or b.numel() < arr.size or b.dtype != dtype:
+            b = self.bufs[k] = torch.empty(max(arr.size, 1), dtype=dtype, pin_memory=True)
+            self.events[k] = None
+        if self.events[k] is not None:
+            self.events[k].synchronize()          # the copy that last used this slot (8 uploads ago) is long done
+        b.numpy()[:arr.size] = arr.reshape(-1)
+        out = b[:arr.size].to(device, non_blocking=True).view(arr.shape)
+        self.events[k] = torch.cuda.Event()
+        self.events[k].record()
+        return out
 
 
 class TrainBuffers:
@@ -262,6 +287,14 @@ class SignalTrainer:
         self.pose_stride = int(self.poses[0].numel())
         self.device = dev
 
+    def frame_id(self, frame):
+        """[1] int32 device tensor holding `frame` without a host-to-device copy (a pageable copy blocks the host until
+        the stream has drained: it serialises every step with the previous one)."""
+        ar = getattr(self, "_frame_ids", None)
+        if ar is None or frame >= ar.numel():
+            ar = self._frame_ids = torch.arange(max(int(frame) + 1, 4096), dtype=torch.int32, device=self.device)
+        return ar[frame:frame + 1]
+
     def encode(self, frame, smo_size, smo_torso_size, length):
         for n in self.nets:
             n.refresh()
@@ -273,7 +306,7 @@ class _SignalFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, tr, frame, smo, smo_t, length):
         dev, st = tr.device, _stream()
-        ids = torch.tensor([frame], dtype=torch.int32, device=dev)
+        ids = tr.frame_id(frame)
         sig = torch.empty(1, 96, dtype=torch.float32, device=dev)
         sigt = torch.empty(1, 42, dtype=torch.float32, device=dev)
         a, e, t, p = [n.flat for n in tr.nets]
