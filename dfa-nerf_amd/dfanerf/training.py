@@ -56,6 +56,20 @@ def fold_bias_torch(dec, sig_head, sig_torso, z_shape, z_app):
     return torch.cat([head, torso])
 
 
+def _sync_flat(params, views):
+    """Make `views` (slices of one flat f32 buffer, state_dict order) hold the values of `params`.  The first time the
+    tensors are f32 and contiguous the flat buffer BECOMES their storage (p.data = view): optimizers, state_dict and
+    load_state_dict then work on the flat buffer directly and no per-step copy is needed; if somebody re-points a
+    parameter later, the next call notices and adopts it again.  Anything else: one multi-tensor copy per call."""
+    if all(p.data_ptr() == v.data_ptr() for p, v in zip(params, views)):
+        return
+    with torch.no_grad():
+        torch._foreach_copy_(views, [p.detach() for p in params])
+        if all(p.dtype == torch.float32 and p.is_contiguous() and p.device == v.device for p, v in zip(params, views)):
+            for p, v in zip(params, views):
+                p.data = v
+
+
 class PinnedUpload:
     """numpy -> device through a small ring of pinned staging buffers, asynchronously.  torch.as_tensor(ndarray,
     device=...) copies from pageable memory, which blocks the host until the stream has drained - once per training
@@ -106,8 +120,8 @@ class TrainBuffers:
 
     def bind(self, dec):
         """Parameter list of `dec` in state_dict order and the matching views of one flat buffer: the kernels read
-        the flat copy (one multi-tensor copy per step) and write gradients into a flat buffer whose slices become
-        the parameters' .grad (no per-tensor copies)."""
+        the flat buffer, which becomes the parameters' own storage (_sync_flat), and write gradients into a flat buffer
+        whose slices become the parameters' .grad (no per-tensor copies either way)."""
         if self.flat is None or getattr(self, "_dec", None) is not dec:
             self.params = list(dec.state_dict(keep_vars=True).values())
             n = sum(p.numel() for p in self.params)
@@ -119,8 +133,7 @@ class TrainBuffers:
                 o += p.numel()
             self.flat_views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
             self._dec = dec
-        with torch.no_grad():
-            torch._foreach_copy_(self.flat_views, [p.detach() for p in self.params])
+        _sync_flat(self.params, self.flat_views)
         return self.flat
 
 
@@ -259,8 +272,7 @@ class _FlatNet:
         self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
 
     def refresh(self):
-        with torch.no_grad():
-            torch._foreach_copy_(self.views, [p.detach() for p in self.params])
+        _sync_flat(self.params, self.views)
 
     def deposit(self, grad_flat):
         for p, o in zip(self.params, self.offsets):
