@@ -132,12 +132,14 @@ def bench_training(args, world, rank, local, dev, desc):
     tgt_h = torch.rand(H, W, 3, device=dev)
     tgt_c = torch.rand(H, W, 3, device=dev)
     gstep = 300000                                   # all five optimizers' gates exercised except ExpNet
+    upload = training.PinnedUpload()
 
     def step():
         img_i = int(rng_frame.randint(0, 8))
         sel = run_nerf.select_coords(H, W, N_RAND, 0, None, rng)
-        ys, xs = t(sel[:, 0]).to(dev), t(sel[:, 1]).to(dev)
-        loss, *_ = run_nerf.train_step_loss_hip(mods, ds, 0, img_i, sel, tgt_h[ys, xs], tgt_c[ys, xs], zs, za, gstep, a,
+        sel_d = upload(np.asarray(sel, dtype=np.int64), torch.int64, dev)        # pinned staging: no blocking copy
+        ys, xs = sel_d[:, 0], sel_d[:, 1]
+        loss, *_ = run_nerf.train_step_loss_hip(mods, ds, 0, img_i, sel_d, tgt_h[ys, xs], tgt_c[ys, xs], zs, za, gstep, a,
                                                 8, embed_fn, ds[0]["poses"][0], buf)
         for o in opts.values():
             o.zero_grad()

@@ -70,9 +70,11 @@ class HipAdam(torch.optim.Adam):
             items[i] = (p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
             chunks.extend((i, k) for k in range((p.numel() + ADAM_CHUNK - 1) // ADAM_CHUNK))
         dev = ps[0].device
-        c = {"pkey": pkey, "gkey": gkey, "ps": ps, "t": t, "n_chunks": len(chunks),
-             "items": torch.from_numpy(items).to(dev),
-             "chunks": torch.from_numpy(np.asarray(chunks, dtype=np.int32).reshape(-1, 2)).to(dev)}
+        # pinned + asynchronous: a pageable upload would block the host until the stream has drained
+        h_items = torch.from_numpy(items).pin_memory()
+        h_chunks = torch.from_numpy(np.asarray(chunks, dtype=np.int32).reshape(-1, 2)).pin_memory()
+        c = {"pkey": pkey, "gkey": gkey, "ps": ps, "t": t, "n_chunks": len(chunks), "host": (h_items, h_chunks),
+             "items": h_items.to(dev, non_blocking=True), "chunks": h_chunks.to(dev, non_blocking=True)}
         self._cache[gi] = c
         return c
 

@@ -662,14 +662,18 @@ def train():
     from tqdm import trange, tqdm
     for i in trange(global_step + 1, args.N_iters + 1, disable=rank != 0):
         img_i = rng.choice(i_train)
-        target_com = torch.as_tensor(_imread(ds['imgs_com'][img_i])).to(dev).float() / 255.0
-        target_head = torch.as_tensor(_imread(ds['imgs'][img_i])).to(dev).float() / 255.0
         sel = select_coords(H, W, args.N_rand, args.sample_rate, ds['sample_rects'][img_i], rng)
-        ys, xs = torch.as_tensor(sel[:, 0], device=dev), torch.as_tensor(sel[:, 1], device=dev)
+        # target[select_coords] (MAIN:791-800): the N_rand pixels are picked on the host and go up through pinned
+        # staging buffers - uploading both whole frames from pageable memory blocked the host twice per step until the
+        # stream had drained
+        if getattr(train_buf, "upload", None) is None:
+            train_buf.upload = training.PinnedUpload()
+        pick = lambda path: train_buf.upload(np.asarray(_imread(path))[sel[:, 0], sel[:, 1]], torch.uint8, dev).float() / 255.0
+        target_com_s, target_head_s = pick(ds['imgs_com'][img_i]), pick(ds['imgs'][img_i])
         step_fn = train_step_loss if args.train_aten else train_step_loss_hip
         extra = () if args.train_aten else (train_buf,)
-        loss, l_head, l_com, _, _ = step_fn(nets, datasets, itr_obj, img_i, sel, target_head[ys, xs],
-                                            target_com[ys, xs], z_shape, z_app, global_step, args,
+        loss, l_head, l_com, _, _ = step_fn(nets, datasets, itr_obj, img_i, sel, target_head_s,
+                                            target_com_s, z_shape, z_app, global_step, args,
                                             len(i_train), embed_fn, ds['poses'][0, :3, :4], *extra)
         for o in opts.values():
             o.zero_grad()

@@ -70,6 +70,22 @@ def _sync_flat(params, views):
                 p.data = v
 
 
+def _grad_buffer(owner, name, like, params):
+    """Zeroed flat gradient buffer for one backward.  The SAME buffer every step while the parameters' .grad are None
+    when the backward starts (optimizer.zero_grad() with set_to_none, the default): the .grad views then keep their
+    addresses from step to step and optim.HipAdam reuses its device-side tensor table.  If gradients are being
+    accumulated (.grad still set) the buffer of the previous step is alive inside them: a fresh one is used."""
+    if any(p.grad is not None for p in params):
+        return torch.zeros_like(like)
+    g = getattr(owner, name, None)
+    if g is None or g.shape != like.shape or g.device != like.device:
+        g = torch.zeros_like(like)
+        setattr(owner, name, g)
+    else:
+        g.zero_()
+    return g
+
+
 class PinnedUpload:
     """numpy -> device through a small ring of pinned staging buffers, asynchronously.  torch.as_tensor(ndarray,
     device=...) copies from pageable memory, which blocks the host until the stream has drained - once per training
@@ -232,7 +248,7 @@ class FusedTrainFn(torch.autograd.Function):
         bg_u8 = bg if bg.dtype == torch.uint8 else None
         check(lib.dfn_composite_bwd(C.byref(frame), _ptr(ctx.pix), _ptr(bg_f32), _ptr(bg_u8), _ptr(buf.samples),
                                     _ptr(d_h), _ptr(d_c), _ptr(buf.dsamples), st), "dfn_composite_bwd")
-        g_flat = torch.zeros(flat.numel(), dtype=torch.float32, device=dev)
+        g_flat = _grad_buffer(buf, "_g_flat", flat, buf.params)
         g_bias = torch.empty(buf.nb[0] + buf.nb[1], dtype=torch.float32, device=dev)
         d_sig = torch.zeros(96 + 42, dtype=torch.float32, device=dev)
         for f in (0, 1):
@@ -334,7 +350,7 @@ class _SignalFn(torch.autograd.Function):
         tr, (frame, smo, smo_t, length) = ctx.tr, ctx.args
         st = _stream()
         a, e, t, p = [n.flat for n in tr.nets]
-        g = [torch.zeros_like(n.flat) for n in tr.nets]
+        g = [_grad_buffer(n, "_g_flat", n.flat, n.params) for n in tr.nets]
         d_sig = d_sig.contiguous().float()
         d_sigt = d_sigt.contiguous().float()
         check(lib.dfn_encode_signal_bwd(_ptr(a), _ptr(e), _ptr(t), _ptr(tr.auds), _ptr(tr.exps), length, frame, smo,

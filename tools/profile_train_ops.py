@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
-"""Developer tool: which torch ops launch the small kernels of a training step (torch.profiler over tools/time_train.py's
-bf16 loop): ops by number of calls per step with their device time."""
+"""Developer tool: which torch ops launch the small kernels of a training step - torch.profiler over the TIMED steps of
+bench.py --workload c4 (switched on / off at the synchronize() calls that bracket the timed region): ops by number of
+calls per step with their host and device time."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.argv = [sys.argv[0], "bf16"]
+sys.path.insert(0, ROOT)
+STEPS = 20
+sys.argv = ["bench.py", "--workload", "c4", "--steps", str(STEPS), "--warmup", "5", "--no-cpu-baseline"]
 import torch
 from torch.profiler import profile, ProfilerActivity
-src = open(os.path.join(ROOT, "tools", "time_train.py")).read()
-src = src.replace("    n = 20\n", "    n = 20\n    prof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]); prof.__enter__()\n")
-src = src.replace("    torch.cuda.synchronize(); dt =", "    torch.cuda.synchronize(); prof.__exit__(None, None, None); dt =")
-g = {"__name__": "__main__", "__file__": os.path.join(ROOT, "tools", "time_train.py"), "profile": profile, "ProfilerActivity": ProfilerActivity}
-exec(compile(src, "time_train.py", "exec"), g)
-ka = g["prof"].key_averages()
-rows = sorted(ka, key=lambda e: -e.count)
-print(f"{'op':60s} calls/step  cpu us/step  device us/step")
-for e in rows[:45]:
+import bench
+prof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA])
+real_sync, state = torch.cuda.synchronize, {"n": 0}
+def sync(*a, **k):
+    r = real_sync(*a, **k)
+    state["n"] += 1
+    if state["n"] == 2: prof.__enter__()
+    if state["n"] == 3: prof.__exit__(None, None, None)
+    return r
+torch.cuda.synchronize = sync
+bench.main()
+rows = sorted(prof.key_averages(), key=lambda e: -e.count)
+print(f"{'op':70s} calls/step  cpu us/step  device us/step")
+for e in rows[:60]:
     dev = getattr(e, "device_time_total", getattr(e, "cuda_time_total", 0))
-    print(f"{e.key[:60]:60s} {e.count / 20:9.1f} {e.cpu_time_total / 20:11.1f} {dev / 20:11.1f}")
+    print(f"{e.key[:70]:70s} {e.count / STEPS:9.1f} {e.cpu_time_total / STEPS:11.1f} {dev / STEPS:11.1f}")
