@@ -124,7 +124,16 @@ class SignalEncoder:
         if isinstance(frame_ids, torch.Tensor):
             ids = frame_ids.to(device=self.device, dtype=torch.int32).reshape(-1)
         else:
-            ids = torch.as_tensor(list(frame_ids), dtype=torch.int32, device=self.device)
+            frame_ids = list(frame_ids)
+            if len(frame_ids) == 1 and 0 <= int(frame_ids[0]) < (1 << 20):
+                # one frame (the render loop): a slice of a device arange instead of a pageable host-to-device copy,
+                # which would block the host until the previous frame's kernels have finished
+                ar = getattr(self, "_arange", None)
+                if ar is None or int(frame_ids[0]) >= ar.numel():
+                    ar = self._arange = torch.arange(max(int(frame_ids[0]) + 1, 8192), dtype=torch.int32, device=self.device)
+                ids = ar[int(frame_ids[0]):int(frame_ids[0]) + 1]
+            else:
+                ids = torch.as_tensor(frame_ids, dtype=torch.int32, device=self.device)
         n_total = self.n if length is None else int(length)
         B = ids.numel()
         sig = torch.empty(B, 96, dtype=torch.float32, device=self.device)
