@@ -308,7 +308,8 @@ DFN_DEV void rec_mask(const CT& c, int dword0, const Vec<TIER, NT>& v) {
 #endif
 constexpr int PF_DEPTH = DFN_PF_DEPTH;
 template <int TIER, class CT> constexpr bool use_asm_fetch() { return TIER == TIER_BF16 && CT::asm_fetch; }
-template <int TIER, class CT> constexpr bool use_asm_dma() { return TIER == TIER_BF16 && CT::asm_dma; }
+// (the asm fragment READS are bf16-only; the asm DMA alone - storing kernels - serves both tiers)
+template <int TIER, class CT> constexpr bool use_asm_dma() { return CT::asm_fetch ? TIER == TIER_BF16 : CT::asm_dma; }
 
 #define DFN_FRAG_CASE(K)                                                                                      \
     case K:                                                                                                   \
