@@ -18,6 +18,18 @@ from ._lib import lib, check
 ADAM_CHUNK = 2048          # DFN_ADAM_CHUNK in include/dfanerf.h
 
 
+def _bump_versions(tensors):
+    inc = getattr(torch.autograd.graph, "increment_version", None)
+    if inc is None:                                  # older torch: an in-place no-op per tensor list
+        torch._foreach_add_(list(tensors), 0.0)
+        return
+    try:
+        inc(tensors)                                 # iterable accepted by recent versions
+    except TypeError:
+        for t in tensors:
+            inc(t)
+
+
 class HipAdam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, lr=lr, betas=betas, eps=eps, fused=True)
@@ -112,4 +124,7 @@ class HipAdam(torch.optim.Adam):
             check(lib.dfn_adam_multi(C.c_void_p(c["items"].data_ptr()), C.c_void_p(c["chunks"].data_ptr()), c["n_chunks"],
                                      float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                      float(1.0 - b1 ** t), float(math.sqrt(1.0 - b2 ** t)), st), "dfn_adam_multi")
+            # the kernel wrote the parameters behind torch's back: bump their version counters like an in-place op would,
+            # or everything keyed on them (Decoder.packed()'s repack-on-change, autograd's saved-tensor checks) goes stale
+            _bump_versions(c["ps"])
         return loss

@@ -250,3 +250,26 @@ def test_hip_adam_fresh_optimizer_many_steps():
     assert oa._cache and oa._cache[0]["t"] == 50
     for p, q in zip(a, b):
         assert torch.allclose(p, q, rtol=1e-5, atol=2e-6), (p - q).abs().max().item()
+
+
+def test_hip_adam_bumps_versions_and_decoder_repacks(states):
+    """HipAdam writes the parameters through raw pointers: their version counters must move like after an in-place op,
+    otherwise Decoder.packed() (repack when a parameter changed; used by the test renders inside the training loop)
+    keeps rendering with the weights of the first step."""
+    from dfanerf import run_nerf
+    from dfanerf.decoder import Decoder
+    dec = Decoder(z_dim=256, hidden_size=256, dim_signal=96, use_deformation_field=True)
+    dec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in states["decoder"].items()})
+    dec.cuda()
+    opt = run_nerf.make_adam(dec.parameters(), 1e-2)
+    pk = dec.packed("bf16")
+    before = pk.flat.clone()
+    v0 = [p._version for p in dec.parameters()]
+    for p in dec.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    assert all(p._version > v for p, v in zip(dec.parameters(), v0))
+    pk2 = dec.packed("bf16")
+    assert not torch.equal(pk2.flat, before)
+    ref = torch.cat([p.detach().reshape(-1).float() for p in dec.state_dict().values()])
+    assert torch.equal(pk2.flat, ref)
