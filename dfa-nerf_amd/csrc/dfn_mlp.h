@@ -260,7 +260,11 @@ DFN_DEV void store_tiles_T(void* arr, int rows, long tile, int row0, const Vec<T
                         const int f = 32 * (t - t0) + tile_feat(0, 8 * h + 2 * e);      // + 4 for the upper half (in base)
                         const unsigned own = q[e];
                         const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-                        *(__attribute__((address_space(1))) unsigned*)(ubase + f * 64 + voff) = __builtin_amdgcn_perm(own, nbr, sel);
+                        // non-temporal: these arrays are written once and read once by a later kernel; left in the
+                        // L2 as dirty lines they evict the weight stream and are written back under the next kernel
+                        // (measured: training forward 553 -> 453 us, dX head 232 -> 195 us, wgrad 890 -> 810 us)
+                        __builtin_nontemporal_store(__builtin_amdgcn_perm(own, nbr, sel),
+                                                    (__attribute__((address_space(1))) unsigned*)(ubase + f * 64 + voff));
                     }
                 }
     } else {
@@ -269,7 +273,7 @@ DFN_DEV void store_tiles_T(void* arr, int rows, long tile, int row0, const Vec<T
             if ((L >> 4) >= t0 && (L >> 4) < t0 + n) {
                 const int f = 32 * ((L >> 4) - t0) + tile_feat(0, L & 15);
                 const unsigned voff = (unsigned)(4 * c.half * 32 + (c.lane & 31)) * (unsigned)sizeof(T);
-                *(__attribute__((address_space(1))) T*)(ubase + f * 32 * (int)sizeof(T) + voff) = (T)v.get(L);
+                __builtin_nontemporal_store((T)v.get(L), (__attribute__((address_space(1))) T*)(ubase + f * 32 * (int)sizeof(T) + voff));
             }
     }
 }
@@ -293,7 +297,7 @@ DFN_DEV void rec_mask(const CT& c, int dword0, const Vec<TIER, NT>& v) {
         for (int b = 0; b < 32; ++b)
             if (32 * w + b < 16 * NT) bits |= (v.get(32 * w + b) > 0.f) ? (1u << b) : 0u;
         gchar* mb = uniform_ptr(c.rec.masks + ((long)c.rec.pass * c.rec.mask_dwords + dword0 + w) * 64);
-        *(__attribute__((address_space(1))) unsigned*)(mb + (unsigned)c.lane * 4u) = bits;
+        *(__attribute__((address_space(1))) unsigned*)(mb + (unsigned)c.lane * 4u) = bits;      // (ordinary: the dX kernels read these next)
     }
 }
 
@@ -513,7 +517,7 @@ DFN_DEV void rec_mask_pair(const CT& c, int mask_dword, const f32x16 (&acc)[2]) 
 #pragma unroll
             for (int b = 0; b < 32; ++b) bits |= (acc[b >> 4][b & 15] > 0.f) ? (1u << b) : 0u;
             gchar* mb = uniform_ptr(c.rec.masks + ((long)c.rec.pass * c.rec.mask_dwords + mask_dword) * 64);
-            *(__attribute__((address_space(1))) unsigned*)(mb + (unsigned)c.lane * 4u) = bits;
+            *(__attribute__((address_space(1))) unsigned*)(mb + (unsigned)c.lane * 4u) = bits;      // (ordinary: the dX kernels read these next)
         }
     }
 }
