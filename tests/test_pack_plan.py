@@ -66,6 +66,9 @@ def test_error_paths_without_gpu():
     assert L.dfn_encode_signal_torso_bwd(one, one, 16, 8, 0, 0, one, N, N) == 0                           # smo 0: nothing to do
     assert L.dfn_bias_grad(1, 0, N, 64, one, N) == -1 and L.dfn_weight_grad(1, 5, one, one, 64, one, one, N) == -1
     assert L.dfn_decoder_fwd(1, 0, one, one, N, one, 4, one, one, N) == -1
+    assert L.dfn_adam_multi(N, N, 4, 1e-3, 0.9, 0.999, 1e-8, 0.1, 0.03, N) == -1                          # no tables
+    assert L.dfn_adam_multi(one, one, 4, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0.03, N) == -1                      # t = 0: bias_c1 = 0
+    assert L.dfn_adam_multi(N, N, 0, 1e-3, 0.9, 0.999, 1e-8, 0.1, 0.03, N) == 0                           # nothing to do
     assert L.dfn_sample_pdf(one, one, 4, 300, 8, N, one, N) == -1                                         # nb <= 256
 
 
