@@ -32,7 +32,7 @@ import torch.distributed as dist
 
 # algorithmic FLOPs per sample point: 2 * MACs of the layers the reference evaluates
 FLOP_PT_HEAD, FLOP_PT_TORSO = 1222656.0, 1285120.0
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}       # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}       # dense MFMA peaks, MI355X_MICROARCH.md
 
 WORKLOADS = {
     # name: (n_fine, fields, description)
@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--tier", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--tier", default="f16", choices=["f16", "bf16", "f32"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -97,6 +97,8 @@ def cpu_baseline(args, sc, st, zs, za, n_fine, fields):
 
 
 def bench_training(args, world, rank, local, dev, desc):
+    if args.tier == "f16":
+        args.tier = "bf16"          # the 16-bit training tier (f16 is inference only)
     """configs[3]: one optimisation step per `step`: signals -> fold -> fused HIP forward (recorder on) -> MSE
     losses -> HIP backward (compositing, dX chain, weight-gradient GEMMs) -> flat-bucket all_reduce -> gated Adams."""
     from dfanerf import nets, parallel, run_nerf, synth, training

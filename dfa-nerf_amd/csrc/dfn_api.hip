@@ -31,7 +31,9 @@ int hip_fail(hipError_t e, const char* what) {
     return fail(DFN_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 
-bool tier_ok(int tier) { return tier == DFN_TIER_F32 || tier == DFN_TIER_BF16; }
+bool tier_ok(int tier) { return tier == DFN_TIER_F32 || tier == DFN_TIER_BF16 || tier == DFN_TIER_F16; }
+// the training entry points: the f16 tier is inference only (gradients underflow its 5-bit exponent)
+bool train_tier_ok(int tier) { return tier == DFN_TIER_F32 || tier == DFN_TIER_BF16; }
 bool field_ok(int field) { return field >= 0 && field <= 2; }
 int prog_field(int field) { return field == DFN_FIELD_TORSO ? FIELD_TORSO : FIELD_HEAD; }
 
@@ -42,7 +44,7 @@ struct PlanEntry {
     int32_t* dev = nullptr;
 };
 std::mutex g_plan_mu;
-PlanEntry g_plans[2][3];
+PlanEntry g_plans[3][3];
 
 PlanEntry& plan_of(int tier, int field) {
     std::lock_guard<std::mutex> lk(g_plan_mu);
@@ -75,8 +77,9 @@ struct WgradEntry {
 };
 WgradEntry g_wgrad[2];
 constexpr int WGRAD_KSPLIT = 32;
+constexpr int WS_KSPLIT_MAX = 32;       // slices the workspace is sized for (>= every tier's split)
 int wgrad_ksplit_bf16() {              // slices of the points per GEMM, bf16 tier (DFN_WGRAD_KSPLIT: developer override)
-    static const int v = [] { const char* e = getenv("DFN_WGRAD_KSPLIT"); const int k = e ? atoi(e) : 0; return k > 0 ? k : 24; }();
+    static const int v = [] { const char* e = getenv("DFN_WGRAD_KSPLIT"); const int k = e ? atoi(e) : 0; return k > 0 && k <= WS_KSPLIT_MAX ? k : 24; }();
     return v;
 }
 
@@ -145,7 +148,7 @@ int dfn_pack_weights(int tier, int field, const float* params, void* packed, voi
             if (err != hipSuccess) return hip_fail(err, "hipMemcpy(plan)");
         }
     }
-    hipError_t err = launch_pack(e.dev, params, packed, n, tier == DFN_TIER_BF16, st);
+    hipError_t err = launch_pack(e.dev, params, packed, n, tier, st);
     if (err != hipSuccess) return hip_fail(err, "pack_kernel");
     return DFN_OK;
 }
@@ -261,20 +264,24 @@ long dfn_train_rows(int field, int what) {
     case 0: return t ? 64 + 640 + 128 + 9 * 256 + 32 : 64 + 9 * 256 + 32;          // activation rows (RecMap)
     case 1: return t ? 896 + 10 * 256 + 64 : 10 * 256 + 64;                          // gradient rows (GradMap)
     case 2: return t ? 10 + 36 : 36;                                                  // mask dwords per pass
-    case 3: return (long)wgrad_of(field).map.size();                                  // wgrad workspace floats
+    case 3: {        // workspace floats: split-K partials of the weight gradients + of the bias gradients
+        const long W = (long)wgrad_of(field).map.size(), nb = dfn_bias_floats(DFN_TIER_BF16, field);
+        return WS_KSPLIT_MAX * W + std::max(WS_KSPLIT_MAX, BIAS_GRAD_SLICES) * nb;
+    }
+    case 4: return (long)BIAS_GRAD_SLICES * dfn_bias_floats(DFN_TIER_BF16, field);   // dfn_bias_grad workspace floats
     default: return fail(DFN_E_ARG, "dfn_train_rows: bad selector");
     }
 }
 
 long dfn_packed_bwd_bytes(int tier, int field) {
-    if (!tier_ok(tier) || (field != 0 && field != 1)) return fail(DFN_E_ARG, "dfn_packed_bwd_bytes: bad tier/field");
+    if (!train_tier_ok(tier) || (field != 0 && field != 1)) return fail(DFN_E_ARG, "dfn_packed_bwd_bytes: bad tier/field");
     ProgramInfo pi;
     bwd_program_info(tier, field, &pi);
     return (long)pi.n_slabs * SLAB_BYTES;
 }
 
 int dfn_pack_weights_bwd(int tier, int field, const float* params, void* packed_T, void* stream) {
-    if (!tier_ok(tier) || (field != 0 && field != 1) || !params || !packed_T)
+    if (!train_tier_ok(tier) || (field != 0 && field != 1) || !params || !packed_T)
         return fail(DFN_E_ARG, "dfn_pack_weights_bwd: bad argument");
     BwdPlanEntry& e = g_bwd_plans[tier][field];
     {
@@ -292,7 +299,7 @@ int dfn_pack_weights_bwd(int tier, int field, const float* params, void* packed_
             if (err != hipSuccess) return hip_fail(err, "upload(bwd plan)");
         }
     }
-    hipError_t err = launch_pack(e.dev, params, packed_T, (long)e.host.size(), tier == DFN_TIER_BF16,
+    hipError_t err = launch_pack(e.dev, params, packed_T, (long)e.host.size(), tier,
                                  (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "pack_kernel(bwd)");
     return DFN_OK;
@@ -302,7 +309,7 @@ int dfn_train_fwd(int tier, const DfnFrame* frame, const void* packed_head, cons
                   const float* bias_head, const float* bias_torso, const float* bg_f32, const uint8_t* bg_u8,
                   const int32_t* pix_index, float* rgb_head, float* rgb_com, float* samples, void* act_head,
                   uint32_t* masks_head, void* act_torso, uint32_t* masks_torso, void* stream) {
-    if (!tier_ok(tier) || !frame || !packed_head || !packed_torso || !bias_head || !bias_torso || !rgb_head ||
+    if (!train_tier_ok(tier) || !frame || !packed_head || !packed_torso || !bias_head || !bias_torso || !rgb_head ||
         !rgb_com || !samples || !act_head || !masks_head || !act_torso || !masks_torso)
         return fail(DFN_E_ARG, "dfn_train_fwd: bad argument");
     const DfnFrame& F = *frame;
@@ -365,7 +372,7 @@ int dfn_composite_bwd(const DfnFrame* frame, const int32_t* pix_index, const flo
 
 int dfn_mlp_bwd(int tier, int field, const void* packed_T, const float* samples, const float* dsamples,
                 const uint32_t* masks, long NP, void* dy_T, void* stream) {
-    if (!tier_ok(tier) || (field != 0 && field != 1) || !packed_T || !samples || !dsamples || !masks || !dy_T ||
+    if (!train_tier_ok(tier) || (field != 0 && field != 1) || !packed_T || !samples || !dsamples || !masks || !dy_T ||
         NP <= 0 || NP % 32)
         return fail(DFN_E_ARG, "dfn_mlp_bwd: bad argument");
     ProgramInfo pi;
@@ -404,7 +411,7 @@ static int ensure_eof(WgradEntry& w, int tier, int field) {
 
 static int weight_grad_impl(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
                             float* grad_flat, float* dbias, void* stream, const char* who) {
-    if (!tier_ok(tier) || (field != 0 && field != 1) || !dy_T || !act_T || !workspace || !grad_flat || NP <= 0 ||
+    if (!train_tier_ok(tier) || (field != 0 && field != 1) || !dy_T || !act_T || !workspace || !grad_flat || NP <= 0 ||
         NP % 32)
         return fail(DFN_E_ARG, std::string(who) + ": bad argument (NP must be a multiple of 32)");
     WgradEntry& w = wgrad_of(field);
@@ -418,7 +425,7 @@ static int weight_grad_impl(int tier, int field, const void* dy_T, const void* a
             hipError_t e = upload(&w.ops_dev, ops.data(), ops.size());
             if (e == hipSuccess) e = upload(&w.map_dev, w.map.data(), w.map.size());
             if (e == hipSuccess) e = upload(&w.prefix_dev, w.prefix.data(), w.prefix.size());
-            if (e == hipSuccess) e = upload(&w.rows_dev, w.bias_rows.data(), w.bias_rows.size());
+            if (e == hipSuccess && !w.rows_dev) e = upload(&w.rows_dev, w.bias_rows.data(), w.bias_rows.size());
             std::vector<int> order(ops.size());
             for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
             std::stable_sort(order.begin(), order.end(),
@@ -427,30 +434,39 @@ static int weight_grad_impl(int tier, int field, const void* dy_T, const void* a
             if (e != hipSuccess) return hip_fail(e, "upload(wgrad plan)");
         }
     }
-    hipError_t err = hipMemsetAsync(workspace, 0, w.map.size() * sizeof(float), st);
-    if (err != hipSuccess) return hip_fail(err, "memset(workspace)");
+    // Split-K without atomics: every (GEMM, slice of the points) writes its own slice of the partial arrays in the
+    // workspace, the reduce kernels add the slices in index order -> bit-reproducible gradients.
+    const long W = (long)w.map.size(), n_tiles = NP / 32;
+    const int nb = (int)w.bias_rows.size();
+    const int ks = tier == DFN_TIER_BF16 ? wgrad_ksplit_bf16() : WGRAD_KSPLIT;
+    const long per = (n_tiles + ks - 1) / ks;
+    const int valid = (int)((n_tiles + per - 1) / per);           // slices that hold points (the others write nothing)
+    float* c_parts = workspace;
+    float* b_parts = workspace + (long)WS_KSPLIT_MAX * W;
+    hipError_t err = hipSuccess;
     if (dbias) {
         const int rc = ensure_eof(w, tier, field);
         if (rc != DFN_OK) return rc;
-        err = hipMemsetAsync(dbias, 0, w.bias_rows.size() * sizeof(float), st);
-        if (err != hipSuccess) return hip_fail(err, "memset(dbias)");
     }
     // bf16 tier: the row sums ride along in the GEMMs (two cheap MFMAs per step).  f32 tier: an f32 MFMA costs 16x
     // more, the streaming row-sum kernel is cheaper there (measured).
     const bool fuse = dbias && tier == DFN_TIER_BF16;
     if (tier == DFN_TIER_BF16)
-        err = launch_wgrad_bf16(field, w.ops_dev, w.order_dev, (int)w.ops.size(), dy_T, act_T, NP, wgrad_ksplit_bf16(),
-                                workspace, fuse ? w.eof_dev : nullptr, fuse ? dbias : nullptr, st);
+        err = launch_wgrad_bf16(field, w.ops_dev, w.order_dev, (int)w.ops.size(), dy_T, act_T, NP, ks, c_parts, W,
+                                fuse ? w.eof_dev : nullptr, fuse ? b_parts : nullptr, nb, st);
     else
-        err = launch_wgrad(tier, field, w.ops_dev, (int)w.ops.size(), w.prefix_dev, w.prefix.back(), dy_T, act_T, NP,
-                           WGRAD_KSPLIT, workspace, fuse ? w.eof_dev : nullptr, fuse ? dbias : nullptr, st);
+        err = launch_wgrad(tier, field, w.ops_dev, (int)w.ops.size(), w.prefix_dev, w.prefix.back(), dy_T, act_T, NP, ks,
+                           c_parts, W, nullptr, nullptr, nb, st);
     if (err != hipSuccess) return hip_fail(err, "wgrad_kernel");
-    if (dbias && !fuse) {
-        err = launch_bias_grad(tier, field, w.eof_dev, (int)w.bias_rows.size(), dy_T, NP, dbias, st);
+    if (fuse) {
+        err = launch_reduce_bias(w.rows_dev, b_parts, nb, valid, dbias, st);
+        if (err != hipSuccess) return hip_fail(err, "reduce_bias_kernel");
+    } else if (dbias) {
+        err = launch_bias_grad(tier, field, w.eof_dev, w.rows_dev, nb, dy_T, NP, b_parts, dbias, st);
         if (err != hipSuccess) return hip_fail(err, "bias_grad_kernel");
     }
-    err = launch_scatter_add(w.map_dev, workspace, (long)w.map.size(), grad_flat, st);
-    if (err != hipSuccess) return hip_fail(err, "scatter_add_kernel");
+    err = launch_reduce_scatter(w.map_dev, c_parts, W, W, valid, grad_flat, st);
+    if (err != hipSuccess) return hip_fail(err, "reduce_scatter_kernel");
     return DFN_OK;
 }
 
@@ -465,15 +481,21 @@ int dfn_weight_bias_grad(int tier, int field, const void* dy_T, const void* act_
     return weight_grad_impl(tier, field, dy_T, act_T, NP, workspace, grad_flat, dbias, stream, "dfn_weight_bias_grad");
 }
 
-int dfn_bias_grad(int tier, int field, const void* dy_T, long NP, float* dbias, void* stream) {
-    if (!tier_ok(tier) || (field != 0 && field != 1) || !dy_T || !dbias || NP <= 0)
+int dfn_bias_grad(int tier, int field, const void* dy_T, long NP, float* workspace, float* dbias, void* stream) {
+    if (!train_tier_ok(tier) || (field != 0 && field != 1) || !dy_T || !workspace || !dbias || NP <= 0)
         return fail(DFN_E_ARG, "dfn_bias_grad: bad argument");
     WgradEntry& w = wgrad_of(field);
     {
         const int rc = ensure_eof(w, tier, field);
         if (rc != DFN_OK) return rc;
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        if (!w.rows_dev) {
+            hipError_t e = upload(&w.rows_dev, w.bias_rows.data(), w.bias_rows.size());
+            if (e != hipSuccess) return hip_fail(e, "upload(bias rows)");
+        }
     }
-    hipError_t err = launch_bias_grad(tier, field, w.eof_dev, (int)w.bias_rows.size(), dy_T, NP, dbias, (hipStream_t)stream);
+    hipError_t err = launch_bias_grad(tier, field, w.eof_dev, w.rows_dev, (int)w.bias_rows.size(), dy_T, NP, workspace, dbias,
+                                      (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "bias_grad_kernel");
     return DFN_OK;
 }
@@ -551,8 +573,41 @@ int dfn_decoder_fwd(int tier, int field, const void* packed, const float* bias, 
     A.n_points = n;
     A.feat = feat;
     A.sigma = sigma;
+    A.samples = nullptr;
+    A.act_T = nullptr;
+    A.masks = nullptr;
     hipError_t err = launch_decoder(tier, A, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "decoder_kernel");
+    return DFN_OK;
+}
+
+int dfn_decoder_train_fwd(int tier, int field, const void* packed, const float* bias, const float* points,
+                          const float* dirs, long n, float* feat, float* sigma, float* samples, void* act_T,
+                          uint32_t* masks, void* stream) {
+    if (!train_tier_ok(tier) || (field != DFN_FIELD_HEAD && field != DFN_FIELD_TORSO) || !packed || !bias || !points ||
+        !dirs || !feat || !sigma || !samples || !act_T || !masks)
+        return fail(DFN_E_ARG, "dfn_decoder_train_fwd: bad argument (tiers f32 / bf16, fields head / torso)");
+    if (n <= 0) return DFN_OK;
+    const long NP = (n + 31) / 32 * 32;
+    if (dfn_train_rows(1, 0) * NP >= (1L << 32)) return fail(DFN_E_ARG, "dfn_decoder_train_fwd: too many points per call");
+    ProgramInfo pi;
+    program_info(tier, prog_field(field), &pi);
+    DecoderArgs A;
+    A.wblob = (const char*)packed;
+    A.nslab = pi.n_slabs;
+    A.field = prog_field(field);
+    A.bias = bias;
+    A.n_bias = pi.n_bias;
+    A.points = points;
+    A.dirs = dirs;
+    A.n_points = n;
+    A.feat = feat;
+    A.sigma = sigma;
+    A.samples = samples;
+    A.act_T = act_T;
+    A.masks = masks;
+    hipError_t err = launch_decoder(tier, A, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "decoder_kernel(train)");
     return DFN_OK;
 }
 

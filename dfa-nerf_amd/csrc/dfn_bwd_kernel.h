@@ -23,8 +23,8 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     typedef CtxT<false, false, true> CtxB;      // LDS-DMA as asm: the ReLU mask loads must not drain the dY stores
     const CtxB ctx = {lds, wave, lane, lane >> 5, {}};
     Stream s;
-    s.base[0] = s.base[1] = A.wblob_T;
-    s.nslab[0] = s.nslab[1] = A.nslab;
+    s.base0 = s.base1 = A.wblob_T;
+    s.nslab0 = s.nslab1 = A.nslab;
     s.sched = 0;
     stream_begin<TIER, use_asm_dma<TIER, CtxB>()>(s, lds, wave, lane);
     const long n_tiles = A.NP / 32;

@@ -22,13 +22,17 @@
 namespace dfn {
 
 // ---- precision tiers ---------------------------------------------------------------------------
-enum Tier : int { TIER_F32 = 0, TIER_BF16 = 1 };
+enum Tier : int { TIER_F32 = 0, TIER_BF16 = 1, TIER_F16 = 2 };
 // k-slots per half-wave per k-unit: one k-unit = what one 16-byte A-fragment read feeds.
 //   bf16: 8 bf16 per lane  = one v_mfma_f32_32x32x16_bf16  (K=16)
+//   f16 : 8 f16 per lane   = one v_mfma_f32_32x32x16_f16   (K=16; same rate and fragment map as bf16, 10 mantissa
+//                            bits instead of 7: the throughput tier whose rendered RGB stays within the accuracy clause;
+//                            inference only - gradients would underflow f16's 5-bit exponent)
 //   f32 : 4 f32 per lane   = four v_mfma_f32_32x32x2_f32   (K=2 each)
-DFN_HD int tier_E(int tier) { return tier == TIER_BF16 ? 8 : 4; }
-DFN_HD int tier_UPT(int tier) { return tier == TIER_BF16 ? 2 : 4; }        // k-units per 32-feature tile
-DFN_HD int tier_elem_bytes(int tier) { return tier == TIER_BF16 ? 2 : 4; }
+DFN_HD constexpr bool tier_is16(int tier) { return tier != TIER_F32; }
+DFN_HD int tier_E(int tier) { return tier_is16(tier) ? 8 : 4; }
+DFN_HD int tier_UPT(int tier) { return tier_is16(tier) ? 2 : 4; }        // k-units per 32-feature tile
+DFN_HD int tier_elem_bytes(int tier) { return tier_is16(tier) ? 2 : 4; }
 
 constexpr int FRAG_BYTES = 1024;            // one A fragment: 64 lanes x 16 B, lane-linear
 constexpr int SLAB_FRAGS = 32;              // ring slot = 32 fragments = 32 KiB

@@ -4,7 +4,7 @@
 #include "dfanerf.h"
 
 namespace dfn {
-hipError_t launch_pack(const int* plan, const float* params, void* out, long n, int bf16, hipStream_t st);
+hipError_t launch_pack(const int* plan, const float* params, void* out, long n, int tier, hipStream_t st);
 hipError_t launch_fold_bwd(int field, const float* params, const float* sig, const float* zs, const float* za,
                            const float* dbias, float* grad_flat, float* dsig, int n, hipStream_t st);
 hipError_t launch_fold(int field, const float* params, const float* sig, const float* zs, const float* za,

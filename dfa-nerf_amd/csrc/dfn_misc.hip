@@ -14,17 +14,18 @@ namespace dfn {
 
 // ---- pack: gather flat params through the plan ---------------------------------------------------------
 __global__ void pack_kernel(const int* __restrict__ plan, const float* __restrict__ params, void* out, long n,
-                            int bf16) {
+                            int tier) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int src = plan[i];
     const float v = src >= 0 ? params[src] : 0.f;
-    if (bf16) ((__bf16*)out)[i] = (__bf16)v;       // round-to-nearest-even
+    if (tier == TIER_BF16) ((__bf16*)out)[i] = (__bf16)v;       // round-to-nearest-even
+    else if (tier == TIER_F16) ((_Float16*)out)[i] = (_Float16)v;
     else ((float*)out)[i] = v;
 }
-hipError_t launch_pack(const int* plan, const float* params, void* out, long n, int bf16, hipStream_t st) {
+hipError_t launch_pack(const int* plan, const float* params, void* out, long n, int tier, hipStream_t st) {
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, plan, params, out, n,
-                       bf16);
+                       tier);
     return hipGetLastError();
 }
 
@@ -456,6 +457,18 @@ __global__ void mfma_probe_kernel(float* out) {
         for (int r = 0; r < 16; ++r) c[r] = 0.f;
         c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
         for (int r = 0; r < 16; ++r) out[1024 + (tile_feat(h, r)) * 32 + i] = c[r];
+    }
+    // f16: slot (h=1, e=5), the bf16 probe with f16 operands
+    {
+        f16x8 a, b;
+        for (int e = 0; e < 8; ++e) {
+            a[e] = (_Float16)((h == 1 && e == 5) ? (float)(i + 1) : 0.f);
+            b[e] = (_Float16)((h == 1 && e == 5) ? (float)(2 * i + 1) : 0.f);
+        }
+        f32x16 c;
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) out[2048 + (tile_feat(h, r)) * 32 + i] = c[r];
     }
 }
 hipError_t launch_mfma_probe(float* out, hipStream_t st) {

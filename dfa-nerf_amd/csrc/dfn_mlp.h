@@ -17,6 +17,7 @@
 //     bias vectors by dfn_fold_kernel and enter as accumulator initial values.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "dfn_layout.h"
 
 namespace dfn {
@@ -24,6 +25,7 @@ namespace dfn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define DFN_DEV __device__ __forceinline__
@@ -45,6 +47,7 @@ template <int TIER> struct TierCfg;
 template <> struct TierCfg<TIER_BF16> {
     static constexpr int E = 8, UPT = 2, WAVES = 8, THREADS = 512, LOADS_PER_SLAB = 4;
 };
+template <> struct TierCfg<TIER_F16> : TierCfg<TIER_BF16> {};
 template <> struct TierCfg<TIER_F32> {
     static constexpr int E = 4, UPT = 4, WAVES = 4, THREADS = 256, LOADS_PER_SLAB = 8;
 };
@@ -60,6 +63,11 @@ template <int NT> struct Vec<TIER_BF16, NT> {
     DFN_DEV void set(int L, float x) { u[L >> 3][L & 7] = (__bf16)x; }
     DFN_DEV float get(int L) const { return (float)u[L >> 3][L & 7]; }
 };
+template <int NT> struct Vec<TIER_F16, NT> {
+    f16x8 u[2 * NT];
+    DFN_DEV void set(int L, float x) { u[L >> 3][L & 7] = (_Float16)x; }
+    DFN_DEV float get(int L) const { return (float)u[L >> 3][L & 7]; }
+};
 template <int NT> struct Vec<TIER_F32, NT> {
     float v[16 * NT];
     DFN_DEV void set(int L, float x) { v[L] = x; }
@@ -70,8 +78,12 @@ template <int NT> struct Vec<TIER_F32, NT> {
 // All state is wave-uniform.  The stream of one MLP pass is nslab[field] slabs; pass p of a workgroup runs
 // field (sched >> p) & 1 (bit mask set by the kernel: 0 = always field 0).
 struct Stream {
-    const char* base[2];     // packed blobs (global)
-    int nslab[2];
+    // packed blobs (global) and slabs per pass of field 0 / field 1.  Scalars on purpose: as two-element arrays they
+    // were indexed by the runtime field bit, which kept the WHOLE struct in scratch memory (88 bytes per lane, every
+    // cursor update a scratch store + load) in the two-field kernels
+    const char* base0;
+    const char* base1;
+    int nslab0, nslab1;
     unsigned sched;          // field of pass p = bit p (passes beyond bit 31: field 0)
     // prefetch cursor
     const char* pf_ptr;
@@ -123,8 +135,8 @@ DFN_DEV void stream_cursor_next(Stream& s) {
 DFN_DEV void stream_pass_begin(Stream& s) {
     const int np = s.pass + 1;
     const int f = (np < 32) ? ((s.sched >> np) & 1u) : 0;
-    s.next_ptr = s.base[f];
-    s.next_left = s.nslab[f];
+    s.next_ptr = f ? s.base1 : s.base0;
+    s.next_left = f ? s.nslab1 : s.nslab0;
     s.pass = np;
 }
 template <int TIER, bool ASM = false>
@@ -147,11 +159,11 @@ DFN_DEV void stream_flush(Stream& s, lds_char* ring, int wave, int lane) {
 
 template <int TIER, bool ASM = false>
 DFN_DEV void stream_begin(Stream& s, lds_char* ring, int wave, int lane) {
-    s.pf_ptr = s.base[0];
-    s.pf_left = s.nslab[0];
+    s.pf_ptr = s.base0;
+    s.pf_left = s.nslab0;
     s.pass = 0;
-    s.next_ptr = s.base[0];
-    s.next_left = s.nslab[0];
+    s.next_ptr = s.base0;
+    s.next_left = s.nslab0;
     s.pf_slot = 0;
     s.rd_slot = RING_SLOTS - 1;     // the first slab_advance moves it to slot 0
     s.rd_off = 0;
@@ -219,6 +231,7 @@ typedef CtxT<false> Ctx;
 
 template <int TIER> struct ActT;
 template <> struct ActT<TIER_BF16> { typedef __bf16 type; };
+template <> struct ActT<TIER_F16> { typedef _Float16 type; };
 template <> struct ActT<TIER_F32> { typedef float type; };
 
 // store a B-operand vector feature-major into a tile-major array [tile][rows][32]: element (row0 + feature, n).
@@ -311,9 +324,9 @@ DFN_DEV void rec_mask(const CT& c, int dword0, const Vec<TIER, NT>& v) {
 #define DFN_PF_DEPTH 4
 #endif
 constexpr int PF_DEPTH = DFN_PF_DEPTH;
-template <int TIER, class CT> constexpr bool use_asm_fetch() { return TIER == TIER_BF16 && CT::asm_fetch; }
-// (the asm fragment READS are bf16-only; the asm DMA alone - storing kernels - serves both tiers)
-template <int TIER, class CT> constexpr bool use_asm_dma() { return CT::asm_fetch ? TIER == TIER_BF16 : CT::asm_dma; }
+template <int TIER, class CT> constexpr bool use_asm_fetch() { return tier_is16(TIER) && CT::asm_fetch; }
+// (the asm fragment READS are for the 16-bit tiers only; the asm DMA alone - storing kernels - serves every tier)
+template <int TIER, class CT> constexpr bool use_asm_dma() { return CT::asm_fetch ? tier_is16(TIER) : CT::asm_dma; }
 
 #define DFN_FRAG_CASE(K)                                                                                      \
     case K:                                                                                                   \
@@ -414,6 +427,9 @@ DFN_DEV void gemm_group(f32x16 (&acc)[G], const Vec<TIER, NTB>& b, int& f, Fetch
             if constexpr (TIER == TIER_BF16) {
                 acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), b.u[ku],
                                                                  acc[g], 0, 0, 0);
+            } else if constexpr (TIER == TIER_F16) {
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), b.u[ku],
+                                                                acc[g], 0, 0, 0);
             } else {
                 const f32x4 af = __builtin_bit_cast(f32x4, a);
 #pragma unroll
@@ -467,9 +483,12 @@ DFN_DEV void acc_relu_add(f32x16 (&acc)[G], const lds_f32* bias_lds, int half) {
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 template <int TIER, int G, int NT, bool RELU>
 DFN_DEV void acc_to_vec(const f32x16 (&acc)[G], Vec<TIER, NT>& v, int t0) {
-    if constexpr (TIER == TIER_BF16) {
+    if constexpr (tier_is16(TIER)) {
+        typedef typename std::conditional<TIER == TIER_F16, f16x2, bf16x2>::type pk2;     // v_cvt_pk_{f16,bf16}_f32 (RNE)
+        typedef typename std::conditional<TIER == TIER_F16, f16x8, bf16x8>::type pk8;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
 #pragma unroll
@@ -478,7 +497,7 @@ DFN_DEV void acc_to_vec(const f32x16 (&acc)[G], Vec<TIER, NT>& v, int t0) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const f32x2 x = {acc[g][8 * h + 2 * e], acc[g][8 * h + 2 * e + 1]};
-                    const bf16x2 pk = __builtin_convertvector(x, bf16x2);                        // v_cvt_pk_bf16_f32
+                    const pk2 pk = __builtin_convertvector(x, pk2);
                     if constexpr (RELU) {
                         const s16x2 m = __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk), (s16x2)(0));   // v_pk_max_i16
                         w[e] = __builtin_bit_cast(unsigned, m);
@@ -487,7 +506,7 @@ DFN_DEV void acc_to_vec(const f32x16 (&acc)[G], Vec<TIER, NT>& v, int t0) {
                     }
                 }
                 const u32x4 q = {w[0], w[1], w[2], w[3]};
-                v.u[2 * (t0 + g) + h] = __builtin_bit_cast(bf16x8, q);
+                v.u[2 * (t0 + g) + h] = __builtin_bit_cast(pk8, q);
             }
         }
     } else {

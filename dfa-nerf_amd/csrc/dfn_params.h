@@ -38,6 +38,10 @@ struct DecoderArgs {
     long n_points;
     float* feat;
     float* sigma;
+    // training recorder (all null for inference): dfn_decoder_train_fwd
+    float* samples;             // [ceil32(n)][8]: (sigma, rgb) in floats 0..3 (head) or 4..7 (torso)
+    void* act_T;
+    unsigned* masks;
 };
 
 hipError_t launch_render(int tier, const RenderArgs& A, hipStream_t st);

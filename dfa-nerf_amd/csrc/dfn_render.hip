@@ -1,19 +1,5 @@
-// dfn_render.hip - fused frame renderer and fused decoder for gfx950 (MI355X).
-//
-// One wavefront = one ray.  A workgroup of W waves (8 in the bf16 tier, 4 in the f32 tier) walks W rays
-// through: ray generation -> 64 coarse samples -> [head MLP (+ torso MLP)] on 32-sample tiles ->
-// online alpha compositing -> (optional) inverse-CDF fine sampling, rank merge -> the same MLPs on the
-// merged 64+n_fine samples -> compositing -> 12 (or 24) bytes of RGB per ray.  Nothing but the packed
-// weight stream, the per-frame bias blob and one background pixel per ray is read from memory.
-//
-// Reference semantics (paths under /root/reference/NeRFs/DFANeRF/):
-//   rays            run_nerf_helpers.py:449-465 (get_rays)
-//   coarse z        run_nerf_com_trainExpLater.py:612-619, 638-641
-//   decoder         decoder.py:277-349, 109-134       (dfn_mlp.h)
-//   bg / sigma fix  run_nerf_com_trainExpLater.py:669-671, 678-679, 688-694
-//   composite       run_nerf_com_trainExpLater.py:146-166 (composite_function)
-//   weights         run_nerf_com_trainExpLater.py:169-179 (calc_volume_weights), 706-709
-//   fine sampling   run_nerf_helpers.py:537-581 (sample_pdf); composition = SURVEY.md 8(a) row H
+// dfn_render.hip - tier dispatch of the fused frame renderer and the fused decoder.
+// The kernels are templates in dfn_render_kernels.h, instantiated per precision tier in dfn_render_{f32,bf16,f16}.hip.
 #include <hip/hip_runtime.h>
 #include "dfn_layout.h"
 #include "dfn_mlp.h"
@@ -21,606 +7,33 @@
 
 namespace dfn {
 
-// ---- exact-rounding helpers (no fma contraction: the reference is separate f32 mul/add) -------------
-DFN_DEV float mul_(float a, float b) { return __fmul_rn(a, b); }
-DFN_DEV float add_(float a, float b) { return __fadd_rn(a, b); }
-DFN_DEV float sub_(float a, float b) { return __fsub_rn(a, b); }
-DFN_DEV float div_(float a, float b) { return __fdiv_rn(a, b); }
-
-// torch.linspace(0,1,n)[i] (see oracle/dfa_oracle.py:linspace01)
-DFN_DEV float linspace01(int i, int n) {
-    const float step = div_(1.0f, (float)(n - 1));
-    return (i < n / 2) ? mul_(step, (float)i) : fmaf(-step, (float)(n - 1 - i), 1.0f);
-}
-
-DFN_DEV void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// pinhole ray through pixel `pix` (row-major y*W+x): get_rays, run_nerf_helpers.py:449-465
-DFN_DEV void make_ray(const float* pose, int pix, int W, float focal, float cx, float cy, float (&o)[3],
-                      float (&d)[3]) {
-    const int y = pix / W, x = pix - y * W;
-    const float dx = div_(sub_((float)x, cx), focal);
-    const float dy = div_(-sub_((float)y, cy), focal);
-    const float dz = -1.0f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        d[k] = add_(add_(mul_(dx, pose[4 * k + 0]), mul_(dy, pose[4 * k + 1])), mul_(dz, pose[4 * k + 2]));
-        o[k] = pose[4 * k + 3];
-    }
-}
-
-DFN_DEV float norm3(const float (&d)[3]) {
-    return sqrtf(add_(add_(mul_(d[0], d[0]), mul_(d[1], d[1])), mul_(d[2], d[2])));
-}
-
-// ---- per-wave ray state, kept in LDS so that nothing but the sample point is live across an MLP pass ----
-enum RayState : int {
-    RS_OH = 0, RS_DH = 3, RS_OT = 6, RS_DT = 9, RS_NH = 12, RS_NT = 13, RS_DHAT_H = 14, RS_DHAT_T = 17,
-    RS_BG = 20, RS_TH = 23, RS_TC = 24, RS_RGB_H = 25, RS_RGB_C = 28, RS_COUNT = 32
-};
-
-// One 32-sample tile of calc_volume_weights + the weighted colour sum
-// (run_nerf_com_trainExpLater.py:169-179, 706-709).  sigma >= 0 already composited; dist already multiplied
-// by the ray norm.  T (running transmittance) and rgb (running sums) live in LDS; returns the weight.
-DFN_DEV float integrate_tile(volatile lds_f32* st, int rs_T, int rs_rgb, float sigma, float dist,
-                             const float (&col)[3], int n, int lane) {
-    const float alpha = sub_(1.0f, expf(-mul_(add_(fmaxf(sigma, 0.f), 1e-6f), dist)));
-    const float v = add_(sub_(1.0f, alpha), 1e-10f);
-    float inc = v;      // inclusive prefix product over the 32 samples of the tile
-#pragma unroll
-    for (int dlt = 1; dlt < 32; dlt <<= 1) {
-        const float up = __shfl_up(inc, dlt, 32);
-        if (n >= dlt) inc *= up;
-    }
-    float exc = __shfl_up(inc, 1, 32);
-    if (n == 0) exc = 1.0f;
-    const float T = st[rs_T];
-    const float w = alpha * (T * exc);
-    float part[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        float x = w * col[k];
-#pragma unroll
-        for (int dlt = 16; dlt >= 1; dlt >>= 1) x += __shfl_xor(x, dlt, 32);
-        part[k] = x;
-    }
-    const float Tn = T * __shfl(inc, 31, 32);
-    const float r0 = st[rs_rgb + 0] + part[0], r1 = st[rs_rgb + 1] + part[1], r2 = st[rs_rgb + 2] + part[2];
-    wave_lds_fence();
-    if (lane == 0) {
-        st[rs_T] = Tn;
-        st[rs_rgb + 0] = r0;
-        st[rs_rgb + 1] = r1;
-        st[rs_rgb + 2] = r2;
-    }
-    wave_lds_fence();
-    return w;
-}
-
-template <int TIER, bool TWO = false> struct KernelLds {
-    using P = Prog<TIER>;
-    static constexpr int BIAS_H = RING_BYTES;
-    static constexpr int BIAS_T = BIAS_H + P::H_NBIAS * 4;
-    static constexpr int SCRATCH = BIAS_T + P::T_NBIAS * 4;
-    // per wave (floats): zall[192] | M[4][192] | rank8[128 bytes] | state[32]
-    //   zall   sample depths: the 64 coarse z, then the merged, sorted 64 + n_fine
-    //   M      per merged sample (sigma, r, g, b) of the field set being composited; while the coarse pass and
-    //          sample_pdf run its first 256 floats hold tmp[64] cdf[64] zf[128]
-    //   rank8  merged rank of fine sample j (u8)
-    // (decoder_kernel keeps its per-lane d/|d| [3][64] at float 544 of the same area)
-    //   keepc  (two-field kernel only) the coarse samples' two-field mix (ssum, fm) [4][64]
-    static constexpr int Z_ALL = 0, M_OFF = 192, M_STRIDE = 192, RANK8 = 960, STATE = 992, KEEPC = 1024;
-    static constexpr int PARK_H = 256;       // inside M: the coarse samples' head outputs [4][64] until the merge
-    static constexpr int SCRATCH_FLOATS = TWO ? 1280 : 1024;
-    static constexpr int SCRATCH_PER_WAVE = SCRATCH_FLOATS * 4;
-    static constexpr int TOTAL = SCRATCH + TierCfg<TIER>::WAVES * SCRATCH_PER_WAVE;
-    static_assert(TOTAL <= 160 * 1024, "LDS budget");
-};
-
-// ================================================================================================
-// Frame renderer
-// ================================================================================================
-// Pass order of one ray (= one wave): coarse tiles 0,1 (head, then torso when two fields are rendered), the
-// fine sampler, then the decoder on the n_fine NEW points only - there is one network (SURVEY.md 8(a) row H,
-// step 4), so its outputs at the 64 coarse points are kept from the coarse pass instead of being evaluated a
-// second time: head on the fine tiles, compositing of the head image over the merged samples, torso on the fine
-// tiles, compositing of the two-field image.  Every sample's (sigma, rgb) is bit-identical to what a pass over
-// all 64 + n_fine merged points gives (an MFMA column depends on its own point only).
-template <int TIER, bool TWO, bool TRAIN>
-__global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 256) void render_kernel(
-    const RenderArgs A) {
-    using C = TierCfg<TIER>;
-    using L = KernelLds<TIER, TWO>;
-    using P = Prog<TIER>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 31;
-    const DfnFrame& F = A.frame;
-    lds_char* lds = (lds_char*)smem;
-    typedef CtxT<TRAIN, !TRAIN, TRAIN> CtxK;     // inference: asm fragment fetch (DFN_ASM_FETCH); training: asm LDS-DMA only
-    CtxK ctx = {lds, wave, lane, lane >> 5, {}};
-    constexpr bool two = TWO;
-    const int NF = TRAIN ? 0 : F.n_fine;          // the training forward is the reference's coarse renderer
-    const bool hier = NF > 0;
-    const int KF = NF / 32;                        // fine tiles
-    const int S = 64 + NF;
-
-    Stream s;
-    s.base[0] = A.wblob[0];
-    s.base[1] = A.wblob[1];
-    s.nslab[0] = A.nslab[0];
-    s.nslab[1] = A.nslab[1];
-    // coarse: H T H T; fine: KF x H, then KF x T
-    s.sched = two ? (0xAu | (((1u << KF) - 1u) << (4 + KF))) : 0u;
-#ifdef DFN_TIMING
-    s.t_wait = s.t_bar = s.t_issue = 0;
-    unsigned long long T_mlp = 0, T_pdf = 0;
-    const unsigned long long T_start = __builtin_readcyclecounter();
-    const unsigned long long R_start = __builtin_amdgcn_s_memrealtime();
-#endif
-    stream_begin<TIER, use_asm_dma<TIER, CtxK>()>(s, lds, wave, lane);
-    {
-        lds_f32* bl = (lds_f32*)(lds + L::BIAS_H);
-        const int nb = P::H_NBIAS + (TWO ? P::T_NBIAS : 0);
-        for (int i = tid; i < nb; i += C::THREADS) bl[i] = A.bias[i];
-    }
-    const lds_f32* bias_h = (const lds_f32*)(lds + L::BIAS_H);
-    const lds_f32* bias_t = (const lds_f32*)(lds + L::BIAS_T);
-
-    lds_f32* scr = (lds_f32*)(lds + L::SCRATCH + wave * L::SCRATCH_PER_WAVE);
-    lds_f32* zall = scr + L::Z_ALL;      // [192]
-    lds_f32* zc = zall;                  // [64]  the coarse z (until the merge overwrites the area)
-    lds_f32* M = scr + L::M_OFF;         // [4][192]
-    lds_f32* tmp = M;                    // [64]  coarse weights, then pdf / bins
-    lds_f32* cdf = M + 64;               // [64]
-    lds_f32* zf = M + 128;               // [128]
-    DFN_LDS unsigned char* rank8 = (DFN_LDS unsigned char*)(scr + L::RANK8);
-    volatile lds_f32* st = scr + L::STATE;
-
-    // ---- this wave's ray -----------------------------------------------------------------------
-    const int r_raw = blockIdx.x * C::WAVES + wave;
-    const bool valid = r_raw < F.ray_count;
-    {
-        const int r = valid ? r_raw : F.ray_count - 1;
-        const int pix = A.pix_index ? A.pix_index[r] : F.ray_begin + r;
-        float bg[3];
-        if (A.bg_u8) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) bg[k] = div_((float)A.bg_u8[(size_t)pix * 3 + k], 255.0f);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) bg[k] = A.bg_f32[(size_t)pix * 3 + k];
-        }
-        float oh[3], dh[3], ot[3], dt[3];
-        make_ray(F.pose, pix, F.W, F.focal, F.cx, F.cy, oh, dh);
-        make_ray(F.pose_body, pix, F.W, F.focal, F.cx, F.cy, ot, dt);
-        const float nh = norm3(dh), nt = norm3(dt);
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                st[RS_OH + k] = oh[k];
-                st[RS_DH + k] = dh[k];
-                st[RS_OT + k] = ot[k];
-                st[RS_DT + k] = dt[k];
-                st[RS_DHAT_H + k] = div_(dh[k], nh);      // decoder.py:337
-                st[RS_DHAT_T + k] = div_(dt[k], nt);
-                st[RS_BG + k] = bg[k];
-            }
-            st[RS_NH] = nh;
-            st[RS_NT] = nt;
-            st[RS_TH] = 1.0f;
-            st[RS_TC] = 1.0f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) st[RS_RGB_H + k] = st[RS_RGB_C + k] = 0.f;
-        }
-        // coarse z: near*(1-t) + far*t (run_nerf_com_trainExpLater.py:617-618)
-        const float t = linspace01(lane, 64);
-        zall[lane] = add_(mul_(F.z_near, sub_(1.0f, t)), mul_(F.z_far, t));
-    }
-    __syncthreads();     // bias blob + ray state visible (also drains the first two slab loads)
-
-    const bool cbg = F.concate_bg != 0;
-    const DhatRef dref_h = {st + RS_DHAT_H, 1}, dref_t = {st + RS_DHAT_T, 1};
-
-    // head-image inputs of one sample: background colour / sigma bump on the last sample (:669-671, :693)
-    auto head_inputs = [&](float sg_h, float (&fh)[3], bool last, float& s1) {
-        if (cbg && last) { fh[0] = st[RS_BG]; fh[1] = st[RS_BG + 1]; fh[2] = st[RS_BG + 2]; }
-        s1 = fmaxf(sg_h, 0.f);                     // head-only image: K = 1 (composite_function is a squeeze)
-        if (cbg && last) s1 = add_(s1, 1e-6f);
-    };
-    // composite_function over {head, torso} for one sample (:158-162, :678-679, :694); fh after head_inputs
-    auto combine = [&](float sg_h, const float (&fh)[3], float sg_t, const float (&ft)[3], bool last, float& ssum,
-                       float (&fm)[3]) {
-        if (cbg && last) sg_t = 0.f;
-        const float sh = fmaxf(sg_h, 0.f);
-        float stt = fmaxf(sg_t, 0.f);
-        if (cbg && last) stt = add_(stt, 1e-6f);   // last stacked field
-        ssum = add_(sh, stt);
-        const float den = (ssum == 0.f) ? 1e-4f : ssum;
-        const float wh = div_(sh, den), wt = div_(stt, den);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) fm[k] = add_(mul_(fh[k], wh), mul_(ft[k], wt));
-    };
-    // calc_volume_weights + colour sum over the S merged samples held in M (4 rows: sigma, r, g, b)
-    auto composite_merged = [&](bool head_image, float* w_out) {
-        for (int t = 0; t < S / 32; ++t) {
-            const int si = t * 32 + n;
-            const float z = ((volatile lds_f32*)zall)[si];
-            const bool last = (si == S - 1);
-            const float znext = ((volatile lds_f32*)zall)[last ? si : si + 1];
-            const float dz = last ? F.last_dist : sub_(znext, z);
-            const volatile lds_f32* Mv = M;
-            float sg = Mv[si], col[3] = {Mv[L::M_STRIDE + si], Mv[2 * L::M_STRIDE + si], Mv[3 * L::M_STRIDE + si]};
-            float w;
-            if (head_image) {
-                float s1;
-                head_inputs(sg, col, last, s1);
-                w = integrate_tile(st, RS_TH, RS_RGB_H, s1, mul_(dz, st[RS_NH]), col, n, lane);
-            } else {
-                w = integrate_tile(st, RS_TC, RS_RGB_C, sg, mul_(dz, st[RS_NT]), col, n, lane);
-            }
-            if (valid && lane < 32) {
-                if (w_out) w_out[(size_t)r_raw * S + si] = w;
-                if (head_image && A.z_out) A.z_out[(size_t)r_raw * S + si] = z;
-            }
-        }
-    };
-
-    // what the coarse pass leaves for the merged compositing, parked in LDS so that nothing of it is live in
-    // registers across the MLP passes: the coarse samples' head outputs (inside M until the merge scatters them to
-    // their ranks) and, with two fields, their mix (ssum, fm)
-    lds_f32* park_h = M + L::PARK_H;          // [4][64]
-    lds_f32* keepc = scr + L::KEEPC;          // [4][64]  (allocated for the two-field kernel only)
-    int rank_c = lane;
-
-    enum { PH_COARSE = 0, PH_FINE_H = 1, PH_FINE_T = 2 };
-    int phase = PH_COARSE, tile = 0;
-    // one call site per MLP: the loop is a small state machine around them
-    for (;;) {
-        const int idx = tile * 32 + n;
-        const int ri = (phase == PH_COARSE) ? idx : (int)rank8[idx];       // sample's index in zall
-        const float z = ((volatile lds_f32*)zall)[ri];
-        MlpOut a = {}, b = {};
-        if (phase != PH_FINE_T) {
-            float p[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) p[k] = add_(st[RS_OH + k], mul_(st[RS_DH + k], z));
-            if constexpr (TRAIN) {      // idle waves (ray >= ray_count) record into the last ray's slots: same values
-                const long rr = valid ? r_raw : F.ray_count - 1;
-                ctx.rec = {A.act_T[0], A.masks[0], RecMap::H_ROWS, rr * 2 + tile, RecMap::H_MDWORDS};
-            }
-#ifdef DFN_TIMING
-            const unsigned long long tm0 = __builtin_readcyclecounter();
-#endif
-            a = mlp_head<TIER>(p, dref_h, bias_h, s, ctx);
-#ifdef DFN_TIMING
-            T_mlp += __builtin_readcyclecounter() - tm0;
-#endif
-        }
-        if (two && phase != PH_FINE_H) {
-            float p[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) p[k] = add_(st[RS_OT + k], mul_(st[RS_DT + k], z));
-            if constexpr (TRAIN) {
-                const long rr = valid ? r_raw : F.ray_count - 1;
-                ctx.rec = {A.act_T[1], A.masks[1], RecMap::S_ROWS, rr * 2 + tile, RecMap::S_MDWORDS};
-            }
-            b = mlp_torso<TIER>(p, dref_t, bias_t, s, ctx);
-        }
-
-        if (phase == PH_COARSE) {
-            const int si = idx;
-            if (TRAIN && valid && lane < 32) {
-                float* so = A.samples_out + ((size_t)r_raw * 64 + si) * 8;
-                so[0] = a.sigma; so[1] = a.r; so[2] = a.g; so[3] = a.b;
-                so[4] = b.sigma; so[5] = b.r; so[6] = b.g; so[7] = b.b;
-            }
-            // results live in lanes 0..31; mirror them so that both halves run the same arithmetic
-            const bool last = (si == 63);
-            const float znext = ((volatile lds_f32*)zall)[last ? si : si + 1];
-            const float dz = last ? F.last_dist : sub_(znext, z);
-            const float sg_h = __shfl(a.sigma, n);
-            float fh[3] = {__shfl(a.r, n), __shfl(a.g, n), __shfl(a.b, n)};
-            if (hier && lane < 32) {
-                park_h[si] = sg_h; park_h[64 + si] = fh[0]; park_h[128 + si] = fh[1]; park_h[192 + si] = fh[2];
-            }
-            float s1;
-            head_inputs(sg_h, fh, last, s1);
-            const float w_h = integrate_tile(st, RS_TH, RS_RGB_H, s1, mul_(dz, st[RS_NH]), fh, n, lane);
-            float w_c = 0.f;
-            if (two) {
-                const float sg_t = __shfl(b.sigma, n);
-                const float ft[3] = {__shfl(b.r, n), __shfl(b.g, n), __shfl(b.b, n)};
-                float ssum, fm[3];
-                combine(sg_h, fh, sg_t, ft, last, ssum, fm);
-                if (hier && lane < 32) {
-                    keepc[si] = ssum; keepc[64 + si] = fm[0]; keepc[128 + si] = fm[1]; keepc[192 + si] = fm[2];
-                }
-                w_c = integrate_tile(st, RS_TC, RS_RGB_C, ssum, mul_(dz, st[RS_NT]), fm, n, lane);
-            }
-            if (hier) {
-                if (lane < 32) tmp[si] = two ? w_c : w_h;
-            } else if (valid && lane < 32) {
-                if (A.w_head) A.w_head[(size_t)r_raw * 64 + si] = w_h;
-                if (A.w_com && two) A.w_com[(size_t)r_raw * 64 + si] = w_c;
-                if (A.z_out) A.z_out[(size_t)r_raw * 64 + si] = z;
-            }
-            if (++tile < 2) continue;
-            if (!hier) break;
-#ifdef DFN_TIMING
-            const unsigned long long tp0 = __builtin_readcyclecounter();
-#endif
-            // ---- sample_pdf(z_mid, weights[1:-1], n_fine, det=True), run_nerf_helpers.py:537-581 ----
-            wave_lds_fence();
-            const float wp = (lane >= 1 && lane <= 62) ? add_(tmp[lane], 1e-5f) : 0.f;
-            float Ssum = wp;
-#pragma unroll
-            for (int dlt = 32; dlt >= 1; dlt >>= 1) Ssum += __shfl_xor(Ssum, dlt);
-            const float pdf = div_(wp, Ssum);
-            const float zmid = (lane < 63) ? mul_(0.5f, add_(zc[lane + 1], zc[lane])) : 0.f;
-            wave_lds_fence();
-            tmp[lane] = pdf;                 // pdf of weights index k lives at tmp[k]
-            wave_lds_fence();
-            float c = 0.f, mine_c = 0.f;     // sequential cumsum like torch.cumsum
-            for (int k = 0; k < 62; ++k) {
-                c = add_(c, tmp[k + 1]);
-                if (lane == k + 1) mine_c = c;
-            }
-            cdf[lane] = (lane <= 62) ? mine_c : 3.0e38f;
-            wave_lds_fence();
-            tmp[lane] = zmid;                // bins
-            wave_lds_fence();
-            for (int m = 0; m < NF / 64; ++m) {
-                const int j = lane + 64 * m;
-                const float u = linspace01(j, NF);
-                int inds = 0;                // searchsorted(cdf[0..62], u, right=True)
-#pragma unroll
-                for (int stp = 32; stp >= 1; stp >>= 1) {
-                    const int t = inds + stp;
-                    if (t <= 63 && cdf[t - 1] <= u) inds = t;
-                }
-                const int below = max(inds - 1, 0), above = min(inds, 62);
-                const float cb = cdf[below], ca = cdf[above];
-                const float bb = tmp[below], ba = tmp[above];
-                float den = sub_(ca, cb);
-                if (den < 1e-5f) den = 1.0f;
-                const float t = div_(sub_(u, cb), den);
-                zf[j] = add_(bb, mul_(t, sub_(ba, bb)));
-            }
-            wave_lds_fence();
-            // ---- z_all = sort(cat(z, z_fine)): ranks by counting, no sortedness assumption on z_fine ----
-            const float myc = zc[lane];
-            int rank_f[3] = {0, 0, 0};
-            float myf[3] = {0, 0, 0};
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                if (m < NF / 64) {
-                    myf[m] = zf[lane + 64 * m];
-                    int cnt = 0;             // coarse values <= mine (zc strictly increasing)
-#pragma unroll
-                    for (int stp = 64; stp >= 1; stp >>= 1) {
-                        const int t = cnt + stp;
-                        if (t <= 64 && zc[t - 1] <= myf[m]) cnt = t;
-                    }
-                    rank_f[m] = cnt;
-                }
-            }
-            for (int i = 0; i < NF; ++i) {
-                const float v = zf[i];
-                rank_c += (v < myc) ? 1 : 0;
-#pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    const int j = lane + 64 * m;
-                    rank_f[m] += (v < myf[m] || (v == myf[m] && i < j)) ? 1 : 0;
-                }
-            }
-            float keep_h[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) keep_h[q] = park_h[q * 64 + lane];
-            wave_lds_fence();                // every read of zc / zf / tmp / cdf / park_h is done: the areas are reused
-            zall[rank_c] = myc;
-#pragma unroll
-            for (int m = 0; m < 3; ++m)
-                if (m < NF / 64) {
-                    zall[rank_f[m]] = myf[m];
-                    rank8[lane + 64 * m] = (unsigned char)rank_f[m];
-                }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) M[q * L::M_STRIDE + rank_c] = keep_h[q];
-            if (lane == 0) {                 // the merged compositing starts from scratch
-                st[RS_TH] = 1.0f;
-                st[RS_TC] = 1.0f;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) st[RS_RGB_H + k] = st[RS_RGB_C + k] = 0.f;
-            }
-            wave_lds_fence();
-#ifdef DFN_TIMING
-            T_pdf += __builtin_readcyclecounter() - tp0;
-#endif
-            phase = PH_FINE_H;
-            tile = 0;
-        } else if (phase == PH_FINE_H) {
-            if (lane < 32) {
-                M[ri] = a.sigma;
-                M[L::M_STRIDE + ri] = a.r;
-                M[2 * L::M_STRIDE + ri] = a.g;
-                M[3 * L::M_STRIDE + ri] = a.b;
-            }
-            if (++tile < KF) continue;
-            wave_lds_fence();
-            composite_merged(true, A.w_head);
-            if (!two) break;
-            phase = PH_FINE_T;
-            tile = 0;
-        } else {
-            if (lane < 32) {                 // the sample's head outputs are in M: replace them by the two-field mix
-                const volatile lds_f32* Mv = M;
-                const float sg_h = Mv[ri];
-                float fh[3] = {Mv[L::M_STRIDE + ri], Mv[2 * L::M_STRIDE + ri], Mv[3 * L::M_STRIDE + ri]};
-                const bool last = (ri == S - 1);
-                float s1, ssum, fm[3];
-                head_inputs(sg_h, fh, last, s1);
-                const float ft[3] = {b.r, b.g, b.b};
-                combine(sg_h, fh, b.sigma, ft, last, ssum, fm);
-                M[ri] = ssum;
-                M[L::M_STRIDE + ri] = fm[0];
-                M[2 * L::M_STRIDE + ri] = fm[1];
-                M[3 * L::M_STRIDE + ri] = fm[2];
-            }
-            if (++tile < KF) continue;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) M[q * L::M_STRIDE + rank_c] = keepc[q * 64 + lane];
-            wave_lds_fence();
-            composite_merged(false, A.w_com);
-            break;
-        }
-    }
-#ifdef DFN_TIMING
-    if (valid && lane == 0 && A.z_out) {
-        const unsigned long long T_end = __builtin_readcyclecounter();
-        const unsigned long long R_end = __builtin_amdgcn_s_memrealtime();
-        float* o = A.z_out + (size_t)r_raw * S + 64;
-        o[0] = (float)(T_end - T_start); o[1] = (float)(R_end - R_start); o[2] = (float)T_mlp; o[3] = (float)T_pdf;
-        o[4] = (float)s.t_wait; o[5] = (float)s.t_bar; o[6] = (float)s.t_issue; o[7] = (float)wave;
-    }
-#endif
-    if (valid && lane == 0) {
-        if (A.out_u8) {      // to8b (run_nerf_helpers.py:17): (255 * clip(x, 0, 1)) truncated, straight from the epilogue
-            unsigned char* o8h = (unsigned char*)A.rgb_head;
-            unsigned char* o8c = (unsigned char*)A.rgb_com;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                o8h[(size_t)r_raw * 3 + k] = (unsigned char)(int)mul_(255.0f, fminf(fmaxf(st[RS_RGB_H + k], 0.f), 1.f));
-                if (two && o8c)
-                    o8c[(size_t)r_raw * 3 + k] = (unsigned char)(int)mul_(255.0f, fminf(fmaxf(st[RS_RGB_C + k], 0.f), 1.f));
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                A.rgb_head[(size_t)r_raw * 3 + k] = st[RS_RGB_H + k];
-                if (two && A.rgb_com) A.rgb_com[(size_t)r_raw * 3 + k] = st[RS_RGB_C + k];
-            }
-        }
-    }
-    // drain the prefetched slabs before the LDS allocation is released
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// ================================================================================================
-// Decoder.forward on explicit points (decoder.py:277-349): 32 points per wave, one MLP pass
-// ================================================================================================
-template <int TIER, bool TORSO>
-__global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 256) void decoder_kernel(
-    const DecoderArgs A) {
-    using C = TierCfg<TIER>;
-    using L = KernelLds<TIER>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 31;
-    lds_char* lds = (lds_char*)smem;
-    Ctx ctx = {lds, wave, lane, lane >> 5, {}};
-    ctx.rec.act_T = nullptr;
-    ctx.rec.masks = nullptr;
-
-    Stream s;
-    s.base[0] = s.base[1] = A.wblob;
-    s.nslab[0] = s.nslab[1] = A.nslab;
-    s.sched = 0;
-    stream_begin<TIER>(s, lds, wave, lane);
-    constexpr bool torso = TORSO;
-    lds_f32* bias_l = (lds_f32*)(lds + (torso ? L::BIAS_T : L::BIAS_H));
-    for (int i = tid; i < A.n_bias; i += C::THREADS) bias_l[i] = A.bias[i];
-
-    lds_f32* scr = (lds_f32*)(lds + L::SCRATCH + wave * L::SCRATCH_PER_WAVE);
-    volatile lds_f32* dl = scr + 544;      // per-lane d/|d|: [3][64]
-    const long pt_raw = ((long)blockIdx.x * C::WAVES + wave) * 32 + n;
-    const long pt = pt_raw < A.n_points ? pt_raw : A.n_points - 1;
-    float p[3];
-    {
-        float d[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            p[k] = A.points[pt * 3 + k];
-            d[k] = A.dirs[pt * 3 + k];
-        }
-        const float nd = norm3(d);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) dl[64 * k + lane] = div_(d[k], nd);
-    }
-    __syncthreads();
-    const DhatRef dref = {dl + lane, 64};
-    MlpOut o;
-    if constexpr (torso) o = mlp_torso<TIER>(p, dref, bias_l, s, ctx);
-    else o = mlp_head<TIER>(p, dref, bias_l, s, ctx);
-    if (lane < 32 && pt_raw < A.n_points) {
-        A.feat[pt_raw * 3 + 0] = o.r;
-        A.feat[pt_raw * 3 + 1] = o.g;
-        A.feat[pt_raw * 3 + 2] = o.b;
-        A.sigma[pt_raw] = o.sigma;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// ---- launchers (called from dfn_api.hip) ---------------------------------------------------------------------
-template <typename K> static hipError_t set_lds(K kernel, int lds) {
-    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-}
-template <int TIER, bool TWO, bool TRAIN = false> static hipError_t launch_render_t(const RenderArgs& A, hipStream_t st) {
-    using C = TierCfg<TIER>;
-    const int lds = KernelLds<TIER, TWO>::TOTAL;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = set_lds(render_kernel<TIER, TWO, TRAIN>, lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    const int blocks = (A.frame.ray_count + C::WAVES - 1) / C::WAVES;
-    hipLaunchKernelGGL((render_kernel<TIER, TWO, TRAIN>), dim3(blocks), dim3(C::THREADS), lds, st, A);
-    return hipGetLastError();
-}
-template <int TIER, bool TORSO> static hipError_t launch_decoder_t(const DecoderArgs& A, hipStream_t st) {
-    using C = TierCfg<TIER>;
-    const int lds = KernelLds<TIER>::TOTAL;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = set_lds(decoder_kernel<TIER, TORSO>, lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    const long per_block = (long)C::WAVES * 32;
-    const int blocks = (int)((A.n_points + per_block - 1) / per_block);
-    hipLaunchKernelGGL((decoder_kernel<TIER, TORSO>), dim3(blocks), dim3(C::THREADS), lds, st, A);
-    return hipGetLastError();
-}
+hipError_t launch_render_f32(const RenderArgs& A, hipStream_t st);
+hipError_t launch_render_bf16(const RenderArgs& A, hipStream_t st);
+hipError_t launch_render_f16(const RenderArgs& A, hipStream_t st);
+hipError_t launch_decoder_f32(const DecoderArgs& A, hipStream_t st);
+hipError_t launch_decoder_bf16(const DecoderArgs& A, hipStream_t st);
+hipError_t launch_decoder_f16(const DecoderArgs& A, hipStream_t st);
 
 hipError_t launch_render(int tier, const RenderArgs& A, hipStream_t st) {
-    const bool two = A.frame.fields == 2;
-    if (A.samples_out) {     // training step: two fields, coarse only, recorder on
-        return tier == TIER_BF16 ? launch_render_t<TIER_BF16, true, true>(A, st)
-                                 : launch_render_t<TIER_F32, true, true>(A, st);
+    switch (tier) {
+    case TIER_BF16: return launch_render_bf16(A, st);
+    case TIER_F16: return launch_render_f16(A, st);
+    default: return launch_render_f32(A, st);
     }
-    if (tier == TIER_BF16)
-        return two ? launch_render_t<TIER_BF16, true>(A, st) : launch_render_t<TIER_BF16, false>(A, st);
-    return two ? launch_render_t<TIER_F32, true>(A, st) : launch_render_t<TIER_F32, false>(A, st);
 }
 hipError_t launch_decoder(int tier, const DecoderArgs& A, hipStream_t st) {
-    const bool torso = A.field == FIELD_TORSO;
-    if (tier == TIER_BF16)
-        return torso ? launch_decoder_t<TIER_BF16, true>(A, st) : launch_decoder_t<TIER_BF16, false>(A, st);
-    return torso ? launch_decoder_t<TIER_F32, true>(A, st) : launch_decoder_t<TIER_F32, false>(A, st);
+    switch (tier) {
+    case TIER_BF16: return launch_decoder_bf16(A, st);
+    case TIER_F16: return launch_decoder_f16(A, st);
+    default: return launch_decoder_f32(A, st);
+    }
 }
 
+// the 16-bit tiers share one program (same fragment counts and bias blob)
 void program_info(int tier, int field, ProgramInfo* out) {
-    if (tier == TIER_BF16) {
+    if (tier != TIER_F32) {
         using P = Prog<TIER_BF16>;
+        static_assert(Prog<TIER_F16>::H_FRAGS == P::H_FRAGS && Prog<TIER_F16>::T_FRAGS == P::T_FRAGS, "16-bit tiers");
         *out = field == FIELD_TORSO ? ProgramInfo{P::T_FRAGS, P::T_SLABS, P::T_NBIAS}
                                     : ProgramInfo{P::H_FRAGS, P::H_SLABS, P::H_NBIAS};
     } else {

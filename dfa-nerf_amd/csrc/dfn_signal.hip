@@ -142,11 +142,11 @@ __global__ __launch_bounds__(SIG_THREADS) void encode_signal_kernel(const float*
     const int f = frame_ids[blockIdx.x];
     for (int e = threadIdx.x; e < S * 512; e += blockDim.x) {
         const int t = e >> 9, k = e & 511, src = smo > 0 ? f - half + t : f;
-        xa[t * 512 + k] = (src >= 0 && src < N) ? auds[(long)src * 512 + k] : 0.f;      // zero rows outside, MAIN:36-57
+        xa[t * 512 + k] = (smo == 0 || (src >= 0 && src < N)) ? auds[(long)src * 512 + k] : 0.f;      // zero rows outside, MAIN:36-57
     }
     for (int e = threadIdx.x; e < S * 64; e += blockDim.x) {
         const int t = e >> 6, k = e & 63, src = smo > 0 ? f - half + t : f;
-        xe[t * 64 + k] = (src >= 0 && src < N) ? exps[(long)src * 64 + k] : 0.f;
+        xe[t * 64 + k] = (smo == 0 || (src >= 0 && src < N)) ? exps[(long)src * 64 + k] : 0.f;
     }
     __syncthreads();
     // AudioNet_W2L: 512 -> 256 -> 128 -> 64
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(SIG_THREADS) void encode_signal_torso_kernel(const 
     for (int e = threadIdx.x; e < S * 6; e += blockDim.x) {
         const int t = e / 6, c = e - t * 6, src = smo > 0 ? f - half + t : f;
         float v = 0.f;                                   // zero rows of (euler, trans) outside the sequence, MAIN:96-103
-        if (src >= 0 && src < N) {
+        if (smo == 0 || (src >= 0 && src < N)) {
             const float* R = poses + (long)src * pose_stride;        // rows of the pose matrix, 4 floats each
             if (c == 0) v = atan2f(R[2 * 4 + 2], R[1 * 4 + 2]);
             else if (c == 1) v = asinf(-R[0 * 4 + 2]);
@@ -442,11 +442,11 @@ __global__ __launch_bounds__(SIG_THREADS) void encode_signal_bwd_kernel(
     __shared__ float dout_s[96];
     for (int e = threadIdx.x; e < S * 512; e += blockDim.x) {
         const int t = e >> 9, k = e & 511, src = smo > 0 ? f - half + t : f;
-        xa[t * 512 + k] = (src >= 0 && src < N) ? auds[(long)src * 512 + k] : 0.f;
+        xa[t * 512 + k] = (smo == 0 || (src >= 0 && src < N)) ? auds[(long)src * 512 + k] : 0.f;
     }
     for (int e = threadIdx.x; e < S * 64; e += blockDim.x) {
         const int t = e >> 6, k = e & 63, src = smo > 0 ? f - half + t : f;
-        xe[t * 64 + k] = (src >= 0 && src < N) ? exps[(long)src * 64 + k] : 0.f;
+        xe[t * 64 + k] = (smo == 0 || (src >= 0 && src < N)) ? exps[(long)src * 64 + k] : 0.f;
     }
     for (int d = threadIdx.x; d < 96; d += blockDim.x) dout_s[d] = d_out[d];
     __syncthreads();
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(SIG_THREADS) void encode_signal_torso_bwd_kernel(co
     for (int e = threadIdx.x; e < S * 6; e += blockDim.x) {
         const int t = e / 6, c = e - t * 6, src = f - half + t;
         float v = 0.f;
-        if (src >= 0 && src < N) {
+        if (smo == 0 || (src >= 0 && src < N)) {
             const float* R = poses + (long)src * pose_stride;
             if (c == 0) v = atan2f(R[2 * 4 + 2], R[1 * 4 + 2]);
             else if (c == 1) v = asinf(-R[0 * 4 + 2]);

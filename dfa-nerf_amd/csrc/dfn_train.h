@@ -36,19 +36,27 @@ hipError_t launch_mlp_bwd(int tier, int field, const MlpBwdArgs& A, hipStream_t 
 hipError_t launch_mlp_bwd_bf16(bool torso, const MlpBwdArgs& A, hipStream_t st);     // dfn_bwd_bf16.hip
 void bwd_program_info(int tier, int field, ProgramInfo* out);
 hipError_t launch_composite_bwd(const CompositeBwdArgs& A, hipStream_t st);
+// Split-K partials: C [ksplit][c_stride] and dbias [ksplit][n_bias], one writer per element and slice (no atomics);
+// launch_reduce_scatter / launch_reduce_bias add the slices in index order (bit-reproducible gradients).
 hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, const int* prefix_dev, int total_items,
-                        const void* dy_T, const void* act_T, long NP, int ksplit, float* C, const int* e_of, float* dbias,
-                        hipStream_t st);
+                        const void* dy_T, const void* act_T, long NP, int ksplit, float* C, long c_stride, const int* e_of,
+                        float* dbias, int n_bias, hipStream_t st);
 // bf16 tier: one workgroup per (GEMM, slice of the points), operands through LDS (dfn_wgrad_bf16.hip); order = GEMMs by
 // decreasing size
 hipError_t launch_wgrad_bf16(int field, const WOp* ops_dev, const int* order_dev, int n_ops, const void* dy_T,
-                             const void* act_T, long NP, int ksplit, float* C, const int* e_of, float* dbias,
-                             hipStream_t st);
-hipError_t launch_scatter_add(const int* map, const float* dense, long n, float* grad_flat, hipStream_t st);
+                             const void* act_T, long NP, int ksplit, float* C, long c_stride, const int* e_of,
+                             float* dbias, int n_bias, hipStream_t st);
+// grad_flat[map[i]] += sum over the first `slices` slices of parts[.][i]   (i < n; map[i] < 0: structural padding)
+hipError_t launch_reduce_scatter(const int* map, const float* parts, long n, long stride, int slices, float* grad_flat,
+                                 hipStream_t st);
+// dbias[e] = sum over slices of parts[.][e] for the elements that have a gradient row (rows[e] >= 0), 0 otherwise
+hipError_t launch_reduce_bias(const int* rows, const float* parts, int n_bias, int slices, float* dbias, hipStream_t st);
+constexpr int BIAS_GRAD_SLICES = 128;      // slices of the points in the streaming bias_grad_kernel
 // macro-tile of one wgrad wave, in 32x32 output tiles (dfn_api.hip sizes the work list with the same numbers)
 constexpr int WG_MT = 2, WG_NT = 4;
 constexpr int WG_PF = 4;      // register prefetch depth of wgrad_kernel (f32 tier), in 8-point steps
-hipError_t launch_bias_grad(int tier, int field, const int* row_of, int n, const void* dy_T, long NP, float* dbias,
-                            hipStream_t st);
+// streaming row sums: parts [BIAS_GRAD_SLICES][n] (workspace), then launch_reduce_bias
+hipError_t launch_bias_grad(int tier, int field, const int* e_of, const int* rows, int n, const void* dy_T, long NP,
+                            float* parts, float* dbias, hipStream_t st);
 
 }  // namespace dfn

@@ -180,7 +180,8 @@ hipError_t launch_composite_bwd(const CompositeBwdArgs& A, hipStream_t st) {
 // f32 tier only: the bf16 tier shares the operands of a whole GEMM through LDS (dfn_wgrad_bf16.hip).
 __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, const int* work_prefix, const void* dy_T,
                                                     const void* act_T, long n_tiles, int g_rows, int a_rows,
-                                                    int ksplit, float* C, const int* e_of, float* dbias) {
+                                                    int ksplit, float* C, long c_stride, const int* e_of, float* dbias,
+                                                    int n_bias) {
     typedef float T;
     const int lane = threadIdx.x & 63;
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -271,11 +272,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int e = e_of[o.a_row + 32 * (WG_MT * mb + i) + tile_feat(lane >> 5, r)];
-                    if (e >= 0) atomicAdd(dbias + e, accb[i][r]);
+                    if (e >= 0) dbias[(long)ks * n_bias + e] = accb[i][r];      // one writer per (slice, element)
                 }
             }
     }
-    float* c = C + o.c_off;
+    float* c = C + (long)ks * c_stride + o.c_off;       // this wave's slice of the split-K partials (no atomics)
 #pragma unroll
     for (int i = 0; i < WG_MT; ++i)
 #pragma unroll
@@ -284,40 +285,58 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = 32 * (WG_MT * mb + i) + tile_feat(lane >> 5, r), col = 32 * (WG_NT * nb + j) + (lane & 31);
-                    atomicAdd(c + (long)row * o.N + col, acc[i][j][r]);
+                    c[(long)row * o.N + col] = acc[i][j][r];
                 }
             }
 }
 hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, const int* prefix_dev, int total_items,
-                        const void* dy_T, const void* act_T, long NP, int ksplit, float* C, const int* e_of, float* dbias,
-                        hipStream_t st) {
+                        const void* dy_T, const void* act_T, long NP, int ksplit, float* C, long c_stride, const int* e_of,
+                        float* dbias, int n_bias, hipStream_t st) {
     const int blocks = (total_items + 3) / 4;
     const bool torso = field == FIELD_TORSO;
     const int g_rows = torso ? GradMap::S_ROWS : GradMap::H_ROWS, a_rows = torso ? RecMap::S_ROWS : RecMap::H_ROWS;
     if (tier != TIER_F32) return hipErrorInvalidValue;          // bf16: launch_wgrad_bf16
     hipLaunchKernelGGL(wgrad_kernel, dim3(blocks), dim3(256), 0, st, ops_dev, n_ops, prefix_dev, dy_T, act_T, NP / 32,
-                       g_rows, a_rows, ksplit, C, e_of, dbias);
+                       g_rows, a_rows, ksplit, C, c_stride, e_of, dbias, n_bias);
     return hipGetLastError();
 }
 
-__global__ void scatter_add_kernel(const int* map, const float* dense, long n, float* grad_flat) {
+// grad_flat[map[i]] += parts[0][i] + parts[1][i] + ... (fixed order): the second stage of the split-K reduction
+__global__ void reduce_scatter_kernel(const int* map, const float* parts, long n, long stride, int slices, float* grad_flat) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int dst = map[i];
-    if (dst >= 0) grad_flat[dst] += dense[i];          // every parameter appears at most once per field
+    if (dst < 0) return;
+    float a = 0.f;
+    for (int k = 0; k < slices; ++k) a += parts[(long)k * stride + i];
+    grad_flat[dst] += a;          // every parameter appears at most once per field
 }
-hipError_t launch_scatter_add(const int* map, const float* dense, long n, float* grad_flat, hipStream_t st) {
-    hipLaunchKernelGGL(scatter_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, map, dense, n,
-                       grad_flat);
+hipError_t launch_reduce_scatter(const int* map, const float* parts, long n, long stride, int slices, float* grad_flat,
+                                 hipStream_t st) {
+    hipLaunchKernelGGL(reduce_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, map, parts, n, stride,
+                       slices, grad_flat);
+    return hipGetLastError();
+}
+__global__ void reduce_bias_kernel(const int* rows, const float* parts, int n_bias, int slices, float* dbias) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_bias) return;
+    float a = 0.f;
+    if (rows[e] >= 0)
+        for (int k = 0; k < slices; ++k) a += parts[(long)k * n_bias + e];
+    dbias[e] = a;
+}
+hipError_t launch_reduce_bias(const int* rows, const float* parts, int n_bias, int slices, float* dbias, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_bias_kernel, dim3((n_bias + 255) / 256), dim3(256), 0, st, rows, parts, n_bias, slices, dbias);
     return hipGetLastError();
 }
 
 // d(bias blob)[e] = sum over points of dy_T[.., row_of[e], ..]   (tile-major array [tile][rows][32]).
 // Streaming row sums: thread = one row, block = 256 consecutive rows, blockIdx.y = a slice of the tiles; a wave
-// reads 64 rows x 32 points = one contiguous 4 KiB (bf16) / 8 KiB (f32) run per tile.  Partial sums are added
-// atomically to the (zeroed) blob through e_of[row] (bias element of a row, -1 = none).
+// reads 64 rows x 32 points = one contiguous 4 KiB (bf16) / 8 KiB (f32) run per tile.  The partial sum of slice y goes
+// to parts[y][e_of[row]] (bias element of a row, -1 = none; one writer per slice and element), reduce_bias_kernel adds the
+// slices in order.
 template <typename T>
-__global__ void bias_grad_kernel(const int* e_of, const T* dy_T, long n_tiles, int rows, float* dbias) {
+__global__ void bias_grad_kernel(const int* e_of, const T* dy_T, long n_tiles, int rows, float* parts, int n_bias) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= rows) return;
     const int e = e_of[row];
@@ -344,20 +363,21 @@ __global__ void bias_grad_kernel(const int* e_of, const T* dy_T, long n_tiles, i
             }
         }
     }
-    atomicAdd(dbias + e, acc);
+    parts[(long)blockIdx.y * n_bias + e] = acc;
 }
-hipError_t launch_bias_grad(int tier, int field, const int* e_of, int n_bias, const void* dy_T, long NP, float* dbias,
-                            hipStream_t st) {
+hipError_t launch_bias_grad(int tier, int field, const int* e_of, const int* bias_rows, int n_bias, const void* dy_T,
+                            long NP, float* parts, float* dbias, hipStream_t st) {
     const int rows = field == FIELD_TORSO ? GradMap::S_ROWS : GradMap::H_ROWS;
-    hipError_t err = hipMemsetAsync(dbias, 0, (size_t)n_bias * sizeof(float), st);
-    if (err != hipSuccess) return err;
-    const dim3 grid((rows + 255) / 256, 128);
+    const dim3 grid((rows + 255) / 256, BIAS_GRAD_SLICES);
     if (tier == TIER_BF16)
         hipLaunchKernelGGL(bias_grad_kernel<__bf16>, grid, dim3(256), 0, st, e_of, (const __bf16*)dy_T, NP / 32, rows,
-                           dbias);
+                           parts, n_bias);
     else
-        hipLaunchKernelGGL(bias_grad_kernel<float>, grid, dim3(256), 0, st, e_of, (const float*)dy_T, NP / 32, rows, dbias);
-    return hipGetLastError();
+        hipLaunchKernelGGL(bias_grad_kernel<float>, grid, dim3(256), 0, st, e_of, (const float*)dy_T, NP / 32, rows, parts,
+                           n_bias);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    return launch_reduce_bias(bias_rows, parts, n_bias, BIAS_GRAD_SLICES, dbias, st);
 }
 
 }  // namespace dfn

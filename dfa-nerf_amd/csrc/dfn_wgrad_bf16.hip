@@ -31,7 +31,8 @@ template <int N> DFN_DEV void wl_wait_vm() { asm volatile("s_waitcnt vmcnt(%0) l
 
 __global__ __launch_bounds__(WL_THREADS) void wgrad_lds_kernel(const WOp* ops, const int* order, const void* dy_T,
                                                                 const void* act_T, long n_tiles, int g_rows, int a_rows,
-                                                                int ksplit, float* C, const int* e_of, float* dbias) {
+                                                                int ksplit, float* C, long c_stride, const int* e_of,
+                                                                float* dbias, int n_bias) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     lds_char* lds = (lds_char*)smem;
     const int lane = threadIdx.x & 63;
@@ -156,14 +157,17 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_lds_kernel(const WOp* ops, c
         }
     }
 
+    // Split-K WITHOUT atomics: this workgroup owns slice `ks` of the partial arrays (C: [ksplit][c_stride], dbias:
+    // [ksplit][n_bias]); every element of a slice has exactly one writer, and reduce_scatter_kernel / reduce_bias_kernel
+    // add the slices in index order - the gradients are bit-reproducible run to run (float atomicAdd was not).
     if (do_bias && (lane & 31) == 0) {          // every column of accb holds the row sums: take column 0
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int e = e_of[o.a_row + 32 * (4 * rg + cg) + tile_feat(lane >> 5, r)];
-            if (e >= 0) atomicAdd(dbias + e, accb[r]);
+            if (e >= 0) dbias[(long)ks * n_bias + e] = accb[r];
         }
     }
-    float* c = C + o.c_off;
+    float* c = C + (long)ks * c_stride + o.c_off;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -172,14 +176,14 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_lds_kernel(const WOp* ops, c
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = 32 * (4 * rg + i) + tile_feat(lane >> 5, r), col = 32 * (2 * cg + j) + (lane & 31);
-                    atomicAdd(c + (long)row * o.N + col, acc[i][j][r]);
+                    c[(long)row * o.N + col] = acc[i][j][r];
                 }
             }
 }
 
 hipError_t launch_wgrad_bf16(int field, const WOp* ops_dev, const int* order_dev, int n_ops, const void* dy_T,
-                             const void* act_T, long NP, int ksplit, float* C, const int* e_of, float* dbias,
-                             hipStream_t st) {
+                             const void* act_T, long NP, int ksplit, float* C, long c_stride, const int* e_of,
+                             float* dbias, int n_bias, hipStream_t st) {
     constexpr int lds = WL_DEPTH * WL_STEP_BYTES;
     static bool done = false;
     if (!done) {
@@ -190,7 +194,7 @@ hipError_t launch_wgrad_bf16(int field, const WOp* ops_dev, const int* order_dev
     const bool torso = field == FIELD_TORSO;
     const int g_rows = torso ? GradMap::S_ROWS : GradMap::H_ROWS, a_rows = torso ? RecMap::S_ROWS : RecMap::H_ROWS;
     hipLaunchKernelGGL(wgrad_lds_kernel, dim3(n_ops * ksplit), dim3(WL_THREADS), lds, st, ops_dev, order_dev, dy_T, act_T,
-                       NP / 32, g_rows, a_rows, ksplit, C, e_of, dbias);
+                       NP / 32, g_rows, a_rows, ksplit, C, c_stride, e_of, dbias, n_bias);
     return hipGetLastError();
 }
 

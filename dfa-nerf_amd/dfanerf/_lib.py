@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DFN_LIB: developer override (A/B builds of the kernels); the shipped path is the in-tree library
 LIB_PATH = os.environ.get("DFN_LIB") or os.path.join(_HERE, "libdfanerf.so")
 
-TIER_F32, TIER_BF16 = 0, 1
+TIER_F32, TIER_BF16, TIER_F16 = 0, 1, 2
 FIELD_HEAD, FIELD_TORSO, FIELD_LISTENER = 0, 1, 2
 N_DECODER_PARAMS = 955242
 
@@ -52,6 +52,7 @@ def _load():
         "dfn_render_fwd": (i32, [i32, C.POINTER(DfnFrame), vp, vp, fp, fp, fp, vp, ip, fp, fp, fp, fp, fp, vp]),
         "dfn_render_fwd_u8": (i32, [i32, C.POINTER(DfnFrame), vp, vp, fp, fp, fp, vp, ip, vp, vp, vp]),
         "dfn_decoder_fwd": (i32, [i32, i32, vp, fp, fp, fp, lg, fp, fp, vp]),
+        "dfn_decoder_train_fwd": (i32, [i32, i32, vp, fp, fp, fp, lg, fp, fp, fp, vp, vp, vp]),
         "dfn_get_rays": (i32, [i32, i32, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), fp, fp, vp]),
         "dfn_ndc_rays": (i32, [i32, i32, C.c_float, C.c_float, fp, fp, lg, fp, fp, vp]),
         "dfn_sample_pdf": (i32, [fp, fp, lg, i32, i32, fp, fp, vp]),
@@ -67,7 +68,7 @@ def _load():
         "dfn_mlp_bwd": (i32, [i32, i32, vp, fp, fp, vp, lg, vp, vp]),
         "dfn_weight_grad": (i32, [i32, i32, vp, vp, lg, fp, fp, vp]),
         "dfn_weight_bias_grad": (i32, [i32, i32, vp, vp, lg, fp, fp, fp, vp]),
-        "dfn_bias_grad": (i32, [i32, i32, vp, lg, fp, vp]),
+        "dfn_bias_grad": (i32, [i32, i32, vp, lg, fp, fp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = header and library out of sync

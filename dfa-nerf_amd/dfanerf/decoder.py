@@ -3,18 +3,17 @@ order (so the reference's .tar checkpoints load unchanged), same forward() signa
 
 Reference: /root/reference/NeRFs/DFANeRF/decoder.py:77-134 (DeformationField_ori), :137-349 (Decoder).
 
-forward() has two execution paths:
-  * no-grad (inference, rendering): the fused HIP decoder kernel (dfn_decoder_fwd) on the module's device.
-    There is no CPU fallback: calling forward() on CPU tensors under no_grad raises.
-  * grad mode (training): the same arithmetic expressed in ATen ops so that torch autograd provides the
-    backward pass.  (Round-1 status: the HIP forward/backward pair for training is the next step; see
-    DESIGN.md.)  This path also runs on CPU tensors, which is what the CPU unit tests use.
+Single backend: forward() always runs the fused HIP decoder on the module's device -
+  * no-grad (inference): dfn_decoder_fwd;
+  * grad mode (training on explicit points, as the reference's loop calls it, MAIN:855-866): the same kernel with its
+    recorder on and the HIP backward chain behind a torch.autograd.Function (training.DecoderTrainFn).
+There is no ATen / CPU path in this module: CPU tensors raise.  (The torch-op restatement the tests cross-check against
+lives in tests/twins.py.)
 """
 import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 
 class DeformationField_ori(nn.Module):
@@ -36,19 +35,9 @@ class DeformationField_ori(nn.Module):
             self.fc_embed_skips = nn.ModuleList([nn.Linear(dim_embed, hidden_size) for _ in range(n_skips)])
             self.fc_signal_skips = nn.ModuleList([nn.Linear(dim_signal, hidden_size) for _ in range(n_skips)])
 
-    def _branch(self, x, blocks, skips, skip_in, out):
-        net, k = x, 0
-        for idx, layer in enumerate(blocks):
-            net = F.relu(layer(net))
-            if (idx + 1) in self.skips and idx < len(blocks) - 1:
-                net = net + skips[k](skip_in)
-                k += 1
-        return out(net)
-
     def forward(self, x):
-        embed, signal = x[..., :self.dim_embed], x[..., -self.dim_signal:]
-        return torch.cat((self._branch(x, self.blocks_embed, self.fc_embed_skips, embed, self.out_embed),
-                          self._branch(x, self.blocks_signal, self.fc_signal_skips, signal, self.out_signal)), -1)
+        raise RuntimeError("DeformationField_ori is evaluated inside the fused HIP decoder (Decoder.forward, "
+                           "head_or_torso='torso'); it has no stand-alone path")
 
 
 class Decoder(nn.Module):
@@ -143,54 +132,20 @@ class Decoder(nn.Module):
             if self.use_expression and signal[1] is not None:
                 raise NotImplementedError("expression branch (use_expression) is not enabled by the reference scripts")
             signal = signal[0]
-        needs_grad = torch.is_grad_enabled() and (
-            any(p.requires_grad for p in self.parameters()) or p_in.requires_grad or
-            (signal is not None and signal.requires_grad))
-        if needs_grad or ray_d is None or z_shape is None or z_app is None:
-            return self._forward_aten(p_in, ray_d, z_shape, z_app, signal, head_or_torso)
+        if ray_d is None or z_shape is None or z_app is None:
+            raise ValueError("Decoder.forward needs ray_d, z_shape and z_app (the reference's random-latent default, "
+                             "decoder.py:282-287, is never used by its driver)")
         if not p_in.is_cuda:
-            raise RuntimeError("Decoder.forward under no_grad runs the HIP kernel and needs device tensors "
+            raise RuntimeError("Decoder.forward runs the fused HIP kernel and needs device tensors "
                                "(there is no CPU fallback)")
         from . import engine
         field = 1 if head_or_torso == 'torso' else (0 if signal is not None else 2)
+        needs_grad = torch.is_grad_enabled() and (
+            any(p.requires_grad for p in self.parameters()) or (signal is not None and signal.requires_grad))
+        if needs_grad:
+            from . import training
+            return training.decoder_train(self, field, p_in, ray_d, z_shape, z_app, signal, tier)
         pk = self.packed(tier)
         bias = pk.fold_single(field, signal, z_shape.reshape(-1)[:self.z_dim], z_app.reshape(-1)[:self.z_dim])
         feat, sigma = engine.decoder_forward(pk, field, bias, p_in.reshape(-1, 3), ray_d.reshape(-1, 3))
         return feat.reshape(p_in.shape[0], -1, 3), sigma.reshape(p_in.shape[0], -1)
-
-    def _forward_aten(self, p_in, ray_d, z_shape, z_app, signal, head_or_torso):
-        if self.z_dim > 0:
-            if z_shape is None:
-                z_shape = torch.randn(p_in.shape[0], self.z_dim).to(p_in.device)
-            if z_app is None:
-                z_app = torch.randn(p_in.shape[0], self.z_dim).to(p_in.device)
-        p = self.transform_points(p_in)
-        if signal is not None:
-            p = torch.cat((p, signal.expand(p.shape[1], -1).unsqueeze(0)), -1)
-        if head_or_torso == 'torso':
-            if self.use_deformation_field:
-                p = self.deform_net(p) + p
-            net, p_skip = self.fc_in_torso(p), self.fc_p_skips_torso
-        elif signal is not None:
-            net, p_skip = self.fc_in(p), self.fc_p_skips
-        else:
-            net, p_skip = self.fc_in_listener(p), self.fc_p_skips_listener
-        net = F.relu(net + self.fc_z(z_shape).unsqueeze(1))
-        k = 0
-        for idx, layer in enumerate(self.blocks):
-            net = F.relu(layer(net))
-            if (idx + 1) in self.skips and idx < len(self.blocks) - 1:
-                net = net + self.fc_z_skips[k](z_shape).unsqueeze(1) + p_skip[k](p)
-                k += 1
-        sigma_out = self.sigma_out(net).squeeze(-1)
-        net = self.feat_view(net) + self.fc_z_view(z_app).unsqueeze(1)
-        if self.use_viewdirs and ray_d is not None:
-            d = ray_d / torch.norm(ray_d, dim=-1, keepdim=True)
-            net = F.relu(net + self.fc_view(self.transform_points(d, views=True)))
-            if self.n_blocks_view > 1:
-                for layer in self.blocks_view:
-                    net = F.relu(layer(net))
-        feat_out = self.feat_out(net)
-        if self.final_sigmoid_activation:
-            feat_out = torch.sigmoid(feat_out)
-        return feat_out, sigma_out

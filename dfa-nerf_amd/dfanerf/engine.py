@@ -9,10 +9,12 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (DfnFrame, FIELD_HEAD, FIELD_LISTENER, FIELD_TORSO, N_DECODER_PARAMS, TIER_BF16, TIER_F32, check,
-                   lib)
+from ._lib import (DfnFrame, FIELD_HEAD, FIELD_LISTENER, FIELD_TORSO, N_DECODER_PARAMS, TIER_BF16, TIER_F16, TIER_F32,
+                   check, lib)
 
-TIERS = {"f32": TIER_F32, "bf16": TIER_BF16, TIER_F32: TIER_F32, TIER_BF16: TIER_BF16}
+# "f16": v_mfma_f32_32x32x16_f16, the throughput tier (inference only); "bf16": also the 16-bit training tier
+TIERS = {"f32": TIER_F32, "bf16": TIER_BF16, "f16": TIER_F16, TIER_F32: TIER_F32, TIER_BF16: TIER_BF16,
+         TIER_F16: TIER_F16}
 
 
 def _stream():
@@ -171,6 +173,9 @@ def render(packed, bias, frame, bg, pix_index=None, want_weights=False, out_head
     two = frame.fields == 2
     rgb_h = out_head if out_head is not None else torch.empty(n, 3, dtype=torch.float32, device=dev)
     rgb_c = (out_com if out_com is not None else torch.empty(n, 3, dtype=torch.float32, device=dev)) if two else None
+    for o in (rgb_h, rgb_c):
+        if o is not None and (o.dtype != torch.float32 or not o.is_contiguous() or o.numel() != n * 3):
+            raise ValueError("render: output buffers must be contiguous float32 [ray_count, 3]")
     S = frame.n_coarse + frame.n_fine
     w_h = torch.empty(n, S, dtype=torch.float32, device=dev) if want_weights else None
     w_c = torch.empty(n, S, dtype=torch.float32, device=dev) if (want_weights and two) else None
@@ -195,13 +200,16 @@ def render(packed, bias, frame, bg, pix_index=None, want_weights=False, out_head
     return out
 
 
-def render_u8(packed, bias, frame, bg, pix_index=None):
+def render_u8(packed, bias, frame, bg, pix_index=None, out_head=None, out_com=None):
     """dfn_render_fwd_u8: the same launch with to8b fused into the epilogue -> uint8 [n,3] images (head, composite)."""
     dev = packed.device
     n = frame.ray_count
     two = frame.fields == 2
-    out_h = torch.empty(n, 3, dtype=torch.uint8, device=dev)
-    out_c = torch.empty(n, 3, dtype=torch.uint8, device=dev) if two else None
+    out_h = out_head if out_head is not None else torch.empty(n, 3, dtype=torch.uint8, device=dev)
+    out_c = (out_com if out_com is not None else torch.empty(n, 3, dtype=torch.uint8, device=dev)) if two else None
+    for o in (out_h, out_c):
+        if o is not None and (o.dtype != torch.uint8 or not o.is_contiguous() or o.numel() != n * 3):
+            raise ValueError("render_u8: output buffers must be contiguous uint8 [ray_count, 3]")
     bg_f32 = bg if bg.dtype == torch.float32 else None
     bg_u8 = bg if bg.dtype == torch.uint8 else None
     if bg_f32 is None and bg_u8 is None:
@@ -304,6 +312,6 @@ def to8b(x):
 
 
 def mfma_layout_probe(device="cuda"):
-    out = torch.zeros(2, 32, 32, dtype=torch.float32, device=device)
+    out = torch.zeros(3, 32, 32, dtype=torch.float32, device=device)
     check(lib.dfn_debug_mfma_layout(_ptr(out), _stream()), "dfn_debug_mfma_layout")
     return out

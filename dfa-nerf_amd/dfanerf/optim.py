@@ -5,8 +5,9 @@ torch's fused multi-tensor kernel gives a block a 64 K-element chunk: the decode
 its step takes 104 us on an MI355X, the five optimizers of a training step 250 us; dfn_adam_multi cuts tensors into
 2048-element chunks and is bound by the bytes it moves.  Same update rule and the same state / state_dict layout as
 torch.optim.Adam(fused=True) (state[p] = {"step": 0-dim f32 device tensor, "exp_avg", "exp_avg_sq"}), so checkpoints
-move freely between the two; anything this class does not cover (weight decay, amsgrad, maximize, non-f32 or
-non-contiguous tensors, parameters of one group at different step counts) goes through torch's own step()."""
+move freely between the two; parameters of one group at different step counts (a resumed reference checkpoint has no
+state for the parameters its autograd never reached) are stepped in one launch per distinct count; anything this class
+does not cover (weight decay, amsgrad, maximize, non-f32 or non-contiguous tensors) goes through torch's own step()."""
 import ctypes as C
 import math
 
@@ -33,14 +34,17 @@ def _bump_versions(tensors):
 class HipAdam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, lr=lr, betas=betas, eps=eps, fused=True)
-        self._cache = {}           # group index -> {"pkey", "gkey", "ps", "items", "chunks", "n_chunks", "t"}
+        # group index -> {"pkey", "gkey", "buckets": [{"ps", "t", "items", "chunks", "n_chunks", "host"}]}: one bucket
+        # (= one launch) per distinct step count of the group's parameters
+        self._cache = {}
 
-    # ---- state bookkeeping: torch keeps a step counter per parameter, the launch needs one per group -------------
+    # ---- state bookkeeping: torch keeps a step counter per parameter, a launch needs one per bucket ---------------
     def _sync_steps(self):
         for c in self._cache.values():
-            if c.get("t") is not None:
-                torch._foreach_zero_([self.state[p]["step"] for p in c["ps"]])
-                torch._foreach_add_([self.state[p]["step"] for p in c["ps"]], float(c["t"]))
+            for b in c["buckets"]:
+                steps = [self.state[p]["step"] for p in b["ps"]]
+                torch._foreach_zero_(steps)
+                torch._foreach_add_(steps, float(b["t"]))
 
     def state_dict(self):
         self._sync_steps()
@@ -58,7 +62,8 @@ class HipAdam(torch.optim.Adam):
     def _build(self, gi, ps, pkey, gkey):
         old = self._cache.get(gi)
         if old is not None and old["pkey"] == pkey:
-            t = old["t"]                       # same parameters, new gradient buffers: the count carries on
+            # same parameters, new gradient buffers: the counts carry on
+            counts = {id(p): b["t"] for b in old["buckets"] for p in b["ps"]}
         else:
             if old is not None:
                 self._sync_steps()
@@ -68,25 +73,29 @@ class HipAdam(torch.optim.Adam):
                     st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            # one device-to-host copy when the table is (re)built - e.g. after load_state_dict: a resumed reference
+            # checkpoint holds no state for parameters whose gradients were None upstream, so counts can differ
             steps = torch.stack([self.state[p]["step"].reshape(()).to(ps[0].device) for p in ps]).cpu()
-            if not bool((steps == steps[0]).all()):
-                return None
-            t = int(steps[0].item())
-        items = np.zeros((len(ps), 5), dtype=np.int64)
-        chunks = []
-        for i, p in enumerate(ps):
-            st = self.state[p]
-            m, v = st["exp_avg"], st["exp_avg_sq"]
-            if not (m.is_contiguous() and v.is_contiguous() and m.dtype == torch.float32 and v.dtype == torch.float32):
-                return None
-            items[i] = (p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
-            chunks.extend((i, k) for k in range((p.numel() + ADAM_CHUNK - 1) // ADAM_CHUNK))
+            counts = {id(p): int(s) for p, s in zip(ps, steps.tolist())}
         dev = ps[0].device
-        # pinned + asynchronous: a pageable upload would block the host until the stream has drained
-        h_items = torch.from_numpy(items).pin_memory()
-        h_chunks = torch.from_numpy(np.asarray(chunks, dtype=np.int32).reshape(-1, 2)).pin_memory()
-        c = {"pkey": pkey, "gkey": gkey, "ps": ps, "t": t, "n_chunks": len(chunks), "host": (h_items, h_chunks),
-             "items": h_items.to(dev, non_blocking=True), "chunks": h_chunks.to(dev, non_blocking=True)}
+        buckets = []
+        for t in sorted(set(counts[id(p)] for p in ps)):
+            bps = [p for p in ps if counts[id(p)] == t]
+            items = np.zeros((len(bps), 5), dtype=np.int64)
+            chunks = []
+            for i, p in enumerate(bps):
+                st = self.state[p]
+                m, v = st["exp_avg"], st["exp_avg_sq"]
+                if not (m.is_contiguous() and v.is_contiguous() and m.dtype == torch.float32 and v.dtype == torch.float32):
+                    return None
+                items[i] = (p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
+                chunks.extend((i, k) for k in range((p.numel() + ADAM_CHUNK - 1) // ADAM_CHUNK))
+            # pinned + asynchronous: a pageable upload would block the host until the stream has drained
+            h_items = torch.from_numpy(items).pin_memory()
+            h_chunks = torch.from_numpy(np.asarray(chunks, dtype=np.int32).reshape(-1, 2)).pin_memory()
+            buckets.append({"ps": bps, "t": t, "n_chunks": len(chunks), "host": (h_items, h_chunks),
+                            "items": h_items.to(dev, non_blocking=True), "chunks": h_chunks.to(dev, non_blocking=True)})
+        c = {"pkey": pkey, "gkey": gkey, "buckets": buckets}
         self._cache[gi] = c
         return c
 
@@ -118,13 +127,16 @@ class HipAdam(torch.optim.Adam):
                     return self._torch_step(None) or loss
             plans.append((group, c))
         for group, c in plans:
-            c["t"] += 1
-            t, (b1, b2) = c["t"], group["betas"]
-            st = C.c_void_p(torch.cuda.current_stream(c["ps"][0].device).cuda_stream)
-            check(lib.dfn_adam_multi(C.c_void_p(c["items"].data_ptr()), C.c_void_p(c["chunks"].data_ptr()), c["n_chunks"],
-                                     float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                     float(1.0 - b1 ** t), float(math.sqrt(1.0 - b2 ** t)), st), "dfn_adam_multi")
-            # the kernel wrote the parameters behind torch's back: bump their version counters like an in-place op would,
-            # or everything keyed on them (Decoder.packed()'s repack-on-change, autograd's saved-tensor checks) goes stale
-            _bump_versions(c["ps"])
+            b1, b2 = group["betas"]
+            for b in c["buckets"]:
+                b["t"] += 1
+                t = b["t"]
+                st = C.c_void_p(torch.cuda.current_stream(b["ps"][0].device).cuda_stream)
+                check(lib.dfn_adam_multi(C.c_void_p(b["items"].data_ptr()), C.c_void_p(b["chunks"].data_ptr()),
+                                         b["n_chunks"], float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                         float(1.0 - b1 ** t), float(math.sqrt(1.0 - b2 ** t)), st), "dfn_adam_multi")
+                # the kernel wrote the parameters behind torch's back: bump their version counters like an in-place op
+                # would, or everything keyed on them (Decoder.packed()'s repack-on-change, autograd's saved-tensor
+                # checks) goes stale
+                _bump_versions(b["ps"])
         return loss

@@ -50,6 +50,41 @@ def gather_rays(shard, n_rays, group=None):
     return out[:n_rays]
 
 
+def broadcast_replicas(nets, opts, extra=(), src=0, group=None):
+    """Make every rank's replica identical to rank `src`'s: all parameters and buffers of `nets` (dict of modules), the
+    per-parameter Adam state of `opts` (dict of optimizers; state entries that exist on `src` are created elsewhere) and
+    the tensors in `extra` (returned, broadcast).  Called once after create_nerf / load_checkpoint: FlatGradBucket only
+    averages gradients, so replicas that start different stay different."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return list(extra)
+    with torch.no_grad():
+        for k in sorted(nets):
+            for t in list(nets[k].parameters()) + list(nets[k].buffers()):
+                dist.broadcast(t.data, src=src, group=group)
+        for k in sorted(opts):
+            sd = [opts[k].state_dict()] if dist.get_rank(group) == src else [None]
+            dist.broadcast_object_list(sd, src=src, group=group)
+            if dist.get_rank(group) != src:
+                dev = next(iter(nets[k].parameters())).device if k in nets else None
+                opts[k].load_state_dict(_to_device(sd[0], dev))
+        out = []
+        for t in extra:
+            t = t.contiguous()
+            dist.broadcast(t, src=src, group=group)
+            out.append(t)
+    return out
+
+
+def _to_device(obj, dev):
+    if isinstance(obj, torch.Tensor):
+        return obj.to(dev) if dev is not None else obj
+    if isinstance(obj, dict):
+        return {k: _to_device(v, dev) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_to_device(v, dev) for v in obj)
+    return obj
+
+
 class FlatGradBucket:
     """One flat fp32 buffer for the gradients of several modules -> a single all_reduce per step."""
 

@@ -22,8 +22,6 @@ import time
 
 import numpy as np
 import torch
-import torch.nn as nn
-import torch.nn.functional as F
 
 from . import parallel
 from .decoder import Decoder
@@ -96,7 +94,9 @@ _FLAGS = [
     ("use_aud_net", None, None), ("use_ori", None, None), ("test_offset", int, 0),
 ]
 # build-side additions (not in the reference): precision tier of the HIP renderer and the hierarchical mode
-_EXTRA_FLAGS = [("hip_tier", str, 'f32'), ("hierarchical", None, None), ("train_aten", None, None)]
+# --hip_tier: f32 (exact, the parity tier; default) | f16 (the throughput tier: f16 MFMA operands, PSNR-gated) | bf16
+# (the 16-bit TRAINING tier; also selected for the training step when --hip_tier f16)
+_EXTRA_FLAGS = [("hip_tier", str, 'f32'), ("hierarchical", None, None)]
 
 
 def config_parser():
@@ -136,60 +136,46 @@ def euler2rot(euler_angle):
 # ------------------------------------------------------------------------------------------------------------
 # compositing API
 # ------------------------------------------------------------------------------------------------------------
-def _use_hip(*tensors):
-    return all(t.is_cuda for t in tensors) and not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors))
+def _need_device(name, *tensors):
+    if not all(t.is_cuda for t in tensors):
+        raise RuntimeError(f"{name} runs the HIP kernel and needs device tensors (there is no CPU fallback)")
 
 
 def composite_function(sigma, feat):
-    """sigma [K,B,R,S], feat [K,B,R,S,3] -> sigma_sum [B,R,S], feat_weighted [B,R,S,3]."""
-    if _use_hip(sigma, feat):
-        from . import engine
-        return engine.composite(sigma, feat)
-    if sigma.shape[0] > 1:
-        denom = torch.sum(sigma, dim=0, keepdim=True)
-        denom = torch.where(denom == 0, torch.full_like(denom, 1e-4), denom)
-        return torch.sum(sigma, dim=0), (feat * (sigma / denom).unsqueeze(-1)).sum(0)
-    return sigma.squeeze(0), feat.squeeze(0)
+    """sigma [K,B,R,S], feat [K,B,R,S,3] -> sigma_sum [B,R,S], feat_weighted [B,R,S,3]  (dfn_composite; forward only:
+    the differentiable compositing of the training step is inside the fused renderer, training.FusedTrainFn)."""
+    _need_device("composite_function", sigma, feat)
+    from . import engine
+    return engine.composite(sigma.detach(), feat.detach())
 
 
 def calc_volume_weights(z_vals, ray_vector, sigma, last_dist=1e10):
-    """z [B,R,S], ray_vector [B,R,3], sigma [B,R,S] -> weights [B,R,S]."""
-    if _use_hip(z_vals, ray_vector, sigma):
-        from . import engine
-        return engine.volume_weights(z_vals, ray_vector, sigma, last_dist)
-    dists = z_vals[..., 1:] - z_vals[..., :-1]
-    dists = torch.cat([dists, torch.full_like(dists[..., :1], last_dist)], dim=-1)
-    dists = dists * torch.norm(ray_vector, dim=-1, keepdim=True)
-    alpha = 1. - torch.exp(-(F.relu(sigma) + 1e-6) * dists)
-    trans = torch.cumprod(torch.cat([torch.ones_like(alpha[..., :1]), (1. - alpha + 1e-10)], dim=-1), dim=-1)
-    return alpha * trans[..., :-1]
-
-
-def _bump_last(sigma, on):
-    """relu(sigma) with +1e-6 on the last sample of the last stacked field (MAIN:692-694), out of place."""
-    sigma = F.relu(sigma)
-    if not on:
-        return sigma
-    bump = torch.zeros(sigma.shape[-1], device=sigma.device, dtype=sigma.dtype)
-    bump[-1] = 1e-6
-    return torch.cat([sigma[:-1], sigma[-1:] + bump], 0)
+    """z [B,R,S], ray_vector [B,R,3], sigma [B,R,S] -> weights [B,R,S]  (dfn_volume_weights; forward only)."""
+    _need_device("calc_volume_weights", z_vals, ray_vector, sigma)
+    from . import engine
+    return engine.volume_weights(z_vals.detach(), ray_vector.detach(), sigma.detach(), last_dist)
 
 
 def render_rays(decoder, p_i, r_i, z_shape_i, z_app_i, signal, head_or_torso, batch_size, bc_rgb, view_dir, z_vals,
                 args, coarse_or_fine='coarse', raw_noise_std=0):
-    """One field through decoder -> bg / sigma fix-ups -> composite -> weights -> (rgb, weights).
-    p_i, r_i [B, R*S, 3]; bc_rgb [B,R,1,3]; view_dir [B,R,3]; z_vals [B,R,S]."""
+    """One field through decoder -> bg / sigma fix-ups -> composite -> weights -> (rgb, weights)   (MAIN:114-143; dead
+    upstream - TypeError at :138 - here with the semantics of the live inline renderer MAIN:653-709 for one field).
+    p_i, r_i [B, R*S, 3]; bc_rgb [B,R,1,3]; view_dir [B,R,3]; z_vals [B,R,S].  Inference entry point (every stage a
+    HIP launch: dfn_decoder_fwd, dfn_composite, dfn_volume_weights); the training step differentiates the fused
+    renderer instead (training.render_train)."""
     S = args.N_samples + (args.N_importance if coarse_or_fine == 'fine' else 0)
-    feat_i, sigma_i = decoder(p_i, r_i, z_shape_i, z_app_i, signal, head_or_torso)
-    sigma_i = sigma_i.reshape(batch_size, -1, S)
-    feat_i = feat_i.reshape(batch_size, -1, S, 3)
-    if args.concate_bg:
-        feat_i = torch.cat((feat_i[..., :-1, :], bc_rgb), dim=-2)
-    sigma = _bump_last(torch.stack([sigma_i], dim=0), args.concate_bg)
-    feat = torch.stack([feat_i], dim=0)
-    sigma_sum, feat_weighted = composite_function(sigma, feat)
-    weights = calc_volume_weights(z_vals, view_dir, sigma_sum, last_dist=args.last_dist)
-    rgb = torch.sum(weights.unsqueeze(-1) * feat_weighted, dim=-2).squeeze(0)
+    with torch.no_grad():
+        feat_i, sigma_i = decoder(p_i, r_i, z_shape_i, z_app_i, signal, head_or_torso)
+        sigma_i = sigma_i.reshape(batch_size, -1, S)
+        feat_i = feat_i.reshape(batch_size, -1, S, 3)
+        if args.concate_bg:
+            feat_i = torch.cat((feat_i[..., :-1, :], bc_rgb.to(feat_i)), dim=-2)          # MAIN:669-671
+        sigma = torch.clamp_min(sigma_i, 0.0)                                              # MAIN:688 F.relu
+        if args.concate_bg:
+            sigma[..., -1] += 1e-6                                                         # MAIN:692-694
+        sigma_sum, feat_weighted = composite_function(sigma.unsqueeze(0), feat_i.unsqueeze(0))
+        weights = calc_volume_weights(z_vals, view_dir, sigma_sum, last_dist=args.last_dist)
+        rgb = torch.sum(weights.unsqueeze(-1) * feat_weighted, dim=-2).squeeze(0)          # MAIN:706
     return rgb, weights
 
 
@@ -266,8 +252,9 @@ class FrameRenderer:
         self.n_fine = args.N_importance if getattr(args, "hierarchical", False) else 0
 
     def render(self, pose, pose_body, signal, signal_torso, ray_begin=0, ray_count=None, pix_index=None, fields=2,
-               out_u8=False):
-        """-> rgb_head [n,3], rgb_com [n,3] (None if fields == 1); out_u8: uint8 images, to8b fused into the kernel."""
+               out_u8=False, out=None):
+        """-> rgb_head [n,3], rgb_com [n,3] (None if fields == 1); out_u8: uint8 images, to8b fused into the kernel;
+        out: (head, com) tensors the kernel writes into (e.g. slices of the shard that is gathered)."""
         eng = self.engine
         pk = self.decoder.packed(self.tier)
         bias = pk.fold(signal[0] if isinstance(signal, (list, tuple)) else signal,
@@ -278,21 +265,33 @@ class FrameRenderer:
         fr = eng.make_frame(self.H, self.W, self.focal, self.cx, self.cy, _host(pose), _host(pose_body), self.near,
                             self.far, self.args.last_dist, ray_begin, n, self.args.N_samples, self.n_fine, fields,
                             self.args.concate_bg)
+        oh, oc = out if out is not None else (None, None)
         if out_u8:
-            return eng.render_u8(pk, bias, fr, self.bg, pix_index=pix_index)
-        return eng.render(pk, bias, fr, self.bg, pix_index=pix_index)
+            return eng.render_u8(pk, bias, fr, self.bg, pix_index=pix_index, out_head=oh, out_com=oc)
+        return eng.render(pk, bias, fr, self.bg, pix_index=pix_index, out_head=oh, out_com=oc)
 
     def render_image(self, pose, pose_body, signal, signal_torso, fields=2, out_u8=False):
         """Whole frame, sharded over the ranks when torch.distributed is initialised -> [H,W,3] images
-        (float32, or uint8 with out_u8: 76 KB instead of 304 KB per rank in the gather)."""
+        (float32, or uint8 with out_u8: 76 KB instead of 304 KB per rank in the gather).  ONE collective per frame:
+        the kernel writes both images into one padded [n_img, per, 3] shard, all_gather_into_tensor moves it."""
         import torch.distributed as dist
         R = self.H * self.W
         if dist.is_initialized() and dist.get_world_size() > 1:
-            begin, count, per = parallel.shard_range(R, dist.get_world_size(), dist.get_rank())
-            rh, rc = self.render(pose, pose_body, signal, signal_torso, begin, count, fields=fields, out_u8=out_u8)
-            pad = lambda x: torch.cat([x, x.new_zeros(per - x.shape[0], 3)]) if x.shape[0] < per else x
-            rh = parallel.gather_rays(pad(rh), R)
-            rc = parallel.gather_rays(pad(rc), R) if rc is not None else None
+            world = dist.get_world_size()
+            begin, count, per = parallel.shard_range(R, world, dist.get_rank())
+            n_img = 2 if fields == 2 else 1
+            key = (n_img, per, out_u8, world)
+            if getattr(self, "_shard_key", None) != key:
+                dt = torch.uint8 if out_u8 else torch.float32
+                self._shard = torch.zeros(n_img, per, 3, dtype=dt, device=self.bg.device)
+                self._gathered = torch.empty(world, n_img, per, 3, dtype=dt, device=self.bg.device)
+                self._shard_key = key
+            out = (self._shard[0, :count], self._shard[1, :count] if fields == 2 else None)
+            if count:
+                self.render(pose, pose_body, signal, signal_torso, begin, count, fields=fields, out_u8=out_u8, out=out)
+            dist.all_gather_into_tensor(self._gathered, self._shard)
+            g = self._gathered.permute(1, 0, 2, 3).reshape(n_img, world * per, 3)[:, :R]
+            rh, rc = g[0], (g[1] if fields == 2 else None)
         else:
             rh, rc = self.render(pose, pose_body, signal, signal_torso, fields=fields, out_u8=out_u8)
         return rh.reshape(self.H, self.W, 3), (rc.reshape(self.H, self.W, 3) if rc is not None else None)
@@ -305,15 +304,14 @@ def run_network(inputs, viewdirs, decoder, z_shape, z_app, signal, head_or_torso
 
 
 def make_adam(params, lr):
-    """torch.optim.Adam(lr, betas=(0.9, 0.999)) as upstream (MAIN:522-547).  On the GPU: optim.HipAdam, the same
-    optimizer (update rule, state_dict layout) with step() as one dfn_adam_multi launch - torch's fused multi-tensor
-    kernel takes 104 us for the decoder's 68 tensors, the five optimizers 250 us of a 2.9 ms step (its foreach
-    implementation another 1 ms of host time)."""
+    """torch.optim.Adam(lr, betas=(0.9, 0.999)) as upstream (MAIN:522-547), as optim.HipAdam: the same optimizer (update
+    rule, state_dict layout) with step() as one dfn_adam_multi launch per distinct step count - torch's fused
+    multi-tensor kernel takes 104 us for the decoder's 68 tensors, the five optimizers 250 us of a 2.9 ms step."""
     params = list(params)
-    if params and all(p.is_cuda for p in params):
-        from .optim import HipAdam
-        return HipAdam(params, lr=lr, betas=(0.9, 0.999))
-    return torch.optim.Adam(params=params, lr=lr, betas=(0.9, 0.999))
+    if not params or not all(p.is_cuda for p in params):
+        raise RuntimeError("make_adam: the parameters must live on the GPU (HipAdam; there is no CPU path)")
+    from .optim import HipAdam
+    return HipAdam(params, lr=lr, betas=(0.9, 0.999))
 
 
 def create_nerf(args, dev=None):
@@ -424,53 +422,6 @@ def select_coords(H, W, N_rand, sample_rate, rect, rng=np.random):
     return np.stack([sel // W, sel % W], 1).astype(np.int64)
 
 
-def train_step_loss(nets, dataset, itr_obj, img_i, sel_yx, target_head, target_com, z_shape, z_app, global_step, args,
-                    len_train, embed_fn, pose_torso):
-    """Forward of one training step (MAIN:779-907) on the selected pixels; autograd-capable (ATen) path.
-    Returns loss, loss_head, loss_com, rgb_head, rgb_com."""
-    dec = nets["decoder"]
-    dev = next(dec.parameters()).device
-    poses, bc_img = dataset[itr_obj]['poses'], dataset[itr_obj]['bc_img']
-    H, W, focal, cx, cy = dataset[itr_obj]['hwfcxy']
-    H, W = int(H), int(W)
-    N = sel_yx.shape[0]
-    signal = encode_signal(dataset, itr_obj, img_i, args.dim_aud, nets["AudNet"], nets["ExpNet"], nets["AudAttNet"],
-                           global_step, args, len_train, embed_fn=embed_fn)
-    signal_torso = encode_signal_torso(dataset, itr_obj, img_i, nets.get("PoseAttNet"), global_step, args, len_train,
-                                       embed_fn=embed_fn)
-    ys, xs = torch.as_tensor(sel_yx[:, 0], device=dev), torch.as_tensor(sel_yx[:, 1], device=dev)
-    t_vals = torch.linspace(0., 1., steps=args.N_samples, device=dev)
-    z_vals = (dataset[itr_obj]['near'] * (1. - t_vals) + dataset[itr_obj]['far'] * t_vals).expand(N, args.N_samples)
-
-    def rays(pose):
-        ro, rd = _get_rays_any(H, W, focal, pose, cx, cy, dev)
-        ro, rd = ro[ys, xs], rd[ys, xs]
-        p = (ro[..., None, :] + rd[..., None, :] * z_vals[..., :, None]).reshape(1, -1, 3)
-        r = rd.unsqueeze(1).expand(N, args.N_samples, 3).reshape(1, -1, 3)
-        return rd, p, r
-    rd_h, p_h, r_h = rays(poses[img_i, :3, :4])
-    rd_t, p_t, r_t = rays(pose_torso)
-    bc_rgb = bc_img[ys, xs].reshape(1, N, 1, 3)
-    feat_h, sig_h = dec(p_h, r_h, z_shape[:, itr_obj * 2], z_app[:, itr_obj * 2], signal, 'head')
-    feat_t, sig_t = dec(p_t, r_t, z_shape[:, itr_obj * 2 + 1], z_app[:, itr_obj * 2 + 1], signal_torso, 'torso')
-    sig_h, feat_h = sig_h.reshape(1, N, -1), feat_h.reshape(1, N, args.N_samples, -1)
-    sig_t, feat_t = sig_t.reshape(1, N, -1), feat_t.reshape(1, N, args.N_samples, -1)
-    if args.concate_bg:
-        feat_h = torch.cat((feat_h[..., :-1, :], bc_rgb), dim=-2)
-        sig_t = torch.cat((sig_t[..., :-1], torch.zeros_like(sig_t[..., -1:])), -1)
-    sigma = _bump_last(torch.stack([sig_h], 0), args.concate_bg)
-    sigma_to = _bump_last(torch.stack([sig_h, sig_t], 0), args.concate_bg)
-    ssum, fw = composite_function(sigma, torch.stack([feat_h], 0))
-    ssum_t, fw_t = composite_function(sigma_to, torch.stack([feat_h, feat_t], 0))
-    w_h = calc_volume_weights(z_vals.unsqueeze(0), rd_h.unsqueeze(0), ssum, last_dist=args.last_dist)
-    w_c = calc_volume_weights(z_vals.unsqueeze(0), rd_t.unsqueeze(0), ssum_t, last_dist=args.last_dist)
-    rgb_head = torch.sum(w_h.unsqueeze(-1) * fw, dim=-2).squeeze(0)
-    rgb_com = torch.sum(w_c.unsqueeze(-1) * fw_t, dim=-2).squeeze(0)
-    l_head = img2mse(rgb_head, target_head)
-    l_com = img2mse(rgb_com, target_com)
-    return l_com + l_head, l_head, l_com, rgb_head, rgb_com
-
-
 def train_step_loss_hip(nets, dataset, itr_obj, img_i, sel_yx, target_head, target_com, z_shape, z_app, global_step,
                         args, len_train, embed_fn, pose_torso, buf):
     """Same step as train_step_loss, with the decoder forward+backward, ray generation, sampling and compositing
@@ -516,20 +467,21 @@ def train_step_loss_hip(nets, dataset, itr_obj, img_i, sel_yx, target_head, targ
     rgb_head, rgb_com = training.render_train(dec, buf, frame, bg, pix, signal[0], signal_torso, zs, za)
     l_head = img2mse(rgb_head, target_head)
     l_com = img2mse(rgb_com, target_com)
-    return l_com + l_head, l_head, l_com, rgb_head, rgb_com
+    loss = l_com + l_head
+    if args.use_L1:
+        # MAIN:909-912 as written upstream: the L1 term pairs the HEAD image with the composite target and replaces
+        # the MSE sum; without --train_together upstream's loss is the integer 0 and backward() fails
+        if not args.train_together:
+            raise ValueError("--use_L1 needs --train_together (upstream's loss is the constant 0 otherwise, MAIN:909-912)")
+        loss = torch.mean(torch.abs(rgb_head - target_com))
+    return loss, l_head, l_com, rgb_head, rgb_com
 
 
-def _get_rays_any(H, W, focal, c2w, cx, cy, dev):
-    """get_rays on the GPU through the HIP kernel; on CPU (unit tests of the host logic) in ATen."""
-    if torch.device(dev).type == 'cuda':
-        return get_rays(H, W, focal, c2w.to(dev), cx, cy)
-    xs = torch.arange(W, dtype=torch.float32)[None, :].expand(H, W)
-    ys = torch.arange(H, dtype=torch.float32)[:, None].expand(H, W)
-    dirs = torch.stack([(xs - cx) / focal, -(ys - cy) / focal, -torch.ones_like(xs)], -1)
-    c2w = c2w.float().cpu()
-    rd = torch.stack([(dirs[..., 0] * c2w[k, 0] + dirs[..., 1] * c2w[k, 1]) + dirs[..., 2] * c2w[k, 2]
-                      for k in range(3)], -1)
-    return c2w[:3, 3].expand(rd.shape), rd
+def _hip_signals_ok(args):
+    """The HIP signal encoders (dfn_encode_signal*) cover the reference configuration: 96-wide audio+expression signal,
+    even attention windows up to 8 frames.  Anything else goes through the torch modules (nets.encode_signal*)."""
+    ok = lambda n: 0 < n <= 8 and n % 2 == 0
+    return args.dim_aud == 96 and ok(args.smo_size) and ok(args.smo_torse_size)
 
 
 def optimizer_steps(opts, global_step, args):
@@ -595,6 +547,10 @@ def train():
     if args.resume is not None:
         global_step, z_shape, z_app = load_checkpoint(args.resume, nets, opts, map_location=dev)
         z_shape, z_app = z_shape.to(dev), z_app.to(dev)
+    if world > 1:
+        # data-parallel replicas must start identical: every rank initialised its own networks and latents from its own
+        # RNG (and only rank 0's are ever saved) - rank 0's parameters, buffers, Adam moments and latent codes go to all
+        z_shape, z_app = parallel.broadcast_replicas(nets, opts, [z_shape, z_app], src=0)
     print('N_rand', args.N_rand, 'no_batching', args.no_batching, 'sample_rate', args.sample_rate)
     print('Begin')
     itr_obj = 0
@@ -611,7 +567,7 @@ def train():
         # conditioning signals through the HIP encoders (dfn_encode_signal*, rows A7 / A8) when the whole path is on
         # the GPU with the reference's configuration (pose attention on); otherwise the torch modules
         enc = None
-        if dev.type == 'cuda' and "PoseAttNet" in nets and args.dim_aud == 96 and embed_fn is not None:
+        if "PoseAttNet" in nets and embed_fn is not None and _hip_signals_ok(args):
             from . import engine
             enc = engine.SignalEncoder(nets["AudNet"], nets["ExpNet"], nets["AudAttNet"], nets["PoseAttNet"],
                                        ds['auds'], ds['exp'], ds['poses'])
@@ -652,8 +608,10 @@ def train():
         return
 
     from . import training
-    train_buf = training.TrainBuffers(getattr(args, "hip_tier", "f32"), args.N_rand, dev)
-    if dev.type == 'cuda' and "PoseAttNet" in nets and args.dim_aud == 96 and not getattr(args, "train_aten", False):
+    # the 16-bit training tier is bf16 (f16, the inference throughput tier, has too little exponent range for gradients)
+    tier = getattr(args, "hip_tier", "f32")
+    train_buf = training.TrainBuffers("bf16" if tier == "f16" else tier, args.N_rand, dev)
+    if "PoseAttNet" in nets and _hip_signals_ok(args):
         train_buf.signal_trainer = training.SignalTrainer(nets["AudNet"], nets["ExpNet"], nets["AudAttNet"],
                                                           nets["PoseAttNet"], ds['auds'], ds['exp'], ds['poses'])
     bucket = parallel.FlatGradBucket(list(nets.values())) if world > 1 else None
@@ -670,11 +628,9 @@ def train():
             train_buf.upload = training.PinnedUpload()
         pick = lambda path: train_buf.upload(np.asarray(_imread(path))[sel[:, 0], sel[:, 1]], torch.uint8, dev).float() / 255.0
         target_com_s, target_head_s = pick(ds['imgs_com'][img_i]), pick(ds['imgs'][img_i])
-        step_fn = train_step_loss if args.train_aten else train_step_loss_hip
-        extra = () if args.train_aten else (train_buf,)
-        loss, l_head, l_com, _, _ = step_fn(nets, datasets, itr_obj, img_i, sel, target_head_s,
-                                            target_com_s, z_shape, z_app, global_step, args,
-                                            len(i_train), embed_fn, ds['poses'][0, :3, :4], *extra)
+        loss, l_head, l_com, _, _ = train_step_loss_hip(nets, datasets, itr_obj, img_i, sel, target_head_s,
+                                                        target_com_s, z_shape, z_app, global_step, args,
+                                                        len(i_train), embed_fn, ds['poses'][0, :3, :4], train_buf)
         for o in opts.values():
             o.zero_grad()
         loss.backward()

@@ -1,12 +1,14 @@
 """Training step on the HIP path: torch autograd drives, the HIP kernels compute.
 
-  flat decoder params --\\
-  per-frame bias blob ---+--> RenderTrainFn (dfn_train_fwd | dfn_composite_bwd, dfn_mlp_bwd, dfn_weight_grad,
-  (fold_bias_torch)     /     dfn_bias_grad) --> rgb_head, rgb_com --> MSE losses (run_nerf_com_trainExpLater.py:902-907)
+  conditioning signals [96] + [42] --> FusedTrainFn (dfn_fold_bias, dfn_train_fwd | dfn_composite_bwd, dfn_mlp_bwd,
+      (SignalTrainer: HIP too)          dfn_weight_bias_grad, dfn_fold_bias_bwd) --> rgb_head, rgb_com --> MSE losses
+                                                                              (run_nerf_com_trainExpLater.py:902-907)
 
-The decoder's forward AND backward run in the fused HIP kernels; torch autograd only chains the result into
-the tiny per-frame pieces that surround it: the bias fold (fc_z, fc_z_skips, fc_z_view, signal columns) and the
-conditioning networks (AudioNet_W2L, ExpressionEnc, AudioAttNet) that produce the 96 + 42 signal floats."""
+The decoder's forward AND backward run in the fused HIP kernels, including the bias fold and its backward; the
+decoder's gradients are deposited into the parameters' .grad as slices of one flat buffer, and autograd only carries
+d(signal) on into the conditioning networks (whose forward / backward are HIP as well: SignalTrainer).
+DecoderTrainFn is the same chain for Decoder.forward on explicit points under autograd (the way the reference's own
+training loop calls the decoder, MAIN:855-866).  The torch-op twins the tests compare against live in tests/twins.py."""
 import ctypes as C
 
 import numpy as np
@@ -15,45 +17,6 @@ import torch
 from . import engine
 from ._lib import FIELD_HEAD, FIELD_TORSO, check, lib
 from .engine import TIERS, _ptr, _stream
-
-
-def _perm(n, device):
-    """blob order [tile][half][16] -> feature index."""
-    e = torch.arange(n, device=device)
-    return 32 * (e >> 5) + (e & 3) + 8 * ((e & 15) >> 2) + 4 * ((e >> 4) & 1)
-
-
-def _pad(v, n):
-    return torch.cat([v, v.new_zeros(n - v.shape[0])]) if v.shape[0] < n else v
-
-
-def fold_bias_torch(dec, sig_head, sig_torso, z_shape, z_app):
-    """Differentiable twin of dfn_fold_bias (dfn_misc.hip: fold_kernel): [head blob | torso blob].
-    z_shape, z_app: [2,256] rows (head, torso)."""
-    dev = z_shape.device
-    p256, p288, p64, p32 = _perm(256, dev), _perm(288, dev), _perm(64, dev), _perm(32, dev)
-    sh, st = sig_head.reshape(-1), sig_torso.reshape(-1)
-
-    def trunk(zs, za, b_in, b_skip):
-        fczv = dec.fc_z_view(za)
-        view = torch.cat([dec.feat_view.bias + fczv + dec.fc_view.bias, _pad(dec.sigma_out.bias, 32)])
-        parts = [b_in[p256]] + [dec.blocks[l].bias[p256] for l in range(4)] + [b_skip[p256]] + \
-                [dec.blocks[l].bias[p256] for l in range(4, 7)] + [view[p288], _pad(dec.feat_out.bias, 32)[p32]]
-        return torch.cat(parts)
-    zs0, zs1, za0, za1 = z_shape[0], z_shape[1], z_app[0], z_app[1]
-    head = trunk(zs0, za0,
-                 dec.fc_in.bias + dec.fc_in.weight[:, 60:] @ sh + dec.fc_z(zs0),
-                 dec.fc_z_skips[0](zs0) + dec.fc_p_skips[0].bias + dec.fc_p_skips[0].weight[:, 60:] @ sh)
-    d = dec.deform_net
-    dv = [d.blocks_embed[0].bias + d.blocks_embed[0].weight[:, 60:] @ st,
-          d.blocks_signal[0].bias + d.blocks_signal[0].weight[:, 60:] @ st,
-          d.blocks_embed[1].bias, d.blocks_signal[1].bias, d.blocks_embed[2].bias, d.blocks_signal[2].bias,
-          d.blocks_embed[3].bias, d.fc_embed_skips[0].bias, d.blocks_signal[3].bias, d.fc_signal_skips[0](st),
-          d.blocks_embed[4].bias, d.blocks_signal[4].bias, _pad(d.out_embed.bias, 64), _pad(d.out_signal.bias + st, 64)]
-    torso = torch.cat([v[p64] for v in dv] +
-                      [trunk(zs1, za1, dec.fc_in_torso.bias + dec.fc_z(zs1),
-                             dec.fc_z_skips[0](zs1) + dec.fc_p_skips_torso[0].bias)])
-    return torch.cat([head, torso])
 
 
 def _sync_flat(params, views):
@@ -117,6 +80,9 @@ class TrainBuffers:
         self.flat = None            # [955242] f32 copy of the decoder parameters (state_dict order), see bind()
         self.flat_views = None
         self.tier = TIERS[tier]
+        if self.tier not in (0, 1):
+            raise ValueError("the training step runs in the f32 or the bf16 tier (f16 is the inference tier: gradients "
+                             "underflow its exponent range)")
         self.n_rays, self.NP = n_rays, n_rays * 64
         assert self.NP % 512 == 0, "N_rand must be a multiple of 8"
         dt = torch.bfloat16 if self.tier == 1 else torch.float32
@@ -135,67 +101,13 @@ class TrainBuffers:
         self.bias = torch.empty(self.nb[0] + self.nb[1], dtype=torch.float32, device=device)
 
     def bind(self, dec):
-        """Parameter list of `dec` in state_dict order and the matching views of one flat buffer: the kernels read
-        the flat buffer, which becomes the parameters' own storage (_sync_flat), and write gradients into a flat buffer
-        whose slices become the parameters' .grad (no per-tensor copies either way)."""
-        if self.flat is None or getattr(self, "_dec", None) is not dec:
-            self.params = list(dec.state_dict(keep_vars=True).values())
-            n = sum(p.numel() for p in self.params)
-            dev = self.params[0].device
-            self.flat = torch.empty(n, dtype=torch.float32, device=dev)
-            self.offsets, o = [], 0
-            for p in self.params:
-                self.offsets.append(o)
-                o += p.numel()
-            self.flat_views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
-            self._dec = dec
-        _sync_flat(self.params, self.flat_views)
+        """Parameter list of `dec` in state_dict order and the matching views of one flat buffer (_FlatNet.of: one per
+        module, shared by every consumer): the kernels read the flat buffer, which becomes the parameters' own storage
+        (_sync_flat), and write gradients into a flat buffer whose slices become the parameters' .grad."""
+        fn = _FlatNet.of(dec)
+        fn.refresh()
+        self.net, self.flat, self.params, self.offsets = fn, fn.flat, fn.params, fn.offsets
         return self.flat
-
-
-class RenderTrainFn(torch.autograd.Function):
-    """(flat params [955242], bias blob [head|torso]) -> rgb_head [n,3], rgb_com [n,3] for the selected pixels."""
-
-    @staticmethod
-    def forward(ctx, flat, bias, buf, frame, bg, pix_index):
-        flat_c = flat.detach().contiguous()
-        bias_c = bias.detach().contiguous()
-        t, st = buf.tier, _stream()
-        for f in (0, 1):
-            check(lib.dfn_pack_weights(t, f, _ptr(flat_c), _ptr(buf.packed[f]), st), "dfn_pack_weights")
-            check(lib.dfn_pack_weights_bwd(t, f, _ptr(flat_c), _ptr(buf.packed_T[f]), st), "dfn_pack_weights_bwd")
-        n = frame.ray_count
-        rgb_h = torch.empty(n, 3, dtype=torch.float32, device=flat.device)
-        rgb_c = torch.empty(n, 3, dtype=torch.float32, device=flat.device)
-        bg_f32 = bg if bg.dtype == torch.float32 else None
-        bg_u8 = bg if bg.dtype == torch.uint8 else None
-        check(lib.dfn_train_fwd(t, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias_c),
-                                C.c_void_p(bias_c.data_ptr() + 4 * buf.nb[0]), _ptr(bg_f32), _ptr(bg_u8),
-                                _ptr(pix_index), _ptr(rgb_h), _ptr(rgb_c), _ptr(buf.samples), _ptr(buf.act[0]),
-                                _ptr(buf.masks[0]), _ptr(buf.act[1]), _ptr(buf.masks[1]), st), "dfn_train_fwd")
-        ctx.buf, ctx.frame, ctx.bg, ctx.pix = buf, frame, bg, pix_index
-        ctx.n_flat, ctx.dev = flat.numel(), flat.device
-        return rgb_h, rgb_c
-
-    @staticmethod
-    def backward(ctx, d_h, d_c):
-        buf, frame, bg, st = ctx.buf, ctx.frame, ctx.bg, _stream()
-        d_h = d_h.contiguous().float()
-        d_c = d_c.contiguous().float()
-        bg_f32 = bg if bg.dtype == torch.float32 else None
-        bg_u8 = bg if bg.dtype == torch.uint8 else None
-        check(lib.dfn_composite_bwd(C.byref(frame), _ptr(ctx.pix), _ptr(bg_f32), _ptr(bg_u8), _ptr(buf.samples),
-                                    _ptr(d_h), _ptr(d_c), _ptr(buf.dsamples), st), "dfn_composite_bwd")
-        g_flat = torch.zeros(ctx.n_flat, dtype=torch.float32, device=ctx.dev)
-        g_bias = torch.empty(buf.nb[0] + buf.nb[1], dtype=torch.float32, device=ctx.dev)
-        for f in (0, 1):
-            check(lib.dfn_mlp_bwd(buf.tier, f, _ptr(buf.packed_T[f]), _ptr(buf.samples), _ptr(buf.dsamples),
-                                  _ptr(buf.masks[f]), buf.NP, _ptr(buf.dy[f]), st), "dfn_mlp_bwd")
-            check(lib.dfn_weight_grad(buf.tier, f, _ptr(buf.dy[f]), _ptr(buf.act[f]), buf.NP, _ptr(buf.ws[f]),
-                                      _ptr(g_flat), st), "dfn_weight_grad")
-            check(lib.dfn_bias_grad(buf.tier, f, _ptr(buf.dy[f]), buf.NP,
-                                    C.c_void_p(g_bias.data_ptr() + (4 * buf.nb[0] if f else 0)), st), "dfn_bias_grad")
-        return g_flat, g_bias, None, None, None, None
 
 
 class FusedTrainFn(torch.autograd.Function):
@@ -248,7 +160,7 @@ class FusedTrainFn(torch.autograd.Function):
         bg_u8 = bg if bg.dtype == torch.uint8 else None
         check(lib.dfn_composite_bwd(C.byref(frame), _ptr(ctx.pix), _ptr(bg_f32), _ptr(bg_u8), _ptr(buf.samples),
                                     _ptr(d_h), _ptr(d_c), _ptr(buf.dsamples), st), "dfn_composite_bwd")
-        g_flat = _grad_buffer(buf, "_g_flat", flat, buf.params)
+        g_flat = _grad_buffer(buf.net, "_g_flat", flat, buf.params)
         g_bias = torch.empty(buf.nb[0] + buf.nb[1], dtype=torch.float32, device=dev)
         d_sig = torch.zeros(96 + 42, dtype=torch.float32, device=dev)
         for f in (0, 1):
@@ -260,24 +172,19 @@ class FusedTrainFn(torch.autograd.Function):
             check(lib.dfn_fold_bias_bwd(buf.tier, FIELD_TORSO if f else FIELD_HEAD, _ptr(flat), _ptr(stt if f else sh),
                                         _ptr(zs[f]), _ptr(za[f]), gb, _ptr(g_flat),
                                         C.c_void_p(d_sig.data_ptr() + (4 * 96 if f else 0)), st), "dfn_fold_bias_bwd")
-        for p, o in zip(buf.params, buf.offsets):
-            if not p.requires_grad:
-                continue
-            g = g_flat[o:o + p.numel()].view_as(p)
-            if p.grad is None:
-                p.grad = g
-            else:
-                p.grad.add_(g)
+        buf.net.deposit(g_flat, touched=_decoder_touched(buf.net, (0, 1)))
         return (d_sig[:96].reshape(ctx.sig_shapes[0]), d_sig[96:].reshape(ctx.sig_shapes[1]), None, None, None, None,
                 None, None)
 
 
 class _FlatNet:
-    """Flat f32 copy of one small network's parameters (state_dict order) + the matching gradient buffer."""
+    """Flat f32 copy of one network's parameters (state_dict order) + the matching gradient buffer.  One per module
+    (_FlatNet.of): the flat buffer becomes the parameters' storage, so two binders of one module would fight over it."""
 
     def __init__(self, module):
         self.module = module
-        self.params = list(module.state_dict(keep_vars=True).values())
+        sd = module.state_dict(keep_vars=True)
+        self.names, self.params = list(sd.keys()), list(sd.values())
         dev = self.params[0].device
         n = sum(p.numel() for p in self.params)
         self.flat = torch.empty(n, dtype=torch.float32, device=dev)
@@ -287,18 +194,52 @@ class _FlatNet:
             o += p.numel()
         self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
 
+    @staticmethod
+    def of(module):
+        fn = module.__dict__.get("_dfn_flat")
+        cur = list(module.state_dict(keep_vars=True).values())
+        if fn is None or len(cur) != len(fn.params) or any(a is not b for a, b in zip(cur, fn.params)) or \
+                cur[0].device != fn.flat.device:
+            fn = module.__dict__["_dfn_flat"] = _FlatNet(module)
+        return fn
+
     def refresh(self):
         _sync_flat(self.params, self.views)
 
-    def deposit(self, grad_flat):
-        for p, o in zip(self.params, self.offsets):
-            if not p.requires_grad:
+    def deposit(self, grad_flat, touched=None):
+        """.grad of every parameter (of those in `touched`, a list of bools, if given) = its slice of grad_flat (added
+        to an existing .grad).  Parameters outside `touched` keep .grad = None, as torch autograd leaves parameters a
+        forward never used (the listener layers; the other field's layers when one field is evaluated)."""
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            if not p.requires_grad or (touched is not None and not touched[i]):
                 continue
             g = grad_flat[o:o + p.numel()].view_as(p)
             if p.grad is None:
                 p.grad = g
             else:
                 p.grad.add_(g)
+
+
+_HEAD_ONLY = ("fc_in.", "fc_p_skips.")
+_TORSO_ONLY = ("deform_net.", "fc_in_torso.", "fc_p_skips_torso.")
+_LISTENER = ("fc_in_listener.", "fc_p_skips_listener.")
+
+
+def _decoder_touched(net, fields):
+    """Per parameter of the decoder: does a forward through `fields` (0 head, 1 torso) use it?  (decoder.py:297-325)"""
+    key = ("touched", tuple(fields))
+    hit = net.__dict__.get(key)
+    if hit is None:
+        def used(name):
+            if name.startswith(_LISTENER):
+                return False
+            if name.startswith(_HEAD_ONLY):
+                return 0 in fields
+            if name.startswith(_TORSO_ONLY):
+                return 1 in fields
+            return True
+        hit = net.__dict__[key] = [used(n) for n in net.names]
+    return hit
 
 
 class SignalTrainer:
@@ -308,7 +249,7 @@ class SignalTrainer:
 
     def __init__(self, aud_net, exp_net, att_net, pose_att_net, auds, exps, poses):
         engine.require_gpu()
-        self.nets = [_FlatNet(m) for m in (aud_net, exp_net, att_net, pose_att_net)]
+        self.nets = [_FlatNet.of(m) for m in (aud_net, exp_net, att_net, pose_att_net)]
         dev = auds.device
         self.auds, self.exps = auds.detach().float().contiguous(), exps.detach().float().contiguous()
         self.poses = poses.detach().float().contiguous()
@@ -366,16 +307,104 @@ class _SignalFn(torch.autograd.Function):
         return None, None, None, None, None, None
 
 
-def render_train(dec, buf, frame, bg, pix_index, sig_head, sig_torso, z_shape, z_app, fused=True):
+def render_train(dec, buf, frame, bg, pix_index, sig_head, sig_torso, z_shape, z_app):
     """Differentiable (w.r.t. the decoder parameters and the two signals) coarse two-field render of the
-    pixels `pix_index` [n] (int32, y*W+x).  Returns rgb_head, rgb_com [n,3].
-    fused=True: fold and its backward in HIP, decoder gradients deposited into .grad by the backward (FusedTrainFn);
-    fused=False: the fold as differentiable torch ops around RenderTrainFn (the twin the tests compare against)."""
-    if fused:
-        buf.bind(dec)
-        if not sig_head.requires_grad:      # keep the Function in the graph even when no conditioning net trains
-            sig_head = sig_head.detach().requires_grad_(True)
-        return FusedTrainFn.apply(sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app)
-    flat = torch.cat([p.reshape(-1) for p in dec.state_dict(keep_vars=True).values()])
-    bias = fold_bias_torch(dec, sig_head, sig_torso, z_shape, z_app)
-    return RenderTrainFn.apply(flat, bias, buf, frame, bg, pix_index)
+    pixels `pix_index` [n] (int32, y*W+x).  Returns rgb_head, rgb_com [n,3].  Fold and its backward run in HIP, the
+    decoder gradients are deposited into .grad by the backward (FusedTrainFn).  One forward per backward: the recorded
+    activations live in `buf` and the next forward overwrites them."""
+    if frame.ray_count != buf.n_rays or (pix_index is not None and pix_index.numel() != buf.n_rays):
+        raise ValueError(f"render_train: the buffers were sized for {buf.n_rays} rays, the frame has {frame.ray_count}"
+                         f" (pix_index {None if pix_index is None else pix_index.numel()})")
+    buf.bind(dec)
+    if not sig_head.requires_grad:      # keep the Function in the graph even when no conditioning net trains
+        sig_head = sig_head.detach().requires_grad_(True)
+    return FusedTrainFn.apply(sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app)
+
+
+# ---- Decoder.forward on explicit points under autograd -------------------------------------------------------------
+class _PointBuffers:
+    """Device buffers of one decoder-on-points training call (one field), sized for NP = ceil32(n) points."""
+
+    def __init__(self, tier, field, n, device):
+        self.tier, self.field, self.n = tier, field, n
+        self.NP = NP = (n + 31) // 32 * 32
+        dt = torch.bfloat16 if tier == 1 else torch.float32
+        rows = lambda w: check(lib.dfn_train_rows(field, w), "dfn_train_rows")
+        self.act = torch.empty(rows(0), NP, dtype=dt, device=device)
+        self.dy = torch.empty(rows(1), NP, dtype=dt, device=device)
+        self.masks = torch.empty(NP // 32, rows(2), 64, dtype=torch.int32, device=device)
+        self.ws = torch.empty(rows(3), dtype=torch.float32, device=device)
+        self.samples = torch.zeros(NP, 8, dtype=torch.float32, device=device)
+        self.packed = torch.empty(check(lib.dfn_packed_bytes(tier, field), "packed"), dtype=torch.uint8, device=device)
+        self.packed_T = torch.empty(check(lib.dfn_packed_bwd_bytes(tier, field), "packed_T"), dtype=torch.uint8,
+                                    device=device)
+        self.nb = check(lib.dfn_bias_floats(tier, field), "bias")
+        self.bias = torch.empty(self.nb, dtype=torch.float32, device=device)
+
+
+class DecoderTrainFn(torch.autograd.Function):
+    """signal [96] / [42] -> feat [n,3], sigma [n] of ONE field at explicit points: dfn_fold_bias + dfn_decoder_train_fwd
+    (the fused decoder with its recorder on); backward = dfn_mlp_bwd, dfn_weight_bias_grad, dfn_fold_bias_bwd: returns
+    d(signal) to autograd and deposits the decoder gradients into the parameters' .grad (like FusedTrainFn).
+    The points and directions get no gradient (upstream they come from get_rays / linspace: constants)."""
+
+    @staticmethod
+    def forward(ctx, signal, net, pb, pts, dirs, zs, za):
+        t, f, st = pb.tier, pb.field, _stream()
+        flat, dev = net.flat, net.flat.device
+        sg = signal.detach().reshape(-1).float().contiguous()
+        check(lib.dfn_fold_bias(t, f, _ptr(flat), _ptr(sg), _ptr(zs), _ptr(za), _ptr(pb.bias), st), "dfn_fold_bias")
+        check(lib.dfn_pack_weights(t, f, _ptr(flat), _ptr(pb.packed), st), "dfn_pack_weights")
+        check(lib.dfn_pack_weights_bwd(t, f, _ptr(flat), _ptr(pb.packed_T), st), "dfn_pack_weights_bwd")
+        feat = torch.empty(pb.n, 3, dtype=torch.float32, device=dev)
+        sigma = torch.empty(pb.n, dtype=torch.float32, device=dev)
+        check(lib.dfn_decoder_train_fwd(t, f, _ptr(pb.packed), _ptr(pb.bias), _ptr(pts), _ptr(dirs), pb.n, _ptr(feat),
+                                        _ptr(sigma), _ptr(pb.samples), _ptr(pb.act), _ptr(pb.masks), st),
+              "dfn_decoder_train_fwd")
+        ctx.net, ctx.pb, ctx.keep, ctx.sig_shape = net, pb, (sg, zs, za, pts, dirs), signal.shape
+        return feat, sigma
+
+    @staticmethod
+    def backward(ctx, d_feat, d_sigma):
+        net, pb, (sg, zs, za, _, _), st = ctx.net, ctx.pb, ctx.keep, _stream()
+        t, f, dev = pb.tier, pb.field, net.flat.device
+        o = 4 * f
+        ds = torch.zeros(pb.NP, 8, dtype=torch.float32, device=dev)
+        ds[:pb.n, o] = d_sigma.reshape(-1)
+        ds[:pb.n, o + 1:o + 4] = d_feat.reshape(-1, 3)
+        check(lib.dfn_mlp_bwd(t, f, _ptr(pb.packed_T), _ptr(pb.samples), _ptr(ds), _ptr(pb.masks), pb.NP, _ptr(pb.dy),
+                              st), "dfn_mlp_bwd")
+        g_flat = _grad_buffer(net, "_g_flat", net.flat, net.params)
+        g_bias = torch.empty(pb.nb, dtype=torch.float32, device=dev)
+        d_sig = torch.zeros(sg.numel(), dtype=torch.float32, device=dev)
+        check(lib.dfn_weight_bias_grad(t, f, _ptr(pb.dy), _ptr(pb.act), pb.NP, _ptr(pb.ws), _ptr(g_flat), _ptr(g_bias),
+                                       st), "dfn_weight_bias_grad")
+        check(lib.dfn_fold_bias_bwd(t, f, _ptr(net.flat), _ptr(sg), _ptr(zs), _ptr(za), _ptr(g_bias), _ptr(g_flat),
+                                    _ptr(d_sig), st), "dfn_fold_bias_bwd")
+        net.deposit(g_flat, touched=_decoder_touched(net, (f,)))
+        return d_sig.reshape(ctx.sig_shape), None, None, None, None, None, None
+
+
+def decoder_train(dec, field, p_in, ray_d, z_shape, z_app, signal, tier="f32"):
+    """Decoder.forward(p_in [B,N,3], ray_d [B,N,3], ...) under autograd, in HIP: -> feat [B,N,3], sigma [B,N].
+    field: 0 head, 1 torso.  Gradients flow to the decoder's parameters (deposited into .grad) and to `signal`."""
+    if field not in (FIELD_HEAD, FIELD_TORSO):
+        raise NotImplementedError("training the listener input layers (signal None) is not supported: the reference "
+                                  "driver never evaluates them (decoder.py:306-307, 322-323)")
+    if not dec.hip_supported():
+        raise NotImplementedError("the HIP path supports the scripts/test_obama.sh decoder configuration only")
+    t = TIERS["bf16" if tier in ("f16", 2) else tier]
+    net = _FlatNet.of(dec)
+    net.refresh()
+    dev = net.flat.device
+    pts = p_in.detach().reshape(-1, 3).to(dev, torch.float32).contiguous()
+    dirs = ray_d.detach().reshape(-1, 3).to(dev, torch.float32).contiguous()
+    n = pts.shape[0]
+    # a fresh set of buffers per call: several forwards may be alive before their backwards run (head, then torso)
+    pb = _PointBuffers(t, field, n, dev)
+    zs = z_shape.detach().reshape(-1)[:256].to(dev, torch.float32).contiguous()
+    za = z_app.detach().reshape(-1)[:256].to(dev, torch.float32).contiguous()
+    if not signal.requires_grad:
+        signal = signal.detach().requires_grad_(True)
+    feat, sigma = DecoderTrainFn.apply(signal, net, pb, pts, dirs, zs, za)
+    return feat.reshape(p_in.shape[0], -1, 3), sigma.reshape(p_in.shape[0], -1)

@@ -34,6 +34,9 @@ extern "C" {
 
 #define DFN_TIER_F32 0      /* v_mfma_f32_32x32x2_f32: exact f32 products, k-ordered accumulate */
 #define DFN_TIER_BF16 1     /* v_mfma_f32_32x32x16_bf16: bf16 operands, f32 accumulate */
+#define DFN_TIER_F16 2      /* v_mfma_f32_32x32x16_f16: f16 operands (10 mantissa bits), f32 accumulate; same rate as bf16.
+                             * Inference entry points only (pack / fold / render / decoder): the training entry points
+                             * return DFN_E_ARG for it (gradients underflow f16's exponent range). */
 
 #define DFN_FIELD_HEAD 0        /* DEC:303-305  fc_in / fc_p_skips       */
 #define DFN_FIELD_TORSO 1       /* DEC:297-299, 308-309, 324-325 deform_net + fc_in_torso / fc_p_skips_torso */
@@ -135,7 +138,8 @@ int dfn_render_fwd_u8(int tier, const DfnFrame* frame, const void* packed_head, 
  *   act_<field>        [dfn_train_rows(field,0)][NP]   inputs of every GEMM, feature-major
  *   masks_<field>      u32 [NP/32][dfn_train_rows(field,2)][64]   ReLU bits
  *   dy_T               [dfn_train_rows(field,1)][NP]   pre-activation gradients, feature-major
- *   workspace          f32 [dfn_train_rows(field,3)]                                                        */
+ *   workspace          f32 [dfn_train_rows(field,3)]  split-K partial slices; the reduction adds them in a fixed
+ *                      order (no float atomics): the gradients are bit-reproducible run to run                      */
 long dfn_train_rows(int field, int what);
 long dfn_packed_bwd_bytes(int tier, int field);
 int dfn_pack_weights_bwd(int tier, int field, const float* params, void* packed_T, void* stream);
@@ -150,7 +154,8 @@ int dfn_mlp_bwd(int tier, int field, const void* packed_T, const float* samples,
                 const uint32_t* masks, long NP, void* dy_T, void* stream);
 int dfn_weight_grad(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
                     float* grad_flat, void* stream);
-int dfn_bias_grad(int tier, int field, const void* dy_T, long NP, float* dbias, void* stream);
+/* workspace: f32 [dfn_train_rows(field,4)] (partial row sums per slice of the points) */
+int dfn_bias_grad(int tier, int field, const void* dy_T, long NP, float* workspace, float* dbias, void* stream);
 /* dfn_weight_grad and dfn_bias_grad in ONE pass over dy_T (the GEMM that owns a block of dy_T rows multiplies it by a
  * tile of ones as well): same outputs, the gradient array is read once less. */
 int dfn_weight_bias_grad(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
@@ -184,6 +189,17 @@ int dfn_adam_multi(const DfnAdamItem* items_dev, const int32_t* chunks_dev, int 
 int dfn_decoder_fwd(int tier, int field, const void* packed, const float* bias, const float* points,
                     const float* dirs, long n, float* feat, float* sigma, void* stream);
 
+/* The same evaluation with the training recorder on: replaces DEC:277-349 when the reference's training loop calls
+ * decoder(...) on explicit points under autograd (MAIN:855-866).  field: DFN_FIELD_HEAD or DFN_FIELD_TORSO; tiers
+ * f32 / bf16.  With NP = n rounded up to a multiple of 32 (padding points repeat point n - 1):
+ *   samples [NP][8] (this field's (sigma, rgb) in floats 0..3 (head) / 4..7 (torso); the other half untouched),
+ *   act_T [NP/32][dfn_train_rows(field,0)][32], masks [NP/32][dfn_train_rows(field,2)][64].
+ * Backward: fill dsamples [NP][8] with d loss / d (sigma, rgb) (zeros for the padding points), then dfn_mlp_bwd,
+ * dfn_weight_bias_grad and dfn_fold_bias_bwd with NP as above. */
+int dfn_decoder_train_fwd(int tier, int field, const void* packed, const float* bias, const float* points,
+                          const float* dirs, long n, float* feat, float* sigma, float* samples, void* act_T,
+                          uint32_t* masks, void* stream);
+
 /* ---- building blocks kept for API parity ---------------------------------------------------------------- */
 /* get_rays, HELP:449-465: rays_o, rays_d [H*W,3] for c2w (3x4, host memory, 12 floats). */
 int dfn_get_rays(int H, int W, float focal, float cx, float cy, const float* c2w_host, float* rays_o,
@@ -205,8 +221,9 @@ int dfn_volume_weights(const float* z, const float* ray, const float* sigma, lon
 int dfn_to8b(const float* x, long n, uint8_t* out, void* stream);
 
 /* ---- debug / self-test ------------------------------------------------------------------------------------ */
-/* Runs one v_mfma_f32_32x32x16_bf16 and one v_mfma_f32_32x32x2_f32 with A = (row,k) / B = (k,col) probes
- * and writes D as the kernels interpret it: out[2][32][32].  Used by tests to pin the fragment maps. */
+/* Runs one v_mfma_f32_32x32x16_bf16, one v_mfma_f32_32x32x2_f32 and one v_mfma_f32_32x32x16_f16 with
+ * A = (row,k) / B = (k,col) probes and writes D as the kernels interpret it: out[3][32][32] (bf16, f32, f16).
+ * Used by tests to pin the fragment maps. */
 int dfn_debug_mfma_layout(float* out, void* stream);
 
 #ifdef __cplusplus

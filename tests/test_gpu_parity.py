@@ -30,7 +30,7 @@ def flat(eng, states):
 
 @pytest.fixture(scope="module")
 def packed(eng, flat):
-    return {tier: eng.PackedDecoder(flat, tier, fields=(0, 1, 2)) for tier in ("f32", "bf16")}
+    return {tier: eng.PackedDecoder(flat, tier, fields=(0, 1, 2)) for tier in ("f32", "bf16", "f16")}
 
 
 def psnr(a, b):
@@ -46,6 +46,7 @@ def test_mfma_fragment_maps(eng):
     want = np.outer(i + 1, 2 * i + 1).astype(np.float32)       # asymmetric: catches a transposed map
     assert np.array_equal(d[0], want), "v_mfma_f32_32x32x16_bf16 fragment map"
     assert np.array_equal(d[1], want), "v_mfma_f32_32x32x2_f32 fragment map"
+    assert np.array_equal(d[2], want), "v_mfma_f32_32x32x16_f16 fragment map"
 
 
 def test_get_rays_bitwise_full_frame(eng, scene, golden):
@@ -160,6 +161,16 @@ def test_decoder_bf16_tier_vs_reference_golden(eng, packed, golden, latents, fie
     assert np.sqrt(((sigma - rs) ** 2).mean()) < 0.5
 
 
+@pytest.mark.parametrize("field", [0, 1, 2])
+def test_decoder_f16_tier_vs_reference_golden(eng, packed, golden, latents, field):
+    """f16 operands carry 10 mantissa bits (bf16: 7): 8x tighter gates than the bf16 tier's."""
+    feat, sigma, rf, rs = _decoder_case(eng, packed, golden, latents, "f16", field, 192)
+    print(f"f16 field {field}: max|dfeat| {np.abs(feat - rf).max():.2e}  max|dsigma| {np.abs(sigma - rs).max():.2e}"
+          f"  rms dsigma {np.sqrt(((sigma - rs) ** 2).mean()):.2e}")
+    assert np.abs(feat - rf).max() < 2.5e-3
+    assert np.sqrt(((sigma - rs) ** 2).mean()) < 0.06
+
+
 def test_decoder_ragged_sizes(eng, packed, golden, latents):
     g = golden("g3_decoder")
     zs, za = latents
@@ -251,13 +262,22 @@ def test_render_hierarchical_f32_vs_reference_golden(eng, packed, scene, latents
         np.testing.assert_allclose(rc.cpu().numpy(), oc.numpy(), atol=5e-5, rtol=0)
 
 
+# "PSNR within 0.05 dB of reference" (BASELINE.json north_star) for a model that itself scores 30 dB against ground truth:
+# an independent error of x dB costs 10 log10(1 + 10^((30 - x) / 10)) dB  ->  x >= 49.4 dB keeps the loss <= 0.05 dB.
+PSNR_CLAUSE_DB = 49.4
+# the bf16 tier (7 mantissa bits) is the 16-bit TRAINING tier; its rendered RGB is gated at what it measures
+PSNR_GATE = {"f16": PSNR_CLAUSE_DB, "bf16": 42.0}
+
+
+@pytest.mark.parametrize("tier", ["f16", "bf16"])
 @pytest.mark.parametrize("n_fine,fields", [(0, 1), (128, 1), (128, 2), (64, 2)])
-def test_render_bf16_psnr_vs_oracle(eng, packed, scene, latents, golden, states, n_fine, fields):
-    """bf16 tier: PSNR of the rendered RGB against the fp32 oracle on a strided subset of the frame."""
+def test_render_16bit_psnr_vs_oracle(eng, packed, scene, latents, golden, states, tier, n_fine, fields):
+    """16-bit tiers: PSNR of the rendered RGB against the fp32 ORACLE on a strided subset of the frame.  The f16 tier
+    (the throughput tier bench.py reports) must hold the north star's accuracy clause (>= 49.4 dB, see above)."""
     gc = golden("g7_frame_coarse")
     idx = np.arange(0, scene["H"] * scene["W"], 397)[:256]
     sig, sigt = gc["signal"][0], gc["signal_torso"].reshape(-1)
-    rh, rc = _render_subset(eng, packed, scene, latents, sig, sigt, idx, "bf16", n_fine, fields)
+    rh, rc = _render_subset(eng, packed, scene, latents, sig, sigt, idx, tier, n_fine, fields)
     P = O.params_to_torch(states["decoder"])
     zs, za = [t(v) for v in latents]
     H, W = scene["H"], scene["W"]
@@ -269,13 +289,48 @@ def test_render_bf16_psnr_vs_oracle(eng, packed, scene, latents, golden, states,
         oh, oc = O.render_rays_chunk(P, *rays, bg, scene["near"], scene["far"], zs, za, [t(sig)[None], None],
                                      t(sigt)[None], 64, n_fine, fields)
     p_h = psnr(rh.cpu().numpy(), oh.numpy())
-    msg = f"bf16 n_fine={n_fine} fields={fields}: PSNR(head) {p_h:.1f} dB"
-    assert p_h > 30.0
+    msg = f"{tier} n_fine={n_fine} fields={fields}: PSNR(head) {p_h:.1f} dB"
     if fields == 2:
         p_c = psnr(rc.cpu().numpy(), oc.numpy())
         msg += f", PSNR(com) {p_c:.1f} dB"
-        assert p_c > 30.0
     print(msg)
+    assert p_h >= PSNR_GATE[tier], msg
+    if fields == 2:
+        assert p_c >= PSNR_GATE[tier], msg
+
+
+@pytest.mark.parametrize("fields", [1, 2])
+def test_full_frame_psnr_16bit_tiers_vs_f32_tier(eng, packed, scene, latents, golden, fields):
+    """BASELINE configs[1] / configs[2] at FULL size (all 202,500 rays, 64+128 samples): the 16-bit tiers against the f32
+    tier on the device.  The f32 tier is pinned to the reference's own output (test_render_coarse_f32_vs_reference_golden,
+    139 dB), so it is a valid on-device proxy for the reference at a size the CPU oracle cannot render in a test.
+    f16 (the tier bench.py's headline is measured on): >= 49.4 dB on the whole frame AND on the worst 2,500-ray block."""
+    gc = golden("g7_frame_coarse")
+    zs, za = latents
+    H, W = scene["H"], scene["W"]
+    R = H * W
+    bg8 = t(scene["bg"]).reshape(-1, 3).cuda()
+    fr = eng.make_frame(H, W, scene["focal"], scene["cx"], scene["cy"], scene["poses"][2], scene["pose_body"],
+                        scene["near"], scene["far"], ray_count=R, n_fine=128, fields=fields)
+    out = {}
+    for tier in ("f32", "f16", "bf16"):
+        pk = packed[tier]
+        bias = pk.fold(gc["signal"][0], gc["signal_torso"].reshape(-1) if fields == 2 else None, zs[0], za[0])
+        rh, rc = eng.render(pk, bias, fr, bg8)
+        out[tier] = [x.cpu().numpy().astype(np.float64) for x in ((rh, rc) if fields == 2 else (rh,))]
+    for tier in ("f16", "bf16"):
+        for img, ref, name in zip(out[tier], out["f32"], ("head", "com")):
+            whole = psnr(img, ref)
+            blk = ((img - ref) ** 2).reshape(-1, 2500, 3).mean((1, 2))          # 81 blocks of 2,500 rays
+            worst = -10.0 * np.log10(blk.max())
+            print(f"full frame fields={fields} {tier} {name}: PSNR {whole:.1f} dB, worst 2500-ray block {worst:.1f} dB, "
+                  f"max |err| {np.abs(img - ref).max():.2e}")
+            assert whole >= PSNR_GATE[tier], (tier, name, whole)
+            if tier == "f16":
+                assert worst >= PSNR_CLAUSE_DB, (tier, name, worst)
+        # the u8 image a user sees: identical up to +-1 LSB except where the sampler's switch moved a depth
+        d = np.abs(O.to8b(out[tier][0]).astype(int) - O.to8b(out["f32"][0]).astype(int))
+        print(f"  u8 head image {tier}: {(d > 0).mean() * 100:.2f} % of values differ, max {d.max()} LSB")
 
 
 def test_render_full_frame_properties(eng, packed, scene, latents, golden):

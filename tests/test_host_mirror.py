@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 
+import twins
 from conftest import GOLDEN, ROOT
 from dfanerf import nets, parallel, run_nerf, synth
 from dfanerf.decoder import Decoder
@@ -44,7 +45,7 @@ def test_cli_flags_match_reference():
             if f["type"]:
                 assert a.type.__name__ == f["type"], f
     extra = set(acts) - {f["name"] for f in want} - {"help"}
-    assert extra == {"hip_tier", "hierarchical", "train_aten"}
+    assert extra == {"hip_tier", "hierarchical"}
 
 
 def test_config_file_and_script_flags(tmp_path):
@@ -77,21 +78,28 @@ def test_state_dict_manifest(states):
     assert not Decoder().hip_supported()
 
 
-def test_decoder_aten_path_vs_golden(states, latents, golden):
+def test_decoder_twin_vs_golden_and_no_cpu_path(states, latents, golden):
+    """tests/twins.py:decoder_forward_aten (the torch-op restatement the GPU tests cross-check the HIP training path
+    with) against golden G3; and the product's Decoder.forward refuses CPU tensors in both modes (single backend)."""
     g = golden("g3_decoder")
     dec = _modules(states)["decoder"]
     zs, za = [t(v) for v in latents]
     p, r = t(g["p_64"]), t(g["r_64"])
-    with torch.enable_grad():
-        fh, sh = dec(p, r, zs[:, 0], za[:, 0], [t(g["sig_aud"]), None], 'head')
-        ft, st = dec(p, r, zs[:, 1], za[:, 1], t(g["sig_torso"]), 'torso')
-        fl, sl = dec(p, r, zs[:, 0], za[:, 0], [None, None], 'head')
+    with torch.no_grad():
+        fh, sh = twins.decoder_forward_aten(dec, p, r, zs[:, 0], za[:, 0], [t(g["sig_aud"]), None], 'head')
+        ft, st = twins.decoder_forward_aten(dec, p, r, zs[:, 1], za[:, 1], t(g["sig_torso"]), 'torso')
+        fl, sl = twins.decoder_forward_aten(dec, p, r, zs[:, 0], za[:, 0], [None, None], 'head')
     for got, ref in ((fh, "feat_head_64"), (sh, "sigma_head_64"), (ft, "feat_torso_64"), (st, "sigma_torso_64"),
                      (fl, "feat_listener_64"), (sl, "sigma_listener_64")):
         np.testing.assert_allclose(got.detach().numpy(), g[ref], rtol=1e-5, atol=2e-5)
     assert np.array_equal(dec.transform_points(p[:, :8]).numpy(), g["pe_p"])
-    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
-        dec(p, r, zs[:, 0], za[:, 0], [t(g["sig_aud"]), None], 'head')       # no silent CPU path for inference
+    for ctx in (torch.no_grad(), torch.enable_grad()):
+        with ctx, pytest.raises(RuntimeError, match="no CPU fallback"):
+            dec(p, r, zs[:, 0], za[:, 0], [t(g["sig_aud"]), None], 'head')
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        run_nerf.composite_function(torch.zeros(1, 1, 2, 4), torch.zeros(1, 1, 2, 4, 3))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        run_nerf.make_adam(torch.nn.Linear(3, 2).parameters(), 5e-4)
 
 
 def _args():
@@ -103,7 +111,9 @@ def _args():
 
 @pytest.mark.parametrize("step", [0, 300000, 400000])
 def test_training_step_vs_golden(states, scene, latents, golden, step):
-    """train_step_loss (MAIN:779-907) + gated Adam steps (MAIN:916-931) against golden G8."""
+    """Host logic of the training step on CPU: the torch-op twin of the forward (tests/twins.py, MAIN:779-907) + the
+    product's optimizer gating and LR schedule (run_nerf.optimizer_steps / update_lrate, MAIN:916-931, 1081-1094)
+    against golden G8."""
     g = golden("g8_train_step")
     mods = _modules(states)
     args = _args()
@@ -117,9 +127,9 @@ def test_training_step_vs_golden(states, scene, latents, golden, step):
     zs, za = [t(v) for v in latents]
     embed_fn, _ = nets.get_embedder(3, 0)
     opts = {k: torch.optim.Adam(m.parameters(), lr=5e-4, betas=(0.9, 0.999)) for k, m in mods.items()}
-    loss, lh, lc, _, _ = run_nerf.train_step_loss(mods, ds, 0, 3, sel, tgt_h[sel[:, 0], sel[:, 1]],
-                                                  tgt_c[sel[:, 0], sel[:, 1]], zs, za, step, args, scene["aud"].shape[0],
-                                                  embed_fn, ds[0]["poses"][0, :3, :4])
+    loss, lh, lc, _, _ = twins.train_step_loss_aten(mods, ds, 0, 3, sel, tgt_h[sel[:, 0], sel[:, 1]],
+                                                    tgt_c[sel[:, 0], sel[:, 1]], zs, za, step, args,
+                                                    scene["aud"].shape[0], embed_fn, ds[0]["poses"][0, :3, :4])
     np.testing.assert_allclose([loss.item(), lh.item(), lc.item()], g[f"loss_{step}"], rtol=3e-6)
     for o in opts.values():
         o.zero_grad()
@@ -196,10 +206,34 @@ def _worker(rank, world, port, q):
     g_local = [None if p.grad is None else p.grad.clone() for m in mods for p in m.parameters()]
     bucket = parallel.FlatGradBucket(mods)
     bucket.all_reduce_()
+    # replicas that start DIFFERENT (every rank initialises from its own RNG, as train() does without --resume) must be
+    # identical after broadcast_replicas and stay identical through data-parallel steps with different data per rank
+    torch.manual_seed(100 + rank)
+    nets = {"a": torch.nn.Linear(6, 4), "b": torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 2))}
+    opts = {k: torch.optim.Adam(m.parameters(), lr=1e-2) for k, m in nets.items()}
+    if rank == 0:                       # rank 0 carries optimizer state (a resumed checkpoint), rank 1 none
+        nets["b"](nets["a"](torch.ones(2, 6))).sum().backward()
+        for o in opts.values():
+            o.step(); o.zero_grad()
+    lat = torch.randn(1, 2, 8)
+    (lat,) = parallel.broadcast_replicas(nets, opts, [lat], src=0)
+    bk = parallel.FlatGradBucket(list(nets.values()))
+    for it in range(3):
+        x = torch.randn(5, 6, generator=torch.Generator().manual_seed(1000 * rank + it))      # per-rank data
+        for o in opts.values():
+            o.zero_grad()
+        (nets["b"](nets["a"](x)) ** 2).mean().backward()
+        bk.all_reduce_()
+        for o in opts.values():
+            o.step()
+    rep = np.concatenate([p.detach().numpy().reshape(-1) for k in sorted(nets) for p in nets[k].parameters()] +
+                         [lat.numpy().reshape(-1)])
+    # strong-scaling split of the training step (bench.py c4s): the reference's 2048 rays split over the ranks
+    b0, n0, per0 = parallel.shard_range(2048, world, rank)
     # plain numpy through the queue (tensors would travel as shared-memory file descriptors, which is fragile when
     # the producer exits early)
     q.put((rank, bool(ok_gather), int(bucket.numel), [None if g is None else g.numpy() for g in g_local],
-           [p.grad.detach().clone().numpy() for m in mods for p in m.parameters()]))
+           [p.grad.detach().clone().numpy() for m in mods for p in m.parameters()], rep, (b0, n0, per0)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -238,6 +272,9 @@ def test_gloo_world2_gather_and_grad_bucket():
         z = np.zeros_like(res[0][4][k])
         want = ((a if a is not None else z) + (b if b is not None else z)) / 2
         assert np.allclose(res[0][4][k], want) and np.allclose(res[1][4][k], want)
+    # replicas bit-identical after broadcast + 3 data-parallel Adam steps (they used to diverge from step 0)
+    assert np.array_equal(res[0][5], res[1][5])
+    assert res[0][6] == (0, 1024, 1024) and res[1][6] == (1024, 1024, 1024)
 
 
 def test_dropin_modules_importable():
@@ -324,13 +361,3 @@ def test_frame_writer_pipeline(tmp_path):
         im = np.asarray(Image.open(tmp_path / f"com_{i}.jpg"))
         assert im.shape == (H, W, 3) and abs(int(im.mean()) - 10 * i) <= 2
         assert (tmp_path / f"head_{i}.jpg").exists() == (i % 2 == 0)
-
-
-def test_make_adam_cpu_fallback_and_state_layout():
-    lin = torch.nn.Linear(3, 2)
-    opt = run_nerf.make_adam(lin.parameters(), 5e-4)
-    lin(torch.ones(1, 3)).sum().backward()
-    opt.step()
-    sd = opt.state_dict()
-    assert sd["param_groups"][0]["lr"] == 5e-4 and sd["param_groups"][0]["betas"] == (0.9, 0.999)
-    assert set(sd["state"][0].keys()) >= {"step", "exp_avg", "exp_avg_sq"}

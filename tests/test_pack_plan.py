@@ -64,7 +64,12 @@ def test_error_paths_without_gpu():
     assert L.dfn_encode_signal_torso(one, one, 10, 8, one, 1, 8, one, N) == -1                            # pose stride
     assert L.dfn_encode_signal_bwd(one, one, one, one, one, 8, 0, 4, N, one, one, one, N) == -1
     assert L.dfn_encode_signal_torso_bwd(one, one, 16, 8, 0, 0, one, N, N) == 0                           # smo 0: nothing to do
-    assert L.dfn_bias_grad(1, 0, N, 64, one, N) == -1 and L.dfn_weight_grad(1, 5, one, one, 64, one, one, N) == -1
+    assert L.dfn_bias_grad(1, 0, N, 64, one, one, N) == -1 and L.dfn_weight_grad(1, 5, one, one, 64, one, one, N) == -1
+    # the f16 tier is inference only: pack / fold / render accept it, the training entry points refuse it
+    assert L.dfn_packed_bytes(2, 0) == L.dfn_packed_bytes(1, 0) > 0 and L.dfn_bias_floats(2, 1) == L.dfn_bias_floats(1, 1)
+    assert L.dfn_packed_bwd_bytes(2, 0) == -1 and L.dfn_weight_grad(2, 0, one, one, 64, one, one, N) == -1
+    assert L.dfn_decoder_train_fwd(2, 0, one, one, one, one, 32, one, one, one, one, one, N) == -1
+    assert L.dfn_decoder_train_fwd(1, 2, one, one, one, one, 32, one, one, one, one, one, N) == -1        # listener
     assert L.dfn_decoder_fwd(1, 0, one, one, N, one, 4, one, one, N) == -1
     assert L.dfn_adam_multi(N, N, 4, 1e-3, 0.9, 0.999, 1e-8, 0.1, 0.03, N) == -1                          # no tables
     assert L.dfn_adam_multi(one, one, 4, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0.03, N) == -1                      # t = 0: bias_c1 = 0
@@ -188,6 +193,12 @@ def test_plan_reproduces_reference_decoder(tier, field, golden, states, latents)
     name = {0: "head", 1: "torso", 2: "listener"}[field]
     np.testing.assert_allclose(feat, g[f"feat_{name}_64"][0, :48], atol=2e-5, rtol=0)
     np.testing.assert_allclose(sigma, g[f"sigma_{name}_64"][0, :48], atol=2e-4, rtol=1e-5)
+
+
+def test_f16_tier_shares_the_bf16_plan():
+    """The two 16-bit tiers differ in the operand type only: same fragment order, same structural zeros."""
+    for field in (0, 1, 2):
+        assert np.array_equal(_lib.pack_plan(2, field), _lib.pack_plan(1, field))
 
 
 def test_flat_param_order_matches_state_dict(states):
