@@ -22,6 +22,7 @@ using namespace dfn;
 namespace {
 
 thread_local std::string g_err;
+unsigned long long* g_clock_probe = nullptr;      // dfn_debug_clock_probe (debug only)
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -236,6 +237,7 @@ static int render_fwd_impl(int tier, const DfnFrame* frame, const void* packed_h
     A.act_T[0] = A.act_T[1] = nullptr;
     A.masks[0] = A.masks[1] = nullptr;
     A.NP = 0;
+    A.clock_probe = g_clock_probe;
     hipError_t err = launch_render(tier, A, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "render_kernel");
     return DFN_OK;
@@ -344,6 +346,7 @@ int dfn_train_fwd(int tier, const DfnFrame* frame, const void* packed_head, cons
     A.masks[0] = masks_head;
     A.masks[1] = masks_torso;
     A.NP = NP;
+    A.clock_probe = nullptr;
     hipError_t err = launch_render(tier, A, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "render_kernel(train)");
     return DFN_OK;
@@ -662,6 +665,11 @@ int dfn_to8b(const float* x, long n, uint8_t* out, void* stream) {
     if (n == 0) return DFN_OK;
     hipError_t err = launch_to8b(x, n, out, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "to8b_kernel");
+    return DFN_OK;
+}
+
+int dfn_debug_clock_probe(uint64_t* probe) {
+    g_clock_probe = (unsigned long long*)probe;
     return DFN_OK;
 }
 

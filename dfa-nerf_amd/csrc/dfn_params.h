@@ -25,6 +25,9 @@ struct RenderArgs {
     void* act_T[2];
     unsigned* masks[2];
     long NP;
+    // debug (dfn_debug_clock_probe): the workgroup in the middle of the grid writes {shader cycles, 100 MHz ticks} of its
+    // own lifetime -> the effective shader clock UNDER LOAD of this launch.  Null = off.
+    unsigned long long* clock_probe;
 };
 
 struct DecoderArgs {

@@ -167,6 +167,12 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     const unsigned long long T_start = __builtin_readcyclecounter();
     const unsigned long long R_start = __builtin_amdgcn_s_memrealtime();
 #endif
+    const bool probe = A.clock_probe && blockIdx.x == gridDim.x / 2 && wave == 0;       // wave-uniform
+    unsigned long long probe_c0 = 0, probe_r0 = 0;
+    if (probe) {
+        probe_c0 = __builtin_readcyclecounter();
+        probe_r0 = __builtin_amdgcn_s_memrealtime();
+    }
     stream_begin<TIER, use_asm_dma<TIER, CtxK>()>(s, lds, wave, lane);
     {
         lds_f32* bl = (lds_f32*)(lds + L::BIAS_H);
@@ -510,6 +516,10 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
                 if (two && A.rgb_com) A.rgb_com[(size_t)r_raw * 3 + k] = st[RS_RGB_C + k];
             }
         }
+    }
+    if (probe && lane == 0) {
+        A.clock_probe[0] = __builtin_readcyclecounter() - probe_c0;
+        A.clock_probe[1] = __builtin_amdgcn_s_memrealtime() - probe_r0;
     }
     // drain the prefetched slabs before the LDS allocation is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -225,6 +225,11 @@ int dfn_to8b(const float* x, long n, uint8_t* out, void* stream);
  * A = (row,k) / B = (k,col) probes and writes D as the kernels interpret it: out[3][32][32] (bf16, f32, f16).
  * Used by tests to pin the fragment maps. */
 int dfn_debug_mfma_layout(float* out, void* stream);
+/* Measurement aid (process-global; NULL = off, the default): while set, every dfn_render_fwd* launch makes the workgroup
+ * in the middle of its grid write probe[0] = shader cycles (s_memtime) and probe[1] = 100 MHz ticks (s_memrealtime) of
+ * its own lifetime into this device array of two uint64: probe[0] / probe[1] x 0.1 GHz = the effective shader clock
+ * under load (the launch is power-bound: bench.py reports it next to the roofline fraction). */
+int dfn_debug_clock_probe(uint64_t* probe);
 
 #ifdef __cplusplus
 }
