@@ -125,7 +125,8 @@ def cpu_baseline(args, sc, st, zs, za, n_fine, fields):
 def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.0):
     """configs[3]: one optimisation step per `step`: signals -> fold -> fused HIP forward (recorder on) -> MSE
     losses -> HIP backward (compositing, dX chain, weight-gradient GEMMs) -> flat-bucket all_reduce -> gated Adams.
-    Targets and background are resident u8 device tensors; pixels are drawn and targets gathered on the device."""
+    Ground-truth frames and background are resident uint8 device tensors; pixels are drawn and targets gathered on
+    the device (frames.PixelSampler, dfn_mse_loss_u8): no host image read, no host-to-device copy per step."""
     from dfanerf import nets, parallel, run_nerf, synth, training
     from dfanerf.decoder import Decoder
     tier = "bf16" if args.tier == "f16" else args.tier           # the 16-bit training tier (f16 is inference only)
@@ -158,17 +159,19 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
     bucket = parallel.FlatGradBucket(list(mods.values())) if world > 1 else None
     rng = np.random.RandomState(100 + rank)
     rng_frame = np.random.RandomState(100) if strong else rng      # strong: ONE frame per step on all ranks (MAIN:779)
-    tgt_h = torch.rand(H, W, 3, device=dev)
-    tgt_c = torch.rand(H, W, 3, device=dev)
+    # the training input stage as train() runs it (dfanerf/frames.py): uint8 ground-truth frames resident on the device,
+    # pixels drawn on the device, targets gathered inside the loss kernel
+    from dfanerf import frames
+    g8 = torch.Generator(device=dev).manual_seed(7)
+    gt = [(torch.randint(0, 256, (H * W, 3), dtype=torch.uint8, device=dev, generator=g8),
+           torch.randint(0, 256, (H * W, 3), dtype=torch.uint8, device=dev, generator=g8)) for _ in range(8)]
+    sampler = frames.PixelSampler(H, W, N_RAND, 0, dev, seed=100 + rank)
     gstep = 300000                                   # all five optimizers' gates exercised except ExpNet
-    upload = training.PinnedUpload()
 
     def step():
         img_i = int(rng_frame.randint(0, 8))
-        sel = run_nerf.select_coords(H, W, N_RAND, 0, None, rng)
-        sel_d = upload(np.asarray(sel, dtype=np.int64), torch.int64, dev)        # pinned staging: no blocking copy
-        ys, xs = sel_d[:, 0], sel_d[:, 1]
-        loss, *_ = run_nerf.train_step_loss_hip(mods, ds, 0, img_i, sel_d, tgt_h[ys, xs], tgt_c[ys, xs], zs, za, gstep, a,
+        pix = sampler.draw()
+        loss, *_ = run_nerf.train_step_loss_hip(mods, ds, 0, img_i, pix, gt[img_i][0], gt[img_i][1], zs, za, gstep, a,
                                                 8, embed_fn, ds[0]["poses"][0], buf)
         for o in opts.values():
             o.zero_grad()

@@ -26,6 +26,6 @@ for t in bf16 f16; do
     python3 "$HERE/../tools/check_scratch.py" "$ISA" || { echo "build.sh: scratch memory in the $t inference kernels" >&2; exit 1; }
   fi
 done
-rm -f "$OBJ"/*.hipi "$OBJ"/*.bc "$OBJ"/*.out "$OBJ"/*.resolution.txt "$OBJ"/*.hipfb "$OBJ"/*-host-*.s      # --save-temps leftovers (the device ISA stays)
+rm -f "$OBJ"/*-hip-amdgcn-*.o "$OBJ"/*.hipi "$OBJ"/*.bc "$OBJ"/*.out "$OBJ"/*.resolution.txt "$OBJ"/*.hipfb "$OBJ"/*-host-*.s      # --save-temps leftovers (the device ISA stays)
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/dfn_render.o "$OBJ"/dfn_render_f32.o "$OBJ"/dfn_render_bf16.o "$OBJ"/dfn_render_f16.o "$OBJ"/dfn_misc.o "$OBJ"/dfn_api.o "$OBJ"/dfn_train.o "$OBJ"/dfn_bwd_bf16.o "$OBJ"/dfn_wgrad_bf16.o "$OBJ"/dfn_signal.o "$OBJ"/dfn_plan.o
 echo "built $OUT"

@@ -352,6 +352,16 @@ int dfn_train_fwd(int tier, const DfnFrame* frame, const void* packed_head, cons
     return DFN_OK;
 }
 
+int dfn_mse_loss_u8(const float* rgb_head, const float* rgb_com, const uint8_t* img_head, const uint8_t* img_com,
+                    const int32_t* pix_index, int n, float* losses, float* d_rgb_head, float* d_rgb_com, void* stream) {
+    if (!rgb_head || !rgb_com || !img_head || !img_com || !pix_index || !losses || !d_rgb_head || !d_rgb_com || n <= 0)
+        return fail(DFN_E_ARG, "dfn_mse_loss_u8: bad argument");
+    hipError_t err = launch_mse_loss(rgb_head, rgb_com, img_head, img_com, pix_index, n, losses, d_rgb_head, d_rgb_com,
+                                     (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "mse_loss_kernel");
+    return DFN_OK;
+}
+
 int dfn_composite_bwd(const DfnFrame* frame, const int32_t* pix_index, const float* bg_f32, const uint8_t* bg_u8,
                       const float* samples, const float* d_rgb_head, const float* d_rgb_com, float* dsamples,
                       void* stream) {

@@ -317,12 +317,12 @@ __global__ void sample_pdf_kernel(const float* bins, const float* weights, long 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane == 0) {                            // sequential cumsum like torch.cumsum
-        float c = 0.f;
+    if (lane == 0) {      // torch.cumsum on the CPU (the reference's goldens): sequential, accumulator in DOUBLE
+        double c = 0.0;   // (at::acc_type<float, false>), every prefix rounded to f32 on output
         cdf[0] = 0.f;
         for (int k = 1; k < nb; ++k) {
-            c = __fadd_rn(c, cdf[k]);
-            cdf[k] = c;
+            c += (double)cdf[k];
+            cdf[k] = (float)c;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

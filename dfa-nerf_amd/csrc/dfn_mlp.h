@@ -39,6 +39,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // vmcnt and drain the weight prefetch)
 #define DFN_LDS __attribute__((address_space(3)))
 typedef DFN_LDS char lds_char;
+typedef const __attribute__((address_space(1))) char gchar_c;
 typedef DFN_LDS float lds_f32;
 typedef DFN_LDS f32x4 lds_f32x4;
 typedef DFN_LDS u32x4 lds_u32x4;
@@ -109,10 +110,13 @@ DFN_DEV void stream_issue_piece(const Stream& s, lds_char* ring, int wave, int l
     if constexpr (ASM) {
         // asm on purpose: with the builtin ("LDS DMA" to the compiler) in the function, hipcc treats lgkmcnt as out of
         // order and puts s_waitcnt lgkmcnt(0) in front of every MFMA whose operands came from LDS
-        const char* src = s.pf_ptr + (size_t)lane * 16 + f * FRAG_BYTES;
         const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)ring + s.pf_slot * SLAB_BYTES +
                                                             (unsigned)f * FRAG_BYTES);
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+        // wave-uniform base in an SGPR pair + 32-bit lane offset (the "saddr" form): no 64-bit VALU address arithmetic per
+        // piece (interleaved A/B on one box, f16 C2: 35.10 -> 34.42 ms)
+        const gchar_c* sb = (const gchar_c*)(s.pf_ptr + f * FRAG_BYTES);
+        const unsigned voff = (unsigned)lane * 16u;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(dst) : "memory", "m0");
     } else {
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(s.pf_ptr + (size_t)lane * 16 + f * FRAG_BYTES),

@@ -167,6 +167,9 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     const unsigned long long T_start = __builtin_readcyclecounter();
     const unsigned long long R_start = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef DFN_PRIO_YOUNG      // experiment (static priority for the second-dispatched half): no effect on C2, not enabled
+    if (wave >= C::WAVES / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     const bool probe = A.clock_probe && blockIdx.x == gridDim.x / 2 && wave == 0;       // wave-uniform
     unsigned long long probe_c0 = 0, probe_r0 = 0;
     if (probe) {
@@ -368,7 +371,9 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
             // ---- sample_pdf(z_mid, weights[1:-1], n_fine, det=True), run_nerf_helpers.py:537-581 ----
             wave_lds_fence();
             const float wp = (lane >= 1 && lane <= 62) ? add_(tmp[lane], 1e-5f) : 0.f;
-            float Ssum = wp;
+            // sum(weights + 1e-5) in the library's documented order (sample_pdf_kernel, oracle wave_sum64): element k
+            // (= coarse weight k + 1) sits in lane k, lanes combine by a butterfly at XOR distances 32, 16, ..., 1
+            float Ssum = __shfl(wp, (lane + 1) & 63);
 #pragma unroll
             for (int dlt = 32; dlt >= 1; dlt >>= 1) Ssum += __shfl_xor(Ssum, dlt);
             const float pdf = div_(wp, Ssum);
@@ -376,10 +381,13 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
             wave_lds_fence();
             tmp[lane] = pdf;                 // pdf of weights index k lives at tmp[k]
             wave_lds_fence();
-            float c = 0.f, mine_c = 0.f;     // sequential cumsum like torch.cumsum
+            // torch.cumsum as the reference's CPU path computes it: sequential, accumulator in DOUBLE
+            // (at::acc_type<float, false>), every prefix rounded to f32 on output
+            double c = 0.0;
+            float mine_c = 0.f;
             for (int k = 0; k < 62; ++k) {
-                c = add_(c, tmp[k + 1]);
-                if (lane == k + 1) mine_c = c;
+                c += (double)tmp[k + 1];
+                if (lane == k + 1) mine_c = (float)c;
             }
             cdf[lane] = (lane <= 62) ? mine_c : 3.0e38f;
             wave_lds_fence();

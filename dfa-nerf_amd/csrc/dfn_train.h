@@ -51,6 +51,9 @@ hipError_t launch_reduce_scatter(const int* map, const float* parts, long n, lon
                                  hipStream_t st);
 // dbias[e] = sum over slices of parts[.][e] for the elements that have a gradient row (rows[e] >= 0), 0 otherwise
 hipError_t launch_reduce_bias(const int* rows, const float* parts, int n_bias, int slices, float* dbias, hipStream_t st);
+hipError_t launch_mse_loss(const float* rgb_head, const float* rgb_com, const unsigned char* img_head,
+                           const unsigned char* img_com, const int* pix, int n, float* losses, float* d_head, float* d_com,
+                           hipStream_t st);
 constexpr int BIAS_GRAD_SLICES = 128;      // slices of the points in the streaming bias_grad_kernel
 // macro-tile of one wgrad wave, in 32x32 output tiles (dfn_api.hip sizes the work list with the same numbers)
 constexpr int WG_MT = 2, WG_NT = 4;

@@ -301,6 +301,55 @@ hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, cons
     return hipGetLastError();
 }
 
+// ================================================================================================
+// loss: target gather + the two MSEs + their gradients in one launch
+// ================================================================================================
+// run_nerf_com_trainExpLater.py:791-800 (target[select_coords] of the head and the composite image), :902-907
+// (img2mse(rgb_com_torso, target_com) + img2mse(rgb_head, target_head)) and what torch autograd makes of them
+// (d loss / d rgb = 2 (rgb - target) / (3 n)).  Targets are uint8 images resident on the device (/ 255 like LOAD:58-60).
+// One workgroup, fixed reduction order: thread t adds its elements t, t + 1024, ... in sequence, then an LDS tree.
+__global__ __launch_bounds__(1024) void mse_loss_kernel(const float* __restrict__ rgb_head, const float* __restrict__ rgb_com,
+                                                        const unsigned char* __restrict__ img_head,
+                                                        const unsigned char* __restrict__ img_com,
+                                                        const int* __restrict__ pix, int n, float* losses, float* d_head,
+                                                        float* d_com) {
+    __shared__ float red[2][1024];
+    const int t = threadIdx.x, total = 3 * n;
+    const float scale = __fdiv_rn(2.0f, (float)total);
+    float sh = 0.f, sc = 0.f;
+    for (int e = t; e < total; e += 1024) {
+        const int r = e / 3, c = e - 3 * r;
+        const size_t src = (size_t)pix[r] * 3 + c;
+        const float dh = __fsub_rn(rgb_head[e], __fdiv_rn((float)img_head[src], 255.0f));
+        const float dc = __fsub_rn(rgb_com[e], __fdiv_rn((float)img_com[src], 255.0f));
+        sh = __fadd_rn(sh, __fmul_rn(dh, dh));
+        sc = __fadd_rn(sc, __fmul_rn(dc, dc));
+        d_head[e] = __fmul_rn(scale, dh);
+        d_com[e] = __fmul_rn(scale, dc);
+    }
+    red[0][t] = sh;
+    red[1][t] = sc;
+    __syncthreads();
+    for (int s = 512; s >= 1; s >>= 1) {
+        if (t < s) {
+            red[0][t] = __fadd_rn(red[0][t], red[0][t + s]);
+            red[1][t] = __fadd_rn(red[1][t], red[1][t + s]);
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        losses[0] = __fdiv_rn(red[0][0], (float)total);      // img2mse(rgb_head, target_head)
+        losses[1] = __fdiv_rn(red[1][0], (float)total);      // img2mse(rgb_com, target_com)
+    }
+}
+hipError_t launch_mse_loss(const float* rgb_head, const float* rgb_com, const unsigned char* img_head,
+                           const unsigned char* img_com, const int* pix, int n, float* losses, float* d_head, float* d_com,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(1024), 0, st, rgb_head, rgb_com, img_head, img_com, pix, n, losses,
+                       d_head, d_com);
+    return hipGetLastError();
+}
+
 // grad_flat[map[i]] += parts[0][i] + parts[1][i] + ... (fixed order): the second stage of the split-K reduction
 __global__ void reduce_scatter_kernel(const int* map, const float* parts, long n, long stride, int slices, float* grad_flat) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

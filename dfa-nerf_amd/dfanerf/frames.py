@@ -1,0 +1,129 @@
+"""Training input stage on the device.
+
+Upstream decodes two JPEGs from disk every optimisation step (run_nerf_com_trainExpLater.py:771-774: imageio.imread of
+the head and the composite ground truth), uploads both 450x450 frames and picks 2048 pixels of each (:791-800) after
+drawing them with NumPy on the host (:786-820).  At a ~2 ms GPU step that host work is the step.  Here:
+
+  * DeviceFrameCache - the ground-truth frames live on the device as uint8 [H*W,3] (607 KB per 450x450 frame; a
+    7000-frame sequence x 2 image sets = 8.5 GB of the 288 GB): decoded once (thread pool) or, when the sequence does
+    not fit the budget, kept in an LRU of decoded frames.  After the first visit of a frame a step reads no file and
+    copies nothing from the host.
+  * PixelSampler - the pixel draw of MAIN:786-820 on the device: N_rand DISTINCT pixels, uniform over the subsets
+    (np.random.choice(replace=False) upstream), with the face-rect / lower-half split when sample_rate > 0; one random
+    key per pixel and a top-k, no host round trip.
+  * the targets are never materialised: dfn_mse_loss_u8 (training.MseLossFn) gathers them from the uint8 frames inside
+    the loss kernel."""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+
+def _imread_u8(path):
+    from PIL import Image
+    return np.asarray(Image.open(path).convert('RGB'), dtype=np.uint8)
+
+
+class DeviceFrameCache:
+    """uint8 ground-truth frames on the device: get(i) -> (head [H*W,3], com [H*W,3]) uint8 device tensors.
+
+    budget_bytes: device memory the cache may use.  If every frame of `ids` fits, preload() decodes them all up front;
+    otherwise frames are decoded on first use and the least recently used ones are dropped."""
+
+    def __init__(self, paths_head, paths_com, H, W, device, budget_bytes=32 << 30, reader=_imread_u8):
+        self.paths = (list(paths_head), list(paths_com))
+        self.H, self.W, self.device, self.reader = int(H), int(W), device, reader
+        self.frame_bytes = 2 * self.H * self.W * 3
+        self.capacity = max(1, int(budget_bytes // self.frame_bytes))
+        self.slots = {}                 # frame id -> (head, com)
+        self.order = []                 # LRU order (oldest first); only maintained once the cache is full
+        self.host_reads = 0             # files decoded so far (tools/profile_train_host.py reports it per step)
+        self._pin = None
+
+    def _decode(self, i):
+        return self.reader(self.paths[0][i]), self.reader(self.paths[1][i])
+
+    def _upload(self, i, head, com):
+        n = self.H * self.W * 3
+        for a in (head, com):
+            if a.shape != (self.H, self.W, 3):
+                raise ValueError(f"frame {i}: image shape {a.shape}, expected {(self.H, self.W, 3)}")
+        if self._pin is None:
+            self._pin = [torch.empty(2 * n, dtype=torch.uint8, pin_memory=torch.cuda.is_available()) for _ in range(2)]
+            self._pin_ev = [None, None]
+            self._pin_k = 0
+        k = self._pin_k
+        self._pin_k ^= 1
+        if self._pin_ev[k] is not None:
+            self._pin_ev[k].synchronize()
+        buf = self._pin[k]
+        buf[:n].numpy()[:] = head.reshape(-1)
+        buf[n:].numpy()[:] = com.reshape(-1)
+        dev = buf.to(self.device, non_blocking=True)
+        if dev.data_ptr() == buf.data_ptr():       # the cache lives on the staging buffer's own device (CPU unit tests)
+            dev = buf.clone()
+        if torch.cuda.is_available():
+            self._pin_ev[k] = torch.cuda.Event()
+            self._pin_ev[k].record()
+        self.host_reads += 2
+        pair = (dev[:n].view(-1, 3), dev[n:].view(-1, 3))
+        if len(self.slots) >= self.capacity:
+            old = self.order.pop(0)
+            del self.slots[old]
+        self.slots[i] = pair
+        self.order.append(i)
+        return pair
+
+    def preload(self, ids, workers=8, log=None):
+        """Decode and upload `ids` (as many as fit the budget) with a pool of decoder threads."""
+        ids = [int(i) for i in ids if int(i) not in self.slots][:self.capacity - len(self.slots)]
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            for k, (i, (h, c)) in enumerate(zip(ids, pool.map(self._decode, ids))):
+                self._upload(i, h, c)
+                if log and (k + 1) % 500 == 0:
+                    log(f"[dfanerf] ground-truth frames on the device: {k + 1}/{len(ids)}")
+        return len(ids)
+
+    def get(self, i):
+        i = int(i)
+        hit = self.slots.get(i)
+        if hit is None:
+            return self._upload(i, *self._decode(i))
+        if len(self.slots) >= self.capacity and self.order and self.order[-1] != i:      # LRU bookkeeping only when full
+            self.order.remove(i)
+            self.order.append(i)
+        return hit
+
+
+class PixelSampler:
+    """MAIN:786-820 on the device.  draw(rect) -> int32 [N_rand] pixel ids y*W+x, all distinct:
+      sample_rate == 0: a uniformly random N_rand-subset of the H*W pixels in random order;
+      sample_rate > 0:  int(N_rand * sample_rate) of them from (face rect | lower half of the image), the rest from the
+                        complement (`rect` = [y0, x0, h, w] of the frame, a device tensor row or a host sequence).
+    One uniform key per pixel + top-k: exactly uniform over the subsets, like np.random.choice(replace=False)."""
+
+    def __init__(self, H, W, n_rand, sample_rate, device, seed=0):
+        self.H, self.W, self.n, self.rate, self.device = int(H), int(W), int(n_rand), float(sample_rate), device
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed(int(seed))
+        self.keys = torch.empty(self.H * self.W, dtype=torch.float32, device=device)
+        if self.rate > 0:
+            p = torch.arange(self.H * self.W, device=device)
+            self.y, self.x = (p // self.W).to(torch.int32), (p % self.W).to(torch.int32)
+            self.rect_num = int(self.n * self.rate)
+        if self.n > self.H * self.W:
+            raise ValueError("PixelSampler: more rays than pixels")
+
+    def draw(self, rect=None):
+        k = self.keys.uniform_(0.0, 1.0, generator=self.gen)
+        if self.rate <= 0:
+            return torch.topk(k, self.n, sorted=True).indices.to(torch.int32)
+        r = rect if isinstance(rect, torch.Tensor) else torch.as_tensor(np.asarray(rect), device=self.device)
+        r = r.to(device=self.device, dtype=torch.int32)
+        inside = ((self.y >= r[0]) & (self.y <= r[0] + r[2]) & (self.x >= r[1]) & (self.x <= r[1] + r[3])) | \
+                 (self.y.float() >= self.H / 2)
+        # keys of the other class drop below every real key: top-k then never crosses the class boundary as long as
+        # the class has enough pixels (checked once per sampler on the host: the lower half alone has H*W/2 >> N_rand)
+        a = torch.topk(torch.where(inside, k, k - 2.0), self.rect_num, sorted=True).indices
+        b = torch.topk(torch.where(inside, k - 2.0, k), self.n - self.rect_num, sorted=True).indices
+        return torch.cat((a, b)).to(torch.int32)

@@ -96,7 +96,9 @@ _FLAGS = [
 # build-side additions (not in the reference): precision tier of the HIP renderer and the hierarchical mode
 # --hip_tier: f32 (exact, the parity tier; default) | f16 (the throughput tier: f16 MFMA operands, PSNR-gated) | bf16
 # (the 16-bit TRAINING tier; also selected for the training step when --hip_tier f16)
-_EXTRA_FLAGS = [("hip_tier", str, 'f32'), ("hierarchical", None, None)]
+# --image_ext: file type of the rendered frames (upstream writes .jpg, MAIN:722-732; png = the kernel's uint8 output
+# losslessly, which is what the parity tests read back)
+_EXTRA_FLAGS = [("hip_tier", str, 'f32'), ("hierarchical", None, None), ("image_ext", str, 'jpg')]
 
 
 def config_parser():
@@ -424,8 +426,11 @@ def select_coords(H, W, N_rand, sample_rate, rect, rng=np.random):
 
 def train_step_loss_hip(nets, dataset, itr_obj, img_i, sel_yx, target_head, target_com, z_shape, z_app, global_step,
                         args, len_train, embed_fn, pose_torso, buf):
-    """Same step as train_step_loss, with the decoder forward+backward, ray generation, sampling and compositing
-    in the fused HIP kernels (dfanerf.training.RenderTrainFn).  `buf`: training.TrainBuffers for len(sel_yx) rays."""
+    """Forward of one training step (MAIN:779-907) with the decoder forward+backward, ray generation, sampling and
+    compositing in the fused HIP kernels (training.FusedTrainFn).  `buf`: training.TrainBuffers for len(sel_yx) rays.
+    sel_yx: [n,2] (y, x) pixel coordinates (numpy or device tensor) or an int32 device tensor [n] of pixel ids y*W+x
+    (frames.PixelSampler).  target_head / target_com: float [n,3] targets, or the whole uint8 ground-truth frames
+    [H*W,3] on the device (frames.DeviceFrameCache) - then the loss kernel gathers the targets itself."""
     from . import engine, training
     dec = nets["decoder"]
     dev = next(dec.parameters()).device
@@ -443,7 +448,9 @@ def train_step_loss_hip(nets, dataset, itr_obj, img_i, sel_yx, target_head, targ
                                global_step, args, len_train, embed_fn=embed_fn)
         signal_torso = encode_signal_torso(dataset, itr_obj, img_i, nets.get("PoseAttNet"), global_step, args,
                                            len_train, embed_fn=embed_fn)
-    if isinstance(sel_yx, torch.Tensor):
+    if isinstance(sel_yx, torch.Tensor) and sel_yx.dim() == 1:
+        pix = sel_yx.to(device=dev, dtype=torch.int32)
+    elif isinstance(sel_yx, torch.Tensor):
         pix = (sel_yx[:, 0] * W + sel_yx[:, 1]).to(device=dev, dtype=torch.int32)
     else:
         if getattr(buf, "upload", None) is None:
@@ -465,8 +472,15 @@ def train_step_loss_hip(nets, dataset, itr_obj, img_i, sel_yx, target_head, targ
     zs = z_shape[0, itr_obj * 2:itr_obj * 2 + 2]
     za = z_app[0, itr_obj * 2:itr_obj * 2 + 2]
     rgb_head, rgb_com = training.render_train(dec, buf, frame, bg, pix, signal[0], signal_torso, zs, za)
-    l_head = img2mse(rgb_head, target_head)
-    l_com = img2mse(rgb_com, target_com)
+    if target_head.dtype == torch.uint8:
+        # whole uint8 ground-truth frames [H*W,3] resident on the device (frames.DeviceFrameCache): the targets are gathered
+        # inside the loss kernel (dfn_mse_loss_u8: MAIN:791-800 + 902-907 + their autograd in one launch)
+        l_head, l_com = training.mse_losses(rgb_head, rgb_com, target_head, target_com, pix)
+        if args.use_L1:
+            target_com = target_com[pix.long()].float() / 255.0
+    else:                                   # explicit float targets [n,3]
+        l_head = img2mse(rgb_head, target_head)
+        l_com = img2mse(rgb_com, target_com)
     loss = l_com + l_head
     if args.use_L1:
         # MAIN:909-912 as written upstream: the L1 term pairs the HEAD image with the composite target and replaces
@@ -562,6 +576,8 @@ def train():
 
     def render_frames(frame_ids, len_sig, outdir_com, outdir_head, pose_body_t, tag='test_{:06d}.jpg'):
         rgbs = []
+        if args.image_ext != 'jpg':
+            tag = tag[:-3] + args.image_ext
         writer = _FrameWriter(H, W, 2)
         body_host = _host(pose_body_t)
         # conditioning signals through the HIP encoders (dfn_encode_signal*, rows A7 / A8) when the whole path is on
@@ -617,18 +633,25 @@ def train():
     bucket = parallel.FlatGradBucket(list(nets.values())) if world > 1 else None
     rng = np.random.RandomState(1234 + rank) if world > 1 else np.random
     i_train = ds['i_train']
+    # training input stage on the device: uint8 ground-truth frames resident in HBM (decoded
+    # once; an LRU of decoded frames if the sequence does not fit), pixels drawn on the device, targets gathered inside
+    # the loss kernel - upstream decodes two JPEGs and uploads two frames every step (MAIN:771-774, 791-800)
+    from . import frames
+    cache = frames.DeviceFrameCache(ds['imgs'], ds['imgs_com'], H, W, dev,
+                                    budget_bytes=int(float(os.environ.get("DFN_FRAME_CACHE_GB", "32")) * (1 << 30)))
+    if len(i_train) <= cache.capacity:
+        t0 = time.time()
+        n_pre = cache.preload(i_train, log=print if rank == 0 else None)
+        if rank == 0:
+            print(f'[dfanerf] {n_pre} ground-truth frame pairs decoded to the device in {time.time() - t0:.1f} s')
+    sampler = frames.PixelSampler(H, W, args.N_rand, args.sample_rate, dev, seed=1234 + rank)
+    rects_dev = torch.as_tensor(np.asarray(ds['sample_rects']), device=dev) if args.sample_rate > 0 else None
     from tqdm import trange, tqdm
     for i in trange(global_step + 1, args.N_iters + 1, disable=rank != 0):
         img_i = rng.choice(i_train)
-        sel = select_coords(H, W, args.N_rand, args.sample_rate, ds['sample_rects'][img_i], rng)
-        # target[select_coords] (MAIN:791-800): the N_rand pixels are picked on the host and go up through pinned
-        # staging buffers - uploading both whole frames from pageable memory blocked the host twice per step until the
-        # stream had drained
-        if getattr(train_buf, "upload", None) is None:
-            train_buf.upload = training.PinnedUpload()
-        pick = lambda path: train_buf.upload(np.asarray(_imread(path))[sel[:, 0], sel[:, 1]], torch.uint8, dev).float() / 255.0
-        target_com_s, target_head_s = pick(ds['imgs_com'][img_i]), pick(ds['imgs'][img_i])
-        loss, l_head, l_com, _, _ = train_step_loss_hip(nets, datasets, itr_obj, img_i, sel, target_head_s,
+        pix = sampler.draw(None if rects_dev is None else rects_dev[img_i])
+        target_head_s, target_com_s = cache.get(img_i)
+        loss, l_head, l_com, _, _ = train_step_loss_hip(nets, datasets, itr_obj, img_i, pix, target_head_s,
                                                         target_com_s, z_shape, z_app, global_step, args,
                                                         len(i_train), embed_fn, ds['poses'][0, :3, :4], train_buf)
         for o in opts.values():

@@ -321,6 +321,38 @@ def render_train(dec, buf, frame, bg, pix_index, sig_head, sig_torso, z_shape, z
     return FusedTrainFn.apply(sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app)
 
 
+# ---- the loss ------------------------------------------------------------------------------------------------------------
+class MseLossFn(torch.autograd.Function):
+    """(rgb_head, rgb_com [n,3]) -> losses [2] = (img2mse(rgb_head, target_head), img2mse(rgb_com, target_com)) with the
+    targets gathered from uint8 frames resident on the device (frames.DeviceFrameCache) INSIDE the kernel:
+    dfn_mse_loss_u8 = MAIN:791-800 + :902-907 + their autograd in one launch (upstream: two index_selects, two uint8 ->
+    float conversions, two divisions, two MSE forwards and their backward kernels)."""
+
+    @staticmethod
+    def forward(ctx, rgb_head, rgb_com, img_head, img_com, pix):
+        n = rgb_head.shape[0]
+        if img_head.dtype != torch.uint8 or img_com.dtype != torch.uint8 or pix.dtype != torch.int32:
+            raise TypeError("MseLossFn: uint8 frames and int32 pixel ids expected")
+        rh, rc = rgb_head.detach().contiguous(), rgb_com.detach().contiguous()
+        losses = torch.empty(2, dtype=torch.float32, device=rh.device)
+        d_h, d_c = torch.empty_like(rh), torch.empty_like(rc)
+        check(lib.dfn_mse_loss_u8(_ptr(rh), _ptr(rc), _ptr(img_head), _ptr(img_com), _ptr(pix), n, _ptr(losses), _ptr(d_h),
+                                  _ptr(d_c), _stream()), "dfn_mse_loss_u8")
+        ctx.save_for_backward(d_h, d_c)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        d_h, d_c = ctx.saved_tensors
+        return d_h * g[0], d_c * g[1], None, None, None
+
+
+def mse_losses(rgb_head, rgb_com, img_head, img_com, pix):
+    """-> (loss_head, loss_com) 0-dim tensors; img_*: uint8 [H*W,3] device frames, pix: int32 [n]."""
+    out = MseLossFn.apply(rgb_head, rgb_com, img_head, img_com, pix)
+    return out[0], out[1]
+
+
 # ---- Decoder.forward on explicit points under autograd -------------------------------------------------------------
 class _PointBuffers:
     """Device buffers of one decoder-on-points training call (one field), sized for NP = ceil32(n) points."""

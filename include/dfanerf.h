@@ -147,6 +147,14 @@ int dfn_train_fwd(int tier, const DfnFrame* frame, const void* packed_head, cons
                   const float* bias_head, const float* bias_torso, const float* bg_f32, const uint8_t* bg_u8,
                   const int32_t* pix_index, float* rgb_head, float* rgb_com, float* samples, void* act_head,
                   uint32_t* masks_head, void* act_torso, uint32_t* masks_torso, void* stream);
+/* The loss of a training step in one launch: replaces target[select_coords] (MAIN:791-800: the pixels pix_index of the
+ * head and the composite ground-truth images, here uint8 [H*W,3] resident on the device, / 255 as LOAD:58-60), the two
+ * img2mse (HELP:13; MAIN:902-907) and their autograd:
+ *   losses[0] = mean((rgb_head - target_head)^2), losses[1] = mean((rgb_com - target_com)^2)   (means over 3 n values)
+ *   d_rgb_head / d_rgb_com [n,3] = 2 (rgb - target) / (3 n)  = d (losses[0] + losses[1]) / d rgb
+ * Fixed reduction order (bit-reproducible). */
+int dfn_mse_loss_u8(const float* rgb_head, const float* rgb_com, const uint8_t* img_head, const uint8_t* img_com,
+                    const int32_t* pix_index, int n, float* losses, float* d_rgb_head, float* d_rgb_com, void* stream);
 int dfn_composite_bwd(const DfnFrame* frame, const int32_t* pix_index, const float* bg_f32, const uint8_t* bg_u8,
                       const float* samples, const float* d_rgb_head, const float* d_rgb_com, float* dsamples,
                       void* stream);

@@ -344,12 +344,32 @@ def integrate_fields(z, d_head, d_torso, sig_h, feat_h, sig_t, feat_t, bg, last_
 # --------------------------------------------------------------------------
 # A13: fine sampler
 # --------------------------------------------------------------------------
-def sample_pdf(bins, weights, n_samples, det=False, u=None):
+def wave_sum64(x):
+    """Sum over the last axis in the FIXED order the HIP kernels document (dfn_misc.hip:sample_pdf_kernel,
+    dfn_render_kernels.h): element k is accumulated by lane k % 64 (k, k + 64, ... in sequence), then the 64 lanes are
+    combined by a butterfly: partners at XOR distance 32, 16, 8, 4, 2, 1 (every lane ends with the same value: f32
+    addition is commutative).  torch.sum's own order is not even stable across CPU vector widths, so a kernel cannot be
+    bitwise against it; it can against this."""
+    n = x.shape[-1]
+    xp = F.pad(x, (0, (-n) % 64)).reshape(*x.shape[:-1], -1, 64)
+    part = xp[..., 0, :].clone()
+    for j in range(1, xp.shape[-2]):
+        part = part + xp[..., j, :]
+    lanes = torch.arange(64)
+    for d in (32, 16, 8, 4, 2, 1):
+        part = part + part[..., lanes ^ d]
+    return part[..., :1]
+
+
+def sample_pdf(bins, weights, n_samples, det=False, u=None, fixed_order=False):
     """HELP:537-581.  bins [R,nb], weights [R,nb-1] -> [R,n_samples].
     `u` overrides the uniform draws (the reference's pytest mode feeds
-    np.random.seed(0) numbers here)."""
+    np.random.seed(0) numbers here).  fixed_order: the normaliser sum(weights + 1e-5) in the kernels' documented
+    order (wave_sum64) instead of torch.sum's - everything else is elementwise or sequential and identical: with it the
+    HIP kernel matches this function BIT FOR BIT; without it this function matches the reference bit for bit on the
+    machine that made golden G5."""
     weights = weights + 1e-5
-    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    pdf = weights / (wave_sum64(weights) if fixed_order else torch.sum(weights, -1, keepdim=True))
     cdf = torch.cumsum(pdf, -1)
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
     if u is None:

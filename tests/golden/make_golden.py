@@ -358,6 +358,23 @@ def main():
         g8[f"after_{step}/ExpNet/encoder.2.bias"] = exp2.encoder[2].bias.detach().clone()
         g8[f"after_{step}/AudAttNet/attentionNet.0.bias"] = att2.attentionNet[0].bias.detach().clone()
         g8[f"after_{step}/PoseAttNet/attentionNet.0.bias"] = patt2.attentionNet[0].bias.detach().clone()
+        if step == 300000:
+            # ---- G12: structure of the checkpoint the reference writes after this step (MAIN:1101-1115) --------------
+            # built from the reference's own modules and torch.optim.Adam exactly as upstream does; z_shape / z_app are
+            # the [1, 2 n_object, z_dim] latents of MAIN:549-550 (here n_object = 1)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import json
+            from ckpt_manifest import checkpoint_manifest
+            ck = {'global_step': step + 1, 'z_shape': z_shape, 'z_app': z_app,
+                  'network_decoder_state_dict': dec2.state_dict(), 'network_AudNet_state_dict': aud2.state_dict(),
+                  'network_ExpNet_state_dict': exp2.state_dict(), 'optimizer_decoder_state_dict': opts[0].state_dict(),
+                  'optimizer_Aud_state_dict': opts[1].state_dict(), 'optimizer_Exp_state_dict': opts[2].state_dict(),
+                  "network_AudAttNet_state_dict": att2.state_dict(), "optimizer_AudAtt_state_dict": opts[3].state_dict(),
+                  "network_PoseAttNet_state_dict": patt2.state_dict(),
+                  "optimizer_PoseAtt_state_dict": opts[4].state_dict()}
+            with open(os.path.join(HERE, "g12_ckpt_manifest.json"), "w") as f:
+                json.dump(checkpoint_manifest(ck), f, indent=0, sort_keys=True)
+            print("g12_ckpt_manifest.json written")
     save("g8_train_step", **g8)
 
     # ---- G9: state_dict manifest (text) ---------------------------------------------

@@ -94,20 +94,35 @@ def _assert_samples_match(got, bins, w, n, u=None):
 
 
 def test_sample_pdf(eng, golden):
+    """HIP sample_pdf against (a) the oracle with the normaliser summed in the kernels' documented order: BIT FOR BIT,
+    every mode, ragged shapes; (b) the reference's own output (golden G5 == oracle.sample_pdf bitwise) within the
+    conditioning-aware tolerance - the two differ only by the rounding of torch.sum's ISA-dependent order."""
     g = golden("g5_sample_pdf")
     bins, w = t(g["bins"]), t(g["weights"])
     assert np.array_equal(O.sample_pdf(bins, w, 128, det=True).numpy(), g["det128"])   # oracle == reference here too
-    _assert_samples_match(eng.sample_pdf(bins.cuda(), w.cuda(), 128, det=True).cpu().numpy(), bins, w, 128)
-    _assert_samples_match(eng.sample_pdf(bins.cuda(), w.cuda(), 16, det=True).cpu().numpy(), bins, w, 16)
     u = t(g["u_pytest"])
-    _assert_samples_match(eng.sample_pdf(bins.cuda(), w.cuda(), 128, u=u.cuda()).cpu().numpy(), bins, w, 128, u=u)
+    for n, uu in ((128, None), (16, None), (128, u), (64, None)):
+        got = eng.sample_pdf(bins.cuda(), w.cuda(), n, det=uu is None, u=None if uu is None else uu.cuda()).cpu().numpy()
+        ref = O.sample_pdf(bins, w, n, det=uu is None, u=uu, fixed_order=True).numpy()
+        assert np.array_equal(got, ref), (n, np.abs(got - ref).max())                   # (a) bitwise
+        _assert_samples_match(got, bins, w, n, u=uu)                                    # (b) vs the reference's sum order
+    # the two normalisers differ by at most one ulp
+    s_fix, s_torch = O.wave_sum64(w + 1e-5), torch.sum(w + 1e-5, -1, keepdim=True)
+    assert float(((s_fix - s_torch).abs() / s_torch).max()) <= 4e-7          # a few ulp
+    # wider rows than one wave: the per-lane sequential part of the documented order
+    rs = np.random.RandomState(3)
+    wb = t(rs.rand(37, 200).astype(np.float32) ** 4)
+    bb = t(np.sort(rs.rand(37, 201).astype(np.float32), 1))
+    got = eng.sample_pdf(bb.cuda(), wb.cuda(), 96, det=True).cpu().numpy()
+    assert np.array_equal(got, O.sample_pdf(bb, wb, 96, det=True, fixed_order=True).numpy())
     # random (non-det) mode draws its own u: only the range is checkable
     r = eng.sample_pdf(bins.cuda(), w.cuda(), 64).cpu().numpy()
     assert (r >= g["bins"].min() - 1e-6).all() and (r <= g["bins"].max() + 1e-6).all()
     # ragged / empty shapes
     assert eng.sample_pdf(bins[:0].cuda(), w[:0].cuda(), 8, det=True).shape == (0, 8)
     b2, w1 = bins[:1, :2].contiguous(), w[:1, :1].contiguous()
-    _assert_samples_match(eng.sample_pdf(b2.cuda(), w1.cuda(), 5, det=True).cpu().numpy(), b2, w1, 5)
+    got = eng.sample_pdf(b2.cuda(), w1.cuda(), 5, det=True).cpu().numpy()
+    assert np.array_equal(got, O.sample_pdf(b2, w1, 5, det=True, fixed_order=True).numpy())
 
 
 def test_composite_and_weights(eng, golden):
@@ -242,7 +257,11 @@ def test_render_hierarchical_f32_vs_reference_golden(eng, packed, scene, latents
     clean = (dz <= 2e-6).all(1)
     print(f"fields={fields}: {clean.mean() * 100:.1f}% of rays have all 192 depths equal to the reference's; "
           f"{(dz > 2e-6).mean() * 100:.3f}% of depths moved")
-    assert clean.mean() > 0.25 and (dz > 2e-6).mean() < 0.02
+    # measured (round 2, after the kernel's cumsum accumulates in double like torch's CPU cumsum): 99.85 % of the depths
+    # and 71-80 % of the rays identical; the sampler itself is bit-exact given the coarse weights
+    # (test_hierarchical_sampler_is_bit_exact_given_the_coarse_weights), so what moves a depth is the ~1e-7 difference
+    # of the coarse weights at sample_pdf's `denom < 1e-5` switch
+    assert clean.mean() > 0.65 and (dz > 2e-6).mean() < 0.003
     np.testing.assert_allclose(rh[clean], g[f"rgb_head_f{fields}"][clean], atol=5e-5, rtol=0)      # (1)
     if fields == 2:
         np.testing.assert_allclose(rc.cpu().numpy()[clean], g[f"rgb_com_f{fields}"][clean], atol=5e-5, rtol=0)
@@ -260,6 +279,29 @@ def test_render_hierarchical_f32_vs_reference_golden(eng, packed, scene, latents
     np.testing.assert_allclose(rh, oh.numpy(), atol=5e-5, rtol=0)
     if fields == 2:
         np.testing.assert_allclose(rc.cpu().numpy(), oc.numpy(), atol=5e-5, rtol=0)
+
+
+@pytest.mark.parametrize("tier", ["f32", "f16"])
+@pytest.mark.parametrize("fields,n_fine", [(1, 128), (2, 128), (2, 64)])
+def test_hierarchical_sampler_is_bit_exact_given_the_coarse_weights(eng, packed, scene, latents, golden, tier, fields,
+                                                                     n_fine):
+    """Row H index work, exact: the fused kernel's inverse-CDF sampler + rank merge against the oracle (sample_pdf with
+    the documented sum order, torch.sort) fed with the SAME coarse weights (the kernel's own, from a coarse-only launch:
+    identical arithmetic, so identical bits): all 64 + n_fine merged depths of every ray bit for bit.  What is left
+    between the kernel and the reference golden in the hierarchical tests is therefore only the 1e-7-level difference
+    of the coarse weights themselves, amplified by sample_pdf's `denom < 1e-5` switch in empty space."""
+    gc = golden("g7_frame_coarse")
+    idx = np.arange(3, scene["H"] * scene["W"], 211)[:960]
+    sig, sigt = gc["signal"][0], gc["signal_torso"].reshape(-1)
+    out = _render_subset(eng, packed, scene, latents, sig, sigt, idx, tier, 0, fields, want_weights=True, want_z=True)
+    w = (out[3] if fields == 2 else out[2]).cpu()
+    z = out[-1].cpu()
+    assert np.array_equal(z.numpy(), O.coarse_z(scene["near"], scene["far"], 64)[None].expand(len(idx), 64).numpy())
+    z_all = _render_subset(eng, packed, scene, latents, sig, sigt, idx, tier, n_fine, fields, want_z=True)[-1].cpu()
+    z_mid = .5 * (z[..., 1:] + z[..., :-1])
+    z_f = O.sample_pdf(z_mid, w[..., 1:-1], n_fine, det=True, fixed_order=True)
+    want, _ = torch.sort(torch.cat([z, z_f], -1), -1)
+    assert np.array_equal(z_all.numpy(), want.numpy()), float((z_all - want).abs().max())
 
 
 # "PSNR within 0.05 dB of reference" (BASELINE.json north_star) for a model that itself scores 30 dB against ground truth:

@@ -45,7 +45,7 @@ def test_cli_flags_match_reference():
             if f["type"]:
                 assert a.type.__name__ == f["type"], f
     extra = set(acts) - {f["name"] for f in want} - {"help"}
-    assert extra == {"hip_tier", "hierarchical"}
+    assert extra == {"hip_tier", "hierarchical", "image_ext"}
 
 
 def test_config_file_and_script_flags(tmp_path):
@@ -361,3 +361,64 @@ def test_frame_writer_pipeline(tmp_path):
         im = np.asarray(Image.open(tmp_path / f"com_{i}.jpg"))
         assert im.shape == (H, W, 3) and abs(int(im.mean()) - 10 * i) <= 2
         assert (tmp_path / f"head_{i}.jpg").exists() == (i % 2 == 0)
+
+
+def test_pixel_sampler_matches_select_coords_semantics():
+    """frames.PixelSampler (the device-side draw of MAIN:786-820; on CPU here) against run_nerf.select_coords (the host
+    restatement of the same lines): N_rand distinct pixels; with sample_rate > 0 exactly int(N_rand * rate) of them
+    inside (face rect | lower half) - the same counts select_coords produces; uniform coverage without a rate."""
+    from dfanerf import frames
+    H = W = 450
+    dev = torch.device("cpu")
+    s0 = frames.PixelSampler(H, W, 2048, 0, dev, seed=3)
+    seen = []
+    for _ in range(4):
+        p = s0.draw().numpy()
+        assert p.dtype == np.int32 and p.shape == (2048,) and len(set(p.tolist())) == 2048
+        assert p.min() >= 0 and p.max() < H * W
+        seen.append(p)
+    assert not np.array_equal(seen[0], seen[1])                                  # the generator advances
+    assert abs(np.mean([p.mean() for p in seen]) - (H * W - 1) / 2) < 4000       # uniform over the frame
+    assert np.array_equal(frames.PixelSampler(H, W, 2048, 0, dev, seed=3).draw().numpy(), seen[0])     # seeded
+    rect = np.array([100, 120, 150, 160])
+    host = run_nerf.select_coords(H, W, 2048, 0.95, rect, np.random.RandomState(0))
+    inside_host = ((host[:, 0] >= 100) & (host[:, 0] <= 250) & (host[:, 1] >= 120) & (host[:, 1] <= 280)) | (host[:, 0] >= H / 2)
+    s1 = frames.PixelSampler(H, W, 2048, 0.95, dev, seed=4)
+    for r in (rect, torch.as_tensor(rect)):
+        p = s1.draw(r).numpy()
+        y, x = p // W, p % W
+        inside = ((y >= 100) & (y <= 250) & (x >= 120) & (x <= 280)) | (y >= H / 2)
+        assert len(set(p.tolist())) == 2048 and int(inside.sum()) == int(inside_host.sum()) == int(2048 * 0.95)
+        assert inside[:int(2048 * 0.95)].all() and not inside[int(2048 * 0.95):].any()
+    with pytest.raises(ValueError):
+        frames.PixelSampler(4, 4, 17, 0, dev)
+
+
+def test_device_frame_cache_preload_lru_and_zero_reads_when_warm(tmp_path):
+    """frames.DeviceFrameCache: every frame decoded once; a warm cache serves get() without touching a file; when the
+    sequence does not fit the budget the least recently used frame is dropped and re-read on demand."""
+    from PIL import Image
+    from dfanerf import frames
+    H, W, N = 12, 16, 6
+    rs = np.random.RandomState(0)
+    imgs = [rs.randint(0, 256, (2, H, W, 3)).astype(np.uint8) for _ in range(N)]
+    ph, pc = [], []
+    for i, (a, b) in enumerate(imgs):
+        ph.append(str(tmp_path / f"h{i}.png")); pc.append(str(tmp_path / f"c{i}.png"))
+        Image.fromarray(a).save(ph[-1]); Image.fromarray(b).save(pc[-1])
+    c = frames.DeviceFrameCache(ph, pc, H, W, torch.device("cpu"))
+    assert c.preload(range(N), workers=3) == N and c.host_reads == 2 * N
+    for i in (3, 0, 5, 3):
+        h, cm = c.get(i)
+        assert h.dtype == torch.uint8 and tuple(h.shape) == (H * W, 3)
+        assert np.array_equal(h.numpy().reshape(H, W, 3), imgs[i][0]) and np.array_equal(cm.numpy().reshape(H, W, 3), imgs[i][1])
+    assert c.host_reads == 2 * N                                        # warm: no file was read
+    small = frames.DeviceFrameCache(ph, pc, H, W, torch.device("cpu"), budget_bytes=3 * 2 * H * W * 3)
+    assert small.capacity == 3
+    for i in (0, 1, 2, 0, 3):                                           # 3 evicts 1 (0 was used more recently)
+        small.get(i)
+    assert small.host_reads == 8 and set(small.slots) == {2, 0, 3}
+    small.get(1)
+    assert small.host_reads == 10 and np.array_equal(small.get(1)[0].numpy().reshape(H, W, 3), imgs[1][0])
+    with pytest.raises(ValueError):
+        frames.DeviceFrameCache(ph, pc, H + 1, W, torch.device("cpu")).get(0)

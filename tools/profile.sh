@@ -9,7 +9,7 @@ TAG="$1"; shift
 OUT="$REPO/gpurun_out/profiles_$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline $*"
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-extra --sustain-seconds 0 $*"
 rm -rf /tmp/rp && mkdir -p /tmp/rp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp/stats -- $BENCH --steps 10 --warmup 2 > "$OUT/bench_under_stats.json" 2> /tmp/rp/stats.err
 cp $(find /tmp/rp/stats -name '*kernel_stats.csv' | head -1) "$OUT/kernel_stats.csv" 2>/dev/null
