@@ -455,6 +455,13 @@ DFN_DEV float relu_(float x) { return __builtin_bit_cast(float, max(__builtin_bi
 // bias vectors live in LDS as [tile][half][16]
 template <int G>
 DFN_DEV void acc_init(f32x16 (&acc)[G], const lds_f32* bias_lds, int half) {
+#ifdef DFN_EXP_NOINIT     // timing experiment (wrong results): accumulators start at zero, no bias reads from LDS
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+    return;
+#endif
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const lds_f32x4* p = (const lds_f32x4*)(bias_lds + g * 32 + half * 16);
@@ -490,6 +497,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 template <int TIER, int G, int NT, bool RELU>
 DFN_DEV void acc_to_vec(const f32x16 (&acc)[G], Vec<TIER, NT>& v, int t0) {
+#ifdef DFN_EXP_NOEPI      // timing experiment (wrong results): what does the convert / ReLU epilogue cost?  One value per
+    {                     // tile keeps the data dependency on the accumulators alive
+#pragma unroll
+        for (int g = 0; g < G; ++g) v.set(16 * (t0 + g), acc[g][0]);
+        return;
+    }
+#endif
     if constexpr (tier_is16(TIER)) {
         typedef typename std::conditional<TIER == TIER_F16, f16x2, bf16x2>::type pk2;     // v_cvt_pk_{f16,bf16}_f32 (RNE)
         typedef typename std::conditional<TIER == TIER_F16, f16x8, bf16x8>::type pk8;

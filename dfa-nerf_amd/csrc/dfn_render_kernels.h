@@ -378,18 +378,18 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
             for (int dlt = 32; dlt >= 1; dlt >>= 1) Ssum += __shfl_xor(Ssum, dlt);
             const float pdf = div_(wp, Ssum);
             const float zmid = (lane < 63) ? mul_(0.5f, add_(zc[lane + 1], zc[lane])) : 0.f;
-            wave_lds_fence();
-            tmp[lane] = pdf;                 // pdf of weights index k lives at tmp[k]
-            wave_lds_fence();
-            // torch.cumsum as the reference's CPU path computes it: sequential, accumulator in DOUBLE
-            // (at::acc_type<float, false>), every prefix rounded to f32 on output
-            double c = 0.0;
-            float mine_c = 0.f;
-            for (int k = 0; k < 62; ++k) {
-                c += (double)tmp[k + 1];
-                if (lane == k + 1) mine_c = (float)c;
+            // torch.cumsum as the reference's CPU path computes it: accumulator in DOUBLE (at::acc_type<float, false>),
+            // every prefix rounded to f32 on output.  Here as a 6-step wave scan instead of the 62-step sequential loop,
+            // bit-identical to it: every pdf entry is an f32 in [1e-5 / 1.0007, 1] (compositing weights are >= 0 and sum
+            // to <= 1) and every prefix is < 2, i.e. a multiple of 2^-40 below 2 = 41 bits: double additions of them are
+            // EXACT in any order.  (The stand-alone sample_pdf_kernel takes arbitrary weights and keeps the loop.)
+            double c = (double)pdf;          // lanes 0 and 63 hold 0
+#pragma unroll
+            for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                const double up = __shfl_up(c, dlt);
+                if (lane >= dlt) c += up;
             }
-            cdf[lane] = (lane <= 62) ? mine_c : 3.0e38f;
+            cdf[lane] = (lane <= 62) ? (float)c : 3.0e38f;
             wave_lds_fence();
             tmp[lane] = zmid;                // bins
             wave_lds_fence();
@@ -428,13 +428,36 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
                     rank_f[m] = cnt;
                 }
             }
-            for (int i = 0; i < NF; ++i) {
-                const float v = zf[i];
-                rank_c += (v < myc) ? 1 : 0;
+            // The deterministic fine samples come out non-decreasing (inverse CDF of an increasing u) except for 1-ulp
+            // effects of the lerp rounding at bin borders.  Sorted: a fine sample's rank among the fine samples is its
+            // index, a coarse sample's is a binary search - instead of the NF-step counting loop (6 k of the 30 k cycles
+            // this section used to take per ray).  Checked per ray; the counting loop stays as the general path.
+            bool sorted_f = true;
 #pragma unroll
-                for (int m = 0; m < 3; ++m) {
+            for (int m = 0; m < 3; ++m)
+                if (m < NF / 64) {
                     const int j = lane + 64 * m;
-                    rank_f[m] += (v < myf[m] || (v == myf[m] && i < j)) ? 1 : 0;
+                    if (j + 1 < NF && zf[j + 1] < myf[m]) sorted_f = false;
+                }
+            if (__builtin_amdgcn_ballot_w64(!sorted_f) == 0) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) rank_f[m] += lane + 64 * m;       // fine samples before mine: exactly j
+                int cntf = 0;                                                   // fine values < my coarse value
+#pragma unroll
+                for (int stp = 128; stp >= 1; stp >>= 1) {
+                    const int t = cntf + stp;
+                    if (t <= NF && zf[t - 1] < myc) cntf = t;
+                }
+                rank_c += cntf;
+            } else {
+                for (int i = 0; i < NF; ++i) {
+                    const float v = zf[i];
+                    rank_c += (v < myc) ? 1 : 0;
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        const int j = lane + 64 * m;
+                        rank_f[m] += (v < myf[m] || (v == myf[m] && i < j)) ? 1 : 0;
+                    }
                 }
             }
             float keep_h[4];

@@ -343,11 +343,19 @@ _CKPT_OPT = {"decoder": "optimizer_decoder_state_dict", "AudNet": "optimizer_Aud
              "PoseAttNet": "optimizer_PoseAtt_state_dict"}
 
 
+# key order of the dict upstream saves (MAIN:1101-1115; golden G12 pins it)
+_CKPT_ORDER = [("net", "decoder"), ("net", "AudNet"), ("net", "ExpNet"), ("opt", "decoder"), ("opt", "AudNet"),
+               ("opt", "ExpNet"), ("net", "AudAttNet"), ("opt", "AudAttNet"), ("net", "PoseAttNet"), ("opt", "PoseAttNet")]
+
+
 def save_checkpoint(path, global_step, z_shape, z_app, nets, opts):
     ck = {'global_step': global_step, 'z_shape': z_shape, 'z_app': z_app}
-    for k, m in nets.items():
-        ck[_CKPT_NET[k]] = m.state_dict()
-        ck[_CKPT_OPT[k]] = opts[k].state_dict()
+    for kind, k in _CKPT_ORDER:
+        if k in nets:
+            if kind == "net":
+                ck[_CKPT_NET[k]] = nets[k].state_dict()
+            else:
+                ck[_CKPT_OPT[k]] = opts[k].state_dict()
     torch.save(ck, path)
 
 

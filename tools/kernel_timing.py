@@ -17,7 +17,7 @@ dev = torch.device("cuda:0")
 sc = synth.bench_scene(0, n_frames=2)
 st = synth.synth_all_states(0)
 flat = engine.flatten_state(st["decoder"], dev)
-pk = engine.PackedDecoder(flat, "bf16")
+pk = engine.PackedDecoder(flat, sys.argv[2] if len(sys.argv) > 2 else "f16")
 zs, za = [torch.from_numpy(v).to(dev) for v in synth.synth_latents(0)]
 sig_h = torch.randn(96, device=dev) * 0.1
 sig_t = torch.randn(42, device=dev) * 0.1
