@@ -223,10 +223,13 @@ struct Rec {
 // ASMD = only the LDS-DMA as inline asm (fragment reads stay with the compiler): for the kernels that also STORE a lot
 // (recorder, dX chain).  With the builtin in the function hipcc drains the whole vector-memory queue - every store
 // still in flight - at each use of an ordinary load (a ReLU mask word, a spill reload); without it the waits are counted.
-template <bool REC, bool ASMF = false, bool ASMD = false> struct CtxT {
+// PIPE = software-pipelined layers (layer_pipe below): the convert / ReLU epilogue of a tile pair and the bias reads of the
+// next one are issued between the MFMAs of the pair in between, on a second set of accumulators (+32 registers).
+template <bool REC, bool ASMF = false, bool ASMD = false, bool PIPE = false> struct CtxT {
     static constexpr bool rec_on = REC;
     static constexpr bool asm_fetch = ASMF && !REC && (DFN_ASM_FETCH != 0);
     static constexpr bool asm_dma = asm_fetch || ASMD;
+    static constexpr bool pipe = PIPE && !REC;
     lds_char* ring;
     int wave, lane, half;
     Rec rec;
@@ -324,6 +327,12 @@ DFN_DEV void rec_mask(const CT& c, int dword0, const Vec<TIER, NT>& v) {
 // layers: LDS latency hides behind the MFMAs of earlier fragments.  `fp` = index of the next fragment to
 // PREFETCH; both indices are compile-time after inlining/unrolling (in the runtime layer loops only their
 // slab phase matters, and one 256x256 layer is a whole number of slabs and of ring turns).
+// 1: the seven trunk layers as straight-line code (no `act = nxt` copies: 384 v_mov per pass, one in eight of the kernel's
+// non-MFMA vector instructions - the SIMD's vector issue port is what the MFMAs compete for - at +21 KB of code per MLP);
+// 0: two runtime loops of one layer body each.  (A ping-pong loop of two bodies makes hipcc spill ~60 VGPRs.)
+#ifndef DFN_TRUNK_UNROLL
+#define DFN_TRUNK_UNROLL 0
+#endif
 #ifndef DFN_PF_DEPTH
 #define DFN_PF_DEPTH 4
 #endif
@@ -373,6 +382,7 @@ static_assert((PF_DEPTH & (PF_DEPTH - 1)) == 0, "PF_DEPTH must be a power of two
 // issued before those pieces - behind the hand-over a store burst has a whole slab period to drain while the MFMAs
 // run; at the end of a pair it had none (measured: stores cost their full HBM time ON TOP of the compute).
 struct NoHook { DFN_DEV void operator()() const {} };
+struct NoSide { DFN_DEV void operator()(int) const {} };      // work issued between the MFMAs of a tile group: side(k-step)
 
 template <int TIER> struct Fetch {
     u32x4 buf[PF_DEPTH];
@@ -411,9 +421,9 @@ template <int TIER> struct Fetch {
 // One tile-group: acc[g] (g < G output tiles) += W x b over k-units [0, KU) of b.
 // Fragments are consumed in stream order [ku][g]; `f` is the running fragment index of the pass.
 // TAIL: number of fragments that follow this group in the pass (-1 = plenty): no prefetch past the end.
-template <int TIER, int G, int KU, int NTB, int TAIL = -1, class CT, class H = NoHook>
+template <int TIER, int G, int KU, int NTB, int TAIL = -1, class CT, class H = NoHook, class SD = NoSide>
 DFN_DEV void gemm_group(f32x16 (&acc)[G], const Vec<TIER, NTB>& b, int& f, Fetch<TIER>& fe, Stream& s,
-                        const CT& c, H&& hook = H{}) {
+                        const CT& c, H&& hook = H{}, SD&& side = SD{}) {
 #pragma unroll
     for (int ku = 0; ku < KU; ++ku) {
 #pragma unroll
@@ -445,6 +455,12 @@ DFN_DEV void gemm_group(f32x16 (&acc)[G], const Vec<TIER, NTB>& b, int& f, Fetch
             }
             ++f;
         }
+        side(ku);
+#ifdef DFN_PIPE_SCHEDBAR
+        // pin the side work of a k-step between its MFMAs and the next step's: without it the scheduler pulls the
+        // convert / ReLU units together right behind the last MFMA of their accumulators (where they wait for it)
+        if constexpr (!std::is_same<typename std::decay<SD>::type, NoSide>::value) __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 }
 
@@ -559,11 +575,79 @@ DFN_DEV void rec_mask_pair(const CT& c, int mask_dword, const f32x16 (&acc)[2]) 
     }
 }
 
+// ---- software-pipelined tile pairs (16-bit inference kernels) ----------------------------------------------------------
+// Word w (0..15) of a tile pair's epilogue: accumulator registers (2j, 2j+1) of tile w >> 3 -> one packed 32-bit word of the
+// next layer's operand (v_cvt_pk_{f16,bf16}_f32 + v_pk_max_i16), exactly what acc_to_vec does for the whole pair.
+template <int TIER, int NT, bool RELU>
+DFN_DEV void epi_word(const f32x16 (&acc)[2], Vec<TIER, NT>& v, int t0, int w) {
+    typedef typename std::conditional<TIER == TIER_F16, f16x2, bf16x2>::type pk2;
+    typedef typename std::conditional<TIER == TIER_F16, f16x8, bf16x8>::type pk8;
+    const int g = w >> 3, h = (w >> 2) & 1, e = w & 3;
+    const f32x2 x = {acc[g][8 * h + 2 * e], acc[g][8 * h + 2 * e + 1]};
+    const pk2 pk = __builtin_convertvector(x, pk2);
+    unsigned word;
+    if constexpr (RELU) word = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk), (s16x2)(0)));
+    else word = __builtin_bit_cast(unsigned, pk);
+    u32x4 q = __builtin_bit_cast(u32x4, v.u[2 * (t0 + g) + h]);
+    q[e] = word;
+    v.u[2 * (t0 + g) + h] = __builtin_bit_cast(pk8, q);
+}
+// bias read q (0..7) of a tile pair's accumulator initialisation (one ds_read_b128 = 4 registers): acc_init, piecewise
+DFN_DEV void init_quad(f32x16 (&acc)[2], const lds_f32* bias_lds, int half, int q) {
+    const int g = q >> 2, qq = q & 3;
+    const f32x4 v = ((const lds_f32x4*)(bias_lds + g * 32 + half * 16))[qq];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[g][4 * qq + e] = v[e];
+}
+// Side work of tile pair tg while its MFMAs issue: k-steps [0, KU/2) convert the PREVIOUS pair (other accumulator set),
+// k-steps [KU/2, KU) read the biases of the NEXT pair into that set.  All indices are compile-time after unrolling.
+template <int TIER, int OT, int KU, bool RELU> struct PipeSide {
+    static constexpr int ES = KU / 2 > 0 ? KU / 2 : 1, WPS = (16 + ES - 1) / ES;          // epilogue steps, words per step
+    static constexpr int BS = KU - ES > 0 ? KU - ES : 1, QPS = (8 + BS - 1) / BS;          // bias steps, reads per step
+    f32x16 (&other)[2];
+    Vec<TIER, OT>& out;
+    const lds_f32* bias_next;       // bias of pair tg + 1 (null: none)
+    int t_prev;                     // first tile of the previous pair (-1: none)
+    int half;
+    DFN_DEV void operator()(int ku) const {
+        if (t_prev >= 0 && ku < ES) {
+#pragma unroll
+            for (int w = 0; w < WPS; ++w)
+                if (ku * WPS + w < 16) epi_word<TIER, OT, RELU>(other, out, t_prev, ku * WPS + w);
+        }
+        if (bias_next && ku >= ES) {
+#pragma unroll
+            for (int q = 0; q < QPS; ++q)
+                if ((ku - ES) * QPS + q < 8) init_quad(other, bias_next, half, (ku - ES) * QPS + q);
+        }
+    }
+};
+template <int TIER, int OT, int KU, int NTB, bool RELU, class CT>
+DFN_DEV void layer_pipe(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_f32* bias, int& f, Fetch<TIER>& fe,
+                        Stream& s, const CT& c) {
+    static_assert(OT % 2 == 0 && KU >= 2, "tile pairs");
+    f32x16 acc[2][2];
+    acc_init<2>(acc[0], bias, c.half);
+#pragma unroll
+    for (int tg = 0; tg < OT / 2; ++tg) {
+        const int cur = tg & 1;
+        const PipeSide<TIER, OT, KU, RELU> side = {acc[cur ^ 1], out, tg + 1 < OT / 2 ? bias + (tg + 1) * 64 : nullptr,
+                                                   tg > 0 ? 2 * (tg - 1) : -1, c.half};
+        gemm_group<TIER, 2, KU, NTB>(acc[cur], in, f, fe, s, c, NoHook{}, side);
+        if (KU - PipeSide<TIER, OT, KU, RELU>::ES < 1 && tg + 1 < OT / 2) acc_init<2>(acc[cur ^ 1], bias + (tg + 1) * 64, c.half);
+    }
+    acc_to_vec<TIER, 2, OT, RELU>(acc[(OT / 2 - 1) & 1], out, OT - 2);        // the last pair: not overlapped
+}
+
 // out[OT tiles] = act( bias + W x in ), tile pairs; KU = k-units of `in` used
 template <int TIER, int OT, int KU, int NTB, bool RELU, class CT>
 DFN_DEV void layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_f32* bias, int& f, Fetch<TIER>& fe,
                    Stream& s, const CT& c, int rec_row = -1, int rec_mask = -1) {
     static_assert(OT % 2 == 0, "tile pairs");
+    if constexpr (CT::pipe && tier_is16(TIER) && OT >= 4 && KU >= 2) {
+        layer_pipe<TIER, OT, KU, NTB, RELU>(out, in, bias, f, fe, s, c);
+        return;
+    }
     bool pend = false;          // the values of pair tg - 1 wait for the next slab hand-over
 #pragma unroll
     for (int tg = 0; tg < OT / 2; ++tg) {
@@ -721,28 +805,49 @@ DFN_DEV MlpOut mlp_trunk(Vec<TIER, 8>& act, const Vec<TIER, NTP>& pvec, const Dh
                          int f_l1, Fetch<TIER>& fe, Stream& s, const CT& c, int r_trunk, int m_trunk) {
     using P = Prog<TIER>;
     Vec<TIER, 8> nxt;
-    // blocks[0..2]  (a0 itself was recorded by the caller's first layer).  Runtime loop on purpose: unrolling it
-    // (act/nxt ping-pong by register renaming instead of a 64-register copy per layer) measured 3 % SLOWER
-    // (code size).
+    // blocks[0..6] with the skip after blocks[3] (decoder.py:313-325), ping-ponging between the two operand vectors:
+    // the trunk's output a7 ends up in `nxt`.  Every layer starts at the same slab phase f_l1 (a layer is 128 fragments,
+    // the skip adds a multiple of 32).  DFN_TRUNK_UNROLL: see below.
+    const auto blk_bias = [&](int k) { return bias + (k < 4 ? b_l1 + 256 * k : b_l5 + 256 * (k - 4)); };
+    const auto blk_row = [&](int k) { return r_trunk + RecMap::T_A0 + 256 * (k + 1); };          // output of blocks[k]
+    const auto blk_mask = [&](int k) { return m_trunk + (k < 4 ? RecMap::TM_A0 + 4 * (k + 1) : RecMap::TM_A5 + 4 * (k - 4)); };
+    int f = f_l1;
+#if DFN_TRUNK_UNROLL
+    // straight-line: seven layer bodies, the operand vectors alternate by name (no copies, no loop-carried vectors)
+#define DFN_PLAIN(OUT, IN, K) f = f_l1; layer<TIER, 8, P::KU_ACT, 8, true>(OUT, IN, blk_bias(K), f, fe, s, c, blk_row(K), blk_mask(K))
+    DFN_PLAIN(nxt, act, 0);
+    DFN_PLAIN(act, nxt, 1);
+    DFN_PLAIN(nxt, act, 2);
+    f = f_l1;       // blocks[3], then the skip: relu(.) + fc_z_skips(z) + fc_p_skips(p)   (decoder.py:316-325)
+    layer_skip<TIER, 8, P::KU_ACT, 8, KUP, NTP>(act, nxt, bias + b_l1 + 256 * 3, pvec, bias + b_skip, f, fe, s, c,
+                                                r_trunk + RecMap::T_A0 + 256 * 4, m_trunk + RecMap::TM_A4R);
+    DFN_PLAIN(nxt, act, 4);
+    DFN_PLAIN(act, nxt, 5);
+    DFN_PLAIN(nxt, act, 6);
+#undef DFN_PLAIN
+#else
+    // runtime loops (one layer body each): the 64-register copy after every layer is the price of the small code
     for (int l = 0; l < 3; ++l) {
-        int f = f_l1;                                       // same slab phase every iteration
+        f = f_l1;
         layer<TIER, 8, P::KU_ACT, 8, true>(nxt, act, bias + b_l1 + 256 * l, f, fe, s, c,
                                            r_trunk + RecMap::T_A0 + 256 * (l + 1), m_trunk + RecMap::TM_A0 + 4 * (l + 1));
         act = nxt;
     }
-    int f = f_l1;
-    // blocks[3], then the skip: relu(.) + fc_z_skips(z) + fc_p_skips(p)   (decoder.py:316-325)
+    f = f_l1;       // blocks[3], then the skip: relu(.) + fc_z_skips(z) + fc_p_skips(p)   (decoder.py:316-325)
     layer_skip<TIER, 8, P::KU_ACT, 8, KUP, NTP>(nxt, act, bias + b_l1 + 256 * 3, pvec, bias + b_skip, f, fe, s, c,
                                                 r_trunk + RecMap::T_A0 + 256 * 4, m_trunk + RecMap::TM_A4R);
     act = nxt;
-    const int f_l5 = f % SLAB_FRAGS;
-    // blocks[4..6]
     for (int l = 0; l < 3; ++l) {
-        f = f_l5;
+        f = f_l1;
         layer<TIER, 8, P::KU_ACT, 8, true>(nxt, act, bias + b_l5 + 256 * l, f, fe, s, c,
                                            r_trunk + RecMap::T_A0 + 256 * (5 + l), m_trunk + RecMap::TM_A5 + 4 * l);
         act = nxt;
     }
+#endif
+    // the trunk's output a7: in `nxt` after the straight-line form, in `act` after the loops; the other vector takes the
+    // view layer's output
+    Vec<TIER, 8>& a7 = DFN_TRUNK_UNROLL ? nxt : act;
+    Vec<TIER, 8>& hid = DFN_TRUNK_UNROLL ? act : nxt;
     // feat_view (+ sigma_out as row 0 of a 9th tile) on [act ; view PE]   (decoder.py:329-340)
     MlpOut o;
     {
@@ -754,24 +859,24 @@ DFN_DEV MlpOut mlp_trunk(Vec<TIER, 8>& act, const Vec<TIER, NTP>& pvec, const Dh
         bool pend = false;      // recorder values of pair tg - 1, issued at the next slab hand-over (NoHook)
         int ptg = 0;
         auto flush = [&] {
-            if (pend) rec_vals<TIER>(c, r_trunk + RecMap::T_H + 64 * ptg, nxt, 2 * ptg);
+            if (pend) rec_vals<TIER>(c, r_trunk + RecMap::T_H + 64 * ptg, hid, 2 * ptg);
             pend = false;
         };
 #pragma unroll
         for (int tg = 0; tg < 4; ++tg) {
             f32x16 acc[2];
             acc_init<2>(acc, bias + b_view + tg * 64, c.half);
-            gemm_group<TIER, 2, P::KU_ACT, 8>(acc, act, f, fe, s, c, flush);
+            gemm_group<TIER, 2, P::KU_ACT, 8>(acc, a7, f, fe, s, c, flush);
             gemm_group<TIER, 2, P::KU_VIEW, 1>(acc, vview, f, fe, s, c, flush);
             flush();
-            acc_to_vec<TIER, 2, 8, true>(acc, nxt, 2 * tg);
+            acc_to_vec<TIER, 2, 8, true>(acc, hid, 2 * tg);
             rec_mask_pair(c, m_trunk + RecMap::TM_H + tg, acc);
             pend = CT::rec_on;
             ptg = tg;
         }
         f32x16 acc1[1];
         acc_init<1>(acc1, bias + b_view + 256, c.half);
-        gemm_group<TIER, 1, P::KU_ACT, 8>(acc1, act, f, fe, s, c, flush);
+        gemm_group<TIER, 1, P::KU_ACT, 8>(acc1, a7, f, fe, s, c, flush);
         gemm_group<TIER, 1, P::KU_VIEW, 1>(acc1, vview, f, fe, s, c, flush);
         flush();
         o.sigma = acc1[0][0];
@@ -780,7 +885,7 @@ DFN_DEV MlpOut mlp_trunk(Vec<TIER, 8>& act, const Vec<TIER, NTP>& pvec, const Dh
     {
         f32x16 acc1[1];
         acc_init<1>(acc1, bias + b_out, c.half);
-        gemm_group<TIER, 1, P::KU_ACT, 8, 0>(acc1, nxt, f, fe, s, c);     // last op of the pass
+        gemm_group<TIER, 1, P::KU_ACT, 8, 0>(acc1, hid, f, fe, s, c);     // last op of the pass
         o.r = sigmoidf_(acc1[0][0]);
         o.g = sigmoidf_(acc1[0][1]);
         o.b = sigmoidf_(acc1[0][2]);

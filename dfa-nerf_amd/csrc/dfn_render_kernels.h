@@ -146,7 +146,12 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     const int n = lane & 31;
     const DfnFrame& F = A.frame;
     lds_char* lds = (lds_char*)smem;
-    typedef CtxT<TRAIN, !TRAIN, TRAIN> CtxK;     // inference: asm fragment fetch (DFN_ASM_FETCH); training: asm LDS-DMA only
+    // inference: asm fragment fetch (DFN_ASM_FETCH); training: asm LDS-DMA only.  Pipelined layers in the head-only
+    // 16-bit kernel (the two-field kernel has no 32 registers to spare)
+#ifndef DFN_PIPE
+#define DFN_PIPE 1
+#endif
+    typedef CtxT<TRAIN, !TRAIN, TRAIN, (DFN_PIPE != 0) && !TRAIN && !TWO> CtxK;
     CtxK ctx = {lds, wave, lane, lane >> 5, {}};
     constexpr bool two = TWO;
     const int NF = TRAIN ? 0 : F.n_fine;          // the training forward is the reference's coarse renderer

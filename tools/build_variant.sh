@@ -32,5 +32,5 @@ for o in "$BASE"/*.o; do
 done
 LINK=""; for f in $UNITS; do LINK="$LINK $OBJ/$f.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/exp_libs/$NAME.so" $LINK $OTHERS
-rm -rf "$OBJ"
+cp "$OBJ"/*.s "$ROOT/exp_libs/" 2>/dev/null; rm -rf "$OBJ"
 echo "built exp_libs/$NAME.so"
