@@ -352,6 +352,17 @@ int dfn_train_fwd(int tier, const DfnFrame* frame, const void* packed_head, cons
     return DFN_OK;
 }
 
+int dfn_sample_pixels(int H, int W, int n, int rect_num, const int32_t* rect, uint64_t seed, uint64_t counter,
+                      int32_t* pix_index, int32_t* status, void* stream) {
+    if (H <= 0 || W <= 0 || n <= 0 || rect_num < 0 || rect_num > n || !pix_index || (rect_num > 0 && !rect))
+        return fail(DFN_E_ARG, "dfn_sample_pixels: bad argument");
+    if ((long)H * W >= (1L << 18) || n > SAMPLE_PIXELS_CANDIDATES / 2)
+        return fail(DFN_E_ARG, "dfn_sample_pixels: at most 2^18 pixels and 4096 rays per call");
+    hipError_t err = launch_sample_pixels(H, W, n, rect_num, rect, seed, counter, pix_index, status, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "sample_pixels_kernel");
+    return DFN_OK;
+}
+
 int dfn_mse_loss_u8(const float* rgb_head, const float* rgb_com, const uint8_t* img_head, const uint8_t* img_com,
                     const int32_t* pix_index, int n, float* losses, float* d_rgb_head, float* d_rgb_com, void* stream) {
     if (!rgb_head || !rgb_com || !img_head || !img_com || !pix_index || !losses || !d_rgb_head || !d_rgb_com || n <= 0)

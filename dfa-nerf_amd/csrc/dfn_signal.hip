@@ -27,24 +27,39 @@ template <int K>
 __device__ void linear_rows(const float* __restrict__ W, const float* __restrict__ b, int M, const float* x, float* y,
                             int S, bool act) {
     constexpr int KU = (K + 63) / 64;
+    // R output rows per iteration: their R * KU weight loads are all in flight together (the layer is a chain of
+    // first-touch HBM / L2 latencies on ONE compute unit; with one row at a time AudioNet's 512 -> 256 layer alone took
+    // 16 round trips per wave)
+    // (measured: R = 4 / 8 made the kernels SLOWER, 77 -> 100 us forward, 181 -> 216 us backward: fewer waves have work -
+    // 256 rows / 16 waves / 4 - and the first-touch latency is paid per wave anyway; R = 1 stays)
+    constexpr int R = 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int o = wave; o < M; o += nw) {
-        const float* w = W + (long)o * K;
-        float wv[KU];
+    for (int o0 = wave * R; o0 < M; o0 += nw * R) {
+        float wv[R][KU], bo[R];
 #pragma unroll
-        for (int u = 0; u < KU; ++u) wv[u] = (lane + 64 * u < K) ? w[lane + 64 * u] : 0.f;
-        const float bo = b[o];
+        for (int r = 0; r < R; ++r) {
+            const int o = o0 + r;
+            const float* w = W + (long)o * K;
 #pragma unroll
-        for (int t = 0; t < SIG_MAX_WIN; ++t) {
-            if (t < S) {
-                float a = 0.f;
+            for (int u = 0; u < KU; ++u) wv[r][u] = (o < M && lane + 64 * u < K) ? w[lane + 64 * u] : 0.f;
+            bo[r] = o < M ? b[o] : 0.f;
+        }
 #pragma unroll
-                for (int u = 0; u < KU; ++u)
-                    if (lane + 64 * u < K) a = fmaf(wv[u], x[t * K + lane + 64 * u], a);
-                for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
-                if (lane == 0) {
-                    a += bo;
-                    y[t * M + o] = act ? leaky(a) : a;
+        for (int r = 0; r < R; ++r) {
+            const int o = o0 + r;
+            if (o >= M) break;
+#pragma unroll
+            for (int t = 0; t < SIG_MAX_WIN; ++t) {
+                if (t < S) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int u = 0; u < KU; ++u)
+                        if (lane + 64 * u < K) a = fmaf(wv[r][u], x[t * K + lane + 64 * u], a);
+                    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
+                    if (lane == 0) {
+                        a += bo[r];
+                        y[t * M + o] = act ? leaky(a) : a;
+                    }
                 }
             }
         }
@@ -239,27 +254,37 @@ template <int K>
 __device__ void linear_rows_bwd(const float* __restrict__ W, float* GW, float* Gb, int M, const float* x, const float* dy,
                                 float* dx, int S) {
     constexpr int KU = (K + 63) / 64;
+    constexpr int R = 1;                       // rows per iteration (more was slower, see linear_rows)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int o = wave; o < M; o += nw) {
-        float* g = GW + (long)o * K;
-        float old[KU];
+    for (int o0 = wave * R; o0 < M; o0 += nw * R) {
+        float old[R][KU];
 #pragma unroll
-        for (int u = 0; u < KU; ++u) old[u] = (lane + 64 * u < K) ? g[lane + 64 * u] : 0.f;      // all loads first
-        float sb = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float* g = GW + (long)(o0 + r) * K;
 #pragma unroll
-        for (int t = 0; t < SIG_MAX_WIN; ++t) {
-            if (t < S) {
-                const float d = dy[t * M + o];
-                sb += d;
-#pragma unroll
-                for (int u = 0; u < KU; ++u)
-                    if (lane + 64 * u < K) old[u] = fmaf(d, x[t * K + lane + 64 * u], old[u]);
-            }
+            for (int u = 0; u < KU; ++u) old[r][u] = (o0 + r < M && lane + 64 * u < K) ? g[lane + 64 * u] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < KU; ++u)
-            if (lane + 64 * u < K) g[lane + 64 * u] = old[u];
-        if (lane == 0) Gb[o] += sb;
+        for (int r = 0; r < R; ++r) {
+            const int o = o0 + r;
+            if (o >= M) break;
+            float* g = GW + (long)o * K;
+            float sb = 0.f;
+#pragma unroll
+            for (int t = 0; t < SIG_MAX_WIN; ++t) {
+                if (t < S) {
+                    const float d = dy[t * M + o];
+                    sb += d;
+#pragma unroll
+                    for (int u = 0; u < KU; ++u)
+                        if (lane + 64 * u < K) old[r][u] = fmaf(d, x[t * K + lane + 64 * u], old[r][u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < KU; ++u)
+                if (lane + 64 * u < K) g[lane + 64 * u] = old[r][u];
+            if (lane == 0) Gb[o] += sb;
+        }
     }
     if (dx) {
         for (int k = threadIdx.x; k < K; k += blockDim.x) {

@@ -51,6 +51,9 @@ hipError_t launch_reduce_scatter(const int* map, const float* parts, long n, lon
                                  hipStream_t st);
 // dbias[e] = sum over slices of parts[.][e] for the elements that have a gradient row (rows[e] >= 0), 0 otherwise
 hipError_t launch_reduce_bias(const int* rows, const float* parts, int n_bias, int slices, float* dbias, hipStream_t st);
+constexpr int SAMPLE_PIXELS_CANDIDATES = 8192;
+hipError_t launch_sample_pixels(int H, int W, int n, int rect_num, const int* rect, unsigned long long seed,
+                                unsigned long long counter, int* out, int* status, hipStream_t st);
 hipError_t launch_mse_loss(const float* rgb_head, const float* rgb_com, const unsigned char* img_head,
                            const unsigned char* img_com, const int* pix, int n, float* losses, float* d_head, float* d_com,
                            hipStream_t st);

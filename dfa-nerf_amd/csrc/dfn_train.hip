@@ -302,6 +302,121 @@ hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, cons
 }
 
 // ================================================================================================
+// pixel sampling: run_nerf_com_trainExpLater.py:786-820 in one launch, one workgroup
+// ================================================================================================
+// n DISTINCT pixels, uniform over the subsets, in random order (np.random.choice(replace=False) upstream); with
+// rect_num > 0 the first rect_num of them from (face rect | lower half of the image), the other n - rect_num from the
+// complement (MAIN:786-817).  Sequential rejection sampling, in parallel: M = 8192 candidates drawn with a counter-based
+// generator (splitmix64 of (seed, counter, i)); candidate i is kept iff no earlier candidate has the same pixel (an LDS
+// hash table holds the smallest index per pixel: atomicMin, so the result does not depend on thread timing); a block
+// scan ranks the kept candidates of each class in draw order.  status[0] / status[1] = kept candidates per class (must
+// be >= the request; the host wrapper sizes the request so that it always is).
+constexpr int SP_M = 8192, SP_TABLE = 16384, SP_THREADS = 1024, SP_PER = SP_M / SP_THREADS;
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(SP_THREADS) void sample_pixels_kernel(int H, int W, int n, int rect_num, const int* rect,
+                                                                    unsigned long long seed, unsigned long long counter,
+                                                                    int* out, int* status) {
+    extern __shared__ unsigned sp_lds[];
+    unsigned* table = sp_lds;                    // [SP_TABLE]  (pixel << 13) | smallest candidate index, 0xffffffff = empty
+    unsigned* cand = sp_lds + SP_TABLE;          // [SP_M]
+    unsigned* part = cand + SP_M;                // [2][SP_THREADS] per-thread counts, then their exclusive prefix
+    const int t = threadIdx.x;
+    const unsigned HW = (unsigned)(H * W);
+    for (int e = t; e < SP_TABLE; e += SP_THREADS) table[e] = 0xffffffffu;
+    const unsigned long long base = splitmix64(seed ^ (counter * 0xD1B54A32D192ED03ull));
+#pragma unroll
+    for (int q = 0; q < SP_PER; ++q) {           // thread t owns the CONSECUTIVE candidates t * SP_PER + q (draw order)
+        const int i = t * SP_PER + q;
+        const unsigned r = (unsigned)(splitmix64(base + (unsigned long long)i) >> 32);
+        cand[i] = (unsigned)(((unsigned long long)r * HW) >> 32);       // uniform in [0, HW) up to HW / 2^32
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < SP_PER; ++q) {
+        const int i = t * SP_PER + q;
+        const unsigned p = cand[i], entry = (p << 13) | (unsigned)i;
+        unsigned slot = (p * 2654435761u) >> 18;                         // 14 bits
+        for (;;) {
+            const unsigned cur = atomicCAS(&table[slot], 0xffffffffu, entry);
+            if (cur == 0xffffffffu) break;
+            if ((cur >> 13) == p) { atomicMin(&table[slot], entry); break; }
+            slot = (slot + 1) & (SP_TABLE - 1);
+        }
+    }
+    __syncthreads();
+    int ry0 = 0, rx0 = 0, ry1 = -1, rx1 = -1;
+    if (rect_num > 0) { ry0 = rect[0]; rx0 = rect[1]; ry1 = ry0 + rect[2]; rx1 = rx0 + rect[3]; }
+    unsigned keep = 0, cls = 0;                  // bit q: candidate kept / candidate inside (face rect | lower half)
+    int c_in = 0, c_out = 0;
+#pragma unroll
+    for (int q = 0; q < SP_PER; ++q) {
+        const int i = t * SP_PER + q;
+        const unsigned p = cand[i];
+        unsigned slot = (p * 2654435761u) >> 18;
+        while ((table[slot] >> 13) != p) slot = (slot + 1) & (SP_TABLE - 1);
+        const bool first = (table[slot] & 0x1fffu) == (unsigned)i;
+        const int y = (int)(p / (unsigned)W), x = (int)(p - (unsigned)y * (unsigned)W);
+        const bool inside = rect_num > 0 && ((y >= ry0 && y <= ry1 && x >= rx0 && x <= rx1) || 2 * y >= H);
+        if (first) {
+            keep |= 1u << q;
+            if (inside) { cls |= 1u << q; ++c_in; } else ++c_out;
+        }
+    }
+    part[t] = (unsigned)c_in;
+    part[SP_THREADS + t] = (unsigned)c_out;
+    __syncthreads();
+    if (t < 128) {                               // exclusive prefix over the 1024 per-thread counts, both classes: wave w
+        const int which = t >> 6, lane = t & 63; // = class; lane owns 16 consecutive entries
+        unsigned* a = part + which * SP_THREADS + lane * 16;
+        unsigned loc[16], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { loc[k] = sum; sum += a[k]; }
+        unsigned inc = sum;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned up = __shfl_up(inc, d);
+            if (lane >= d) inc += up;
+        }
+        const unsigned excl = inc - sum;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = excl + loc[k];
+        if (lane == 63 && status) status[which] = (int)inc;
+    }
+    __syncthreads();
+    int r_in = (int)part[t], r_out = (int)part[SP_THREADS + t];
+    const int n_out = n - rect_num;
+#pragma unroll
+    for (int q = 0; q < SP_PER; ++q) {
+        if (!((keep >> q) & 1u)) continue;
+        const unsigned p = cand[t * SP_PER + q];
+        if ((cls >> q) & 1u) {
+            if (r_in < rect_num) out[r_in] = (int)p;
+            ++r_in;
+        } else {
+            if (r_out < n_out) out[rect_num + r_out] = (int)p;
+            ++r_out;
+        }
+    }
+}
+hipError_t launch_sample_pixels(int H, int W, int n, int rect_num, const int* rect, unsigned long long seed,
+                                unsigned long long counter, int* out, int* status, hipStream_t st) {
+    constexpr int lds = (SP_TABLE + SP_M + 2 * SP_THREADS) * 4;
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void*)sample_pixels_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    hipLaunchKernelGGL(sample_pixels_kernel, dim3(1), dim3(SP_THREADS), lds, st, H, W, n, rect_num, rect, seed, counter, out,
+                       status);
+    return hipGetLastError();
+}
+
+// ================================================================================================
 // loss: target gather + the two MSEs + their gradients in one launch
 // ================================================================================================
 // run_nerf_com_trainExpLater.py:791-800 (target[select_coords] of the head and the composite image), :902-907

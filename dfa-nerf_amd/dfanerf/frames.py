@@ -96,34 +96,93 @@ class DeviceFrameCache:
 
 
 class PixelSampler:
-    """MAIN:786-820 on the device.  draw(rect) -> int32 [N_rand] pixel ids y*W+x, all distinct:
+    """MAIN:786-820 on the device.  draw(...) -> int32 [N_rand] pixel ids y*W+x, all distinct:
       sample_rate == 0: a uniformly random N_rand-subset of the H*W pixels in random order;
       sample_rate > 0:  int(N_rand * sample_rate) of them from (face rect | lower half of the image), the rest from the
-                        complement (`rect` = [y0, x0, h, w] of the frame, a device tensor row or a host sequence).
-    One uniform key per pixel + top-k: exactly uniform over the subsets, like np.random.choice(replace=False)."""
+                        complement.  The face rectangle [y0, x0, h, w] comes from `rects` (host array [frames, 4], uploaded
+                        once) by frame index, or is passed to draw() directly.
+    On the GPU one launch of dfn_sample_pixels (rejection sampling over 8192 counter-based candidates, an LDS hash table
+    for the duplicates, a block scan for the order); when a class is too small for that (tiny images, almost every pixel
+    requested) and on the CPU: one uniform key per pixel + top-k in torch.  Both are exactly uniform over the subsets up
+    to the generator, like np.random.choice(replace=False)."""
+    CANDIDATES = 8192            # SAMPLE_PIXELS_CANDIDATES of the kernel
 
-    def __init__(self, H, W, n_rand, sample_rate, device, seed=0):
+    def __init__(self, H, W, n_rand, sample_rate, device, seed=0, rects=None):
         self.H, self.W, self.n, self.rate, self.device = int(H), int(W), int(n_rand), float(sample_rate), device
-        self.gen = torch.Generator(device=device)
-        self.gen.manual_seed(int(seed))
-        self.keys = torch.empty(self.H * self.W, dtype=torch.float32, device=device)
-        if self.rate > 0:
-            p = torch.arange(self.H * self.W, device=device)
-            self.y, self.x = (p // self.W).to(torch.int32), (p % self.W).to(torch.int32)
-            self.rect_num = int(self.n * self.rate)
         if self.n > self.H * self.W:
             raise ValueError("PixelSampler: more rays than pixels")
+        self.seed, self.counter = int(seed) & ((1 << 63) - 1), 0
+        self.rect_num = int(self.n * self.rate) if self.rate > 0 else 0
+        self.rects_host = None if rects is None else np.asarray(rects, dtype=np.int64).reshape(-1, 4)
+        self.rects_dev = None if rects is None else torch.as_tensor(self.rects_host, dtype=torch.int32, device=device)
+        self.on_gpu = torch.device(device).type == "cuda"
+        self._torch = None
+        self.out = torch.empty(self.n, dtype=torch.int32, device=device) if self.on_gpu else None
 
-    def draw(self, rect=None):
-        k = self.keys.uniform_(0.0, 1.0, generator=self.gen)
-        if self.rate <= 0:
+    # ---- which path -----------------------------------------------------------------------------------------------
+    def _inside_area(self, rect):
+        """pixels of (rect | lower half): rows y >= H / 2 entirely, plus the part of the rectangle above them"""
+        H, W = self.H, self.W
+        half = -(-H // 2)                                        # first row with y >= H / 2
+        y0, x0, h, w = [int(v) for v in rect]
+        ya, yb = max(y0, 0), min(y0 + h, half - 1, H - 1)
+        xa, xb = max(x0, 0), min(x0 + w, W - 1)
+        above = max(0, yb - ya + 1) * max(0, xb - xa + 1)
+        return (H - half) * W + above
+
+    def _kernel_ok(self, rect_host):
+        HW = self.H * self.W
+        if not self.on_gpu or HW >= (1 << 18) or self.n > self.CANDIDATES // 2:
+            return False
+        frac = 1.0 - np.exp(-self.CANDIDATES / HW)               # expected share of a class's pixels among the candidates
+        if self.rect_num == 0:
+            return HW * frac >= 1.25 * self.n
+        if rect_host is None:
+            return False
+        a_in = self._inside_area(rect_host)
+        return a_in * frac >= 1.25 * self.rect_num and (HW - a_in) * frac >= 1.25 * (self.n - self.rect_num)
+
+    # ---- the torch path (CPU tests, tiny images) ----------------------------------------------------------------------
+    def _draw_torch(self, rect):
+        if self._torch is None:
+            gen = torch.Generator(device=self.device)
+            gen.manual_seed(self.seed)
+            p = torch.arange(self.H * self.W, device=self.device)
+            self._torch = (gen, torch.empty(self.H * self.W, dtype=torch.float32, device=self.device),
+                           (p // self.W).to(torch.int32), (p % self.W).to(torch.int32))
+        gen, keys, y, x = self._torch
+        k = keys.uniform_(0.0, 1.0, generator=gen)
+        if self.rect_num == 0:
             return torch.topk(k, self.n, sorted=True).indices.to(torch.int32)
         r = rect if isinstance(rect, torch.Tensor) else torch.as_tensor(np.asarray(rect), device=self.device)
         r = r.to(device=self.device, dtype=torch.int32)
-        inside = ((self.y >= r[0]) & (self.y <= r[0] + r[2]) & (self.x >= r[1]) & (self.x <= r[1] + r[3])) | \
-                 (self.y.float() >= self.H / 2)
-        # keys of the other class drop below every real key: top-k then never crosses the class boundary as long as
-        # the class has enough pixels (checked once per sampler on the host: the lower half alone has H*W/2 >> N_rand)
+        inside = ((y >= r[0]) & (y <= r[0] + r[2]) & (x >= r[1]) & (x <= r[1] + r[3])) | (y.float() >= self.H / 2)
+        # keys of the other class drop below every real key: top-k never crosses the class boundary
         a = torch.topk(torch.where(inside, k, k - 2.0), self.rect_num, sorted=True).indices
         b = torch.topk(torch.where(inside, k - 2.0, k), self.n - self.rect_num, sorted=True).indices
         return torch.cat((a, b)).to(torch.int32)
+
+    def draw(self, rect=None, frame=None):
+        """rect: [y0, x0, h, w] (host sequence or tensor) or frame: index into `rects`; neither when sample_rate == 0."""
+        rect_host = rect_dev = None
+        if self.rect_num > 0:
+            if frame is not None:
+                rect_host, rect_dev = self.rects_host[int(frame)], self.rects_dev[int(frame)]
+            elif isinstance(rect, torch.Tensor):
+                rect_dev = rect.to(device=self.device, dtype=torch.int32)
+                rect_host = None if rect.is_cuda else rect.cpu().numpy()
+            else:
+                rect_host = np.asarray(rect)
+        if not self._kernel_ok(rect_host):
+            return self._draw_torch(rect_dev if rect_dev is not None else rect_host)
+        import ctypes as C
+        from ._lib import check, lib
+        if rect_dev is None and self.rect_num > 0:
+            rect_dev = torch.as_tensor(np.asarray(rect_host, dtype=np.int32), device=self.device)
+        self.counter += 1
+        out = torch.empty_like(self.out)          # a fresh tensor per draw: the previous one may still be in use
+        check(lib.dfn_sample_pixels(self.H, self.W, self.n, self.rect_num,
+                                    None if rect_dev is None else C.c_void_p(rect_dev.contiguous().data_ptr()),
+                                    C.c_uint64(self.seed), C.c_uint64(self.counter), C.c_void_p(out.data_ptr()), None,
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), "dfn_sample_pixels")
+        return out

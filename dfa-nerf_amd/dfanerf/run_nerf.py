@@ -652,12 +652,12 @@ def train():
         n_pre = cache.preload(i_train, log=print if rank == 0 else None)
         if rank == 0:
             print(f'[dfanerf] {n_pre} ground-truth frame pairs decoded to the device in {time.time() - t0:.1f} s')
-    sampler = frames.PixelSampler(H, W, args.N_rand, args.sample_rate, dev, seed=1234 + rank)
-    rects_dev = torch.as_tensor(np.asarray(ds['sample_rects']), device=dev) if args.sample_rate > 0 else None
+    sampler = frames.PixelSampler(H, W, args.N_rand, args.sample_rate, dev, seed=1234 + rank,
+                                  rects=ds['sample_rects'] if args.sample_rate > 0 else None)
     from tqdm import trange, tqdm
     for i in trange(global_step + 1, args.N_iters + 1, disable=rank != 0):
         img_i = rng.choice(i_train)
-        pix = sampler.draw(None if rects_dev is None else rects_dev[img_i])
+        pix = sampler.draw(frame=img_i if args.sample_rate > 0 else None)
         target_head_s, target_com_s = cache.get(img_i)
         loss, l_head, l_com, _, _ = train_step_loss_hip(nets, datasets, itr_obj, img_i, pix, target_head_s,
                                                         target_com_s, z_shape, z_app, global_step, args,

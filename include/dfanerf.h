@@ -147,6 +147,16 @@ int dfn_train_fwd(int tier, const DfnFrame* frame, const void* packed_head, cons
                   const float* bias_head, const float* bias_torso, const float* bg_f32, const uint8_t* bg_u8,
                   const int32_t* pix_index, float* rgb_head, float* rgb_com, float* samples, void* act_head,
                   uint32_t* masks_head, void* act_torso, uint32_t* masks_torso, void* stream);
+/* The pixel draw of a training step in one launch: replaces MAIN:786-820 (np.random.choice(replace=False) over the image,
+ * or over (face rect | lower half) and its complement with --sample_rate > 0).  pix_index [n] receives n DISTINCT pixel
+ * ids y*W+x, uniform over the subsets, in random order; with rect_num > 0 the first rect_num lie inside (rect | lower
+ * half), the rest outside; rect = device int32 [4] = (y0, x0, h, w) of the frame's face rectangle (LOAD:sample_rects).
+ * Counter-based generator: (seed, counter) -> the draw (the caller increments counter per step).  8192 candidates are
+ * drawn per call: H*W < 2^18, n <= 4096, and every class must contain comfortably more pixels than it is asked for
+ * (status[0..1], optional device int32 [2], returns the distinct candidates found inside / outside). */
+int dfn_sample_pixels(int H, int W, int n, int rect_num, const int32_t* rect, uint64_t seed, uint64_t counter,
+                      int32_t* pix_index, int32_t* status, void* stream);
+
 /* The loss of a training step in one launch: replaces target[select_coords] (MAIN:791-800: the pixels pix_index of the
  * head and the composite ground-truth images, here uint8 [H*W,3] resident on the device, / 255 as LOAD:58-60), the two
  * img2mse (HELP:13; MAIN:902-907) and their autograd:

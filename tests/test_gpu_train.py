@@ -315,6 +315,60 @@ def test_checkpoint_structure_matches_the_reference_writer(tmp_path, states, sce
     assert opts2["decoder"]._cache[0]["buckets"][0]["t"] == 2
 
 
+def test_device_pixel_sampler_kernel():
+    """dfn_sample_pixels (MAIN:786-820 in one launch): distinct pixels, exact class counts for the face-rect / lower-half
+    split (the same counts run_nerf.select_coords gives), the inside pixels first, reproducible from (seed, counter),
+    different draws per step, uniform coverage; the status word reports enough distinct candidates; tiny images fall
+    back to the torch path."""
+    import ctypes as C
+    from dfanerf import frames, run_nerf
+    from dfanerf._lib import check, lib
+    dev = torch.device("cuda")
+    H = W = 450
+    s0 = frames.PixelSampler(H, W, 2048, 0, dev, seed=11)
+    assert s0._kernel_ok(None)
+    draws = [s0.draw().cpu().numpy() for _ in range(40)]
+    for p in draws:
+        assert p.dtype == np.int32 and p.shape == (2048,) and len(set(p.tolist())) == 2048
+        assert p.min() >= 0 and p.max() < H * W
+    assert not np.array_equal(draws[0], draws[1])
+    again = frames.PixelSampler(H, W, 2048, 0, dev, seed=11).draw().cpu().numpy()
+    assert np.array_equal(again, draws[0])                                    # (seed, counter) -> the draw
+    allp = np.concatenate(draws)
+    assert abs(allp.mean() - (H * W - 1) / 2) < 1500                          # uniform over the frame ...
+    hist = np.bincount(allp // (H * W // 10 + 1), minlength=10)
+    assert hist.min() > 0.9 * hist.mean() and hist.max() < 1.1 * hist.mean()  # ... in every tenth of it
+    assert np.abs(np.diff(draws[0].astype(np.int64))).mean() > 30000         # random ORDER, not sorted
+    rects = np.array([[100, 120, 150, 160], [10, 10, 40, 40], [300, 0, 100, 449]])
+    s1 = frames.PixelSampler(H, W, 2048, 0.95, dev, seed=5, rects=rects)
+    want = int(2048 * 0.95)
+    for fr in range(3):
+        assert s1._kernel_ok(rects[fr])
+        p = s1.draw(frame=fr).cpu().numpy()
+        y, x = p // W, p % W
+        r = rects[fr]
+        inside = ((y >= r[0]) & (y <= r[0] + r[2]) & (x >= r[1]) & (x <= r[1] + r[3])) | (y >= H / 2)
+        host = run_nerf.select_coords(H, W, 2048, 0.95, r, np.random.RandomState(fr))
+        hin = ((host[:, 0] >= r[0]) & (host[:, 0] <= r[0] + r[2]) & (host[:, 1] >= r[1]) & (host[:, 1] <= r[1] + r[3])) | \
+              (host[:, 0] >= H / 2)
+        assert len(set(p.tolist())) == 2048 and int(inside.sum()) == int(hin.sum()) == want
+        assert inside[:want].all() and not inside[want:].any()
+    # status: distinct candidates per class
+    st = torch.zeros(2, dtype=torch.int32, device=dev)
+    out = torch.empty(2048, dtype=torch.int32, device=dev)
+    rd = torch.as_tensor(rects[0], dtype=torch.int32, device=dev)
+    check(lib.dfn_sample_pixels(H, W, 2048, want, C.c_void_p(rd.data_ptr()), C.c_uint64(1), C.c_uint64(2),
+                                C.c_void_p(out.data_ptr()), C.c_void_p(st.data_ptr()),
+                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "dfn_sample_pixels")
+    c_in, c_out = st.cpu().tolist()
+    assert c_in >= want and c_out >= 2048 - want and c_in + c_out <= 8192
+    # tiny image: the kernel's candidate budget does not cover the request -> torch path, same contract
+    small = frames.PixelSampler(40, 56, 2000, 0, dev, seed=1)
+    assert not small._kernel_ok(None)
+    p = small.draw().cpu().numpy()
+    assert len(set(p.tolist())) == 2000 and p.max() < 40 * 56
+
+
 def test_fused_mse_loss_matches_torch():
     """dfn_mse_loss_u8 (target gather from uint8 frames + the two img2mse + their autograd, MAIN:791-800, 902-907) against
     the torch ops it replaces, forward and backward; bit-reproducible."""
