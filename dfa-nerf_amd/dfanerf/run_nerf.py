@@ -528,9 +528,30 @@ def update_lrate(opts, global_step, args):
     return new_lrate
 
 
+def check_supported(args):
+    """The HIP path implements the configuration scripts/{train,test}_obama.sh build: say so when
+    the arguments are parsed, not at the first kernel launch."""
+    bad = []
+    if (args.n_feat, args.z_dim, args.dim_signal) != (256, 256, 96):
+        bad.append(f"--n_feat {args.n_feat} --z_dim {args.z_dim} --dim_signal {args.dim_signal} (supported: 256 / 256 / 96)")
+    if not args.use_deformation_field or args.use_expression:
+        bad.append("--use_deformation_field is required and --use_expression is not supported")
+    if args.N_samples != 64:
+        bad.append(f"--N_samples {args.N_samples} (supported: 64)")
+    if getattr(args, "hierarchical", False) and args.N_importance not in (64, 128):
+        bad.append(f"--hierarchical with --N_importance {args.N_importance} (supported: 64, 128)")
+    if args.n_object != 1:
+        bad.append(f"--n_object {args.n_object} (the scripts train one person: 1)")
+    if args.hip_tier not in ("f32", "f16", "bf16"):
+        bad.append(f"--hip_tier {args.hip_tier} (f32 | f16 | bf16)")
+    if bad:
+        raise SystemExit("run_nerf_com_trainExpLater.py (MI355X build): unsupported configuration:\n  " + "\n  ".join(bad))
+
+
 def train():
     from .load_audface import load_audface_data_split
     args = config_parser().parse_args()
+    check_supported(args)
     world, rank, local = parallel.init()
     dev = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
     if dev.type != "cuda":
@@ -675,17 +696,41 @@ def train():
             with open(os.path.join(basedir, 'loss.txt'), 'a') as f:
                 f.write(msg + "\n")
         if (i % args.i_test_person == 0 and i > 0) or (i in [100, 500, 1000, 3000]):
+            # periodic test (MAIN:943-1077): every 100th validation frame, body pose = training frame 0; files
+            # test_head_%03d / test_%03d (numbered by the position in i_val) hold render | ground truth side by side,
+            # the PSNR is taken on the float composite image
             outdir = os.path.join(imgdir[0], 'person', 'test_{}'.format(i))
             if rank == 0:
                 os.makedirs(outdir, exist_ok=True)
             i_val = ds['i_val']
-            ids = [i_val[k] for k in range(0, len(i_val), 100)]
-            imgs = render_frames(ids, len(i_train) + len(i_val), outdir, None, ds['poses'][0, :3, :4],
-                                 tag='test_{:03d}.jpg')
-            if rank == 0:
-                for img_id, rgb8 in zip(ids, imgs):
-                    tgt = torch.as_tensor(_imread(ds['imgs_com'][img_id])).float() / 255.0
-                    ps = mse2psnr(img2mse(torch.as_tensor(rgb8).float() / 255.0, tgt))
+            enc_t = None
+            if "PoseAttNet" in nets and embed_fn is not None and _hip_signals_ok(args):
+                from . import engine
+                enc_t = engine.SignalEncoder(nets["AudNet"], nets["ExpNet"], nets["AudAttNet"], nets["PoseAttNet"],
+                                             ds['auds'], ds['exp'], ds['poses'])
+            smoothed = global_step >= args.nosmo_iters
+            for testimg_i in range(0, len(i_val), 100):
+                img_id = i_val[testimg_i]
+                with torch.no_grad():
+                    if enc_t is not None:
+                        s2, t2 = enc_t.encode([img_id], args.smo_size if smoothed else 0,
+                                              args.smo_torse_size if smoothed else 0, length=len(i_train) + len(i_val))
+                        signal, signal_torso = [s2, None], t2[0]
+                    else:
+                        signal = encode_signal(datasets, itr_obj, img_id, args.dim_aud, nets["AudNet"], nets["ExpNet"],
+                                               nets["AudAttNet"], global_step, args, len(i_train) + len(i_val),
+                                               embed_fn=embed_fn)
+                        signal_torso = encode_signal_torso(datasets, itr_obj, img_id, nets.get("PoseAttNet"), global_step,
+                                                           args, len(i_train) + len(i_val), embed_fn=embed_fn)
+                    rgb_head, rgb = renderer.render_image(poses_host[img_id], poses_host[0], signal, signal_torso)
+                if rank == 0:
+                    ext = args.image_ext
+                    for img, tgt_path, name in ((rgb_head, ds['imgs'][img_id], 'test_head_{:03d}.'.format(testimg_i) + ext),
+                                                (rgb, ds['imgs_com'][img_id], 'test_{:03d}.'.format(testimg_i) + ext)):
+                        target_img = _imread(tgt_path)
+                        _imwrite(os.path.join(outdir, name), np.concatenate((to8b(img).cpu().numpy(), target_img), axis=1))
+                    target_rgb = torch.as_tensor(target_img).to(dev).float() / 255.0
+                    ps = mse2psnr(img2mse(rgb, target_rgb))
                     print('Saved test person img, psnr: {}'.format(ps.item()))
                     with open(os.path.join(basedir, 'loss.txt'), 'a') as f:
                         f.write(f"[TEST] Iter: {i} Object: {itr_obj}_person PSNR: {ps.item()}\n")

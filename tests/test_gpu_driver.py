@@ -157,5 +157,12 @@ def test_training_cli_writes_reference_checkpoint(dataset):
     assert ck["global_step"] == 280002 and "network_PoseAttNet_state_dict" in ck and len(ck) == 13
     assert all(np.isfinite(float(ln.split("Com Loss: ")[1].split()[0])) for ln in log)
     assert "ground-truth frame pairs decoded to the device" in out            # the device-resident input stage ran
-    # the face-rect / lower-half pixel split (MAIN:786-817) on the device sampler
-    _run(root, "--N_rand=512 --N_iters=280002 --i_weights=100000 --sample_rate=0.9")
+    # the face-rect / lower-half pixel split (MAIN:786-817) on the device sampler, and the periodic test of MAIN:943-1077:
+    # render | ground truth side by side under the reference's file names, PSNR line in loss.txt
+    from PIL import Image
+    _run(root, "--N_rand=512 --N_iters=280002 --i_weights=100000 --sample_rate=0.9 --i_test_person=280002 --image_ext png")
+    tdir = base / "obama" / "person" / "test_280002"
+    assert sorted(os.listdir(tdir)) == ["test_000.png", "test_head_000.png"]
+    assert np.asarray(Image.open(tdir / "test_000.png")).shape == (H, 2 * W, 3)
+    log = open(base / "loss.txt").read().strip().split("\n")
+    assert log[-1].startswith("[TEST] Iter: 280002 Object: 0_person PSNR: ")

@@ -67,6 +67,18 @@ def test_config_file_and_script_flags(tmp_path):
     assert run_nerf.parse_config_file(str(cfg)) == (0.3127, 0.9127)
 
 
+def test_unsupported_configurations_are_refused_at_parse_time():
+    ok = run_nerf.config_parser().parse_args(
+        "--expname t --n_feat 256 --z_dim 256 --dim_signal 96 --n_object 1 --use_deformation_field".split())
+    run_nerf.check_supported(ok)
+    for extra in ("--n_feat 128", "--N_samples 32", "--dim_signal 128", "--hierarchical --N_importance 96", "--n_object 2",
+                  "--hip_tier fp8", "--use_expression"):
+        a = run_nerf.config_parser().parse_args(
+            ("--expname t --z_dim 256 --dim_signal 96 --n_object 1 --use_deformation_field --n_feat 256 " + extra).split())
+        with pytest.raises(SystemExit, match="unsupported configuration"):
+            run_nerf.check_supported(a)
+
+
 def test_state_dict_manifest(states):
     lines = open(os.path.join(GOLDEN, "g9_manifest.txt")).read().strip().split("\n")
     mods = _modules(states)
