@@ -142,3 +142,49 @@ def test_signal_encoders_single_frame_beyond_sequence_length(states, scene):
     a, _ = enc.encode([n - 4], 4, 8, length=n - 3)
     b, _ = enc.encode([n - 4], 4, 8)
     assert not torch.equal(a, b)
+
+
+def test_rccl_backend_world1_collectives(scene, states, latents, golden):
+    """The collectives of the multi-GPU path on the RCCL backend ("nccl" on ROCm), on the one GPU a gpurun box has
+    (world size 1; RCCL refuses two ranks on one device, so a real exchange needs the driver's multi-GPU node): process
+    group initialisation as bench.py / parallel.init do it, the padded-shard all_gather_into_tensor of
+    FrameRenderer.render_image (the rendered shard IS the frame), all_reduce of the flat gradient bucket, broadcast."""
+    import torch.distributed as dist
+    from dfanerf import engine, parallel
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        assert int(ones.item()) == 1                                    # bench.py's `rccl_ranks`
+        H, W = scene["H"], scene["W"]
+        R = H * W
+        begin, count, per = parallel.shard_range(R, 1, 0)
+        assert (begin, count, per) == (0, R, R)
+        flat = engine.flatten_state(states["decoder"], dev)
+        pk = engine.PackedDecoder(flat, "f16", fields=(0,))
+        gc = golden("g7_frame_coarse")
+        zs, za = latents
+        bias = pk.fold(gc["signal"][0], None, zs[0], za[0])
+        bg8 = t(scene["bg"]).reshape(-1, 3).to(dev)
+        shard = torch.zeros(1, per, 3, dtype=torch.uint8, device=dev)
+        gathered = torch.empty(1, 1, per, 3, dtype=torch.uint8, device=dev)
+        fr = engine.make_frame(H, W, scene["focal"], scene["cx"], scene["cy"], scene["poses"][2], scene["pose_body"],
+                               scene["near"], scene["far"], ray_begin=begin, ray_count=count, n_fine=0, fields=1)
+        engine.render_u8(pk, bias, fr, bg8, out_head=shard[0, :count])
+        dist.all_gather_into_tensor(gathered, shard)
+        assert torch.equal(gathered[0], shard) and int(gathered.sum()) > 0
+        bucket = torch.arange(1138656, dtype=torch.float32, device=dev)      # the flat gradient bucket's size
+        ref = bucket.clone()
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+        dist.broadcast(bucket, src=0)
+        assert torch.equal(bucket, ref)
+    finally:
+        dist.destroy_process_group()
