@@ -740,6 +740,7 @@ def train():
             path = os.path.join(basedir, '{:06d}.tar'.format(i))
             save_checkpoint(path, global_step, z_shape, z_app, nets, opts)
             print('Saved checkpoints at', path)
+    torch.cuda.synchronize()            # the loop never waits for the GPU: make sure the last steps have run before leaving
     if args.render_final_video:
         outdir = os.path.join(imgdir[0], 'person')
         rgbs = render_frames(list(ds['i_val']), len(ds['i_val']), outdir, None, pose_body[:3, :4],
