@@ -23,7 +23,10 @@
 namespace dfn {
 
 constexpr int WL_WAVES = 8, WL_THREADS = 64 * WL_WAVES;
-constexpr int WL_DEPTH = 4;                     // ring depth in steps
+#ifndef DFN_WL_DEPTH
+#define DFN_WL_DEPTH 4
+#endif
+constexpr int WL_DEPTH = DFN_WL_DEPTH;          // ring depth in steps (a power of two)
 constexpr int WL_STEP_BYTES = 32 * 1024;        // 16 operand tiles (512 rows x 32 points) per step at most
 constexpr int WL_PIECES = 4;                    // 1 KiB DMA pieces per wave and step at most (32 per step)
 
