@@ -285,6 +285,14 @@ class SignalTrainer:
         self.pose_stride = int(self.poses[0].numel())
         self.device = dev
 
+    def side_stream(self):
+        """second stream for the pose encoder (None: DFN_TRAIN_OVERLAP=0)"""
+        if not _OVERLAP:
+            return None
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
     def frame_id(self, frame):
         """[1] int32 device tensor holding `frame` without a host-to-device copy (a pageable copy blocks the host until
         the stream has drained: it serialises every step with the previous one)."""
@@ -308,10 +316,18 @@ class _SignalFn(torch.autograd.Function):
         sig = torch.empty(1, 96, dtype=torch.float32, device=dev)
         sigt = torch.empty(1, 42, dtype=torch.float32, device=dev)
         a, e, t, p = [n.flat for n in tr.nets]
+        # the two encoders are independent single-workgroup latency chains: the pose one runs on a second stream
+        # underneath the audio / expression one
+        side, main = tr.side_stream(), torch.cuda.current_stream(dev)
+        if side is not None:
+            side.wait_stream(main)
+        st_t = st if side is None else C.c_void_p(side.cuda_stream)
+        check(lib.dfn_encode_signal_torso(_ptr(p), _ptr(tr.poses), tr.pose_stride, length, _ptr(ids), 1, smo_t,
+                                          _ptr(sigt), st_t), "dfn_encode_signal_torso")
         check(lib.dfn_encode_signal(_ptr(a), _ptr(e), _ptr(t), _ptr(tr.auds), _ptr(tr.exps), length, _ptr(ids), 1, smo,
                                     _ptr(sig), st), "dfn_encode_signal")
-        check(lib.dfn_encode_signal_torso(_ptr(p), _ptr(tr.poses), tr.pose_stride, length, _ptr(ids), 1, smo_t,
-                                          _ptr(sigt), st), "dfn_encode_signal_torso")
+        if side is not None:
+            main.wait_stream(side)
         ctx.tr, ctx.args = tr, (frame, smo, smo_t, length)
         return sig, sigt
 
@@ -323,10 +339,16 @@ class _SignalFn(torch.autograd.Function):
         g = [_grad_buffer(n, "_g_flat", n.flat, n.params) for n in tr.nets]
         d_sig = d_sig.contiguous().float()
         d_sigt = d_sigt.contiguous().float()
+        side, main = tr.side_stream(), torch.cuda.current_stream(tr.device)
+        if side is not None:
+            side.wait_stream(main)
+        st_t = st if side is None else C.c_void_p(side.cuda_stream)
+        check(lib.dfn_encode_signal_torso_bwd(_ptr(p), _ptr(tr.poses), tr.pose_stride, length, frame, smo_t, _ptr(d_sigt),
+                                              _ptr(g[3]), st_t), "dfn_encode_signal_torso_bwd")
         check(lib.dfn_encode_signal_bwd(_ptr(a), _ptr(e), _ptr(t), _ptr(tr.auds), _ptr(tr.exps), length, frame, smo,
                                         _ptr(d_sig), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), st), "dfn_encode_signal_bwd")
-        check(lib.dfn_encode_signal_torso_bwd(_ptr(p), _ptr(tr.poses), tr.pose_stride, length, frame, smo_t, _ptr(d_sigt),
-                                              _ptr(g[3]), st), "dfn_encode_signal_torso_bwd")
+        if side is not None:
+            main.wait_stream(side)
         tr.nets[0].deposit(g[0])
         tr.nets[1].deposit(g[1])
         if smo > 0:
