@@ -156,6 +156,7 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
     buf = training.TrainBuffers(tier, N_RAND, dev)
     buf.signal_trainer = training.SignalTrainer(mods["AudNet"], mods["ExpNet"], mods["AudAttNet"], mods["PoseAttNet"],
                                                 ds[0]["auds"], ds[0]["exp"], ds[0]["poses"])
+    buf.signal_trainer.adopt_optimizers(opts)
     bucket = parallel.FlatGradBucket(list(mods.values())) if world > 1 else None
     rng = np.random.RandomState(100 + rank)
     rng_frame = np.random.RandomState(100) if strong else rng      # strong: ONE frame per step on all ranks (MAIN:779)
@@ -165,7 +166,7 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
     g8 = torch.Generator(device=dev).manual_seed(7)
     gt = [(torch.randint(0, 256, (H * W, 3), dtype=torch.uint8, device=dev, generator=g8),
            torch.randint(0, 256, (H * W, 3), dtype=torch.uint8, device=dev, generator=g8)) for _ in range(8)]
-    sampler = frames.PixelSampler(H, W, N_RAND, 0, dev, seed=100 + rank)
+    sampler = frames.PixelSampler(H, W, N_RAND, 0, dev, seed=100 + rank, pipeline=True, stream=buf.signal_trainer.pose_stream())
     gstep = 300000                                   # all five optimizers' gates exercised except ExpNet
 
     def step():

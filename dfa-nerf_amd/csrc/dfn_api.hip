@@ -74,6 +74,9 @@ struct WgradEntry {
     int32_t* eof_dev = nullptr;      // dy_T row -> bias element
     int* prefix_dev = nullptr;
     int* order_dev = nullptr;        // GEMMs by decreasing operand rows (bf16 tier: one workgroup per GEMM and k-split)
+    int32_t* sig_rows_dev = nullptr; // dfn_signal_grad: dy_T rows / bias elements behind d(signal)
+    int32_t* sig_elems_dev = nullptr;
+    int n_sig = 0;
     int ksplit_uploaded = 0;
 };
 WgradEntry g_wgrad[2];
@@ -132,24 +135,32 @@ long dfn_pack_plan(int tier, int field, int32_t* plan_host, long capacity) {
     return n;
 }
 
+// device copy of the forward pack plan of (tier, field), uploaded on first use
+static int fwd_plan_dev(int tier, int field, const int32_t** dev, long* n_out) {
+    const long n = dfn_pack_plan(tier, field, nullptr, 0);
+    if (n < 0) return (int)n;
+    PlanEntry& e = plan_of(tier, field);
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    if (!e.dev) {
+        hipError_t err = hipMalloc((void**)&e.dev, n * sizeof(int32_t));
+        if (err != hipSuccess) return hip_fail(err, "hipMalloc(plan)");
+        err = hipMemcpy(e.dev, e.host.data(), n * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (err != hipSuccess) return hip_fail(err, "hipMemcpy(plan)");
+    }
+    *dev = e.dev;
+    *n_out = n;
+    return DFN_OK;
+}
+
 int dfn_pack_weights(int tier, int field, const float* params, void* packed, void* stream) {
     if (!tier_ok(tier) || !field_ok(field) || !params || !packed)
         return fail(DFN_E_ARG, "dfn_pack_weights: bad argument");
     if (param_offset(P_COUNT) != N_DECODER_PARAMS) return fail(DFN_E_ARG, "internal: parameter table size");
-    const long n = dfn_pack_plan(tier, field, nullptr, 0);
-    if (n < 0) return (int)n;
-    PlanEntry& e = plan_of(tier, field);
-    hipStream_t st = (hipStream_t)stream;
-    {
-        std::lock_guard<std::mutex> lk(g_plan_mu);
-        if (!e.dev) {
-            hipError_t err = hipMalloc((void**)&e.dev, n * sizeof(int32_t));
-            if (err != hipSuccess) return hip_fail(err, "hipMalloc(plan)");
-            err = hipMemcpy(e.dev, e.host.data(), n * sizeof(int32_t), hipMemcpyHostToDevice);
-            if (err != hipSuccess) return hip_fail(err, "hipMemcpy(plan)");
-        }
-    }
-    hipError_t err = launch_pack(e.dev, params, packed, n, tier, st);
+    const int32_t* plan;
+    long n;
+    const int rc = fwd_plan_dev(tier, field, &plan, &n);
+    if (rc != DFN_OK) return rc;
+    hipError_t err = launch_pack(plan, params, packed, n, tier, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "pack_kernel");
     return DFN_OK;
 }
@@ -271,6 +282,7 @@ long dfn_train_rows(int field, int what) {
         return WS_KSPLIT_MAX * W + std::max(WS_KSPLIT_MAX, BIAS_GRAD_SLICES) * nb;
     }
     case 4: return (long)BIAS_GRAD_SLICES * dfn_bias_floats(DFN_TIER_BF16, field);   // dfn_bias_grad workspace floats
+    case 5: return (long)SIG_ROW_SLICES * 512 + dfn_bias_floats(DFN_TIER_BF16, field);   // dfn_signal_grad workspace floats
     default: return fail(DFN_E_ARG, "dfn_train_rows: bad selector");
     }
 }
@@ -282,28 +294,66 @@ long dfn_packed_bwd_bytes(int tier, int field) {
     return (long)pi.n_slabs * SLAB_BYTES;
 }
 
+// device copy of the transposed (backward) pack plan of (tier, field), built and uploaded on first use
+static int bwd_plan_dev(int tier, int field, const int32_t** dev, long* n_out) {
+    BwdPlanEntry& e = g_bwd_plans[tier][field];
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    if (e.host.empty()) {
+        e.n_frags = build_bwd_plan(tier, field, e.host);
+        ProgramInfo pi;
+        bwd_program_info(tier, field, &pi);
+        if (e.n_frags != pi.n_frags)
+            return fail(DFN_E_ARG, "backward planner and kernel disagree on the fragment count (" +
+                                       std::to_string(e.n_frags) + " vs " + std::to_string(pi.n_frags) + ")");
+    }
+    if (!e.dev) {
+        hipError_t err = upload(&e.dev, e.host.data(), e.host.size());
+        if (err != hipSuccess) return hip_fail(err, "upload(bwd plan)");
+    }
+    *dev = e.dev;
+    *n_out = (long)e.host.size();
+    return DFN_OK;
+}
+
 int dfn_pack_weights_bwd(int tier, int field, const float* params, void* packed_T, void* stream) {
     if (!train_tier_ok(tier) || (field != 0 && field != 1) || !params || !packed_T)
         return fail(DFN_E_ARG, "dfn_pack_weights_bwd: bad argument");
-    BwdPlanEntry& e = g_bwd_plans[tier][field];
-    {
-        std::lock_guard<std::mutex> lk(g_plan_mu);
-        if (e.host.empty()) {
-            e.n_frags = build_bwd_plan(tier, field, e.host);
-            ProgramInfo pi;
-            bwd_program_info(tier, field, &pi);
-            if (e.n_frags != pi.n_frags)
-                return fail(DFN_E_ARG, "backward planner and kernel disagree on the fragment count (" +
-                                           std::to_string(e.n_frags) + " vs " + std::to_string(pi.n_frags) + ")");
-        }
-        if (!e.dev) {
-            hipError_t err = upload(&e.dev, e.host.data(), e.host.size());
-            if (err != hipSuccess) return hip_fail(err, "upload(bwd plan)");
-        }
-    }
-    hipError_t err = launch_pack(e.dev, params, packed_T, (long)e.host.size(), tier,
-                                 (hipStream_t)stream);
+    const int32_t* plan;
+    long n;
+    const int rc = bwd_plan_dev(tier, field, &plan, &n);
+    if (rc != DFN_OK) return rc;
+    hipError_t err = launch_pack(plan, params, packed_T, n, tier, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "pack_kernel(bwd)");
+    return DFN_OK;
+}
+
+int dfn_train_prepare(int tier, const float* params, const float* signal_head, const float* signal_torso,
+                      const float* z_shape, const float* z_app, void* packed_head, void* packed_torso, void* packed_T_head,
+                      void* packed_T_torso, float* bias_head, float* bias_torso, void* stream) {
+    if (!train_tier_ok(tier) || !params || !signal_head || !signal_torso || !z_shape || !z_app || !packed_head ||
+        !packed_torso || !packed_T_head || !packed_T_torso || !bias_head || !bias_torso)
+        return fail(DFN_E_ARG, "dfn_train_prepare: bad argument");
+    if (param_offset(P_COUNT) != N_DECODER_PARAMS) return fail(DFN_E_ARG, "internal: parameter table size");
+    PrepareJobs J{};
+    J.params = params;
+    J.tier = tier;
+    void* outs[4] = {packed_head, packed_torso, packed_T_head, packed_T_torso};
+    for (int k = 0; k < 4; ++k) {
+        const int32_t* plan;
+        const int rc = k < 2 ? fwd_plan_dev(tier, k, &plan, &J.n[k]) : bwd_plan_dev(tier, k - 2, &plan, &J.n[k]);
+        if (rc != DFN_OK) return rc;
+        J.plan[k] = plan;
+        J.out[k] = outs[k];
+    }
+    J.sig[0] = signal_head;  J.sig[1] = signal_torso;
+    J.bias[0] = bias_head;   J.bias[1] = bias_torso;
+    for (int f = 0; f < 2; ++f) {
+        J.zs[f] = z_shape + 256 * f;
+        J.za[f] = z_app + 256 * f;
+        J.nb[f] = (int)dfn_bias_floats(tier, f);
+    }
+    hipError_t err = launch_prepare(J, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "prepare_kernel");
     return DFN_OK;
 }
 
@@ -521,6 +571,38 @@ int dfn_bias_grad(int tier, int field, const void* dy_T, long NP, float* workspa
     hipError_t err = launch_bias_grad(tier, field, w.eof_dev, w.rows_dev, (int)w.bias_rows.size(), dy_T, NP, workspace, dbias,
                                       (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "bias_grad_kernel");
+    return DFN_OK;
+}
+
+int dfn_signal_grad(int tier, int field, const float* params, const void* dy_T, long NP, float* workspace, float* d_signal,
+                    void* stream) {
+    if (!train_tier_ok(tier) || (field != 0 && field != 1) || !params || !dy_T || !workspace || !d_signal || NP <= 0 ||
+        NP % 32)
+        return fail(DFN_E_ARG, "dfn_signal_grad: bad argument (NP must be a multiple of 32)");
+    WgradEntry& w = wgrad_of(field);
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        if (!w.sig_rows_dev) {
+            int elems[512];
+            const int n = sig_term_elements(field, elems);
+            std::vector<int32_t> rows(n), el(elems, elems + n);
+            for (int i = 0; i < n; ++i) {
+                rows[i] = w.bias_rows[elems[i]];
+                if (rows[i] < 0 || n % 64) return fail(DFN_E_ARG, "internal: a signal-term bias element without a gradient row");
+            }
+            hipError_t e = upload(&w.sig_rows_dev, rows.data(), rows.size());
+            if (e == hipSuccess) e = upload(&w.sig_elems_dev, el.data(), el.size());
+            if (e != hipSuccess) return hip_fail(e, "upload(signal rows)");
+            w.n_sig = n;
+        }
+    }
+    float* parts = workspace;
+    float* dbias = workspace + (long)SIG_ROW_SLICES * w.n_sig;
+    hipError_t err = launch_signal_rows(tier, field, w.sig_rows_dev, w.sig_elems_dev, w.n_sig, dy_T, NP, parts, dbias,
+                                        (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "sig_rows_kernel");
+    err = launch_fold_bwd_sig(field, params, dbias, d_signal, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "fold_bwd_sig_kernel");
     return DFN_OK;
 }
 

@@ -4,9 +4,18 @@
 #include "dfanerf.h"
 
 namespace dfn {
+struct PrepareJobs {            // dfn_train_prepare: 4 pack jobs (head, torso, head^T, torso^T) + 2 bias folds (head, torso)
+    const float* params;
+    int tier;
+    const int* plan[4]; void* out[4]; long n[4]; int pack_blocks[4];
+    const float* sig[2]; const float* zs[2]; const float* za[2]; float* bias[2]; int nb[2]; int fold_blocks[2];
+};
+hipError_t launch_prepare(PrepareJobs J, hipStream_t st);
 hipError_t launch_pack(const int* plan, const float* params, void* out, long n, int tier, hipStream_t st);
 hipError_t launch_fold_bwd(int field, const float* params, const float* sig, const float* zs, const float* za,
                            const float* dbias, float* grad_flat, float* dsig, int n, hipStream_t st);
+hipError_t launch_fold_bwd_sig(int field, const float* params, const float* dbias, float* dsig, hipStream_t st);
+int sig_term_elements(int field, int* out);      // <= 512 bias-blob elements whose fold carries a signal term
 hipError_t launch_fold(int field, const float* params, const float* sig, const float* zs, const float* za,
                        float* out, int n, hipStream_t st);
 hipError_t launch_get_rays(int H, int W, float focal, float cx, float cy, const float* c2w_host, float* ro,

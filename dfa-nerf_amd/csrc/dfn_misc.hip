@@ -13,15 +13,18 @@
 namespace dfn {
 
 // ---- pack: gather flat params through the plan ---------------------------------------------------------
-__global__ void pack_kernel(const int* __restrict__ plan, const float* __restrict__ params, void* out, long n,
-                            int tier) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_body(const int* __restrict__ plan, const float* __restrict__ params, void* out, long n,
+                                          int tier, long i) {
     if (i >= n) return;
     const int src = plan[i];
     const float v = src >= 0 ? params[src] : 0.f;
     if (tier == TIER_BF16) ((__bf16*)out)[i] = (__bf16)v;       // round-to-nearest-even
     else if (tier == TIER_F16) ((_Float16*)out)[i] = (_Float16)v;
     else ((float*)out)[i] = v;
+}
+__global__ void pack_kernel(const int* __restrict__ plan, const float* __restrict__ params, void* out, long n,
+                            int tier) {
+    pack_body(plan, params, out, n, tier, (long)blockIdx.x * blockDim.x + threadIdx.x);
 }
 hipError_t launch_pack(const int* plan, const float* params, void* out, long n, int tier, hipStream_t st) {
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, plan, params, out, n,
@@ -43,10 +46,9 @@ __device__ float rowdot(const float* P, int pid, int row, int c0, int n, const f
 
 // One thread per bias element.  Blob layout = Prog<TIER>::*_B_* offsets; within a vector, element
 // t*32 + h*16 + r is feature 32*t + tile_feat(h, r).  The bias layout does not depend on the tier.
-__global__ void fold_kernel(int field, const float* __restrict__ P, const float* __restrict__ sig,
-                            const float* __restrict__ zs, const float* __restrict__ za, float* out, int n) {
+__device__ void fold_body(int field, const float* __restrict__ P, const float* __restrict__ sig,
+                          const float* __restrict__ zs, const float* __restrict__ za, float* out, int n, int i) {
     using PG = Prog<TIER_BF16>;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     // locate the vector this element belongs to
     int base, f;
@@ -128,6 +130,40 @@ __global__ void fold_kernel(int field, const float* __restrict__ P, const float*
         }
     }
     out[i] = v;
+}
+__global__ void fold_kernel(int field, const float* __restrict__ P, const float* __restrict__ sig,
+                            const float* __restrict__ zs, const float* __restrict__ za, float* out, int n) {
+    fold_body(field, P, sig, zs, za, out, n, blockIdx.x * blockDim.x + threadIdx.x);
+}
+// Everything a training step derives from the parameters before its forward, in ONE launch (dfn_train_prepare): the two
+// fields' bias folds and their four packed weight streams (forward + transposed).  Six launches of 3-10 us each, back to
+// back on one stream, cost 37 us of a 2-ms step; the jobs are independent, so one grid covers them (blocks of 256
+// threads; a block's job = the range its index falls into).
+__global__ __launch_bounds__(256) void prepare_kernel(PrepareJobs J) {
+    int b = blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (b < J.pack_blocks[k]) {
+            pack_body(J.plan[k], J.params, J.out[k], J.n[k], J.tier, (long)b * 256 + threadIdx.x);
+            return;
+        }
+        b -= J.pack_blocks[k];
+    }
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        if (b < J.fold_blocks[f]) {
+            fold_body(f, J.params, J.sig[f], J.zs[f], J.za[f], J.bias[f], J.nb[f], b * 256 + threadIdx.x);
+            return;
+        }
+        b -= J.fold_blocks[f];
+    }
+}
+hipError_t launch_prepare(PrepareJobs J, hipStream_t st) {
+    int blocks = 0;
+    for (int k = 0; k < 4; ++k) blocks += (J.pack_blocks[k] = (int)((J.n[k] + 255) / 256));
+    for (int f = 0; f < 2; ++f) blocks += (J.fold_blocks[f] = (J.nb[f] + 255) / 256);
+    hipLaunchKernelGGL(prepare_kernel, dim3(blocks), dim3(256), 0, st, J);
+    return hipGetLastError();
 }
 hipError_t launch_fold(int field, const float* params, const float* sig, const float* zs, const float* za,
                        float* out, int n, hipStream_t st) {
@@ -240,6 +276,21 @@ hipError_t launch_fold_bwd(int field, const float* params, const float* sig, con
         hipLaunchKernelGGL(fold_bwd_sig_kernel, dim3(field == FIELD_TORSO ? NET : NSIG), dim3(64), 0, st, field, params,
                            dbias, dsig);
     return hipGetLastError();
+}
+// d(signal) alone (dfn_signal_grad): dbias needs to hold the elements sig_term_elements() lists, nothing else
+hipError_t launch_fold_bwd_sig(int field, const float* params, const float* dbias, float* dsig, hipStream_t st) {
+    hipLaunchKernelGGL(fold_bwd_sig_kernel, dim3(field == FIELD_TORSO ? NET : NSIG), dim3(64), 0, st, field, params, dbias,
+                       dsig);
+    return hipGetLastError();
+}
+// the bias-blob elements fold_bwd_sig_kernel reads (the vectors whose fold has a signal term), ascending; 512 / 256
+int sig_term_elements(int field, int* out) {
+    using PG = Prog<TIER_BF16>;
+    int n = 0;
+    auto run = [&](int base, int len) { for (int e = 0; e < len; ++e) out[n++] = base + e; };
+    if (field == FIELD_TORSO) { run(PG::T_B_E0, 64); run(PG::T_B_S0, 64); run(PG::T_B_SSKIP, 64); run(PG::T_B_SO, 64); }
+    else { run(PG::H_B_IN, 256); run(PG::H_B_SKIP, 256); }
+    return n;
 }
 
 

@@ -65,4 +65,9 @@ constexpr int WG_PF = 4;      // register prefetch depth of wgrad_kernel (f32 ti
 hipError_t launch_bias_grad(int tier, int field, const int* e_of, const int* rows, int n, const void* dy_T, long NP,
                             float* parts, float* dbias, hipStream_t st);
 
+// row sums of the dy_T rows behind d(signal) only (dfn_signal_grad): parts [SIG_ROW_SLICES][n_sig], dbias[elem_of[i]] = sum
+constexpr int SIG_ROW_SLICES = 128;
+hipError_t launch_signal_rows(int tier, int field, const int* row_of, const int* elem_of, int n_sig, const void* dy_T, long NP,
+                              float* parts, float* dbias, hipStream_t st);
+
 }  // namespace dfn

@@ -544,4 +544,68 @@ hipError_t launch_bias_grad(int tier, int field, const int* e_of, const int* bia
     return launch_reduce_bias(bias_rows, parts, n_bias, BIAS_GRAD_SLICES, dbias, st);
 }
 
+
+// ---- d(signal) ahead of the weight gradients ---------------------------------------------------------------------------
+// The conditioning networks' backward (dfn_encode_signal*_bwd: single-workgroup latency chains, 0.2 ms) only needs
+// d(signal), and d(signal) only needs the row sums of the few dy_T rows whose bias elements fold a signal term (head:
+// fc_in / fc_p_skips = 512 rows, torso: four deformation vectors = 256 rows of ~2700).  Summing those rows right after the
+// dX chain (8 % of dy_T, one extra streaming read) lets that whole chain run on a side stream underneath the weight-gradient
+// GEMMs instead of behind them.  One wave = 64 rows = one contiguous 4 KiB (bf16) run per tile, blockIdx.y = slice of the
+// tiles, parts[slice][i]; sig_reduce_kernel adds the slices in index order (bit-reproducible).
+template <typename T>
+__global__ __launch_bounds__(64) void sig_rows_kernel(const int* __restrict__ row_of, int n_sig, const T* __restrict__ dy_T,
+                                                      long n_tiles, int rows, float* __restrict__ parts) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int row = row_of[i];
+    const long per = (n_tiles + gridDim.y - 1) / gridDim.y;
+    const long t0 = blockIdx.y * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
+    float acc = 0.f;
+#pragma unroll 4
+    for (long t = t0; t < t1; ++t) {
+        const uint4* p = (const uint4*)(dy_T + (t * rows + row) * 32);
+        if constexpr (sizeof(T) == 2) {
+            uint4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = p[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc += __uint_as_float(w[k] << 16) + __uint_as_float(w[k] & 0xffff0000u);
+            }
+        } else {
+            uint4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = p[q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                acc += (__uint_as_float(v[q].x) + __uint_as_float(v[q].y)) + (__uint_as_float(v[q].z) + __uint_as_float(v[q].w));
+        }
+    }
+    parts[(long)blockIdx.y * n_sig + i] = acc;
+}
+__global__ void sig_reduce_kernel(const int* __restrict__ elem_of, int n_sig, const float* __restrict__ parts, int slices,
+                                  float* __restrict__ dbias) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sig) return;
+    float a = 0.f;
+    for (int k = 0; k < slices; ++k) a += parts[(long)k * n_sig + i];
+    dbias[elem_of[i]] = a;
+}
+hipError_t launch_signal_rows(int tier, int field, const int* row_of, const int* elem_of, int n_sig, const void* dy_T, long NP,
+                              float* parts, float* dbias, hipStream_t st) {
+    const int rows = field == FIELD_TORSO ? GradMap::S_ROWS : GradMap::H_ROWS;
+    const long n_tiles = NP / 32;
+    const int slices = (int)(n_tiles < SIG_ROW_SLICES ? n_tiles : SIG_ROW_SLICES);
+    const dim3 grid(n_sig / 64, slices);
+    if (tier == TIER_BF16)
+        hipLaunchKernelGGL(sig_rows_kernel<__bf16>, grid, dim3(64), 0, st, row_of, n_sig, (const __bf16*)dy_T, n_tiles, rows,
+                           parts);
+    else
+        hipLaunchKernelGGL(sig_rows_kernel<float>, grid, dim3(64), 0, st, row_of, n_sig, (const float*)dy_T, n_tiles, rows,
+                           parts);
+    hipLaunchKernelGGL(sig_reduce_kernel, dim3((n_sig + 255) / 256), dim3(256), 0, st, elem_of, n_sig, parts, slices, dbias);
+    return hipGetLastError();
+}
+
 }  // namespace dfn

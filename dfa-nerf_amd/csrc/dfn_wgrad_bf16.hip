@@ -81,7 +81,11 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_lds_kernel(const WOp* ops, c
                 t = t < t1 ? t : t1 - 1;             // ragged last step: refetch the last tile (never multiplied)
                 const char* a = src[k] + t * stride[k];
                 const unsigned d = __builtin_amdgcn_readfirstlane(slot + dst[k]);
+#ifdef DFN_WL_NT
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(a), "s"(d) : "memory", "m0");
+#else
                 asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(a), "s"(d) : "memory", "m0");
+#endif
             }
     };
 
@@ -125,6 +129,9 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_lds_kernel(const WOp* ops, c
         if (s + WL_DEPTH - 1 < n_steps) issue(s + WL_DEPTH - 1);
         const lds_char* slot = lds + (unsigned)(s & (WL_DEPTH - 1)) * WL_STEP_BYTES;
         const long tt = t0 + s * tps;
+#ifdef DFN_WL_NOMFMA          // timing experiment (wrong results): the DMA stream and the barriers alone
+        if (tt >= 0) continue;
+#endif
         for (int u = 0; u < tps; ++u) {
             if (tt + u >= t1) break;
             const lds_char* base = slot + u * ntl * 2048;

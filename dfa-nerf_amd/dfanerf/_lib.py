@@ -64,6 +64,7 @@ def _load():
         "dfn_train_rows": (lg, [i32, i32]),
         "dfn_packed_bwd_bytes": (lg, [i32, i32]),
         "dfn_pack_weights_bwd": (i32, [i32, i32, fp, vp, vp]),
+        "dfn_train_prepare": (i32, [i32, fp, fp, fp, fp, fp, vp, vp, vp, vp, fp, fp, vp]),
         "dfn_train_fwd": (i32, [i32, C.POINTER(DfnFrame), vp, vp, fp, fp, fp, vp, ip, fp, fp, fp, vp, vp, vp, vp, vp]),
         "dfn_sample_pixels": (i32, [i32, i32, i32, i32, ip, C.c_uint64, C.c_uint64, ip, ip, vp]),
         "dfn_mse_loss_u8": (i32, [fp, fp, vp, vp, ip, i32, fp, fp, fp, vp]),
@@ -72,6 +73,7 @@ def _load():
         "dfn_weight_grad": (i32, [i32, i32, vp, vp, lg, fp, fp, vp]),
         "dfn_weight_bias_grad": (i32, [i32, i32, vp, vp, lg, fp, fp, fp, vp]),
         "dfn_bias_grad": (i32, [i32, i32, vp, lg, fp, fp, vp]),
+        "dfn_signal_grad": (i32, [i32, i32, fp, vp, lg, fp, fp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = header and library out of sync

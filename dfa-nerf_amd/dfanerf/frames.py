@@ -107,7 +107,15 @@ class PixelSampler:
     to the generator, like np.random.choice(replace=False)."""
     CANDIDATES = 8192            # SAMPLE_PIXELS_CANDIDATES of the kernel
 
-    def __init__(self, H, W, n_rand, sample_rate, device, seed=0, rects=None):
+    def __init__(self, H, W, n_rand, sample_rate, device, seed=0, rects=None, pipeline=False, stream=None):
+        # pipeline: draw on a side stream into a ring of three buffers - the draw of step n + 1 then runs while the main
+        # stream still works on step n instead of in front of its forward (20 us + a launch gap of a 1.9-ms step).  A
+        # returned tensor is overwritten by the third draw after it: for training loops that consume a draw within its
+        # own step (run_nerf.train, bench.py), not for callers that collect draws.
+        # stream: the side stream to use (default: a new one).  The device runs four hardware queues: a fifth stream shares
+        # one of them with another stream and serialises with it - the training loop passes one of the conditioning
+        # networks' streams (training.SignalTrainer.pose_stream()).
+        self.pipeline, self._ring, self._done, self._k, self._side = bool(pipeline), None, [None] * 3, 0, stream
         self.H, self.W, self.n, self.rate, self.device = int(H), int(W), int(n_rand), float(sample_rate), device
         if self.n > self.H * self.W:
             raise ValueError("PixelSampler: more rays than pixels")
@@ -180,9 +188,28 @@ class PixelSampler:
         if rect_dev is None and self.rect_num > 0:
             rect_dev = torch.as_tensor(np.asarray(rect_host, dtype=np.int32), device=self.device)
         self.counter += 1
-        out = torch.empty_like(self.out)          # a fresh tensor per draw: the previous one may still be in use
-        check(lib.dfn_sample_pixels(self.H, self.W, self.n, self.rect_num,
-                                    None if rect_dev is None else C.c_void_p(rect_dev.contiguous().data_ptr()),
-                                    C.c_uint64(self.seed), C.c_uint64(self.counter), C.c_void_p(out.data_ptr()), None,
-                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), "dfn_sample_pixels")
+        rect_ptr = None if rect_dev is None else C.c_void_p(rect_dev.contiguous().data_ptr())
+        main = torch.cuda.current_stream()
+        if self.pipeline and (self.rect_num == 0 or frame is not None):
+            if self._ring is None:
+                self._ring = [torch.empty_like(self.out) for _ in range(3)]
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                self._side.wait_stream(main)
+            k = self._k = (self._k + 1) % 3
+            # everything enqueued on the main stream so far = the whole step that consumed the previous draw: once that is
+            # done, slot k - 1 may be overwritten (by the draw after next); slot k waits for the step that used IT
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self._done[(k - 1) % 3] = ev
+            if self._done[k] is not None:
+                self._side.wait_event(self._done[k])
+            out, stream = self._ring[k], self._side
+        else:
+            out, stream = torch.empty_like(self.out), main          # a fresh tensor per draw: the previous one may still be in use
+        check(lib.dfn_sample_pixels(self.H, self.W, self.n, self.rect_num, rect_ptr, C.c_uint64(self.seed),
+                                    C.c_uint64(self.counter), C.c_void_p(out.data_ptr()), None,
+                                    C.c_void_p(stream.cuda_stream)), "dfn_sample_pixels")
+        if stream is not main:
+            main.wait_stream(stream)
         return out

@@ -99,8 +99,25 @@ class HipAdam(torch.optim.Adam):
         self._cache[gi] = c
         return c
 
-    @torch.no_grad()
     def step(self, closure=None):
+        """One launch per group and distinct step count.  `self.dfn_stream` (training.SignalTrainer.adopt_optimizers): run
+        the step on that stream instead of the current one - the conditioning networks' gradients are produced there early in
+        the backward, so their update (and the next step's encoder forward behind it) need not queue behind the decoder's
+        weight-gradient GEMMs.  The current stream is ordered behind the update; with more than one rank the side stream
+        first waits for the current one (the gradient all-reduce runs there)."""
+        s = getattr(self, "dfn_stream", None)
+        if s is None:
+            return self._step(closure)
+        cur = torch.cuda.current_stream(s.device)
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            out = self._step(closure)
+        cur.wait_stream(s)
+        return out
+
+    @torch.no_grad()
+    def _step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():

@@ -450,7 +450,8 @@ def train_step_loss_hip(nets, dataset, itr_obj, img_i, sel_yx, target_head, targ
         # rows A7 / A8 forward + backward in HIP (training.SignalTrainer): 4 launches instead of ~200
         smoothed = global_step >= args.nosmo_iters
         s2, t2 = sig_tr.encode(img_i, args.smo_size if smoothed else 0, args.smo_torse_size if smoothed else 0, len_train)
-        signal, signal_torso = [s2, None], (t2[0] if smoothed else t2)
+        signal, signal_torso = [s2, None], t2         # [1,42] as it comes (an index op here would put an autograd node
+                                                      # between the two HIP Functions, see training.render_train)
     else:
         signal = encode_signal(dataset, itr_obj, img_i, args.dim_aud, nets["AudNet"], nets["ExpNet"], nets["AudAttNet"],
                                global_step, args, len_train, embed_fn=embed_fn)
@@ -479,7 +480,8 @@ def train_step_loss_hip(nets, dataset, itr_obj, img_i, sel_yx, target_head, targ
     bg = dataset[itr_obj]['bc_img'].reshape(-1, 3)
     zs = z_shape[0, itr_obj * 2:itr_obj * 2 + 2]
     za = z_app[0, itr_obj * 2:itr_obj * 2 + 2]
-    rgb_head, rgb_com = training.render_train(dec, buf, frame, bg, pix, signal[0], signal_torso, zs, za)
+    rgb_head, rgb_com = training.render_train(dec, buf, frame, bg, pix, signal[0], signal_torso, zs, za,
+                                              signal_trainer=sig_tr if (sig_tr is not None and itr_obj == 0) else None)
     if target_head.dtype == torch.uint8:
         # whole uint8 ground-truth frames [H*W,3] resident on the device (frames.DeviceFrameCache): the targets are gathered
         # inside the loss kernel (dfn_mse_loss_u8: MAIN:791-800 + 902-907 + their autograd in one launch)
@@ -659,6 +661,7 @@ def train():
     if "PoseAttNet" in nets and _hip_signals_ok(args):
         train_buf.signal_trainer = training.SignalTrainer(nets["AudNet"], nets["ExpNet"], nets["AudAttNet"],
                                                           nets["PoseAttNet"], ds['auds'], ds['exp'], ds['poses'])
+        train_buf.signal_trainer.adopt_optimizers(opts)
     bucket = parallel.FlatGradBucket(list(nets.values())) if world > 1 else None
     rng = np.random.RandomState(1234 + rank) if world > 1 else np.random
     i_train = ds['i_train']
@@ -674,7 +677,8 @@ def train():
         if rank == 0:
             print(f'[dfanerf] {n_pre} ground-truth frame pairs decoded to the device in {time.time() - t0:.1f} s')
     sampler = frames.PixelSampler(H, W, args.N_rand, args.sample_rate, dev, seed=1234 + rank,
-                                  rects=ds['sample_rects'] if args.sample_rate > 0 else None)
+                                  rects=ds['sample_rects'] if args.sample_rate > 0 else None, pipeline=True,
+                                  stream=getattr(getattr(train_buf, "signal_trainer", None), "pose_stream", lambda: None)())
     from tqdm import trange, tqdm
     for i in trange(global_step + 1, args.N_iters + 1, disable=rank != 0):
         img_i = rng.choice(i_train)

@@ -23,6 +23,15 @@ import os
 # the head field's weight-gradient GEMMs (HBM reads) run on a second stream underneath the torso field's dX chain (MFMAs +
 # HBM writes): 2.19 -> 2.12 ms per step (interleaved A/B on one box); DFN_TRAIN_OVERLAP=0 turns it off
 _OVERLAP = os.environ.get("DFN_TRAIN_OVERLAP", "1") == "1"
+# developer switches inside the overlapped schedule (A/B timing): the head field's weight gradients on their own stream;
+# the conditioning networks' streams at high priority (their single-workgroup kernels then get the first compute unit a big
+# kernel's workgroup leaves instead of queueing behind its remaining workgroups)
+_WGRAD_SIDE = os.environ.get("DFN_TRAIN_WGRAD_SIDE", "1") == "1"
+_SIG_PRIO = os.environ.get("DFN_TRAIN_SIG_PRIO", "1") == "1"
+
+
+def _side_stream(device, high=False):
+    return torch.cuda.Stream(device=device, priority=-1 if (high and _SIG_PRIO) else 0)
 
 
 def _sync_flat(params, views):
@@ -97,6 +106,7 @@ class TrainBuffers:
         self.dy = [torch.empty(rows(f, 1), self.NP, dtype=dt, device=device) for f in (0, 1)]
         self.masks = [torch.empty(self.NP // 32, rows(f, 2), 64, dtype=torch.int32, device=device) for f in (0, 1)]
         self.ws = [torch.empty(rows(f, 3), dtype=torch.float32, device=device) for f in (0, 1)]
+        self.ws_sig = [torch.empty(rows(f, 5), dtype=torch.float32, device=device) for f in (0, 1)]
         self.samples = torch.empty(self.NP, 8, dtype=torch.float32, device=device)
         self.dsamples = torch.empty(self.NP, 8, dtype=torch.float32, device=device)
         self.packed = [torch.empty(check(lib.dfn_packed_bytes(self.tier, f), "packed"), dtype=torch.uint8, device=device)
@@ -124,7 +134,10 @@ class FusedTrainFn(torch.autograd.Function):
     of the ~600 of the torch fold + cat/split autograd)."""
 
     @staticmethod
-    def forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app):
+    def forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app, defer=None):
+        # defer: the SignalTrainer whose _SignalFn produced both signals (their backward then picks d(signal) up on its own
+        # streams and the main stream never waits for it), or None
+        ctx.defer = defer if _OVERLAP else None
         t, st = buf.tier, _stream()
         flat = buf.flat
         dev = flat.device
@@ -134,13 +147,10 @@ class FusedTrainFn(torch.autograd.Function):
         za = z_app.detach().reshape(2, 256).float().contiguous()
         bias = buf.bias
         bias_t = C.c_void_p(bias.data_ptr() + 4 * buf.nb[0])
-        check(lib.dfn_fold_bias(t, FIELD_HEAD, _ptr(flat), _ptr(sh), _ptr(zs[0]), _ptr(za[0]), _ptr(bias), st),
-              "dfn_fold_bias(head)")
-        check(lib.dfn_fold_bias(t, FIELD_TORSO, _ptr(flat), _ptr(stt), _ptr(zs[1]), _ptr(za[1]), bias_t, st),
-              "dfn_fold_bias(torso)")
-        for f in (0, 1):
-            check(lib.dfn_pack_weights(t, f, _ptr(flat), _ptr(buf.packed[f]), st), "dfn_pack_weights")
-            check(lib.dfn_pack_weights_bwd(t, f, _ptr(flat), _ptr(buf.packed_T[f]), st), "dfn_pack_weights_bwd")
+        # both folds and the four packed weight streams in one launch (six launches back to back cost 37 us of the step)
+        check(lib.dfn_train_prepare(t, _ptr(flat), _ptr(sh), _ptr(stt), _ptr(zs), _ptr(za), _ptr(buf.packed[0]),
+                                    _ptr(buf.packed[1]), _ptr(buf.packed_T[0]), _ptr(buf.packed_T[1]), _ptr(bias), bias_t,
+                                    st), "dfn_train_prepare")
         n = frame.ray_count
         rgb_h = torch.empty(n, 3, dtype=torch.float32, device=dev)
         rgb_c = torch.empty(n, 3, dtype=torch.float32, device=dev)
@@ -166,44 +176,81 @@ class FusedTrainFn(torch.autograd.Function):
         bg_u8 = bg if bg.dtype == torch.uint8 else None
         check(lib.dfn_composite_bwd(C.byref(frame), _ptr(ctx.pix), _ptr(bg_f32), _ptr(bg_u8), _ptr(buf.samples),
                                     _ptr(d_h), _ptr(d_c), _ptr(buf.dsamples), st), "dfn_composite_bwd")
-        g_flat = _grad_buffer(buf.net, "_g_flat", flat, buf.params)
         g_bias = torch.empty(buf.nb[0] + buf.nb[1], dtype=torch.float32, device=dev)
-        d_sig = torch.zeros(96 + 42, dtype=torch.float32, device=dev)
+        main = torch.cuda.current_stream(dev)
+        over = _OVERLAP and _WGRAD_SIDE
+        if over and getattr(buf, "_side", None) is None:
+            buf._side = _side_stream(dev)
+        side = buf._side if over else None
+        # zeroed HERE, on the main stream: a many-workgroup fill on a side stream starves behind the dX chain's workgroups
+        # (measured: 340 us for this 4-MB fill, and the head field's weight gradients queue behind it)
+        g_flat = _grad_buffer(buf.net, "_g_flat", flat, buf.params)
+        if _OVERLAP:
+            if getattr(buf, "_sig_streams", None) is None:
+                buf._sig_streams = (_side_stream(dev, True), _side_stream(dev, True))
+            tr = ctx.defer
+            s_a, s_p = (tr.audio_stream(), tr.pose_stream()) if tr is not None else buf._sig_streams
+            # each half is zeroed on the stream that accumulates into it (after that stream has waited for this one; every
+            # consumer is ordered in front of this stream's later work: _SignalFn.backward / the waits below)
+            d_sig = torch.empty(96 + 42, dtype=torch.float32, device=dev)
+        else:
+            d_sig = torch.zeros(96 + 42, dtype=torch.float32, device=dev)
         def dx(f, stream):
             check(lib.dfn_mlp_bwd(buf.tier, f, _ptr(buf.packed_T[f]), _ptr(buf.samples), _ptr(buf.dsamples),
                                   _ptr(buf.masks[f]), buf.NP, _ptr(buf.dy[f]), stream), "dfn_mlp_bwd")
 
-        def dw(f, stream, g):
+        def dw(f, stream, g, with_sig):
             gb = C.c_void_p(g_bias.data_ptr() + (4 * buf.nb[0] if f else 0))
             check(lib.dfn_weight_bias_grad(buf.tier, f, _ptr(buf.dy[f]), _ptr(buf.act[f]), buf.NP, _ptr(buf.ws[f]),
                                            _ptr(g), gb, stream), "dfn_weight_bias_grad")
+            ds = C.c_void_p(d_sig.data_ptr() + (4 * 96 if f else 0)) if with_sig else None
             check(lib.dfn_fold_bias_bwd(buf.tier, FIELD_TORSO if f else FIELD_HEAD, _ptr(flat), _ptr(stt if f else sh),
-                                        _ptr(zs[f]), _ptr(za[f]), gb, _ptr(g),
-                                        C.c_void_p(d_sig.data_ptr() + (4 * 96 if f else 0)), stream), "dfn_fold_bias_bwd")
+                                        _ptr(zs[f]), _ptr(za[f]), gb, _ptr(g), ds, stream), "dfn_fold_bias_bwd")
+
+        def dsig(f, stream):
+            # d(signal) from the row sums of the dy_T rows behind it, without waiting for the weight gradients
+            check(lib.dfn_signal_grad(buf.tier, f, _ptr(flat), _ptr(buf.dy[f]), buf.NP, _ptr(buf.ws_sig[f]),
+                                      C.c_void_p(d_sig.data_ptr() + (4 * 96 if f else 0)), stream), "dfn_signal_grad")
         if _OVERLAP:
-            # the head field's weight gradients (HBM reads) on a side stream underneath the torso field's dX chain (MFMAs
-            # + HBM writes); its own gradient buffer, added in a fixed order afterwards (bit-reproducible)
-            side = getattr(buf, "_side", None)
-            if side is None:
-                side = buf._side = torch.cuda.Stream(device=dev)
-                buf._g_side = torch.zeros_like(flat)
-            main = torch.cuda.current_stream(dev)
+            # Three chains next to the main one.  (1) the head field's weight gradients (HBM reads) on a side stream
+            # underneath the torso field's dX chain (MFMAs + HBM writes); the main stream waits for that chain before the
+            # torso field's weight gradients, so the two fields accumulate into the one gradient buffer in a fixed order
+            # (bit-reproducible; the side chain ends well before the dX chain it runs under).  (2, 3) d(signal) of each
+            # field as soon as its dX chain is done (dfn_signal_grad) on the conditioning networks' streams: their backward
+            # (single-workgroup latency chains, 0.26 ms) then runs underneath the weight-gradient GEMMs instead of behind
+            # them.  Who consumes d_sig decides whether the main stream has to wait: _SignalFn.backward launches on those
+            # same streams (ctx.defer).
             dx(0, st)
-            buf._g_side.zero_()
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                dw(0, C.c_void_p(side.cuda_stream), buf._g_side)
+            s_a.wait_stream(main)
+            with torch.cuda.stream(s_a):
+                d_sig[:96].zero_()
+            dsig(0, C.c_void_p(s_a.cuda_stream))
+            if over:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    dw(0, C.c_void_p(side.cuda_stream), g_flat, False)
+            else:
+                dw(0, st, g_flat, False)
             dx(1, st)
-            dw(1, st, g_flat)
-            main.wait_stream(side)
-            g_flat.add_(buf._g_side)
+            s_p.wait_stream(main)
+            with torch.cuda.stream(s_p):
+                d_sig[96:].zero_()
+            dsig(1, C.c_void_p(s_p.cuda_stream))
+            if over:
+                main.wait_stream(side)
+            dw(1, st, g_flat, False)
+            if tr is None:          # torch autograd consumes d_sig on the main stream
+                main.wait_stream(s_a)
+                main.wait_stream(s_p)
+            else:
+                tr._deferred = True
         else:
             for f in (0, 1):
                 dx(f, st)
-                dw(f, st, g_flat)
+                dw(f, st, g_flat, True)
         buf.net.deposit(g_flat, touched=_decoder_touched(buf.net, (0, 1)))
         return (d_sig[:96].reshape(ctx.sig_shapes[0]), d_sig[96:].reshape(ctx.sig_shapes[1]), None, None, None, None,
-                None, None)
+                None, None, None)
 
 
 class _FlatNet:
@@ -284,14 +331,42 @@ class SignalTrainer:
         self.poses = poses.detach().float().contiguous()
         self.pose_stride = int(self.poses[0].numel())
         self.device = dev
+        self._pipelined, self._fresh = False, True
 
-    def side_stream(self):
-        """second stream for the pose encoder (None: DFN_TRAIN_OVERLAP=0)"""
+    def audio_stream(self):
+        """stream of the audio / expression encoder's BACKWARD (None: DFN_TRAIN_OVERLAP=0); its forward runs on the caller's
+        stream (the decoder's forward waits for it anyway)"""
+        return self._streams()[0]
+
+    def pose_stream(self):
+        """second stream for the pose encoder, forward and backward (None: DFN_TRAIN_OVERLAP=0)"""
+        return self._streams()[1]
+
+    def _streams(self):
         if not _OVERLAP:
-            return None
+            return None, None
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = (_side_stream(self.device, True), _side_stream(self.device, True))
         return self._side
+
+    def adopt_optimizers(self, opts):
+        """Pipeline the conditioning networks across steps: their optimizers (dict name -> optim.HipAdam, the keys of
+        run_nerf.create_nerf) step on the streams their gradients are produced on, and encode() then runs the next step's
+        forward there too - all of it underneath the decoder's weight-gradient GEMMs of the step before; the main stream
+        only waits for the two signals.  Everything that writes these networks' parameters must go through those optimizers
+        (or call resync() afterwards)."""
+        if not _OVERLAP:
+            return
+        s_a, s_p = self._streams()
+        for k, s in (("AudNet", s_a), ("ExpNet", s_a), ("AudAttNet", s_a), ("PoseAttNet", s_p)):
+            if k in opts and hasattr(opts[k], "_step"):
+                opts[k].dfn_stream = s
+        self._pipelined = True
+        self._fresh = True
+
+    def resync(self):
+        """the parameters were written on the current stream (load_state_dict, ...): the next encode() waits for it"""
+        self._fresh = True
 
     def frame_id(self, frame):
         """[1] int32 device tensor holding `frame` without a host-to-device copy (a pageable copy blocks the host until
@@ -299,13 +374,20 @@ class SignalTrainer:
         ar = getattr(self, "_frame_ids", None)
         if ar is None or frame >= ar.numel():
             ar = self._frame_ids = torch.arange(max(int(frame) + 1, 4096), dtype=torch.int32, device=self.device)
+            self._fresh = True          # made on the current stream: the encoder streams wait for it once
         return ar[frame:frame + 1]
 
     def encode(self, frame, smo_size, smo_torso_size, length):
         for n in self.nets:
             n.refresh()
-        anchor = torch.zeros(1, device=self.device, requires_grad=True)       # keeps the node in the graph
-        return _SignalFn.apply(anchor, self, int(frame), int(smo_size), int(smo_torso_size), int(length))
+        if getattr(self, "_anchor", None) is None:
+            self._anchor = torch.zeros(1, device=self.device, requires_grad=True)       # keeps the node in the graph
+            # two sets of outputs, used alternately: with adopt_optimizers() the next step's forward runs while the
+            # previous step's fold backward may still have to read its signals
+            self._outs = [(torch.empty(1, 96, dtype=torch.float32, device=self.device),
+                           torch.empty(1, 42, dtype=torch.float32, device=self.device)) for _ in range(2)]
+            self._flip = 0
+        return _SignalFn.apply(self._anchor, self, int(frame), int(smo_size), int(smo_torso_size), int(length))
 
 
 class _SignalFn(torch.autograd.Function):
@@ -313,21 +395,31 @@ class _SignalFn(torch.autograd.Function):
     def forward(ctx, anchor, tr, frame, smo, smo_t, length):
         dev, st = tr.device, _stream()
         ids = tr.frame_id(frame)
-        sig = torch.empty(1, 96, dtype=torch.float32, device=dev)
-        sigt = torch.empty(1, 42, dtype=torch.float32, device=dev)
+        tr._flip ^= 1
+        sig, sigt = tr._outs[tr._flip]
         a, e, t, p = [n.flat for n in tr.nets]
         # the two encoders are independent single-workgroup latency chains: the pose one runs on a second stream
-        # underneath the audio / expression one
-        side, main = tr.side_stream(), torch.cuda.current_stream(dev)
-        if side is not None:
-            side.wait_stream(main)
-        st_t = st if side is None else C.c_void_p(side.cuda_stream)
+        # underneath the audio / expression one.  Pipelined (adopt_optimizers): both run on the streams their parameters
+        # were just updated on, behind the previous step's backward + Adam there and ahead of whatever the main stream is
+        # still doing for the previous step; it waits for them only on the first call (parameters loaded on the main stream)
+        s_a, s_p = tr._streams()
+        main = torch.cuda.current_stream(dev)
+        piped = s_a is not None and getattr(tr, "_pipelined", False)
+        if s_p is not None and (not piped or tr._fresh):
+            s_p.wait_stream(main)
+        if piped and tr._fresh:
+            s_a.wait_stream(main)
+        tr._fresh = False
+        st_t = st if s_p is None else C.c_void_p(s_p.cuda_stream)
+        st_a = C.c_void_p(s_a.cuda_stream) if piped else st
         check(lib.dfn_encode_signal_torso(_ptr(p), _ptr(tr.poses), tr.pose_stride, length, _ptr(ids), 1, smo_t,
                                           _ptr(sigt), st_t), "dfn_encode_signal_torso")
         check(lib.dfn_encode_signal(_ptr(a), _ptr(e), _ptr(t), _ptr(tr.auds), _ptr(tr.exps), length, _ptr(ids), 1, smo,
-                                    _ptr(sig), st), "dfn_encode_signal")
-        if side is not None:
-            main.wait_stream(side)
+                                    _ptr(sig), st_a), "dfn_encode_signal")
+        if s_p is not None:
+            main.wait_stream(s_p)
+        if piped:
+            main.wait_stream(s_a)
         ctx.tr, ctx.args = tr, (frame, smo, smo_t, length)
         return sig, sigt
 
@@ -336,19 +428,34 @@ class _SignalFn(torch.autograd.Function):
         tr, (frame, smo, smo_t, length) = ctx.tr, ctx.args
         st = _stream()
         a, e, t, p = [n.flat for n in tr.nets]
-        g = [_grad_buffer(n, "_g_flat", n.flat, n.params) for n in tr.nets]
+        # d_sig / d_sigt were produced on the audio / pose streams by FusedTrainFn.backward (dfn_signal_grad, right after each
+        # field's dX chain) when it deferred to this trainer (tr._deferred): everything below, the zeroing of the gradient
+        # buffers included, is then launched on those streams and never waits for the main one, which meanwhile runs the
+        # weight-gradient GEMMs; the main stream joins them at the end.  A d_sig from anywhere else lives on the main
+        # stream: the side streams wait for it first.
+        s_a, s_p = tr.audio_stream(), tr.pose_stream()
+        main = torch.cuda.current_stream(tr.device)
+        deferred, tr._deferred = getattr(tr, "_deferred", False), False
+        if s_a is not None and not deferred:
+            s_a.wait_stream(main)
+            s_p.wait_stream(main)
+        def buffers(stream, nets):
+            if stream is None:
+                return [_grad_buffer(n, "_g_flat", n.flat, n.params) for n in nets]
+            with torch.cuda.stream(stream):
+                return [_grad_buffer(n, "_g_flat", n.flat, n.params) for n in nets]
+        g = buffers(s_a, tr.nets[:3]) + buffers(s_p, tr.nets[3:])
         d_sig = d_sig.contiguous().float()
         d_sigt = d_sigt.contiguous().float()
-        side, main = tr.side_stream(), torch.cuda.current_stream(tr.device)
-        if side is not None:
-            side.wait_stream(main)
-        st_t = st if side is None else C.c_void_p(side.cuda_stream)
+        st_a = st if s_a is None else C.c_void_p(s_a.cuda_stream)
+        st_t = st if s_p is None else C.c_void_p(s_p.cuda_stream)
         check(lib.dfn_encode_signal_torso_bwd(_ptr(p), _ptr(tr.poses), tr.pose_stride, length, frame, smo_t, _ptr(d_sigt),
                                               _ptr(g[3]), st_t), "dfn_encode_signal_torso_bwd")
         check(lib.dfn_encode_signal_bwd(_ptr(a), _ptr(e), _ptr(t), _ptr(tr.auds), _ptr(tr.exps), length, frame, smo,
-                                        _ptr(d_sig), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), st), "dfn_encode_signal_bwd")
-        if side is not None:
-            main.wait_stream(side)
+                                        _ptr(d_sig), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), st_a), "dfn_encode_signal_bwd")
+        if s_a is not None:
+            main.wait_stream(s_a)
+            main.wait_stream(s_p)
         tr.nets[0].deposit(g[0])
         tr.nets[1].deposit(g[1])
         if smo > 0:
@@ -358,18 +465,25 @@ class _SignalFn(torch.autograd.Function):
         return None, None, None, None, None, None
 
 
-def render_train(dec, buf, frame, bg, pix_index, sig_head, sig_torso, z_shape, z_app):
+def render_train(dec, buf, frame, bg, pix_index, sig_head, sig_torso, z_shape, z_app, signal_trainer=None):
     """Differentiable (w.r.t. the decoder parameters and the two signals) coarse two-field render of the
     pixels `pix_index` [n] (int32, y*W+x).  Returns rgb_head, rgb_com [n,3].  Fold and its backward run in HIP, the
     decoder gradients are deposited into .grad by the backward (FusedTrainFn).  One forward per backward: the recorded
-    activations live in `buf` and the next forward overwrites them."""
+    activations live in `buf` and the next forward overwrites them.  signal_trainer: the SignalTrainer whose encode()
+    produced BOTH signals for this call (None otherwise): d(signal) then stays on its streams (FusedTrainFn.backward)."""
     if frame.ray_count != buf.n_rays or (pix_index is not None and pix_index.numel() != buf.n_rays):
         raise ValueError(f"render_train: the buffers were sized for {buf.n_rays} rays, the frame has {frame.ray_count}"
                          f" (pix_index {None if pix_index is None else pix_index.numel()})")
     buf.bind(dec)
     if not sig_head.requires_grad:      # keep the Function in the graph even when no conditioning net trains
         sig_head = sig_head.detach().requires_grad_(True)
-    return FusedTrainFn.apply(sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app)
+    if signal_trainer is not None:
+        # d(signal) may stay on the trainer's streams only if NOTHING sits between its autograd node and this one: any
+        # torch op in between (an index, a reshape) would run its backward on the main stream, ahead of the side streams
+        node = sig_head.grad_fn
+        if node is None or node is not sig_torso.grad_fn or type(node).__name__ != "_SignalFnBackward":
+            signal_trainer = None
+    return FusedTrainFn.apply(sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app, signal_trainer)
 
 
 # ---- the loss ------------------------------------------------------------------------------------------------------------
@@ -390,18 +504,20 @@ class MseLossFn(torch.autograd.Function):
         check(lib.dfn_mse_loss_u8(_ptr(rh), _ptr(rc), _ptr(img_head), _ptr(img_com), _ptr(pix), n, _ptr(losses), _ptr(d_h),
                                   _ptr(d_c), _stream()), "dfn_mse_loss_u8")
         ctx.save_for_backward(d_h, d_c)
-        return losses
+        # two outputs, not one [2] tensor to be indexed by the caller: every index op would add a SelectBackward (a zeros
+        # fill + a copy each, then an add of the two) to the backward - nine 5-us launches between the forward and the dX
+        # chain of a 2-ms step
+        return losses[0], losses[1]
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g_h, g_c):
         d_h, d_c = ctx.saved_tensors
-        return d_h * g[0], d_c * g[1], None, None, None
+        return (None if g_h is None else d_h * g_h), (None if g_c is None else d_c * g_c), None, None, None
 
 
 def mse_losses(rgb_head, rgb_com, img_head, img_com, pix):
     """-> (loss_head, loss_com) 0-dim tensors; img_*: uint8 [H*W,3] device frames, pix: int32 [n]."""
-    out = MseLossFn.apply(rgb_head, rgb_com, img_head, img_com, pix)
-    return out[0], out[1]
+    return MseLossFn.apply(rgb_head, rgb_com, img_head, img_com, pix)
 
 
 # ---- Decoder.forward on explicit points under autograd -------------------------------------------------------------

@@ -143,6 +143,13 @@ int dfn_render_fwd_u8(int tier, const DfnFrame* frame, const void* packed_head, 
 long dfn_train_rows(int field, int what);
 long dfn_packed_bwd_bytes(int tier, int field);
 int dfn_pack_weights_bwd(int tier, int field, const float* params, void* packed_T, void* stream);
+
+/* Everything a training step derives from the parameters before its forward, in one launch: dfn_fold_bias for both fields
+ * (z_shape / z_app: [2][256], row 0 head, row 1 torso) and dfn_pack_weights + dfn_pack_weights_bwd for both fields.  Same
+ * outputs as the six separate calls (which stay, for single-field callers). */
+int dfn_train_prepare(int tier, const float* params, const float* signal_head, const float* signal_torso,
+                      const float* z_shape, const float* z_app, void* packed_head, void* packed_torso, void* packed_T_head,
+                      void* packed_T_torso, float* bias_head, float* bias_torso, void* stream);
 int dfn_train_fwd(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
                   const float* bias_head, const float* bias_torso, const float* bg_f32, const uint8_t* bg_u8,
                   const int32_t* pix_index, float* rgb_head, float* rgb_com, float* samples, void* act_head,
@@ -184,6 +191,15 @@ int dfn_weight_bias_grad(int tier, int field, const void* dy_T, const void* act_
  * z_shape / z_app get no gradient: they are constants upstream (never handed to an optimizer, MAIN:522-547). */
 int dfn_fold_bias_bwd(int tier, int field, const float* params, const float* signal, const float* z_shape,
                       const float* z_app, const float* dbias, float* grad_flat, float* d_signal, void* stream);
+
+/* d_signal (+=, [96] head / [42] torso) of one field straight from the recorded pre-activation gradients: the row sums
+ * of the few dy_T rows whose bias elements fold a signal term (head: fc_in / fc_p_skips, torso: four deformation
+ * vectors; 8 % of dy_T), then the signal part of dfn_fold_bias_bwd.  Same value as dfn_weight_bias_grad +
+ * dfn_fold_bias_bwd produce (up to f32 summation order), but it does not wait for the weight-gradient GEMMs: the
+ * conditioning networks' backward (autograd of MAIN:28-111) can run on a second stream underneath them.
+ * workspace: f32 [dfn_train_rows(field,5)], private to this call (not the dfn_weight_grad workspace). */
+int dfn_signal_grad(int tier, int field, const float* params, const void* dy_T, long NP, float* workspace, float* d_signal,
+                    void* stream);
 
 /* ---- optimizer step: replaces torch.optim.Adam.step() of MAIN:522-547 / 924-931 (betas (0.9, 0.999), no weight
  * decay, no amsgrad) for a list of tensors in ONE launch.  items [n_items] and chunks [n_chunks] live in DEVICE memory;

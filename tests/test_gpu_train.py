@@ -175,6 +175,37 @@ def test_fused_fold_backward_matches_torch_fold(states, scene, latents):
 
 
 @pytest.mark.parametrize("tier", ["f32", "bf16"])
+def test_signal_grad_shortcut_matches_the_fold_backward(states, tier):
+    """dfn_signal_grad (row sums of the dy_T rows behind d(signal) + the signal part of the fold backward, launched right
+    after a field's dX chain) against the route through the weight-gradient pass: dfn_weight_bias_grad -> dfn_fold_bias_bwd.
+    Same quantity, another f32 summation order."""
+    import ctypes as C
+    from dfanerf import training
+    from dfanerf._lib import lib, check
+    dev = torch.device("cuda")
+    dec = _modules(states, dev)["decoder"]
+    buf = training.TrainBuffers(tier, 264, dev)           # 528 tiles: not a multiple of the 128 slices
+    flat = buf.bind(dec)
+    p = lambda x: C.c_void_p(x.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    gen = torch.Generator(device=dev).manual_seed(11)
+    for f, n in ((0, 96), (1, 42)):
+        buf.dy[f].copy_(torch.randn(buf.dy[f].shape, device=dev, generator=gen) * 0.05 + 0.01)
+        buf.act[f].copy_(torch.randn(buf.act[f].shape, device=dev, generator=gen) * 0.1)
+        sig = torch.randn(n, device=dev, generator=gen)
+        z = torch.randn(2, 256, device=dev, generator=gen)
+        g_flat, g_bias = torch.zeros_like(flat), torch.zeros(buf.nb[f], device=dev)
+        ref, got = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        check(lib.dfn_weight_bias_grad(buf.tier, f, p(buf.dy[f]), p(buf.act[f]), buf.NP, p(buf.ws[f]), p(g_flat), p(g_bias),
+                                       st), "dfn_weight_bias_grad")
+        check(lib.dfn_fold_bias_bwd(buf.tier, f, p(flat), p(sig), p(z[0]), p(z[1]), p(g_bias), p(g_flat), p(ref), st),
+              "dfn_fold_bias_bwd")
+        check(lib.dfn_signal_grad(buf.tier, f, p(flat), p(buf.dy[f]), buf.NP, p(buf.ws_sig[f]), p(got), st), "dfn_signal_grad")
+        assert ref.abs().max().item() > 0
+        torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("tier", ["f32", "bf16"])
 def test_training_step_is_bit_reproducible(states, scene, latents, tier):
     """The same training step twice: loss and EVERY gradient bit-identical (the split-K weight gradients are reduced in
     a fixed order, no float atomics), so that data-parallel replicas can be compared bitwise."""
@@ -255,6 +286,69 @@ def test_decoder_forward_under_grad_is_hip_and_matches_autograd(states, scene, l
     with pytest.raises(NotImplementedError):
         dec = _modules(states, dev)["decoder"]
         dec(p, d, zs[:, 0], za[:, 0], [None, None], "head")                   # listener layers are not trainable here
+
+
+def test_stream_schedules_of_the_training_step_agree(states, scene, latents, golden):
+    """The training step's kernels are deterministic, so HOW they are spread over streams must not change a bit: six
+    steps (Adam included) with (a) the overlapped schedule (weight gradients of the head field, d(signal) and the
+    conditioning networks' backward on side streams) and (b) the same plus the cross-step pipeline (adopt_optimizers: the
+    conditioning networks' Adam and the next step's encoder forward on their streams) end in bit-identical parameters - a
+    race between streams would show up here.  The serial schedule (c) computes d(signal) through the weight-gradient pass
+    (another f32 summation order): equal within tolerance."""
+    from dfanerf import nets, run_nerf, training
+    g = golden("g8_train_step")
+    dev = torch.device("cuda")
+    args = run_nerf.config_parser().parse_args(
+        "--expname t --concate_bg --N_rand=256 --sample_rate=0 --smo_size=4 --smo_torse_size 8 --use_et_embed "
+        "--dim_signal=96 --dim_aud=96 --n_object=1 --use_deformation_field --noexp_iters 400000".split())
+    H, W = scene["H"], scene["W"]
+    ds = [{"auds": t(scene["aud"]).to(dev), "exp": t(scene["exp"]).to(dev), "poses": t(scene["poses"]).to(dev),
+           "bc_img": (t(scene["bg"]).float() / 255.0).to(dev), "hwfcxy": [H, W, scene["focal"], scene["cx"], scene["cy"]],
+           "near": 0.3, "far": 0.9}]
+    sel = g["sel_yx"]
+    zs, za = [t(v).to(dev) for v in latents]
+    embed_fn, _ = nets.get_embedder(3, 0)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    tgts = [torch.rand(sel.shape[0], 3, device=dev, generator=gen) for _ in range(6)]
+
+    def run(mode):
+        keep = training._OVERLAP
+        training._OVERLAP = mode != "serial"
+        try:
+            mods = _modules(states, dev)
+            opts = {k: run_nerf.make_adam(m.parameters(), 5e-4) for k, m in mods.items()}
+            buf = training.TrainBuffers("bf16", sel.shape[0], dev)
+            buf.signal_trainer = training.SignalTrainer(mods["AudNet"], mods["ExpNet"], mods["AudAttNet"],
+                                                        mods["PoseAttNet"], ds[0]["auds"], ds[0]["exp"], ds[0]["poses"])
+            if mode == "pipelined":
+                buf.signal_trainer.adopt_optimizers(opts)
+                assert buf.signal_trainer._pipelined and opts["AudNet"].dfn_stream is not None
+            losses = []
+            for k in range(6):
+                loss, *_ = run_nerf.train_step_loss_hip(mods, ds, 0, 2 + k, sel, tgts[k], tgts[k], zs, za, 300000, args,
+                                                        scene["aud"].shape[0], embed_fn, ds[0]["poses"][0], buf)
+                for o in opts.values():
+                    o.zero_grad()
+                loss.backward()
+                run_nerf.optimizer_steps(opts, 300000, args)
+                losses.append(loss.detach())
+            torch.cuda.synchronize()
+            return torch.stack(losses), {f"{tag}/{k}": p.detach().clone() for tag, m in mods.items()
+                                         for k, p in m.named_parameters()}
+        finally:
+            training._OVERLAP = keep
+    la, pa = run("overlapped")
+    lb, pb = run("pipelined")
+    lc, pc = run("serial")
+    assert torch.equal(la, lb)
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
+    torch.testing.assert_close(la, lc, rtol=1e-4, atol=0)
+    moved = 0
+    for k in pa:
+        torch.testing.assert_close(pa[k], pc[k], rtol=0, atol=2e-4, msg=k)       # six Adam steps of 5e-4 each
+        moved += int((pa[k] != t(states[k.split("/")[0]][k.split("/", 1)[1]]).to(dev)).any())
+    assert moved > 20           # the steps did train
 
 
 def test_checkpoint_structure_matches_the_reference_writer(tmp_path, states, scene, latents, golden):
