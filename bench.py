@@ -169,19 +169,37 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
     sampler = frames.PixelSampler(H, W, N_RAND, 0, dev, seed=100 + rank, pipeline=True, stream=buf.signal_trainer.pose_stream())
     gstep = 300000                                   # all five optimizers' gates exercised except ExpNet
 
+    host_t = [0.0] * 5 if os.environ.get("DFN_BENCH_HOST_TIMING") else None      # developer switch: host time by section
+
     def step():
+        c = time.perf_counter
+        t0 = c()
         img_i = int(rng_frame.randint(0, 8))
         pix = sampler.draw()
         loss, *_ = run_nerf.train_step_loss_hip(mods, ds, 0, img_i, pix, gt[img_i][0], gt[img_i][1], zs, za, gstep, a,
                                                 8, embed_fn, ds[0]["poses"][0], buf)
+        t1 = c()
         for o in opts.values():
             o.zero_grad()
+        t2 = c()
         loss.backward()
+        t3 = c()
         if bucket is not None:
             bucket.all_reduce_()
         run_nerf.optimizer_steps(opts, gstep, a)
+        t4 = c()
         run_nerf.update_lrate(opts, gstep, a)
+        if host_t is not None:
+            for k, d in enumerate((t1 - t0, t2 - t1, t3 - t2, t4 - t3, c() - t4)):
+                host_t[k] += d
         return loss
+
+    def host_report(n):
+        if host_t is not None and rank == 0:
+            names = ("draw + forward", "zero_grad", "backward", "optimizers", "lr")
+            print("host ms/step: " + ", ".join(f"{nm} {1e3 * v / n:.3f}" for nm, v in zip(names, host_t)) +
+                  f"  (sum {1e3 * sum(host_t) / n:.3f})", file=sys.stderr)
+            host_t[:] = [0.0] * 5
 
     def timed(n):
         torch.cuda.synchronize()
@@ -204,7 +222,9 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
         return dt
     for _ in range(warmup):
         step()
+    host_report(max(warmup, 1))
     dt = timed(steps)
+    host_report(steps)
     out = None
     sus = None
     if sustain_s > 0 and dt < sustain_s:

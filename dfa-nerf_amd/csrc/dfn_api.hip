@@ -574,6 +574,14 @@ int dfn_bias_grad(int tier, int field, const void* dy_T, long NP, float* workspa
     return DFN_OK;
 }
 
+int dfn_zero_async(void* p, long bytes, void* stream) {
+    if (!p || bytes < 0) return fail(DFN_E_ARG, "dfn_zero_async: bad argument");
+    if (bytes == 0) return DFN_OK;
+    hipError_t err = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "hipMemsetAsync");
+    return DFN_OK;
+}
+
 int dfn_signal_grad(int tier, int field, const float* params, const void* dy_T, long NP, float* workspace, float* d_signal,
                     void* stream) {
     if (!train_tier_ok(tier) || (field != 0 && field != 1) || !params || !dy_T || !workspace || !d_signal || NP <= 0 ||
@@ -601,7 +609,7 @@ int dfn_signal_grad(int tier, int field, const float* params, const void* dy_T, 
     hipError_t err = launch_signal_rows(tier, field, w.sig_rows_dev, w.sig_elems_dev, w.n_sig, dy_T, NP, parts, dbias,
                                         (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "sig_rows_kernel");
-    err = launch_fold_bwd_sig(field, params, dbias, d_signal, (hipStream_t)stream);
+    err = launch_fold_bwd_sig(field, params, dbias, d_signal, true, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "fold_bwd_sig_kernel");
     return DFN_OK;
 }

@@ -14,7 +14,8 @@ hipError_t launch_prepare(PrepareJobs J, hipStream_t st);
 hipError_t launch_pack(const int* plan, const float* params, void* out, long n, int tier, hipStream_t st);
 hipError_t launch_fold_bwd(int field, const float* params, const float* sig, const float* zs, const float* za,
                            const float* dbias, float* grad_flat, float* dsig, int n, hipStream_t st);
-hipError_t launch_fold_bwd_sig(int field, const float* params, const float* dbias, float* dsig, hipStream_t st);
+hipError_t launch_fold_bwd_sig(int field, const float* params, const float* dbias, float* dsig, bool overwrite,
+                               hipStream_t st);
 int sig_term_elements(int field, int* out);      // <= 512 bias-blob elements whose fold carries a signal term
 hipError_t launch_fold(int field, const float* params, const float* sig, const float* zs, const float* za,
                        float* out, int n, hipStream_t st);

@@ -250,7 +250,8 @@ __global__ void fold_bwd_kernel(int field, const float* __restrict__ sig, const 
 // d(signal)[k] = sum over the bias elements whose fold has a W[., c0 + k] * signal[k] term (+ the identity term of
 // the torso's SO vector).  One wave per k, lanes stride over the elements: no atomics, one writer per output.
 struct SigTerm { int base, len, pid, c0; };
-__global__ void fold_bwd_sig_kernel(int field, const float* __restrict__ P, const float* __restrict__ dbias, float* dsig) {
+__global__ void fold_bwd_sig_kernel(int field, const float* __restrict__ P, const float* __restrict__ dbias, float* dsig,
+                                    bool overwrite) {
     using PG = Prog<TIER_BF16>;
     const int k = blockIdx.x, lane = threadIdx.x;
     auto feat_of = [](int e) { return 32 * (e >> 5) + tile_feat((e >> 4) & 1, e & 15); };
@@ -267,20 +268,21 @@ __global__ void fold_bwd_sig_kernel(int field, const float* __restrict__ P, cons
     if (t)      // SO: bias = out_signal.bias + signal  (identity)
         for (int e = lane; e < 64; e += 64) if (feat_of(e) == k) acc += dbias[PG::T_B_SO + e];
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-    if (lane == 0) dsig[k] += acc;
+    if (lane == 0) dsig[k] = overwrite ? acc : dsig[k] + acc;
 }
 hipError_t launch_fold_bwd(int field, const float* params, const float* sig, const float* zs, const float* za,
                            const float* dbias, float* grad_flat, float* dsig, int n, hipStream_t st) {
     hipLaunchKernelGGL(fold_bwd_kernel, dim3((n + 3) / 4), dim3(256), 0, st, field, sig, zs, za, dbias, grad_flat, n);
     if (dsig && field != 2)
         hipLaunchKernelGGL(fold_bwd_sig_kernel, dim3(field == FIELD_TORSO ? NET : NSIG), dim3(64), 0, st, field, params,
-                           dbias, dsig);
+                           dbias, dsig, false);
     return hipGetLastError();
 }
 // d(signal) alone (dfn_signal_grad): dbias needs to hold the elements sig_term_elements() lists, nothing else
-hipError_t launch_fold_bwd_sig(int field, const float* params, const float* dbias, float* dsig, hipStream_t st) {
+hipError_t launch_fold_bwd_sig(int field, const float* params, const float* dbias, float* dsig, bool overwrite,
+                               hipStream_t st) {
     hipLaunchKernelGGL(fold_bwd_sig_kernel, dim3(field == FIELD_TORSO ? NET : NSIG), dim3(64), 0, st, field, params, dbias,
-                       dsig);
+                       dsig, overwrite);
     return hipGetLastError();
 }
 // the bias-blob elements fold_bwd_sig_kernel reads (the vectors whose fold has a signal term), ascending; 512 / 256

@@ -509,15 +509,16 @@ def _hip_signals_ok(args):
 
 
 def optimizer_steps(opts, global_step, args):
-    """Gating of MAIN:924-931."""
-    opts["decoder"].step()
-    opts["AudNet"].step()
+    """Gating of MAIN:924-931.  (HipAdam.step_unhooked = step() without torch's per-call profiler / hook wrapper.)"""
+    step = lambda o: getattr(o, "step_unhooked", o.step)()
+    step(opts["decoder"])
+    step(opts["AudNet"])
     if global_step >= args.nosmo_iters:
-        opts["AudAttNet"].step()
+        step(opts["AudAttNet"])
         if args.use_et_embed and "PoseAttNet" in opts:
-            opts["PoseAttNet"].step()
+            step(opts["PoseAttNet"])
     if global_step >= args.noexp_iters:
-        opts["ExpNet"].step()
+        step(opts["ExpNet"])
 
 
 def update_lrate(opts, global_step, args):

@@ -192,7 +192,7 @@ int dfn_weight_bias_grad(int tier, int field, const void* dy_T, const void* act_
 int dfn_fold_bias_bwd(int tier, int field, const float* params, const float* signal, const float* z_shape,
                       const float* z_app, const float* dbias, float* grad_flat, float* d_signal, void* stream);
 
-/* d_signal (+=, [96] head / [42] torso) of one field straight from the recorded pre-activation gradients: the row sums
+/* d_signal (OVERWRITTEN, [96] head / [42] torso) of one field straight from the recorded pre-activation gradients: the row sums
  * of the few dy_T rows whose bias elements fold a signal term (head: fc_in / fc_p_skips, torso: four deformation
  * vectors; 8 % of dy_T), then the signal part of dfn_fold_bias_bwd.  Same value as dfn_weight_bias_grad +
  * dfn_fold_bias_bwd produce (up to f32 summation order), but it does not wait for the weight-gradient GEMMs: the
@@ -200,6 +200,10 @@ int dfn_fold_bias_bwd(int tier, int field, const float* params, const float* sig
  * workspace: f32 [dfn_train_rows(field,5)], private to this call (not the dfn_weight_grad workspace). */
 int dfn_signal_grad(int tier, int field, const float* params, const void* dy_T, long NP, float* workspace, float* d_signal,
                     void* stream);
+
+/* hipMemsetAsync(p, 0, bytes) on `stream`: lets a host that juggles several streams zero a buffer on a given one without
+ * switching its framework's current stream (torch: a context manager per fill). */
+int dfn_zero_async(void* p, long bytes, void* stream);
 
 /* ---- optimizer step: replaces torch.optim.Adam.step() of MAIN:522-547 / 924-931 (betas (0.9, 0.999), no weight
  * decay, no amsgrad) for a list of tensors in ONE launch.  items [n_items] and chunks [n_chunks] live in DEVICE memory;
