@@ -45,46 +45,128 @@ DFN_DEV void apply_mask(f32x16 (&acc)[2], unsigned bits) {
 #endif
 }
 DFN_DEV unsigned mask_word(const BwdIO& io, int dword, int lane) {
+#ifdef DFN_EXP_CONSTMASK      // timing experiment (wrong results): no mask LOADS (a value the compiler cannot fold)
+    return (unsigned)io.mask_dwords * 0x9E3779B1u + (unsigned)(dword * 64 + lane) * 0x85EBCA6Bu;
+#endif
     const gchar* mb = uniform_ptr(io.masks + ((long)io.pass * io.mask_dwords + dword) * 64);
     return *(const __attribute__((address_space(1))) unsigned*)(mb + (unsigned)lane * 4u);
-}
-
-// out[OT tiles] = (W^T x in) [* mask]; mask_dword0 < 0: no mask
-template <int TIER, int OT, int KU, int NTB, class CT>
-DFN_DEV void bwd_layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, int mask_dword0, const BwdIO& io, int& f,
-                       Fetch<TIER>& fe, Stream& s, const CT& c) {
-#pragma unroll
-    for (int tg = 0; tg < OT / 2; ++tg) {
-        f32x16 acc[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
-        gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c);
-        if (mask_dword0 >= 0) apply_mask(acc, mask_word(io, mask_dword0 + tg, c.lane));
-        acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);
-    }
-}
-// out = (W1^T x in1 + W2^T x in2) [* mask]
-template <int TIER, int OT, int KU1, int NTB1, int KU2, int NTB2, class CT>
-DFN_DEV void bwd_layer2(Vec<TIER, OT>& out, const Vec<TIER, NTB1>& in1, const Vec<TIER, NTB2>& in2,
-                        int mask_dword0, const BwdIO& io, int& f, Fetch<TIER>& fe, Stream& s, const CT& c) {
-#pragma unroll
-    for (int tg = 0; tg < OT / 2; ++tg) {
-        f32x16 acc[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
-        gemm_group<TIER, 2, KU1, NTB1>(acc, in1, f, fe, s, c);
-        gemm_group<TIER, 2, KU2, NTB2>(acc, in2, f, fe, s, c);
-        if (mask_dword0 >= 0) apply_mask(acc, mask_word(io, mask_dword0 + tg, c.lane));
-        acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);
-    }
 }
 
 template <int TIER, int NT, class CT>
 DFN_DEV void put(const BwdIO& io, int row0, const Vec<TIER, NT>& v, const CT& c) {
 #ifndef DFN_NOPUT
+#ifdef DFN_PUT_EIGHTH     // timing experiment (wrong results): one tile in eight is stored - the chain stays alive, 7/8 of the stores go
+    store_tiles_T<TIER, NT>(io.dy_T, io.rows, io.pass, row0, v, 0, 1, c);
+#elif defined(DFN_PUT_SMALL)      // timing experiment (wrong results): every workgroup writes the same 8 tiles - the stores are issued, HBM is not
+    store_vec_T<TIER, NT>(io.dy_T, io.rows, io.pass & 7, row0, v, c);
+#else
     store_vec_T<TIER, NT>(io.dy_T, io.rows, io.pass, row0, v, c);
 #endif
+#endif
 }
+
+// Pin a finished vector where the source computes it.  The torso kernel's skip-path product (fc_p_skips_torso^T x g4) is
+// only consumed ~500 MFMAs later; left free, the scheduler sinks its 64 MFMAs down to that use and keeps their INPUTS alive
+// instead - 64 weight fragments copied from the LDS ring to scratch memory (256 spilled VGPRs).
+template <int TIER, int NT> DFN_DEV void pin_vec(Vec<TIER, NT>& v) {
+    if constexpr (tier_is16(TIER)) {
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) asm volatile("" : "+v"(v.u[i]));
+    }
+}
+
+// DFN_PUT_SPREAD: how the dy_T stores of a layer's INPUT vector (the previous layer's finished output, alive as this
+// layer's B operand anyway) are issued.  0: one burst of 8 NTB store instructions in front of the layer, all eight waves of
+// the workgroup at once.  1: one store per k-step, between the MFMAs of the whole layer (head 225 -> 213 us, torso 255 ->
+// 240 us: interleaved A/B on one box).  2: two per k-step in the first half of every tile pair (no better than 1).
+// What the stores cost was measured with timing experiments (wrong results): with one tile in eight stored the head kernel
+// takes 139 us - the other 75-85 us are the 0.69 GB of stores, which the same pattern reaches 5.6 TB/s on when nothing
+// else runs (tools/l2_atomic_probe.hip) but only ~3.2 TB/s next to the MFMA chain.  NOT the cause (each ablated, +-3 %): the
+// vmcnt wait of the slab hand-over (vmcnt(63)), the ReLU mask loads or their 2.5 VALU per value, the depth of the
+// fragment prefetch (compiler-sunk ds_reads pinned by sched_barrier), the instruction cache (0.3 % misses).
+#ifndef DFN_PUT_SPREAD
+#define DFN_PUT_SPREAD 1
+#endif
+#ifndef DFN_TORSO_G4_SPREAD
+#define DFN_TORSO_G4_SPREAD 1
+#endif
+#ifndef DFN_TORSO_DY0_SPREAD
+#define DFN_TORSO_DY0_SPREAD 1
+#endif
+template <int TIER, int NTB, int KU, class CT> struct PutSide {
+    const BwdIO& io;
+    const Vec<TIER, NTB>& v;
+    int row0, tg;
+    const CT& c;
+    static constexpr int WORDS = 8 * NTB;
+    DFN_DEV void word(int j) const {
+#ifndef DFN_NOPUT
+        if constexpr (TIER == TIER_BF16) {
+            if (j < WORDS) store_word_T<NTB>(io.dy_T, io.rows, io.pass, row0, v, j, c);
+        }
+#endif
+    }
+    DFN_DEV void operator()(int ku) const {
+        if (row0 < 0) return;
+        if (DFN_PUT_SPREAD == 2) {
+            if (ku < KU / 2) { word(tg * KU + 2 * ku); word(tg * KU + 2 * ku + 1); }
+        } else {
+            word(tg * KU + ku);
+        }
+    }
+};
+template <int TIER> constexpr bool put_spread() { return TIER == TIER_BF16 && DFN_PUT_SPREAD != 0; }
+
+// out[OT tiles] = (W^T x in) [* mask]; mask_dword0 < 0: no mask.  put_row >= 0: `in` is written to rows put_row.. of dy_T
+// on the way (PutSide)
+template <int TIER, int OT, int KU, int NTB, class CT>
+DFN_DEV void bwd_layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, int mask_dword0, const BwdIO& io, int& f,
+                       Fetch<TIER>& fe, Stream& s, const CT& c, int put_row = -1) {
+    if constexpr (!put_spread<TIER>()) {
+        if (put_row >= 0) put<TIER, NTB>(io, put_row, in, c);
+        put_row = -1;
+    }
+#pragma unroll
+    for (int tg = 0; tg < OT / 2; ++tg) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+        gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c, NoHook{}, PutSide<TIER, NTB, KU, CT>{io, in, put_row, tg, c});
+        if (mask_dword0 >= 0) apply_mask(acc, mask_word(io, mask_dword0 + tg, c.lane));
+        acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);
+    }
+    if constexpr (put_spread<TIER>()) {      // what the k-steps did not cover (short layers)
+        if (put_row >= 0)
+#pragma unroll
+            for (int j = (OT / 2) * KU; j < 8 * NTB; ++j) PutSide<TIER, NTB, KU, CT>{io, in, put_row, 0, c}.word(j);
+    }
+}
+// out = (W1^T x in1 + W2^T x in2) [* mask]
+template <int TIER, int OT, int KU1, int NTB1, int KU2, int NTB2, class CT>
+DFN_DEV void bwd_layer2(Vec<TIER, OT>& out, const Vec<TIER, NTB1>& in1, const Vec<TIER, NTB2>& in2,
+                        int mask_dword0, const BwdIO& io, int& f, Fetch<TIER>& fe, Stream& s, const CT& c,
+                        int put_row1 = -1) {
+    if constexpr (!put_spread<TIER>()) {
+        if (put_row1 >= 0) put<TIER, NTB1>(io, put_row1, in1, c);
+        put_row1 = -1;
+    }
+#pragma unroll
+    for (int tg = 0; tg < OT / 2; ++tg) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+        gemm_group<TIER, 2, KU1, NTB1>(acc, in1, f, fe, s, c, NoHook{}, PutSide<TIER, NTB1, KU1, CT>{io, in1, put_row1, tg, c});
+        gemm_group<TIER, 2, KU2, NTB2>(acc, in2, f, fe, s, c);
+        if (mask_dword0 >= 0) apply_mask(acc, mask_word(io, mask_dword0 + tg, c.lane));
+        acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);
+    }
+    if constexpr (put_spread<TIER>()) {
+        if (put_row1 >= 0)
+#pragma unroll
+            for (int j = (OT / 2) * KU1; j < 8 * NTB1; ++j) PutSide<TIER, NTB1, KU1, CT>{io, in1, put_row1, 0, c}.word(j);
+    }
+}
+
 
 // ---- backward fragment counts (transposed streams) -----------------------------------------------------------
 template <int TIER> struct BProg {
@@ -111,6 +193,8 @@ DFN_DEV void bwd_trunk(const BwdIn& in, Vec<TIER, 8>& dy0, Vec<TIER, 4>& gpd_ski
                        int m_trunk, int& f, Fetch<TIER>& fe, Stream& s, const CT& c) {
     using B = BProg<TIER>;
     Vec<TIER, 8> cur, nxt;
+    // Every 8-tile gradient vector is written to dy_T by the layer that CONSUMES it (put_row of bwd_layer: its stores go out
+    // between that layer's MFMAs, PutSide), not in a burst behind the layer that produced it.
     // feat_out^T: d(pre-rgb) [3 of a 32-row tile] -> g_h, masked with h > 0
     {
         Vec<TIER, 1> dout;
@@ -118,7 +202,6 @@ DFN_DEV void bwd_trunk(const BwdIn& in, Vec<TIER, 8>& dy0, Vec<TIER, 4>& gpd_ski
         for (int L = 0; L < 16; ++L) dout.set(L, (c.half == 0 && L < 3) ? in.dpre[L < 3 ? L : 0] : 0.f);
         put<TIER, 1>(io, g_trunk + GradMap::T_DYO, dout, c);
         bwd_layer<TIER, 8, B::KU_T, 1>(cur, dout, m_trunk + RecMap::TM_H, io, f, fe, s, c);
-        put<TIER, 8>(io, g_trunk + GradMap::T_DYV, cur, c);
     }
     // [feat_view ; sigma_out]^T -> g_a7, masked with a7 > 0
     {
@@ -126,22 +209,26 @@ DFN_DEV void bwd_trunk(const BwdIn& in, Vec<TIER, 8>& dy0, Vec<TIER, 4>& gpd_ski
 #pragma unroll
         for (int L = 0; L < 16; ++L) dsig.set(L, (c.half == 0 && L == 0) ? in.dsigma : 0.f);
         put<TIER, 1>(io, g_trunk + GradMap::T_DSIG, dsig, c);
-        bwd_layer2<TIER, 8, B::KU_ACT, 8, B::KU_T, 1>(nxt, cur, dsig, m_trunk + RecMap::TM_A5 + 8, io, f, fe, s, c);
-        cur = nxt;
-        put<TIER, 8>(io, g_trunk + GradMap::T_DY5 + 512, cur, c);                  // dy7
+        bwd_layer2<TIER, 8, B::KU_ACT, 8, B::KU_T, 1>(nxt, cur, dsig, m_trunk + RecMap::TM_A5 + 8, io, f, fe, s, c,
+                                                      g_trunk + GradMap::T_DYV);
+        cur = nxt;                                                                  // dy7
     }
     // blocks[6]^T, blocks[5]^T -> dy6, dy5
-    bwd_layer<TIER, 8, B::KU_ACT, 8>(nxt, cur, m_trunk + RecMap::TM_A5 + 4, io, f, fe, s, c);
+    bwd_layer<TIER, 8, B::KU_ACT, 8>(nxt, cur, m_trunk + RecMap::TM_A5 + 4, io, f, fe, s, c, g_trunk + GradMap::T_DY5 + 512);
     cur = nxt;
-    put<TIER, 8>(io, g_trunk + GradMap::T_DY5 + 256, cur, c);
-    bwd_layer<TIER, 8, B::KU_ACT, 8>(nxt, cur, m_trunk + RecMap::TM_A5, io, f, fe, s, c);
+    bwd_layer<TIER, 8, B::KU_ACT, 8>(nxt, cur, m_trunk + RecMap::TM_A5, io, f, fe, s, c, g_trunk + GradMap::T_DY5 + 256);
     cur = nxt;
-    put<TIER, 8>(io, g_trunk + GradMap::T_DY5, cur, c);
     // blocks[4]^T -> g4 = dL/d a4 (post-skip, no activation)
-    bwd_layer<TIER, 8, B::KU_ACT, 8>(nxt, cur, -1, io, f, fe, s, c);
+    bwd_layer<TIER, 8, B::KU_ACT, 8>(nxt, cur, -1, io, f, fe, s, c, g_trunk + GradMap::T_DY5);
     cur = nxt;
-    put<TIER, 8>(io, g_trunk + GradMap::T_G4, cur, c);
+#if DFN_TORSO_G4_SPREAD
+    if constexpr (TORSO) bwd_layer<TIER, 4, B::KU_ACT, 8>(gpd_skip, cur, -1, io, f, fe, s, c, g_trunk + GradMap::T_G4);   // fc_p_skips_torso^T
+    else put<TIER, 8>(io, g_trunk + GradMap::T_G4, cur, c);           // (masked in place next: no consumer layer to ride on)
+#else
+    put<TIER, 8>(io, g_trunk + GradMap::T_G4, cur, c);                // (masked in place below)
     if constexpr (TORSO) bwd_layer<TIER, 4, B::KU_ACT, 8>(gpd_skip, cur, -1, io, f, fe, s, c);   // fc_p_skips_torso^T
+#endif
+    if constexpr (TORSO) pin_vec(gpd_skip);
     // dy4 = g4 * [y4 > 0]
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -150,8 +237,7 @@ DFN_DEV void bwd_trunk(const BwdIn& in, Vec<TIER, 8>& dy0, Vec<TIER, 4>& gpd_ski
         for (int b = 0; b < 32; ++b)
             if (!((bits >> b) & 1u)) cur.set(32 * w + b, 0.f);
     }
-    put<TIER, 8>(io, g_trunk + GradMap::T_DY4, cur, c);
-    // blocks[3..0]^T -> dy3 .. dy0
+    // blocks[3..0]^T -> dy3 .. dy0; layer l writes its input: dy4 (l = 3), then dy3 .. dy1
     if constexpr (TIER == TIER_F32) {
         // f32 tier: a runtime loop whose iterations all restart the fragment index at the same compile-time value - a
         // 256 x 256 layer is a whole number of slabs and of fetch-ring turns, so the slab phase and the ring slot repeat
@@ -163,19 +249,20 @@ DFN_DEV void bwd_trunk(const BwdIn& in, Vec<TIER, 8>& dy0, Vec<TIER, 4>& gpd_ski
 #pragma nounroll
         for (int l = 3; l >= 0; --l) {
             int fl = f0;
-            bwd_layer<TIER, 8, B::KU_ACT, 8>(nxt, cur, m_trunk + RecMap::TM_A0 + 4 * l, io, fl, fe, s, c);
+            bwd_layer<TIER, 8, B::KU_ACT, 8>(nxt, cur, m_trunk + RecMap::TM_A0 + 4 * l, io, fl, fe, s, c,
+                                             g_trunk + (l == 3 ? GradMap::T_DY4 : GradMap::T_DY0 + 256 * (l + 1)));
             cur = nxt;
-            put<TIER, 8>(io, g_trunk + GradMap::T_DY0 + 256 * l, cur, c);
         }
         f = f0 + 4 * LAYER_FRAGS;
     } else {
 #pragma unroll
         for (int l = 3; l >= 0; --l) {
-            bwd_layer<TIER, 8, B::KU_ACT, 8>(nxt, cur, m_trunk + RecMap::TM_A0 + 4 * l, io, f, fe, s, c);
+            bwd_layer<TIER, 8, B::KU_ACT, 8>(nxt, cur, m_trunk + RecMap::TM_A0 + 4 * l, io, f, fe, s, c,
+                                             g_trunk + (l == 3 ? GradMap::T_DY4 : GradMap::T_DY0 + 256 * (l + 1)));
             cur = nxt;
-            put<TIER, 8>(io, g_trunk + GradMap::T_DY0 + 256 * l, cur, c);
         }
     }
+    if constexpr (!TORSO || !DFN_TORSO_DY0_SPREAD) put<TIER, 8>(io, g_trunk + GradMap::T_DY0, cur, c);      // torso: the caller's next layer writes dy0
     dy0 = cur;
 }
 
@@ -200,7 +287,7 @@ DFN_DEV void bwd_torso(const BwdIn& in, const BwdIO& io, Stream& s, const CT& c)
     bwd_trunk<TIER, true>(in, dy0, gsk, io, GradMap::S_TRUNK, RecMap::S_MTRUNK, f, fe, s, c);
     // dL/d pd = fc_in_torso^T x dy0 + (skip path)
     Vec<TIER, 4> gpd;
-    bwd_layer<TIER, 4, B::KU_ACT, 8>(gpd, dy0, -1, io, f, fe, s, c);
+    bwd_layer<TIER, 4, B::KU_ACT, 8>(gpd, dy0, -1, io, f, fe, s, c, DFN_TORSO_DY0_SPREAD ? GradMap::S_TRUNK + GradMap::T_DY0 : -1);
 #pragma unroll
     for (int L = 0; L < 64; ++L) gpd.set(L, gpd.get(L) + gsk.get(L));
     // pd = [out_embed(.) + pe ; out_signal(.) + signal]: the GEMM outputs get g_pd unchanged

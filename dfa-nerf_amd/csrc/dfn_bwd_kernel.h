@@ -20,7 +20,12 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     lds_char* lds = (lds_char*)smem;
-    typedef CtxT<false, false, true> CtxB;      // LDS-DMA as asm: the ReLU mask loads must not drain the dY stores
+#ifndef DFN_BWD_ASMF
+#define DFN_BWD_ASMF 0
+#endif
+    // LDS-DMA as asm: the ReLU mask loads must not drain the dY stores.  DFN_BWD_ASMF: the fragment reads as asm with counted
+    // waits too (16-bit tiers), like the inference kernels
+    typedef CtxT<false, (DFN_BWD_ASMF != 0), true> CtxB;
     const CtxB ctx = {lds, wave, lane, lane >> 5, {}};
     Stream s;
     s.base0 = s.base1 = A.wblob_T;

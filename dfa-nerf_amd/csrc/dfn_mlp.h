@@ -189,7 +189,11 @@ DFN_DEV void slab_advance(Stream& s, lds_char* ring, int wave, int lane) {
 #ifdef DFN_TIMING
     const unsigned long long t0 = __builtin_readcyclecounter();
 #endif
+#ifdef DFN_EXP_VMCNT      // timing experiment (WRONG results: the weight slab may not have landed): what do the stores in the vmcnt queue cost?
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DFN_EXP_VMCNT) : "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::LOADS_PER_SLAB) : "memory");
+#endif
 #ifdef DFN_TIMING
     const unsigned long long t1 = __builtin_readcyclecounter();
 #endif
@@ -296,6 +300,23 @@ DFN_DEV void store_tiles_T(void* arr, int rows, long tile, int row0, const Vec<T
                 __builtin_nontemporal_store((T)v.get(L), (__attribute__((address_space(1))) T*)(ubase + f * 32 * (int)sizeof(T) + voff));
             }
     }
+}
+// ONE store instruction of store_tiles_T (bf16 tier): word j = ((tile * 2 + half-vector) * 4 + e) of v, j < 8 NT.  Lets a
+// caller spread a vector's stores between MFMAs instead of issuing them as one burst (dfn_bwd.h: PutSide).
+template <int NT, class CT>
+DFN_DEV void store_word_T(void* arr, int rows, long tile, int row0, const Vec<TIER_BF16, NT>& v, int j, const CT& c) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    gchar* ubase = uniform_ptr((__bf16*)arr + (tile * rows + row0) * 32);
+    const int odd = c.lane & 1;
+    const unsigned voff = (unsigned)((4 * c.half + odd) * 32 + (c.lane & 31) - odd) * 2u;
+    const unsigned sel = odd ? 0x07060302u : 0x01000504u;
+    const int t = j >> 3, h = (j >> 2) & 1, e = j & 3;
+    const u32x4_ q = __builtin_bit_cast(u32x4_, v.u[2 * t + h]);
+    const int f = 32 * t + tile_feat(0, 8 * h + 2 * e);
+    const unsigned own = q[e];
+    const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);
+    __builtin_nontemporal_store(__builtin_amdgcn_perm(own, nbr, sel),
+                                (__attribute__((address_space(1))) unsigned*)(ubase + f * 64 + voff));
 }
 template <int TIER, int NT, class CT>
 DFN_DEV void store_vec_T(void* arr, int rows, long tile, int row0, const Vec<TIER, NT>& v, const CT& c) {
@@ -453,6 +474,13 @@ DFN_DEV void gemm_group(f32x16 (&acc)[G], const Vec<TIER, NTB>& b, int& f, Fetch
             if constexpr (ASM) {      // refill the slot just consumed (the MFMA has read its operands when it issued)
                 if (TAIL < 0 || left + TAIL >= PF_DEPTH) fe.load(f % PF_DEPTH, f + PF_DEPTH, s, c, hook);
             }
+#ifdef DFN_GEMM_SCHEDBAR
+            // compiler-scheduled fragment reads: pin every (read of fragment f + PF_DEPTH, MFMA of fragment f) pair where the
+            // source puts it.  Left alone, the machine scheduler sinks each ds_read_b128 next to the MFMA that consumes it
+            // (fewer live registers) and the LDS latency of every fragment is exposed: s_waitcnt lgkmcnt(0/1) in front of
+            // every MFMA, matrix pipe 35 % busy in the dX kernels
+            if constexpr (!ASM) __builtin_amdgcn_sched_barrier(DFN_GEMM_SCHEDBAR);
+#endif
             ++f;
         }
         side(ku);

@@ -105,8 +105,9 @@ class HipAdam(torch.optim.Adam):
         """One launch per group and distinct step count.  `self.dfn_stream` (training.SignalTrainer.adopt_optimizers): run
         the step on that stream instead of the current one - the conditioning networks' gradients are produced there early in
         the backward, so their update (and the next step's encoder forward behind it) need not queue behind the decoder's
-        weight-gradient GEMMs.  The current stream is ordered behind the update; with more than one rank the side stream
-        first waits for the current one (the gradient all-reduce runs there)."""
+        weight-gradient GEMMs.  The current stream is ordered behind the update (unless `dfn_join_later`: the stream's owner
+        does that where the parameters are next read); with more than one rank the side stream first waits for the current
+        one (the gradient all-reduce runs there)."""
         s = getattr(self, "dfn_stream", None)
         if s is None:
             return self._step(closure, None)
@@ -114,7 +115,8 @@ class HipAdam(torch.optim.Adam):
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             s.wait_stream(cur)
         out = self._step(closure, s)
-        cur.wait_stream(s)
+        if not getattr(self, "dfn_join_later", False):     # the owner of the stream orders its readers itself
+            cur.wait_stream(s)                             # (SignalTrainer: encode() and join())
         return out
 
     # torch wraps Optimizer.step of every subclass with its profiler / hook machinery (~40 us per call, four optimizers per

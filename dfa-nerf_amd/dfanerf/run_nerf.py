@@ -700,6 +700,10 @@ def train():
             tqdm.write(msg)
             with open(os.path.join(basedir, 'loss.txt'), 'a') as f:
                 f.write(msg + "\n")
+        sig_tr = getattr(train_buf, "signal_trainer", None)
+        if sig_tr is not None and ((i % args.i_test_person == 0 and i > 0) or i in [100, 500, 1000, 3000] or
+                                   i % args.i_weights == 0):
+            sig_tr.join()       # the conditioning networks' Adam runs on their own streams: order this one behind it
         if (i % args.i_test_person == 0 and i > 0) or (i in [100, 500, 1000, 3000]):
             # periodic test (MAIN:943-1077): every 100th validation frame, body pose = training frame 0; files
             # test_head_%03d / test_%03d (numbered by the position in i_val) hold render | ground truth side by side,

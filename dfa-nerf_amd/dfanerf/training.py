@@ -372,8 +372,18 @@ class SignalTrainer:
         for k, s in (("AudNet", s_a), ("ExpNet", s_a), ("AudAttNet", s_a), ("PoseAttNet", s_p)):
             if k in opts and hasattr(opts[k], "_step"):
                 opts[k].dfn_stream = s
+                opts[k].dfn_join_later = True       # encode() / join() order the main stream behind the update
         self._pipelined = True
         self._fresh = True
+
+    def join(self):
+        """Order the current stream behind everything queued on the conditioning networks' streams (their backward, Adam,
+        the next forward).  encode() does it for the training step; call it before anything ELSE reads these networks'
+        parameters or gradients on the current stream (a periodic test render, a checkpoint, gradient clipping)."""
+        cur = torch.cuda.current_stream(self.device)
+        for s in self._streams():
+            if s is not None:
+                cur.wait_stream(s)
 
     def resync(self):
         """the parameters were written on the current stream (load_state_dict, ...): the next encode() waits for it"""

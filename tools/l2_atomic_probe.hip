@@ -74,6 +74,33 @@ __global__ __launch_bounds__(256) void read_kernel(const u32x4* p, long n, unsig
     if (acc == 0x12345678u) *sink = acc;
 }
 
+// streaming write: every lane 16 bytes per store, grid-stride; NT = non-temporal
+template <int NT>
+__global__ __launch_bounds__(256) void write_kernel(u32x4* p, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const u32x4 v = {1u, 2u, 3u, (unsigned)threadIdx.x};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (NT) __builtin_nontemporal_store(v, p + i);
+        else p[i] = v;
+    }
+}
+// the recorder's pattern: a wave owns a contiguous 16 KiB chunk and writes it with 64 dword stores, each covering two
+// full 128-byte lines (lanes 0..31 one line, 32..63 the line 256 bytes further on)
+template <int NT>
+__global__ __launch_bounds__(512) void write_rec_kernel(unsigned* p, long n_chunks) {
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long c = wave; c < n_chunks; c += waves) {
+        unsigned* base = p + c * 4096;
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) {
+            unsigned* a = base + (i >> 1) * 128 + (i & 1) * 32 + (lane >> 5) * 64 + (lane & 31);
+            if (NT) __builtin_nontemporal_store((unsigned)i, a);
+            else *a = (unsigned)i;
+        }
+    }
+}
+
 template <class F> static float time_ms(F f, int n) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -153,6 +180,20 @@ int main() {
         float ms8 = time_ms([&]() { hipLaunchKernelGGL(read_kernel<8>, dim3(grid), dim3(256), 0, 0, big, bytes / 16, sink); }, 5);
         printf("read 3 GiB, %d x 256-thread blocks per CU: 4 loads in flight %.2f TB/s, 8 in flight %.2f TB/s\n", wgs_per_cu,
                bytes / ms4 / 1e9, bytes / ms8 / 1e9);
+    }
+    for (int wgs_per_cu : {1, 2, 4, 8}) {
+        const int grid = 256 * wgs_per_cu;
+        float a = time_ms([&]() { hipLaunchKernelGGL(write_kernel<0>, dim3(grid), dim3(256), 0, 0, big, bytes / 16); }, 5);
+        float b = time_ms([&]() { hipLaunchKernelGGL(write_kernel<1>, dim3(grid), dim3(256), 0, 0, big, bytes / 16); }, 5);
+        printf("write 3 GiB, %d x 256-thread blocks per CU, 16 B per lane: plain %.2f TB/s, non-temporal %.2f TB/s\n", wgs_per_cu,
+               bytes / a / 1e9, bytes / b / 1e9);
+    }
+    for (int wgs_per_cu : {1, 2}) {
+        const int grid = 256 * wgs_per_cu;
+        float a = time_ms([&]() { hipLaunchKernelGGL(write_rec_kernel<0>, dim3(grid), dim3(512), 0, 0, (unsigned*)big, bytes / 16384); }, 5);
+        float b = time_ms([&]() { hipLaunchKernelGGL(write_rec_kernel<1>, dim3(grid), dim3(512), 0, 0, (unsigned*)big, bytes / 16384); }, 5);
+        printf("write 3 GiB in the recorder's pattern (16 KiB chunk per wave, dword stores, two full lines each), %d x 512 threads per CU: plain %.2f TB/s, non-temporal %.2f TB/s\n",
+               wgs_per_cu, bytes / a / 1e9, bytes / b / 1e9);
     }
     return 0;
 }
