@@ -409,6 +409,61 @@ def test_checkpoint_structure_matches_the_reference_writer(tmp_path, states, sce
     assert opts2["decoder"]._cache[0]["buckets"][0]["t"] == 2
 
 
+def test_train_prepare_equals_the_six_calls(states, latents):
+    """dfn_train_prepare (both bias folds + the four packed weight streams in one launch) against dfn_fold_bias x 2,
+    dfn_pack_weights x 2 and dfn_pack_weights_bwd x 2: every output byte identical, both training tiers."""
+    import ctypes as C
+    from dfanerf import training
+    from dfanerf._lib import lib, check
+    dev = torch.device("cuda")
+    dec = _modules(states, dev)["decoder"]
+    zs, za = [t(v).to(dev)[0, :2].contiguous() for v in latents]
+    p = lambda x: C.c_void_p(x.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    gen = torch.Generator(device=dev).manual_seed(2)
+    sh, stt = torch.randn(96, device=dev, generator=gen), torch.randn(42, device=dev, generator=gen)
+    for tier in ("f32", "bf16"):
+        a, b = training.TrainBuffers(tier, 64, dev), training.TrainBuffers(tier, 64, dev)
+        flat = a.bind(dec)
+        for buf in (a, b):
+            buf.bias.fill_(float("nan"))
+            for x in buf.packed + buf.packed_T:
+                x.fill_(0xA5)
+        bt = lambda buf: C.c_void_p(buf.bias.data_ptr() + 4 * buf.nb[0])
+        check(lib.dfn_train_prepare(a.tier, p(flat), p(sh), p(stt), p(zs), p(za), p(a.packed[0]), p(a.packed[1]),
+                                    p(a.packed_T[0]), p(a.packed_T[1]), p(a.bias), bt(a), st), "dfn_train_prepare")
+        check(lib.dfn_fold_bias(b.tier, 0, p(flat), p(sh), p(zs[0]), p(za[0]), p(b.bias), st), "fold")
+        check(lib.dfn_fold_bias(b.tier, 1, p(flat), p(stt), p(zs[1]), p(za[1]), bt(b), st), "fold")
+        for f in (0, 1):
+            check(lib.dfn_pack_weights(b.tier, f, p(flat), p(b.packed[f]), st), "pack")
+            check(lib.dfn_pack_weights_bwd(b.tier, f, p(flat), p(b.packed_T[f]), st), "pack_bwd")
+        assert torch.equal(a.bias.view(torch.int32), b.bias.view(torch.int32)) and not torch.isnan(a.bias).any()
+        for x, y in zip(a.packed + a.packed_T, b.packed + b.packed_T):
+            assert torch.equal(x, y)
+
+
+def test_pipelined_pixel_draws_are_the_plain_draws():
+    """PixelSampler(pipeline=True) - the draw on a side stream into a ring of three buffers - returns, draw for draw, what
+    the plain sampler returns (same seed and counter), also when every draw is consumed by later work on the main stream."""
+    from dfanerf import frames
+    dev = torch.device("cuda")
+    H = W = 450
+    rects = np.array([[100, 120, 150, 160], [10, 10, 40, 40], [300, 0, 100, 449]])
+    for rate, kw in ((0.0, {}), (0.95, {"rects": rects})):
+        plain = frames.PixelSampler(H, W, 2048, rate, dev, seed=9, **kw)
+        piped = frames.PixelSampler(H, W, 2048, rate, dev, seed=9, pipeline=True, **kw)
+        acc = torch.zeros(2048, dtype=torch.int64, device=dev)
+        want = torch.zeros(2048, dtype=torch.int64, device=dev)
+        for k in range(12):
+            fr = {"frame": k % 3} if rate > 0 else {}
+            a, b = plain.draw(**fr), piped.draw(**fr)
+            assert torch.equal(a, b), k
+            want += a.long() * (k + 1)
+            acc += b.long() * (k + 1)                # main-stream consumer of the ring slot
+            big = torch.randn(1 << 22, device=dev).sum()       # keep the main stream busy behind the draw
+        assert torch.equal(acc, want) and torch.isfinite(big)
+
+
 def test_device_pixel_sampler_kernel():
     """dfn_sample_pixels (MAIN:786-820 in one launch): distinct pixels, exact class counts for the face-rect / lower-half
     split (the same counts run_nerf.select_coords gives), the inside pixels first, reproducible from (seed, counter),
