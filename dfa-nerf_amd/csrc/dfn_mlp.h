@@ -667,6 +667,27 @@ DFN_DEV void layer_pipe(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_
     acc_to_vec<TIER, 2, OT, RELU>(acc[(OT / 2 - 1) & 1], out, OT - 2);        // the last pair: not overlapped
 }
 
+// DFN_REC_SPREAD (training recorder, bf16 tier): 1 = the 16 store instructions of tile pair tg - 1 go out one by one between
+// the MFMAs of pair tg (RecSide), like the dX chain's PutSide (dfn_bwd.h); 0 = as one burst at the next slab hand-over.
+#ifndef DFN_REC_SPREAD
+#define DFN_REC_SPREAD 1
+#endif
+template <int TIER, int OT, int KU, class CT> struct RecSide {
+    const CT& c;
+    const Vec<TIER, OT>& out;
+    int rec_row, prev;              // prev: the pair whose values are stored (-1: none)
+    static constexpr int WPS = (16 + KU - 1) / KU;       // words per k-step
+    DFN_DEV void operator()(int ku) const {
+        if constexpr (CT::rec_on && TIER == TIER_BF16) {
+            if (prev < 0 || rec_row < 0) return;
+#pragma unroll
+            for (int w = 0; w < WPS; ++w)
+                if (ku * WPS + w < 16)
+                    store_word_T<OT>(c.rec.act_T, c.rec.rows, c.rec.pass, rec_row, out, 16 * prev + ku * WPS + w, c);
+        }
+    }
+};
+
 // out[OT tiles] = act( bias + W x in ), tile pairs; KU = k-units of `in` used
 template <int TIER, int OT, int KU, int NTB, bool RELU, class CT>
 DFN_DEV void layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_f32* bias, int& f, Fetch<TIER>& fe,
@@ -676,17 +697,22 @@ DFN_DEV void layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_f32* 
         layer_pipe<TIER, OT, KU, NTB, RELU>(out, in, bias, f, fe, s, c);
         return;
     }
+    constexpr bool SPREAD = CT::rec_on && TIER == TIER_BF16 && (DFN_REC_SPREAD != 0);
     bool pend = false;          // the values of pair tg - 1 wait for the next slab hand-over
 #pragma unroll
     for (int tg = 0; tg < OT / 2; ++tg) {
         f32x16 acc[2];
         acc_init<2>(acc, bias + tg * 64, c.half);
-        auto flush = [&] {
-            if (pend) rec_vals<TIER>(c, rec_row + 64 * (tg - 1), out, 2 * (tg - 1));
-            pend = false;
-        };
-        gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c, flush);
-        flush();                // no hand-over inside this group
+        if constexpr (SPREAD) {
+            gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c, NoHook{}, RecSide<TIER, OT, KU, CT>{c, out, rec_row, tg - 1});
+        } else {
+            auto flush = [&] {
+                if (pend) rec_vals<TIER>(c, rec_row + 64 * (tg - 1), out, 2 * (tg - 1));
+                pend = false;
+            };
+            gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c, flush);
+            flush();                // no hand-over inside this group
+        }
         acc_to_vec<TIER, 2, OT, RELU>(acc, out, 2 * tg);
         rec_mask_pair(c, rec_mask < 0 ? -1 : rec_mask + tg, acc);
         pend = CT::rec_on && rec_row >= 0;
