@@ -131,9 +131,22 @@ DFN_DEV void bwd_layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, int mask_dw
         f32x16 acc[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+#ifdef DFN_TIMING
+        const unsigned long long q0 = __builtin_readcyclecounter();      // (s_memtime: scalar memory, costs an lgkmcnt(0) each)
+#endif
         gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c, NoHook{}, PutSide<TIER, NTB, KU, CT>{io, in, put_row, tg, c});
+#ifdef DFN_TIMING
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
+        const unsigned long long q1 = __builtin_readcyclecounter();
+#endif
         if (mask_dword0 >= 0) apply_mask(acc, mask_word(io, mask_dword0 + tg, c.lane));
         acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);
+#ifdef DFN_TIMING
+        asm volatile("" : "+v"(out.u[4 * tg]), "+v"(out.u[4 * tg + 3]));
+        const unsigned long long q2 = __builtin_readcyclecounter();
+        s.t_issue += q1 - q0;        // MFMA phase of the pair (fragment waits included)
+        s.t_epi += q2 - q1;          // mask + convert epilogue
+#endif
     }
     if constexpr (put_spread<TIER>()) {      // what the k-steps did not cover (short layers)
         if (put_row >= 0)

@@ -12,3 +12,11 @@ hipError_t launch_mlp_bwd_bf16(bool torso, const MlpBwdArgs& A, hipStream_t st) 
 }
 
 }  // namespace dfn
+
+#ifdef DFN_TIMING
+// developer build only (tools/time_dx.py): copy the per-wave cycle counters of the last dX launch to the host
+extern "C" int dfn_debug_bwd_timing(unsigned long long* out, long n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(dfn::g_bwd_timing), sizeof(unsigned long long) * (size_t)n, 0,
+                                    hipMemcpyDeviceToHost);
+}
+#endif

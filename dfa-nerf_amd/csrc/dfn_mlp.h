@@ -98,7 +98,7 @@ struct Stream {
     unsigned rd_vaddr;       // per lane: LDS address of this lane's 16 bytes of fragment 0 of the slab being consumed
     int pf_owed;             // pieces of the slab two ahead still to be issued
 #ifdef DFN_TIMING
-    unsigned long long t_wait, t_bar, t_issue;
+    unsigned long long t_wait, t_bar, t_issue, t_epi;
 #endif
 };
 
@@ -314,7 +314,18 @@ DFN_DEV void store_word_T(void* arr, int rows, long tile, int row0, const Vec<TI
     const u32x4_ q = __builtin_bit_cast(u32x4_, v.u[2 * t + h]);
     const int f = 32 * t + tile_feat(0, 8 * h + 2 * e);
     const unsigned own = q[e];
+#ifdef DFN_PUT_KEEP       // timing experiments (wrong results): only tiles [0, DFN_PUT_KEEP) of every vector are stored
+    if (t >= DFN_PUT_KEEP) return;
+#endif
+#ifdef DFN_PUT_RAW        // ... the packed word as it is, no pair swap (2 VALU less per store)
+    __builtin_nontemporal_store(own, (__attribute__((address_space(1))) unsigned*)(ubase + f * 64 + voff));
+    return;
+#endif
     const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);
+#ifdef DFN_PUT_PLAIN      // ... ordinary stores instead of non-temporal ones
+    *(__attribute__((address_space(1))) unsigned*)(ubase + f * 64 + voff) = __builtin_amdgcn_perm(own, nbr, sel);
+    return;
+#endif
     __builtin_nontemporal_store(__builtin_amdgcn_perm(own, nbr, sel),
                                 (__attribute__((address_space(1))) unsigned*)(ubase + f * 64 + voff));
 }

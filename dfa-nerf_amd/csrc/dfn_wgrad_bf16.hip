@@ -26,7 +26,7 @@ constexpr int WL_WAVES = 8, WL_THREADS = 64 * WL_WAVES;
 #ifndef DFN_WL_DEPTH
 #define DFN_WL_DEPTH 4
 #endif
-constexpr int WL_DEPTH = DFN_WL_DEPTH;          // ring depth in steps (a power of two)
+constexpr int WL_DEPTH = DFN_WL_DEPTH;          // ring depth in steps (5 x 32 KiB = the compute unit's whole LDS)
 constexpr int WL_STEP_BYTES = 32 * 1024;        // 16 operand tiles (512 rows x 32 points) per step at most
 constexpr int WL_PIECES = 4;                    // 1 KiB DMA pieces per wave and step at most (32 per step)
 
@@ -71,8 +71,10 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_lds_kernel(const WOp* ops, c
         dst[k] = (unsigned)(((u * ntl + tl) * 2 + hf) * 1024);
     }
     const unsigned lds_base = (unsigned)(unsigned long)lds;
+    unsigned issue_slot = 0;                         // steps are issued in order: slot of the next issue = step % WL_DEPTH
     auto issue = [&](long s) {                       // DMA of step s into slot s % WL_DEPTH
-        const unsigned slot = lds_base + (unsigned)(s & (WL_DEPTH - 1)) * WL_STEP_BYTES;
+        const unsigned slot = lds_base + issue_slot * WL_STEP_BYTES;
+        issue_slot = issue_slot + 1 == WL_DEPTH ? 0u : issue_slot + 1;
         const long tt = t0 + s * tps;
 #pragma unroll
         for (int k = 0; k < WL_PIECES; ++k)
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_lds_kernel(const WOp* ops, c
 #pragma unroll
     for (int s = 0; s < WL_DEPTH - 1; ++s)
         if (s < n_steps) issue(s);
+    unsigned rd_slot = 0;
     for (long s = 0; s < n_steps; ++s) {
         // my pieces of step s have landed (only those of the next WL_DEPTH - 2 steps are younger) and my reads of
         // step s - 1 have returned; after the barrier that holds for every wave, and slot (s - 1) % 4 is refilled
@@ -127,7 +130,8 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_lds_kernel(const WOp* ops, c
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (s + WL_DEPTH - 1 < n_steps) issue(s + WL_DEPTH - 1);
-        const lds_char* slot = lds + (unsigned)(s & (WL_DEPTH - 1)) * WL_STEP_BYTES;
+        const lds_char* slot = lds + rd_slot * WL_STEP_BYTES;
+        rd_slot = rd_slot + 1 == WL_DEPTH ? 0u : rd_slot + 1;
         const long tt = t0 + s * tps;
 #ifdef DFN_WL_NOMFMA          // timing experiment (wrong results): the DMA stream and the barriers alone
         if (tt >= 0) continue;

@@ -101,6 +101,32 @@ __global__ __launch_bounds__(512) void write_rec_kernel(unsigned* p, long n_chun
     }
 }
 
+// Stores next to arithmetic: every wave alternates ~`work` dependent FMAs with stores of one 16-KiB chunk per 64 iterations.
+// MODE 0: no stores; 1: one dword store per iteration (the recorder's pattern); 2: one dwordx4 store every 4th iteration
+// (the same bytes in a quarter of the instructions).  Does the store STREAM hide under the arithmetic, or add to it?
+template <int MODE>
+__global__ __launch_bounds__(512) void mix_kernel(unsigned* p, long n_chunks, int work, float* sink) {
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = ((long)gridDim.x * blockDim.x) >> 6;
+    float a = (float)lane, b = 1.0001f;
+    for (long c = wave; c < n_chunks; c += waves) {
+        unsigned* base = p + c * 4096;
+#pragma unroll 4
+        for (int i = 0; i < 64; ++i) {
+            for (int k = 0; k < work; ++k) a = __builtin_fmaf(a, b, 0.5f);
+            if (MODE == 1) {
+                __builtin_nontemporal_store(__float_as_uint(a), base + (i >> 1) * 128 + (i & 1) * 32 + (lane >> 5) * 64 + (lane & 31));
+            } else if (MODE == 2) {
+                if ((i & 3) == 3) {
+                    const u32x4 v = {__float_as_uint(a), 1u, 2u, 3u};
+                    __builtin_nontemporal_store(v, (u32x4*)(base + (i >> 2) * 256) + lane);
+                }
+            }
+        }
+    }
+    if (a == 12345.678f) *sink = a;
+}
+
 template <class F> static float time_ms(F f, int n) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -194,6 +220,18 @@ int main() {
         float b = time_ms([&]() { hipLaunchKernelGGL(write_rec_kernel<1>, dim3(grid), dim3(512), 0, 0, (unsigned*)big, bytes / 16384); }, 5);
         printf("write 3 GiB in the recorder's pattern (16 KiB chunk per wave, dword stores, two full lines each), %d x 512 threads per CU: plain %.2f TB/s, non-temporal %.2f TB/s\n",
                wgs_per_cu, bytes / a / 1e9, bytes / b / 1e9);
+    }
+    {
+        float* fs;
+        CK(hipMalloc(&fs, 4));
+        const long chunks = (1l << 30) / 16384;            // 1 GiB of stores per launch: 16 chunks per wave at 512 blocks x 8 waves
+        for (int work : {16, 32, 64}) {
+            float t0 = time_ms([&]() { hipLaunchKernelGGL(mix_kernel<0>, dim3(512), dim3(512), 0, 0, (unsigned*)big, chunks, work, fs); }, 5);
+            float t1 = time_ms([&]() { hipLaunchKernelGGL(mix_kernel<1>, dim3(512), dim3(512), 0, 0, (unsigned*)big, chunks, work, fs); }, 5);
+            float t2 = time_ms([&]() { hipLaunchKernelGGL(mix_kernel<2>, dim3(512), dim3(512), 0, 0, (unsigned*)big, chunks, work, fs); }, 5);
+            printf("mix: %2d FMAs per iteration, 1 GiB of stores: arithmetic alone %.1f us, + dword stores %.1f us (%.2f TB/s), + dwordx4 stores %.1f us (%.2f TB/s)\n",
+                   work, t0 * 1e3, t1 * 1e3, 1.0737 / t1, t2 * 1e3, 1.0737 / t2);
+        }
     }
     return 0;
 }
