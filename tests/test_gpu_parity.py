@@ -186,6 +186,30 @@ def test_decoder_f16_tier_vs_reference_golden(eng, packed, golden, latents, fiel
     assert np.sqrt(((sigma - rs) ** 2).mean()) < 0.06
 
 
+@pytest.mark.parametrize("field", [0, 1])
+def test_decoder_f32_large_coordinates_vs_oracle(eng, packed, golden, latents, states, field):
+    """Row A4 at the arguments where it is delicate: the 64 points of golden G3's `p_big` (|p| up to 1.6: the tenth octave's
+    argument 2^9 pi p/2 reaches 1.3e3 rad, where a sin/cos with a sloppy range reduction is off in the third digit).  The
+    kernel's positional encoding is only observable through the decoder, so the f32 tier's (feat, sigma) at those points are
+    compared with the oracle's decoder (whose own encoding equals the reference's `pe_big` bit for bit,
+    tests/test_oracle_golden.py).  A wrong octave anywhere in the 60 columns moves sigma by percents."""
+    g = golden("g3_decoder")
+    zs, za = latents
+    P = O.params_to_torch(states["decoder"])
+    p_big = t(g["p_big"])                                                        # [1,64,3]
+    gen = torch.Generator().manual_seed(17)
+    r = torch.nn.functional.normalize(torch.randn(1, 64, 3, generator=gen), dim=-1)
+    sig = t(g["sig_aud"]) if field == 0 else t(g["sig_torso"])
+    with torch.no_grad():
+        rf, rs = O.decoder_forward(P, p_big, r, t(zs)[:, field], t(za)[:, field], [sig, None] if field == 0 else sig,
+                                   'head' if field == 0 else 'torso')
+    pk = packed["f32"]
+    bias = pk.fold_single(field, sig[0].numpy(), zs[0, field], za[0, field])
+    feat, sigma = eng.decoder_forward(pk, field, bias, p_big[0].cuda(), r[0].cuda())
+    np.testing.assert_allclose(feat.cpu().numpy(), rf[0].numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(sigma.cpu().numpy(), rs[0].numpy(), atol=5e-4, rtol=2e-5)
+
+
 def test_decoder_ragged_sizes(eng, packed, golden, latents):
     g = golden("g3_decoder")
     zs, za = latents
