@@ -1,5 +1,7 @@
 """GPU tests of the HIP training step (forward with recorder, compositing backward, MLP backward on transposed
 streams, weight-gradient GEMMs, bias gradients) against the oracle's autograd and golden G8."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -309,7 +311,8 @@ def test_stream_schedules_of_the_training_step_agree(states, scene, latents, gol
     zs, za = [t(v).to(dev) for v in latents]
     embed_fn, _ = nets.get_embedder(3, 0)
     gen = torch.Generator(device=dev).manual_seed(3)
-    tgts = [torch.rand(sel.shape[0], 3, device=dev, generator=gen) for _ in range(6)]
+    n_steps = int(os.environ.get("DFN_TEST_STEPS", "6"))          # a soak (e.g. 300) is a one-line developer run
+    tgts = [torch.rand(sel.shape[0], 3, device=dev, generator=gen) for _ in range(n_steps)]
 
     def run(mode):
         keep = training._OVERLAP
@@ -324,8 +327,8 @@ def test_stream_schedules_of_the_training_step_agree(states, scene, latents, gol
                 buf.signal_trainer.adopt_optimizers(opts)
                 assert buf.signal_trainer._pipelined and opts["AudNet"].dfn_stream is not None
             losses = []
-            for k in range(6):
-                loss, *_ = run_nerf.train_step_loss_hip(mods, ds, 0, 2 + k, sel, tgts[k], tgts[k], zs, za, 300000, args,
+            for k in range(n_steps):
+                loss, *_ = run_nerf.train_step_loss_hip(mods, ds, 0, 2 + k % 6, sel, tgts[k], tgts[k], zs, za, 300000, args,
                                                         scene["aud"].shape[0], embed_fn, ds[0]["poses"][0], buf)
                 for o in opts.values():
                     o.zero_grad()
@@ -343,6 +346,8 @@ def test_stream_schedules_of_the_training_step_agree(states, scene, latents, gol
     assert torch.equal(la, lb)
     for k in pa:
         assert torch.equal(pa[k], pb[k]), k
+    if n_steps > 6:
+        return                  # the serial schedule's other summation order drifts apart over a long run
     torch.testing.assert_close(la, lc, rtol=1e-4, atol=0)
     moved = 0
     for k in pa:
