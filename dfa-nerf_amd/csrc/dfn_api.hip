@@ -535,9 +535,11 @@ static int weight_grad_impl(int tier, int field, const void* dy_T, const void* a
                            c_parts, W, nullptr, nullptr, nb, st);
     if (err != hipSuccess) return hip_fail(err, "wgrad_kernel");
     if (fuse) {
-        err = launch_reduce_bias(w.rows_dev, b_parts, nb, valid, dbias, st);
-        if (err != hipSuccess) return hip_fail(err, "reduce_bias_kernel");
-    } else if (dbias) {
+        err = launch_reduce_both(w.map_dev, c_parts, W, W, valid, grad_flat, w.rows_dev, b_parts, nb, dbias, st);
+        if (err != hipSuccess) return hip_fail(err, "reduce_both_kernel");
+        return DFN_OK;
+    }
+    if (dbias) {
         err = launch_bias_grad(tier, field, w.eof_dev, w.rows_dev, nb, dy_T, NP, b_parts, dbias, st);
         if (err != hipSuccess) return hip_fail(err, "bias_grad_kernel");
     }

@@ -44,12 +44,25 @@ __device__ float rowdot(const float* P, int pid, int row, int c0, int n, const f
     return a;
 }
 
-// One thread per bias element.  Blob layout = Prog<TIER>::*_B_* offsets; within a vector, element
-// t*32 + h*16 + r is feature 32*t + tile_feat(h, r).  The bias layout does not depend on the tier.
+// One WAVE per bias element (i = wave index, the same for all 64 lanes).  Blob layout = Prog<TIER>::*_B_* offsets; within a
+// vector, element t*32 + h*16 + r is feature 32*t + tile_feat(h, r).  The bias layout does not depend on the tier.
+// An element is a few bias parameters plus up to two dot products of 96 ... 256 terms with a weight row: the lanes stride
+// over the row (coalesced 256-byte reads) and the partial sums are added by a butterfly - a fixed order, so the blob is
+// reproducible.  (One THREAD per element walked its row alone, 64 uncoalesced rows per load instruction: the fold took
+// 10 + 7 us per frame and most of prepare_kernel's 28 us in front of every training forward.)
 __device__ void fold_body(int field, const float* __restrict__ P, const float* __restrict__ sig,
                           const float* __restrict__ zs, const float* __restrict__ za, float* out, int n, int i) {
     using PG = Prog<TIER_BF16>;
     if (i >= n) return;
+    const int lane = threadIdx.x & 63;
+    // lane 0 carries the terms that are not sums over a row; every lane its share of the rows
+    auto pval = [&](const float* P_, int pid, int r, int c) { return lane == 0 ? dfn::pval(P_, pid, r, c) : 0.f; };
+    auto rowdot = [&](const float* P_, int pid, int row, int c0, int nn, const float* vv) {
+        const float* w = P_ + param_offset(pid) + row * param_shape(pid).cols + c0;
+        float a = 0.f;
+        for (int k = lane; k < nn; k += 64) a = fmaf(w[k], vv[k], a);
+        return a;
+    };
     // locate the vector this element belongs to
     int base, f;
     auto feat_of = [](int e) { return 32 * (e >> 5) + tile_feat((e >> 4) & 1, e & 15); };
@@ -102,7 +115,7 @@ __device__ void fold_body(int field, const float* __restrict__ P, const float* _
             case 10: v = pval(P, P_DE4_B, f, 0); break;
             case 11: v = pval(P, P_DS4_B, f, 0); break;
             case 12: v = f < NPE ? pval(P, P_DEO_B, f, 0) : 0.f; break;                         // EO
-            default: v = f < NET ? pval(P, P_DSO_B, f, 0) + sig[f] : 0.f; break;               // SO + signal
+            default: v = f < NET ? pval(P, P_DSO_B, f, 0) + (lane == 0 ? sig[f] : 0.f) : 0.f; break;   // SO + signal
             }
         } else if (i < PG::T_B_L1) {               // IN: fc_in_torso.b + fc_z(z_shape)
             f = feat_of(i - PG::T_B_IN);
@@ -129,11 +142,12 @@ __device__ void fold_body(int field, const float* __restrict__ P, const float* _
             v = f < 3 ? pval(P, P_FEATO_B, f, 0) : 0.f;
         }
     }
-    out[i] = v;
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if (lane == 0) out[i] = v;
 }
 __global__ void fold_kernel(int field, const float* __restrict__ P, const float* __restrict__ sig,
                             const float* __restrict__ zs, const float* __restrict__ za, float* out, int n) {
-    fold_body(field, P, sig, zs, za, out, n, blockIdx.x * blockDim.x + threadIdx.x);
+    fold_body(field, P, sig, zs, za, out, n, (blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 }
 // Everything a training step derives from the parameters before its forward, in ONE launch (dfn_train_prepare): the two
 // fields' bias folds and their four packed weight streams (forward + transposed).  Six launches of 3-10 us each, back to
@@ -152,7 +166,7 @@ __global__ __launch_bounds__(256) void prepare_kernel(PrepareJobs J) {
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
         if (b < J.fold_blocks[f]) {
-            fold_body(f, J.params, J.sig[f], J.zs[f], J.za[f], J.bias[f], J.nb[f], b * 256 + threadIdx.x);
+            fold_body(f, J.params, J.sig[f], J.zs[f], J.za[f], J.bias[f], J.nb[f], b * 4 + (threadIdx.x >> 6));
             return;
         }
         b -= J.fold_blocks[f];
@@ -161,13 +175,13 @@ __global__ __launch_bounds__(256) void prepare_kernel(PrepareJobs J) {
 hipError_t launch_prepare(PrepareJobs J, hipStream_t st) {
     int blocks = 0;
     for (int k = 0; k < 4; ++k) blocks += (J.pack_blocks[k] = (int)((J.n[k] + 255) / 256));
-    for (int f = 0; f < 2; ++f) blocks += (J.fold_blocks[f] = (J.nb[f] + 255) / 256);
+    for (int f = 0; f < 2; ++f) blocks += (J.fold_blocks[f] = (J.nb[f] + 3) / 4);          // a wave per bias element
     hipLaunchKernelGGL(prepare_kernel, dim3(blocks), dim3(256), 0, st, J);
     return hipGetLastError();
 }
 hipError_t launch_fold(int field, const float* params, const float* sig, const float* zs, const float* za,
                        float* out, int n, hipStream_t st) {
-    hipLaunchKernelGGL(fold_kernel, dim3((n + 63) / 64), dim3(64), 0, st, field, params, sig, zs, za, out, n);
+    hipLaunchKernelGGL(fold_kernel, dim3((n + 3) / 4), dim3(256), 0, st, field, params, sig, zs, za, out, n);
     return hipGetLastError();
 }
 

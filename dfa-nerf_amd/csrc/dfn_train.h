@@ -49,6 +49,9 @@ hipError_t launch_wgrad_bf16(int field, const WOp* ops_dev, const int* order_dev
 // grad_flat[map[i]] += sum over the first `slices` slices of parts[.][i]   (i < n; map[i] < 0: structural padding)
 hipError_t launch_reduce_scatter(const int* map, const float* parts, long n, long stride, int slices, float* grad_flat,
                                  hipStream_t st);
+// launch_reduce_bias + launch_reduce_scatter in one launch (same sums, same order)
+hipError_t launch_reduce_both(const int* map, const float* parts, long n, long stride, int slices, float* grad_flat,
+                              const int* rows, const float* bparts, int n_bias, float* dbias, hipStream_t st);
 // dbias[e] = sum over slices of parts[.][e] for the elements that have a gradient row (rows[e] >= 0), 0 otherwise
 hipError_t launch_reduce_bias(const int* rows, const float* parts, int n_bias, int slices, float* dbias, hipStream_t st);
 constexpr int SAMPLE_PIXELS_CANDIDATES = 8192;
