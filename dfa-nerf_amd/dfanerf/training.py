@@ -376,6 +376,11 @@ class SignalTrainer:
         self._pipelined = True
         self._fresh = True
 
+    def _join_later(self):
+        """pipelined (adopt_optimizers) and alone: nobody reads these networks' gradients on the main stream"""
+        import torch.distributed as dist
+        return self._pipelined and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
     def join(self):
         """Order the current stream behind everything queued on the conditioning networks' streams (their backward, Adam,
         the next forward).  encode() does it for the training step; call it before anything ELSE reads these networks'
@@ -484,7 +489,10 @@ class _SignalFn(torch.autograd.Function):
                                               _ptr(g[3]), st_t), "dfn_encode_signal_torso_bwd")
         check(lib.dfn_encode_signal_bwd(_ptr(a), _ptr(e), _ptr(t), _ptr(tr.auds), _ptr(tr.exps), length, frame, smo,
                                         _ptr(d_sig), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), st_a), "dfn_encode_signal_bwd")
-        if s_a is not None:
+        if s_a is not None and not (deferred and tr._join_later()):
+            # order the main stream behind the gradients (whoever reads .grad there: a gradient all-reduce, clipping).
+            # Pipelined on one GPU the readers are the adopted optimizers, on these very streams, and the main stream joins
+            # at the next encode() (or join()): two queue barriers less between the last weight-gradient GEMM and Adam
             main.wait_stream(s_a)
             main.wait_stream(s_p)
         tr.nets[0].deposit(g[0])
@@ -543,6 +551,10 @@ class MseLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_h, g_c):
         d_h, d_c = ctx.saved_tensors
+        if g_h is not None and g_c is not None and g_h.data_ptr() == g_c.data_ptr():
+            # loss = l_head + l_com hands both the same gradient tensor: one multi-tensor launch instead of two
+            out = torch._foreach_mul((d_h, d_c), g_h)
+            return out[0], out[1], None, None, None
         return (None if g_h is None else d_h * g_h), (None if g_c is None else d_c * g_c), None, None, None
 
 
