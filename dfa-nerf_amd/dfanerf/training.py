@@ -1,8 +1,8 @@
 """Training step on the HIP path: torch autograd drives, the HIP kernels compute.
 
-  conditioning signals [96] + [42] --> FusedTrainFn (dfn_fold_bias, dfn_train_fwd | dfn_composite_bwd, dfn_mlp_bwd,
-      (SignalTrainer: HIP too)          dfn_weight_bias_grad, dfn_fold_bias_bwd) --> rgb_head, rgb_com --> MSE losses
-                                                                              (run_nerf_com_trainExpLater.py:902-907)
+  conditioning signals [96] + [42] --> FusedTrainFn (dfn_train_prepare, dfn_train_fwd | dfn_composite_bwd, dfn_mlp_bwd,
+      (SignalTrainer: HIP too)          dfn_signal_grad, dfn_weight_bias_grad, dfn_fold_bias_bwd) --> rgb_head, rgb_com
+                                        --> MSE losses (MseLossFn; run_nerf_com_trainExpLater.py:902-907)
 
 The decoder's forward AND backward run in the fused HIP kernels, including the bias fold and its backward; the
 decoder's gradients are deposited into the parameters' .grad as slices of one flat buffer, and autograd only carries
@@ -127,11 +127,12 @@ class TrainBuffers:
 
 
 class FusedTrainFn(torch.autograd.Function):
-    """(sig_head [96], sig_torso [42]) -> rgb_head, rgb_com [n,3]: fold + fused forward in HIP; the backward runs
-    dfn_composite_bwd, dfn_mlp_bwd, dfn_weight_grad, dfn_bias_grad and dfn_fold_bias_bwd, returns the gradients of
-    the two signals to autograd (-> conditioning networks) and DEPOSITS the decoder gradients straight into the
-    parameters' .grad as slices of one flat buffer (side effect of backward(), like a DDP hook: ~10 launches instead
-    of the ~600 of the torch fold + cat/split autograd)."""
+    """(sig_head [96], sig_torso [42]) -> rgb_head, rgb_com [n,3]: dfn_train_prepare (folds + weight streams) and the fused
+    forward in HIP; the backward runs dfn_composite_bwd, per field dfn_mlp_bwd, dfn_signal_grad, dfn_weight_bias_grad and
+    dfn_fold_bias_bwd (spread over up to four streams, see backward()), returns the gradients of the two signals to autograd
+    (-> conditioning networks) and DEPOSITS the decoder gradients straight into the parameters' .grad as slices of one
+    flat buffer (side effect of backward(), like a DDP hook: ~12 launches instead of the ~600 of the torch fold +
+    cat/split autograd)."""
 
     @staticmethod
     def forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app, defer=None):
