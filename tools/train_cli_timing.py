@@ -61,8 +61,8 @@ flags = ("--config dataset/obama/HeadNeRF_config_ba.txt --last_dist=1e10 --datad
          "--resume dataset/train_together/obama_TrainExpLater_smoMix/300000.tar").split()
 script = os.path.join(ROOT, "NeRFs", "DFANeRF", "run_nerf_com_trainExpLater.py")
 res = {}
-for n in (100, 100 + steps):                       # two run lengths: the difference is `steps` steady-state steps
-    t0 = time.perf_counter()
+for n in (100, 100, 100 + steps):                  # a discarded warm-up run (file cache, code objects), then two run lengths:
+    t0 = time.perf_counter()                       # their difference is `steps` steady-state steps
     r = subprocess.run([sys.executable, script] + flags + [f"--N_iters={300000 + n}"], cwd=root, capture_output=True, text=True)
     res[n] = time.perf_counter() - t0
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
