@@ -75,6 +75,14 @@ def test_error_paths_without_gpu():
     assert L.dfn_adam_multi(one, one, 4, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0.03, N) == -1                      # t = 0: bias_c1 = 0
     assert L.dfn_adam_multi(N, N, 0, 1e-3, 0.9, 0.999, 1e-8, 0.1, 0.03, N) == 0                           # nothing to do
     assert L.dfn_sample_pdf(one, one, 4, 300, 8, N, one, N) == -1                                         # nb <= 256
+    # the entry points of the training step's schedule (round 2)
+    assert L.dfn_signal_grad(1, 0, one, one, 48, one, one, N) == -1 and b"multiple of 32" in L.dfn_last_error()
+    assert L.dfn_signal_grad(1, 2, one, one, 64, one, one, N) == -1 and L.dfn_signal_grad(2, 0, one, one, 64, one, one, N) == -1
+    assert L.dfn_signal_grad(1, 0, one, one, 64, N, one, N) == -1                                         # no workspace
+    assert L.dfn_train_prepare(1, one, one, N, one, one, one, one, one, one, one, one, N) == -1            # torso signal missing
+    assert L.dfn_train_prepare(2, one, one, one, one, one, one, one, one, one, one, one, N) == -1          # f16: inference only
+    assert L.dfn_zero_async(N, 16, N) == -1 and L.dfn_zero_async(one, -1, N) == -1 and L.dfn_zero_async(one, 0, N) == 0
+    assert L.dfn_train_rows(0, 5) == 128 * 512 + L.dfn_bias_floats(1, 0) and L.dfn_train_rows(1, 5) > 0
 
 
 class Reader:
