@@ -191,9 +191,17 @@ class FusedTrainFn(torch.autograd.Function):
                 buf._sig_streams = (_side_stream(dev, True), _side_stream(dev, True))
             tr = ctx.defer
             s_a, s_p = (tr.audio_stream(), tr.pose_stream()) if tr is not None else buf._sig_streams
-            # dfn_signal_grad overwrites its half (every consumer is ordered in front of this stream's later work:
-            # _SignalFn.backward / the waits below)
-            d_sig = torch.empty(96 + 42, dtype=torch.float32, device=dev)
+            # dfn_signal_grad overwrites its half.  Deferred to a SignalTrainer the buffer is the trainer's own: its readers
+            # run on the trainer's streams and - pipelined - nothing orders the main stream behind them before the next
+            # encode(), so a buffer from the caching allocator would be handed out again (to the next step's pixel upload,
+            # say) while the encoder backward still reads it.  Otherwise a fresh one (autograd may keep it as a .grad); the
+            # waits below order the main stream behind its writers.
+            if tr is not None:
+                if getattr(tr, "_d_sig", None) is None:
+                    tr._d_sig = torch.empty(96 + 42, dtype=torch.float32, device=dev)
+                d_sig = tr._d_sig
+            else:
+                d_sig = torch.empty(96 + 42, dtype=torch.float32, device=dev)
         else:
             d_sig = torch.zeros(96 + 42, dtype=torch.float32, device=dev)
         def dx(f, stream):
@@ -377,11 +385,6 @@ class SignalTrainer:
         self._pipelined = True
         self._fresh = True
 
-    def _join_later(self):
-        """pipelined (adopt_optimizers) and alone: nobody reads these networks' gradients on the main stream"""
-        import torch.distributed as dist
-        return self._pipelined and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-
     def join(self):
         """Order the current stream behind everything queued on the conditioning networks' streams (their backward, Adam,
         the next forward).  encode() does it for the training step; call it before anything ELSE reads these networks'
@@ -490,10 +493,11 @@ class _SignalFn(torch.autograd.Function):
                                               _ptr(g[3]), st_t), "dfn_encode_signal_torso_bwd")
         check(lib.dfn_encode_signal_bwd(_ptr(a), _ptr(e), _ptr(t), _ptr(tr.auds), _ptr(tr.exps), length, frame, smo,
                                         _ptr(d_sig), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), st_a), "dfn_encode_signal_bwd")
-        if s_a is not None and not (deferred and tr._join_later()):
-            # order the main stream behind the gradients (whoever reads .grad there: a gradient all-reduce, clipping).
-            # Pipelined on one GPU the readers are the adopted optimizers, on these very streams, and the main stream joins
-            # at the next encode() (or join()): two queue barriers less between the last weight-gradient GEMM and Adam
+        if s_a is not None:
+            # Order the main stream behind these chains - ALWAYS: dfn_signal_grad's fold backward reads the DECODER's
+            # parameters on these streams, and the decoder's Adam (main stream) must not overtake it.  (Leaving the join to
+            # the next encode() saved two queue barriers and was a race: with 256 rays the main stream reaches Adam before
+            # the starved side kernels have run; the 3000-step bitwise soak of tests/test_gpu_train.py caught it.)
             main.wait_stream(s_a)
             main.wait_stream(s_p)
         tr.nets[0].deposit(g[0])
