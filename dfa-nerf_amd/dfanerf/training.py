@@ -203,7 +203,7 @@ class FusedTrainFn(torch.autograd.Function):
             else:
                 d_sig = torch.empty(96 + 42, dtype=torch.float32, device=dev)
         else:
-            d_sig = torch.zeros(96 + 42, dtype=torch.float32, device=dev)
+            d_sig = torch.empty(96 + 42, dtype=torch.float32, device=dev)
         def dx(f, stream):
             check(lib.dfn_mlp_bwd(buf.tier, f, _ptr(buf.packed_T[f]), _ptr(buf.samples), _ptr(buf.dsamples),
                                   _ptr(buf.masks[f]), buf.NP, _ptr(buf.dy[f]), stream), "dfn_mlp_bwd")
@@ -249,9 +249,12 @@ class FusedTrainFn(torch.autograd.Function):
             else:
                 tr._deferred = True
         else:
+            # one stream, the SAME kernels in the same order per buffer (d(signal) through dfn_signal_grad here too): bit for
+            # bit what the overlapped schedule computes - the reference the stream-schedule test holds it against
             for f in (0, 1):
                 dx(f, st)
-                dw(f, st, g_flat, True)
+                dsig(f, st)
+                dw(f, st, g_flat, False)
         buf.net.deposit(g_flat, touched=_decoder_touched(buf.net, (0, 1)))
         return (d_sig[:96].reshape(ctx.sig_shapes[0]), d_sig[96:].reshape(ctx.sig_shapes[1]), None, None, None, None,
                 None, None, None)
