@@ -166,7 +166,9 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
     g8 = torch.Generator(device=dev).manual_seed(7)
     gt = [(torch.randint(0, 256, (H * W, 3), dtype=torch.uint8, device=dev, generator=g8),
            torch.randint(0, 256, (H * W, 3), dtype=torch.uint8, device=dev, generator=g8)) for _ in range(8)]
-    sampler = frames.PixelSampler(H, W, N_RAND, 0, dev, seed=100 + rank, pipeline=True, stream=buf.signal_trainer.pose_stream())
+    # (DFN_BENCH_FIFTH_STREAM: developer switch - the pixel draw on a stream of its own, i.e. five streams on four hardware queues)
+    sampler = frames.PixelSampler(H, W, N_RAND, 0, dev, seed=100 + rank, pipeline=True,
+                                  stream=None if os.environ.get("DFN_BENCH_FIFTH_STREAM") else buf.signal_trainer.pose_stream())
     gstep = 300000                                   # all five optimizers' gates exercised except ExpNet
 
     host_t = [0.0] * 5 if os.environ.get("DFN_BENCH_HOST_TIMING") else None      # developer switch: host time by section
