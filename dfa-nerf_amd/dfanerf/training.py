@@ -30,6 +30,11 @@ _WGRAD_SIDE = os.environ.get("DFN_TRAIN_WGRAD_SIDE", "1") == "1"
 _SIG_PRIO = os.environ.get("DFN_TRAIN_SIG_PRIO", "1") == "1"
 
 
+def _multi_rank():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 def _side_stream(device, high=False):
     return torch.cuda.Stream(device=device, priority=-1 if (high and _SIG_PRIO) else 0)
 
@@ -179,7 +184,10 @@ class FusedTrainFn(torch.autograd.Function):
                                     _ptr(d_h), _ptr(d_c), _ptr(buf.dsamples), st), "dfn_composite_bwd")
         g_bias = torch.empty(buf.nb[0] + buf.nb[1], dtype=torch.float32, device=dev)
         main = torch.cuda.current_stream(dev)
-        over = _OVERLAP and _WGRAD_SIDE
+        # (with more than one rank RCCL brings its own stream: the head field's weight gradients stay on the main stream then,
+        # so that the process still runs on four streams - a fifth shares a hardware queue with another one and serialises
+        # with it: 1.77 -> 2.39 ms per step)
+        over = _OVERLAP and _WGRAD_SIDE and not _multi_rank()
         if over and getattr(buf, "_side", None) is None:
             buf._side = _side_stream(dev)
         side = buf._side if over else None
