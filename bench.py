@@ -322,7 +322,7 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
             e1.record()
             ev.append((e0, e1))
         if world > 1:
-            dist.all_gather_into_tensor(gathered, shard)
+            dist.all_gather_into_tensor(gathered.view(world * n_img, per, 3), shard)     # concatenation form: every backend
             return gathered
         return shard
 
@@ -424,11 +424,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     rccl_ranks = 1
+    # DFN_BENCH_ONE_GPU=1 (developer switch): every rank on GPU 0 over the gloo backend - a FUNCTIONAL run of the multi-rank
+    # code (ray shards, the per-frame gather, the gradient bucket, the optimizers' stream rules) on a box with one GPU;
+    # RCCL refuses two ranks on one device.  Its timings mean nothing.
+    one_gpu = bool(os.environ.get("DFN_BENCH_ONE_GPU"))
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)                        # the ranks RCCL actually connected
         rccl_ranks = int(ones.item())

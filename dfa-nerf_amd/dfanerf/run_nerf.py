@@ -291,7 +291,9 @@ class FrameRenderer:
             out = (self._shard[0, :count], self._shard[1, :count] if fields == 2 else None)
             if count:
                 self.render(pose, pose_body, signal, signal_torso, begin, count, fields=fields, out_u8=out_u8, out=out)
-            dist.all_gather_into_tensor(self._gathered, self._shard)
+            # the output as the CONCATENATION of the shards along dim 0 (the stacked [world, ...] form is an NCCL / RCCL
+            # extension that gloo rejects)
+            dist.all_gather_into_tensor(self._gathered.view(world * n_img, per, 3), self._shard)
             g = self._gathered.permute(1, 0, 2, 3).reshape(n_img, world * per, 3)[:, :R]
             rh, rc = g[0], (g[1] if fields == 2 else None)
         else:

@@ -1,0 +1,99 @@
+"""Worker of tests/test_gpu_multirank.py: launched twice by torch.distributed.run, BOTH ranks on GPU 0 over the gloo backend
+(RCCL refuses two ranks on one device), so that the product's multi-rank code paths run on hardware on a one-GPU box:
+FrameRenderer.render_image (ray shards + ONE gather per frame) and the data-parallel training step (FlatGradBucket all-reduce,
+replica broadcast, the optimizers' stream rules with more than one rank).  Prints one line 'MULTIRANK_OK ...' from rank 0."""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "dfa-nerf_amd"))
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from dfanerf import frames, nets, parallel, run_nerf, synth, training
+from dfanerf.decoder import Decoder
+
+
+def t(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo")
+    st, sc = synth.synth_all_states(0), synth.bench_scene(0, n_frames=4)
+    zs, za = [t(v).to(dev) for v in synth.synth_latents(0)]
+    H, W = sc["H"], sc["W"]
+    args = run_nerf.config_parser().parse_args(
+        "--expname t --concate_bg --N_rand=512 --sample_rate=0 --smo_size=4 --smo_torse_size 8 --use_et_embed "
+        "--dim_signal=96 --dim_aud=96 --n_object=1 --use_deformation_field --noexp_iters 400000 --hip_tier f16 "
+        "--hierarchical --N_importance 128".split())
+
+    def modules(seed_shift):
+        mods = {"decoder": Decoder(z_dim=256, hidden_size=256, dim_signal=96, use_deformation_field=True),
+                "AudNet": nets.AudioNet_W2L(), "ExpNet": nets.ExpressionEnc(), "AudAttNet": nets.AudioAttNet(96, 4),
+                "PoseAttNet": nets.AudioAttNet(42, 8)}
+        for k, m in mods.items():
+            m.load_state_dict({kk: t(v) + (1e-3 * seed_shift if v.dtype.kind == "f" else 0) for kk, v in st[k].items()})
+            m.to(dev)
+        return mods
+
+    # ---- inference: every rank renders its ray shard, one gather per frame; against the whole frame rendered alone --------
+    mods = modules(0)
+    bg = (t(sc["bg"]).float() / 255.0).to(dev)
+    R = run_nerf.FrameRenderer(mods["decoder"], zs, za, bg, [H, W, sc["focal"], sc["cx"], sc["cy"]], sc["near"], sc["far"], args)
+    sig = [torch.randn(1, 96, device=dev, generator=torch.Generator(device=dev).manual_seed(1)) * 0.1, None]
+    sigt = torch.randn(42, device=dev, generator=torch.Generator(device=dev).manual_seed(2)) * 0.1
+    pose, pose_body = sc["poses"][1], sc["pose_body"]
+    ok_img = True
+    for out_u8 in (False, True):
+        rh, rc = R.render_image(pose, pose_body, sig, sigt, fields=2, out_u8=out_u8)          # sharded + gathered
+        fh, fc = R.render(pose, pose_body, sig, sigt, fields=2, out_u8=out_u8)                # this rank alone, all rays
+        ok_img &= bool(torch.equal(rh.reshape(-1, 3), fh.reshape(-1, 3)) and torch.equal(rc.reshape(-1, 3), fc.reshape(-1, 3)))
+
+    # ---- training: replicas that start DIFFERENT, broadcast, three data-parallel steps on different frames ---------------
+    mods = modules(rank)                                   # rank 1 starts from other values
+    opts = {k: run_nerf.make_adam(m.parameters(), 5e-4) for k, m in mods.items()}
+    parallel.broadcast_replicas(mods, opts)
+    ds = [{"auds": t(sc["aud"]).to(dev), "exp": t(sc["exp"]).to(dev), "poses": t(sc["poses"]).to(dev), "bc_img": bg,
+           "hwfcxy": [H, W, sc["focal"], sc["cx"], sc["cy"]], "near": sc["near"], "far": sc["far"]}]
+    buf = training.TrainBuffers("bf16", 512, dev)
+    buf.signal_trainer = training.SignalTrainer(mods["AudNet"], mods["ExpNet"], mods["AudAttNet"], mods["PoseAttNet"],
+                                                ds[0]["auds"], ds[0]["exp"], ds[0]["poses"])
+    buf.signal_trainer.adopt_optimizers(opts)
+    bucket = parallel.FlatGradBucket(list(mods.values()))
+    sampler = frames.PixelSampler(H, W, 512, 0, dev, seed=50 + rank, pipeline=True, stream=buf.signal_trainer.pose_stream())
+    gen = torch.Generator(device=dev).manual_seed(9 + rank)
+    gt = (torch.randint(0, 256, (H * W, 3), dtype=torch.uint8, device=dev, generator=gen),
+          torch.randint(0, 256, (H * W, 3), dtype=torch.uint8, device=dev, generator=gen))
+    embed_fn, _ = nets.get_embedder(3, 0)
+    assert training._multi_rank()
+    losses = []
+    for k in range(3):
+        loss, *_ = run_nerf.train_step_loss_hip(mods, ds, 0, (k + rank) % 4, sampler.draw(), gt[0], gt[1], zs, za, 300000,
+                                                args, 4, embed_fn, ds[0]["poses"][0], buf)
+        for o in opts.values():
+            o.zero_grad()
+        loss.backward()
+        bucket.all_reduce_()
+        run_nerf.optimizer_steps(opts, 300000, args)
+        losses.append(float(loss))
+    buf.signal_trainer.join()
+    torch.cuda.synchronize()
+    flat = torch.cat([p.detach().reshape(-1) for m in mods.values() for p in m.parameters()])
+    both = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    same = bool(torch.equal(both[0], both[1]))
+    moved = bool((flat != torch.cat([t(v).reshape(-1).to(dev) for k in mods for v in
+                                     [st[k][n] for n, _ in mods[k].named_parameters()]])).any())
+    if rank == 0:
+        print(f"MULTIRANK_OK image={ok_img} replicas_identical={same} trained={moved} finite={all(np.isfinite(losses))}")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
