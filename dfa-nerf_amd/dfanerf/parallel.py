@@ -21,6 +21,11 @@ def env_world():
 def init(backend=None):
     """Initialise the default process group from the torchrun environment; no-op for a single process."""
     world, rank, local = env_world()
+    # DFN_ONE_GPU=1 (developer / test switch): every rank on GPU 0 over gloo - a functional run of the multi-rank paths on a
+    # one-GPU box (RCCL refuses two ranks on one device)
+    if os.environ.get("DFN_ONE_GPU") and torch.cuda.is_available():
+        local, backend = 0, backend or "gloo"
+        torch.cuda.set_device(0)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:

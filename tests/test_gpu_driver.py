@@ -77,6 +77,16 @@ def _run(root, extra):
     return r.stdout
 
 
+def _run2(root, extra, port):
+    """the same CLI as two ranks (torch.distributed.run), both on GPU 0 over gloo (DFN_ONE_GPU)"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "NeRFs", "DFANeRF", "run_nerf_com_trainExpLater.py")] + \
+        (COMMON + " " + extra).split()
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900, env=dict(os.environ, DFN_ONE_GPU="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
 def _oracle_frame_u8(root, sc, states, latents, k):
     """val frame k of the dataset through the oracle's frame loop -> uint8 (head, com) images"""
     from PIL import Image
@@ -166,3 +176,28 @@ def test_training_cli_writes_reference_checkpoint(dataset):
     assert np.asarray(Image.open(tdir / "test_000.png")).shape == (H, 2 * W, 3)
     log = open(base / "loss.txt").read().strip().split("\n")
     assert log[-1].startswith("[TEST] Iter: 280002 Object: 0_person PSNR: ")
+
+
+def test_cli_with_two_ranks_on_one_gpu(dataset):
+    """torchrun --nproc-per-node 2 of the drop-in CLI (both ranks on GPU 0 over gloo): --render_person writes byte-identical
+    PNG frames to the single-process run (ray shards + one gather per frame), and a short data-parallel training run
+    (replica broadcast, per-rank frames and pixels, gradient bucket, gated optimizers) writes its checkpoint."""
+    from PIL import Image
+    root, sc = dataset
+    out = root / "dataset" / "train_together" / "obama_TrainExpLater_smoMix" / "obama" / "person"
+    _run(root, "--render_person --test_file transforms_val_ba.json --N_rand=2048 --N_iters=600000 --image_ext png")
+    one = {sub: [np.asarray(Image.open(out / sub / f"test_{k:06d}.png")).copy() for k in range(F_VAL)]
+           for sub in ("render_com", "render_head")}
+    for sub in one:
+        for f in os.listdir(out / sub):
+            os.remove(out / sub / f)
+    _run2(root, "--render_person --test_file transforms_val_ba.json --N_rand=2048 --N_iters=600000 --image_ext png", 29561)
+    for sub in one:
+        assert sorted(os.listdir(out / sub)) == [f"test_{k:06d}.png" for k in range(F_VAL)]
+        for k in range(F_VAL):
+            assert np.array_equal(np.asarray(Image.open(out / sub / f"test_{k:06d}.png")), one[sub][k]), (sub, k)
+    log = _run2(root, "--N_rand=256 --N_iters=280006 --i_weights=3 --hip_tier bf16", 29563)
+    ck = root / "dataset" / "train_together" / "obama_TrainExpLater_smoMix"
+    assert (ck / "280005.tar").exists(), log[-1500:]          # i_weights=3: saved at loop indices 280002, 280005
+    lines = [ln for ln in open(ck / "loss.txt").read().split("\n") if ln.startswith("[TRAIN] Iter: 280006")]
+    assert lines and np.isfinite(float(lines[-1].split("Com Loss: ")[1].split()[0]))
