@@ -38,3 +38,13 @@ def states():
 def latents():
     from dfanerf import synth
     return synth.synth_latents(0)
+
+
+def free_port():
+    """a TCP port nobody listens on right now (torch.distributed rendezvous of the multi-process tests)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port

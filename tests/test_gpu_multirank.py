@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def test_two_ranks_on_one_gpu_render_and_train():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    for port in (29531, 29547):                  # one retry on another port
+    from conftest import free_port
+    for port in (free_port(), free_port()):      # one retry: a free port can be taken between the probe and the rendezvous
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                             "--master-addr", "127.0.0.1", "--master-port", str(port),
                             os.path.join(HERE, "multirank_worker.py")], env=env, capture_output=True, text=True, timeout=600)
