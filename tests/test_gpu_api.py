@@ -179,7 +179,7 @@ def test_rccl_backend_world1_collectives(scene, states, latents, golden):
         fr = engine.make_frame(H, W, scene["focal"], scene["cx"], scene["cy"], scene["poses"][2], scene["pose_body"],
                                scene["near"], scene["far"], ray_begin=begin, ray_count=count, n_fine=0, fields=1)
         engine.render_u8(pk, bias, fr, bg8, out_head=shard[0, :count])
-        dist.all_gather_into_tensor(gathered, shard)
+        dist.all_gather_into_tensor(gathered.view(1 * 1, per, 3), shard)        # the concatenation form, as the product passes it
         assert torch.equal(gathered[0], shard) and int(gathered.sum()) > 0
         bucket = torch.arange(1138656, dtype=torch.float32, device=dev)      # the flat gradient bucket's size
         ref = bucket.clone()
