@@ -25,7 +25,16 @@ Prints ONE JSON line on rank 0 (fields: see the driver contract), including
                  sample of the same workload on this host's cores, at the best of a sweep over thread counts
                  (rank 0, N == 1 only);
   other_workloads - (N == 1) short runs of the other BASELINE configs in the same process: c3 (two-field render), c1
-                 (coarse), c4 (training step), so that they are driver-timed numbers too.
+                 (coarse), c2_f32 (the exact tier: the one that meets "within 1e-4 PSNR"), c4 / c4h (training step, coarse and
+                 hierarchical), so that they are driver-timed numbers too;
+  parity_check - (N == 1) after the timed loops, 64 rays of the LAST timed frame rendered again in the timed configuration
+                 and compared with the CPU oracle (outside the timed region): binds the timed launch to the parity suite.
+
+`python bench.py --gpus N` (N > 1) without a torchrun environment launches its own N ranks (torch.distributed.run on
+127.0.0.1, a probed free port) - the driver's plain `python bench.py --gpus 8` and the torchrun form give the same run.
+For N > 1 the per-frame gather is issued async_op=True on a double-buffered shard: frame k's gather runs on RCCL's
+stream underneath frame k + 1's render; `--workload c5` renders an 8-frame batch per step with ONE
+gather for the batch (configs[4]).
 """
 import argparse
 import json
@@ -54,7 +63,13 @@ WORKLOADS = {
     "c4": (0, 2, "Obama training step (fwd+bwd, Adam), N_rand=2048 per GPU, data-parallel RCCL grad all-reduce (configs[3])"),
     # the strong-scaling variant SURVEY.md 8(e) asks to report as well: the reference's 2048 rays split over the ranks
     "c4s": (0, 2, "Obama training step (fwd+bwd, Adam), N_rand=2048 GLOBAL (2048/N per GPU), RCCL grad all-reduce"),
+    # the hierarchical variant SURVEY.md 8(d) asks to report beside c4: 64 coarse + 128 fine samples (fine depths detached)
+    "c4h": (128, 2, "Obama training step, hierarchical 64+128 samples (fine depths detached), N_rand=2048 per GPU, fwd+bwd+Adam"),
+    # configs[4]: a step = a batch of 8 audio-driven frames (each the C2 frame), rays of every frame sharded over the ranks,
+    # ONE gather for the whole batch
+    "c5": (128, 1, "8-frame audio-driven batch inference, 450x450, 64+128, rays sharded across the GPUs, one RCCL gather per batch (configs[4])"),
 }
+TRAIN_WORKLOADS = ("c4", "c4s", "c4h")
 
 
 def parse():
@@ -70,6 +85,7 @@ def parse():
                     help="length of the sustained run after the K timed steps (0 = off; skipped when the K steps "
                          "themselves already lasted that long)")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other workloads (N == 1)")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the 64-ray oracle check after the timed loops (N == 1)")
     return ap.parse_args()
 
 
@@ -130,7 +146,7 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
     from dfanerf import nets, parallel, run_nerf, synth, training
     from dfanerf.decoder import Decoder
     tier = "bf16" if args.tier == "f16" else args.tier           # the 16-bit training tier (f16 is inference only)
-    desc = WORKLOADS[workload][2]
+    n_fine, _, desc = WORKLOADS[workload]
     strong = workload == "c4s"
     N_RAND = 2048 // world if strong else 2048
     assert N_RAND % 8 == 0
@@ -145,15 +161,16 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
         m.load_state_dict({kk: t(v) for kk, v in st[k].items()})
         m.to(dev)
     a = run_nerf.config_parser().parse_args(
-        f"--expname b --concate_bg --N_rand={N_RAND} --sample_rate=0 --smo_size=4 --smo_torse_size 8 --use_et_embed "
-        "--dim_signal=96 --dim_aud=96 --n_object=1 --use_deformation_field --noexp_iters 400000".split())
+        (f"--expname b --concate_bg --N_rand={N_RAND} --sample_rate=0 --smo_size=4 --smo_torse_size 8 --use_et_embed "
+         "--dim_signal=96 --dim_aud=96 --n_object=1 --use_deformation_field --noexp_iters 400000" +
+         (f" --hierarchical --N_importance {n_fine}" if n_fine else "")).split())
     ds = [{"auds": t(sc["aud"]).to(dev), "exp": t(sc["exp"]).to(dev), "poses": t(sc["poses"]).to(dev),
            "bc_img": (t(sc["bg"]).float() / 255.0).to(dev), "hwfcxy": [H, W, sc["focal"], sc["cx"], sc["cy"]],
            "near": sc["near"], "far": sc["far"]}]
     zs, za = [t(v).to(dev) for v in synth.synth_latents(0)]
     embed_fn, _ = nets.get_embedder(3, 0)
     opts = {k: run_nerf.make_adam(m.parameters(), 5e-4) for k, m in mods.items()}
-    buf = training.TrainBuffers(tier, N_RAND, dev)
+    buf = training.TrainBuffers(tier, N_RAND, dev, n_fine=n_fine)
     buf.signal_trainer = training.SignalTrainer(mods["AudNet"], mods["ExpNet"], mods["AudAttNet"], mods["PoseAttNet"],
                                                 ds[0]["auds"], ds[0]["exp"], ds[0]["poses"])
     buf.signal_trainer.adopt_optimizers(opts)
@@ -212,6 +229,7 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
         for _ in range(n):
             loss = step()
         torch.cuda.synchronize()
+        dt_rank = time.perf_counter() - t0
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -221,11 +239,14 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         assert torch.isfinite(loss)
+        state["dt_rank"] = dt_rank
         return dt
+    state = {}
     for _ in range(warmup):
         step()
     host_report(max(warmup, 1))
     dt = timed(steps)
+    rank_ms = all_ranks(state["dt_rank"] / steps * 1e3, world, dev)
     host_report(steps)
     out = None
     sus = None
@@ -234,43 +255,115 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
         dts = timed(n_sus)
         sus = {"steps": n_sus, "seconds": dts, "ms_per_step": dts / n_sus * 1e3, "value": N_RAND * world * n_sus / dts}
     if rank == 0:
-        flop_ray = 3 * 64 * (FLOP_PT_HEAD + FLOP_PT_TORSO)          # fwd + 2x bwd, SURVEY.md 8(d)
+        S = 64 + n_fine
+        flop_ray = 3 * S * (FLOP_PT_HEAD + FLOP_PT_TORSO)          # fwd + 2x bwd, SURVEY.md 8(d) (C4: 481.5 MFLOP/ray)
         ach = flop_ray * N_RAND * world * steps / dt / 1e12
-        # The step is bound by the traffic of what the forward records for the backward, not by the MFMAs.  Algorithmic
-        # bytes per step and GPU (every array touched once per use, no re-reads): the forward writes the GEMM inputs
-        # act_T, the dX chain writes the pre-activation gradients dy_T, the weight-gradient GEMMs read both; rows from
-        # dfn_train_rows, NP = 64 * N_rand points, element = the tier's type.
+        # SURVEY.md 8(d) prices the training step as MFMA-bound: `frac` is the MFMA fraction.  What actually bounds the step
+        # today is the traffic of what the forward records for the backward (DESIGN.md 7): `traffic` = bytes the DESIGN moves
+        # per step and GPU - the forward writes the GEMM inputs act_T, the dX chain the pre-activation gradients dy_T, the
+        # weight-gradient GEMMs read both (rows from dfn_train_rows, NP = S * N_rand points, element = the tier's type) -
+        # next to the ALGORITHMIC bytes of the step (pixel ids, targets, background, the four weight streams, the parameter
+        # read of the pack, the gradient write): the ratio is the traffic the recorded design adds.
         from dfanerf._lib import lib as _l
         esz = 2 if tier == "bf16" else 4
-        NP = 64 * N_RAND
+        NP = S * N_RAND
         act_b = sum(_l.dfn_train_rows(f, 0) for f in (0, 1)) * NP * esz
         dy_b = sum(_l.dfn_train_rows(f, 1) for f in (0, 1)) * NP * esz
         step_bytes = 2 * (act_b + dy_b)          # recorded activations and pre-activation gradients: written once, read once (wgrad)
+        t_id = 1 if tier == "bf16" else 0
+        streams = sum(_l.dfn_packed_bytes(t_id, f) + _l.dfn_packed_bwd_bytes(t_id, f) for f in (0, 1))
+        alg_bytes = N_RAND * (4 + 3 + 3 + 3 + 24) + 2 * streams + 2 * 4 * 1138656
         gbs = step_bytes * world * steps / dt / 1e9
+        peak = PEAK_TFLOPS[tier] * world
         out = {
-            "metric": f"training rays/sec (whole node), N_rand={N_RAND} per GPU, 64 coarse samples, 2 fields, fwd+bwd+Adam",
+            "metric": f"training rays/sec (whole node), N_rand={N_RAND} per GPU, {S} samples, 2 fields, fwd+bwd+Adam",
             "value": N_RAND * world * steps / dt, "unit": "rays/s", "n_gpus": world, "steps": steps,
             "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": tier, "data": "synthetic",
-            "config": {"workload": desc, "H": H, "W": W, "N_rand_per_gpu": N_RAND, "n_coarse": 64, "fields": 2,
-                       "parallelism": f"dp{world}, one flat-bucket all_reduce (1,138,656 floats)"},
-            "roofline": {"bound": "hbm", "kernel": "whole step (render_kernel<train>, mlp_bwd, wgrad_lds)",
-                         "achieved": gbs, "peak": 8000.0 * world, "unit": "GB/s", "frac": gbs / (8000.0 * world),
-                         "traffic": None, "bytes_per_step_per_gpu": step_bytes,
-                         "mfma": {"achieved_tflops": ach, "peak_tflops": PEAK_TFLOPS[tier] * world,
-                                  "frac": ach / (PEAK_TFLOPS[tier] * world), "flop_per_ray": flop_ray}}}
+            "config": {"workload": desc, "H": H, "W": W, "N_rand_per_gpu": N_RAND, "n_coarse": 64, "n_fine": n_fine,
+                       "fields": 2, "parallelism": f"dp{world}, one flat-bucket all_reduce (1,138,656 floats)"},
+            "roofline": {"bound": "mfma", "kernel": "whole step (render_kernel<train>, mlp_bwd, wgrad_lds)",
+                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "flop_per_ray": flop_ray,
+                         "traffic": step_bytes, "traffic_source": "design bytes per step and GPU: recorded activations + "
+                                                                  "pre-activation gradients, written once and read once",
+                         "algorithmic_bytes": alg_bytes, "traffic_over_algorithmic": step_bytes / alg_bytes,
+                         "hbm": {"achieved_gbs": gbs, "peak_gbs": 8000.0 * world, "frac": gbs / (8000.0 * world)}},
+            "per_rank": {"ms_per_step": rank_ms}}
         if sus:
             out["sustained"] = sus
     return out
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_s=0.0):
+def all_ranks(x, world, dev):
+    """[value of every rank] (float64), gathered through an all_reduce of a one-hot vector (every backend has that)"""
+    if world == 1:
+        return [float(x)]
+    v = torch.zeros(world, dtype=torch.float64, device=dev)
+    v[dist.get_rank()] = float(x)
+    dist.all_reduce(v)
+    return [float(t) for t in v.cpu()]
+
+
+def parity_check(sc, st, zs, za, pk, n_fine, fields, frame, dev, tier):
+    """64 rays of frame `frame` (the last timed one) through the HIP path exactly as the timed loop ran it - HIP signal
+    encoders, fold, fused render in the timed tier - against the CPU oracle (oracle/dfa_oracle.py: its own signal encoders,
+    decoder, compositing), OUTSIDE the timed region.  Two distances: against the oracle evaluated at the depths the kernel
+    sampled (decoder + compositing; sample_pdf's `denom < 1e-5` switch makes depths in empty space rounding-sensitive) and
+    against the oracle's whole pipeline with its own fine sampler."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dfa_oracle as O
+    from dfanerf import engine, nets
+    H, W = sc["H"], sc["W"]
+    idx = np.arange(0, H * W, (H * W) // 64)[:64].astype(np.int32)
+    t = lambda x: torch.from_numpy(np.asarray(x))
+    mods = {"AudNet": nets.AudioNet_W2L(), "ExpNet": nets.ExpressionEnc(), "AudAttNet": nets.AudioAttNet(96, 4),
+            "PoseAttNet": nets.AudioAttNet(42, 8)}
+    for k, m in mods.items():
+        m.load_state_dict({kk: t(v) for kk, v in st[k].items()})
+        m.to(dev)
+    auds, exps, poses = [t(sc[k]).to(dev) for k in ("aud", "exp", "poses")]
+    enc = engine.SignalEncoder(mods["AudNet"], mods["ExpNet"], mods["AudAttNet"], mods["PoseAttNet"], auds, exps, poses)
+    s2, t2 = enc.encode([frame], 4, 8)
+    bias = pk.fold(s2[0], t2[0] if fields == 2 else None, t(zs[0]).to(dev), t(za[0]).to(dev))
+    bg8 = t(sc["bg"]).reshape(-1, 3).to(dev)
+    fr = engine.make_frame(H, W, sc["focal"], sc["cx"], sc["cy"], sc["poses"][frame], sc["pose_body"], sc["near"], sc["far"],
+                           ray_count=len(idx), n_fine=n_fine, fields=fields)
+    out = engine.render(pk, bias, fr, bg8, pix_index=t(idx).to(dev), want_z=True)
+    torch.cuda.synchronize()
+    rh, rc, z = out[0].cpu(), (out[1].cpu() if fields == 2 else None), out[-1].cpu()
+    P = O.params_to_torch(st["decoder"])
+    onets = {k: O.params_to_torch(v) for k, v in st.items() if k != "decoder"}
+    bg = (t(sc["bg"]).float() / 255.0).reshape(-1, 3)[idx]
+    with torch.no_grad():
+        sig = O.encode_signal(onets, t(sc["aud"]), t(sc["exp"]), frame, 300000, 300000, 4, sc["aud"].shape[0])
+        sigt = O.encode_signal_torso(onets, t(sc["poses"]), frame, 300000, 300000, 8, sc["poses"].shape[0])
+        o_h, d_h = O.get_rays(H, W, sc["focal"], sc["poses"][frame][:3, :4], sc["cx"], sc["cy"])
+        o_t, d_t = O.get_rays(H, W, sc["focal"], sc["pose_body"][:3, :4], sc["cx"], sc["cy"])
+        rays = [x.reshape(-1, 3)[idx] for x in (o_h, d_h, o_t, d_t)]
+        fh, fc = O.render_fixed_samples(P, *rays, bg, z, t(zs), t(za), sig, sigt, fields)
+        ph, pc = O.render_rays_chunk(P, *rays, bg, sc["near"], sc["far"], t(zs), t(za), sig, sigt, 64, n_fine, fields)
+    def dist_(a, b):
+        d = (a - b).double()
+        mse = float((d ** 2).mean())
+        return float(d.abs().max()), (10.0 * np.log10(1.0 / mse) if mse > 0 else float("inf"))
+    got, ref_f, ref_p = (rc, fc, pc) if fields == 2 else (rh, fh, ph)       # the final image of the workload
+    m_f, p_f = dist_(got, ref_f)
+    m_p, p_p = dist_(got, ref_p)
+    return {"rays": int(len(idx)), "frame": int(frame), "tier": tier, "image": "composite" if fields == 2 else "head",
+            "max_abs_rgb": m_f, "psnr_db": p_f, "reference": "oracle decoder + compositing at the depths the kernel sampled",
+            "vs_oracle_pipeline": {"max_abs_rgb": m_p, "psnr_db": p_p,
+                                   "reference": "oracle end to end (own sample_pdf; a fine depth that flips sample_pdf's "
+                                                "`denom < 1e-5` switch moves within one coarse bin)"}}
+
+
+def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_s=0.0, check=False):
     from dfanerf import engine, nets, synth
-    from dfanerf._lib import check, lib
+    from dfanerf._lib import check as chk, lib
     n_fine, fields, desc = WORKLOADS[workload]
     F = 8                                              # frames of the audio-driven sequence (configs[4] batch)
+    B = 8 if workload == "c5" else 1                   # frames per step = frames per gather
     sc = synth.bench_scene(0, n_frames=F)
     st = synth.synth_all_states(0)
     zs, za = synth.synth_latents(0)
@@ -295,10 +388,13 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
     per = (R + world - 1) // world                       # rank r renders [r*per, min(R,(r+1)*per))
     begin = rank * per
     count = max(0, min(R, begin + per) - begin)
-    # one [per, 3] shard per image the workload produces (head; head + two-field composite for c3), gathered together
+    # one [per, 3] shard per image the workload produces (head; head + two-field composite for c3) and frame of the batch,
+    # gathered together.  TWO sets of buffers: the gather of step k is issued async_op=True (RCCL's own stream) and only
+    # waited for when its buffers come round again at step k + 2, so it runs underneath the render of step k + 1.
     n_img = 2 if fields == 2 else 1
-    shard = torch.zeros(n_img, per, 3, dtype=torch.float32, device=dev)
-    gathered = torch.empty(world, n_img, per, 3, dtype=torch.float32, device=dev) if world > 1 else None
+    shards = [torch.zeros(B, n_img, per, 3, dtype=torch.float32, device=dev) for _ in range(2)]
+    gathered = [torch.empty(world, B, n_img, per, 3, dtype=torch.float32, device=dev) if world > 1 else None for _ in range(2)]
+    works = [None, None]
     state = {"bias": None}
     ev = []
 
@@ -308,26 +404,43 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
     probe = torch.zeros(2, dtype=torch.int64, device=dev)
 
     def step(i, timed):
-        f = i % F
-        s2, t2 = enc.encode(fid[f], A.smo_size, A.smo_torse_size)           # 2 launches: [1,96], [1,42]
-        sig, sigt = s2[0], (t2[0] if fields == 2 else None)
-        state["bias"] = pk.fold(sig, sigt, zs_d, za_d, out=state["bias"])
-        fr = engine.make_frame(H, W, sc["focal"], sc["cx"], sc["cy"], sc["poses"][f], sc["pose_body"], sc["near"],
-                               sc["far"], ray_begin=begin, ray_count=count, n_fine=n_fine, fields=fields)
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        engine.render(pk, state["bias"], fr, bg, out_head=shard[0, :count], out_com=shard[1, :count] if fields == 2 else None)
-        if timed:
-            e1.record()
-            ev.append((e0, e1))
+        k = i & 1
+        if works[k] is not None:
+            works[k].wait()                              # the gather that last used these buffers (two steps ago)
+            works[k] = None
+        shard = shards[k]
+        for b in range(B):
+            f = (i * B + b) % F
+            s2, t2 = enc.encode(fid[f], A.smo_size, A.smo_torse_size)           # 2 launches: [1,96], [1,42]
+            sig, sigt = s2[0], (t2[0] if fields == 2 else None)
+            state["bias"] = pk.fold(sig, sigt, zs_d, za_d, out=state["bias"])
+            fr = engine.make_frame(H, W, sc["focal"], sc["cx"], sc["cy"], sc["poses"][f], sc["pose_body"], sc["near"],
+                                   sc["far"], ray_begin=begin, ray_count=count, n_fine=n_fine, fields=fields)
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            engine.render(pk, state["bias"], fr, bg, out_head=shard[b, 0, :count],
+                          out_com=shard[b, 1, :count] if fields == 2 else None)
+            if timed:
+                e1.record()
+                ev.append((e0, e1))
         if world > 1:
-            dist.all_gather_into_tensor(gathered.view(world * n_img, per, 3), shard)     # concatenation form: every backend
-            return gathered
+            # concatenation form (every backend takes it); async: the collective waits for this stream's work so far and
+            # the NEXT step's render does not wait for the collective
+            works[k] = dist.all_gather_into_tensor(gathered[k].view(world * B * n_img, per, 3),
+                                                   shard.view(B * n_img, per, 3), async_op=True)
+            return gathered[k]
         return shard
+
+    def drain():
+        for k in (0, 1):
+            if works[k] is not None:
+                works[k].wait()
+                works[k] = None
 
     def timed(n, i0):
         ev.clear()
+        drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -335,7 +448,9 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
         t0 = time.perf_counter()
         for i in range(n):
             img = step(i0 + i, True)
+        drain()                                          # every gather of the timed steps has completed
         torch.cuda.synchronize()
+        dt_rank = time.perf_counter() - t0               # this rank's own time, before it waits for the others
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -345,7 +460,7 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         assert torch.isfinite(img).all()
-        return dt, float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+        return dt, (float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")), dt_rank
 
     def clock():
         """effective shader clock of the last launch (GHz), read inside the kernel"""
@@ -354,18 +469,31 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
 
     for i in range(warmup):
         step(i, False)
-    check(lib.dfn_debug_clock_probe(probe.data_ptr()), "dfn_debug_clock_probe")
+    chk(lib.dfn_debug_clock_probe(probe.data_ptr()), "dfn_debug_clock_probe")
     try:
-        dt, kern_ms = timed(steps, warmup)
+        dt, kern_ms, dt_rank = timed(steps, warmup)
         ghz = clock()
         sus = None
         if sustain_s > 0 and dt < sustain_s:
             n_sus = max(steps, int(sustain_s / (dt / steps)))
-            dts, kms = timed(n_sus, warmup + steps)
-            sus = {"steps": n_sus, "seconds": dts, "ms_per_step": dts / n_sus * 1e3, "value": R * n_sus / dts,
+            dts, kms, _ = timed(n_sus, warmup + steps)
+            sus = {"steps": n_sus, "seconds": dts, "ms_per_step": dts / n_sus * 1e3, "value": R * B * n_sus / dts,
                    "kernel_ms": kms, "clock_ghz": clock()}
     finally:
         lib.dfn_debug_clock_probe(None)
+    # per-rank figures (every rank contributes): its own wall time per step and its render_kernel time per launch
+    rank_ms = all_ranks(dt_rank / steps * 1e3, world, dev)
+    rank_kern = all_ranks(kern_ms, world, dev)
+    # the collective alone (nothing to overlap with): 20 gathers of the step's shard, synchronised
+    gather_ms = None
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            dist.all_gather_into_tensor(gathered[0].view(world * B * n_img, per, 3), shards[0].view(B * n_img, per, 3))
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - t0) / 20 * 1e3
     if rank != 0:
         return None
     ms_step = dt / steps * 1e3
@@ -386,8 +514,8 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
     traffic, traffic_src = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            tr = json.load(f).get(f"{workload}_{tier}")
-        if tr:
+            tr = json.load(f).get(f"{'c2' if workload == 'c5' else workload}_{tier}")
+        if tr and world == 1:
             traffic, traffic_src = tr["hbm_bytes_per_launch"], "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
     except OSError:
         pass
@@ -395,13 +523,14 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
     out = {
         "metric": "rays/sec (whole node) at 450x450, 64c+128f samples" if n_fine else
                   "rays/sec (whole node) at 450x450, 64 coarse samples",
-        "value": R * steps / dt, "unit": "rays/s", "n_gpus": world, "steps": steps,
-        "warmup": warmup, "ms_per_step": ms_step, "ms_per_frame": ms_step, "higher_is_better": True,
+        "value": R * B * steps / dt, "unit": "rays/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": ms_step, "ms_per_frame": ms_step / B, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": tier, "data": "synthetic",
         "config": {"workload": desc, "H": H, "W": W, "n_coarse": 64, "n_fine": n_fine, "fields": fields,
-                   "frames": F, "rays_per_step": R,
-                   "parallelism": f"rays sharded over {world} GPU(s), all_gather of RGB" if world > 1
-                   else "single GPU"},
+                   "frames": F, "frames_per_step": B, "rays_per_step": R * B,
+                   "parallelism": (f"rays of every frame sharded over {world} GPUs ({per} rays per rank), one async "
+                                   f"all_gather_into_tensor of the RGB shards per {'batch of 8 frames' if B > 1 else 'frame'}, "
+                                   "double-buffered (overlaps the next step's render)") if world > 1 else "single GPU"},
         "roofline": {"bound": "mfma", "kernel": "render_kernel", "achieved": achieved,
                      "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms, "clock_ghz": ghz,
@@ -410,16 +539,59 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
                                                "flop_per_ray": evals_ref * per_pt, "tflops": ref_comp,
                                                "frac": ref_comp / peak},
                      "rays_per_launch": count},
+        "per_rank": {"ms_per_step": rank_ms, "render_kernel_ms": rank_kern},
     }
+    if world > 1:
+        out["gather"] = {"ms_alone": gather_ms, "bytes_per_rank": int(B * n_img * per * 12), "async": True,
+                         "collective": "all_gather_into_tensor"}
     if sus:
         sus["roofline_frac"] = flop_ray * count / (sus["kernel_ms"] * 1e-3) / 1e12 / peak
         out["sustained"] = sus
+    if check and world == 1:
+        try:
+            out["parity_check"] = parity_check(sc, st, zs, za, pk, n_fine, fields, ((warmup + steps) * B - 1) % F, dev, tier)
+        except Exception as e:                      # never lose the headline line to the check; the failure is in the line
+            out["parity_check"] = {"error": f"{type(e).__name__}: {e}"}
     out["_scene"] = (sc, st, zs, za, n_fine, fields)
     return out
 
 
+def free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside a torchrun environment: run the N ranks ourselves - the command the driver
+    documents, on 127.0.0.1 and a probed free port (one retry: a free port can be taken between the probe and the
+    rendezvous).  The ranks' stdout / stderr pass through; rank 0 prints the JSON line."""
+    import subprocess
+    one_gpu = bool(os.environ.get("DFN_BENCH_ONE_GPU"))
+    if not one_gpu and torch.cuda.device_count() < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} HIP device(s) visible "
+              "(DFN_BENCH_ONE_GPU=1 runs every rank on GPU 0 over gloo: functional, not a measurement)", file=sys.stderr)
+        return 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    rc = 1
+    for _ in range(2):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        rc = subprocess.call(cmd, env=env)
+        if rc == 0:
+            break
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -432,8 +604,10 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if one_gpu else "nccl"
         if one_gpu:
             dist.init_process_group("gloo")
         else:
@@ -444,29 +618,34 @@ def main():
     if world != args.gpus and rank == 0:
         print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}; using {world}", file=sys.stderr)
 
-    train_wl = args.workload in ("c4", "c4s")
+    train_wl = args.workload in TRAIN_WORKLOADS
     if train_wl:
         out = bench_training(args, args.workload, args.steps, args.warmup, world, rank, dev, args.sustain_seconds)
     else:
         out = bench_render(args, args.workload, args.tier, args.steps, args.warmup, world, rank, dev,
-                           args.sustain_seconds)
+                           args.sustain_seconds, check=not args.no_parity_check)
     extra = {}
     if world == 1 and not args.no_extra:
-        # the other BASELINE configs, short runs in the same process (driver-timed, not builder-only numbers)
-        for wl, k, w in (("c3", 40, 5), ("c1", 60, 5), ("c4", 150, 20)):
-            if wl == args.workload:
+        # the other BASELINE configs, short runs in the same process (driver-timed, not builder-only numbers); c2_f32 = the
+        # exact tier, the one that meets the north star's "within 1e-4 PSNR" clause
+        for name, wl, tier, k, w in (("c3", "c3", args.tier, 40, 5), ("c1", "c1", args.tier, 60, 5),
+                                     ("c2_f32", "c2", "f32", 5, 1), ("c4", "c4", args.tier, 150, 20),
+                                     ("c4h", "c4h", args.tier, 60, 10)):
+            if wl == args.workload and tier == args.tier:
                 continue
             try:
-                r = bench_training(args, wl, k, w, 1, 0, dev) if wl == "c4" else \
-                    bench_render(args, wl, args.tier, k, w, 1, 0, dev)
+                r = bench_training(args, wl, k, w, 1, 0, dev) if wl in TRAIN_WORKLOADS else \
+                    bench_render(args, wl, tier, k, w, 1, 0, dev, check=(name == "c2_f32" and not args.no_parity_check))
                 r.pop("_scene", None)
-                extra[wl] = {kk: r[kk] for kk in ("metric", "value", "unit", "steps", "ms_per_step", "dtype", "roofline")}
-                extra[wl]["workload"] = r["config"]["workload"]
+                extra[name] = {kk: r[kk] for kk in ("metric", "value", "unit", "steps", "ms_per_step", "dtype", "roofline",
+                                                    "parity_check") if kk in r}
+                extra[name]["workload"] = r["config"]["workload"]
             except Exception as e:                      # never lose the headline line to a side measurement
-                extra[wl] = {"error": f"{type(e).__name__}: {e}"}
+                extra[name] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         scene = out.pop("_scene", None)
         out["rccl_ranks"] = rccl_ranks
+        out["backend"] = backend
         if world == 1 and not args.no_cpu_baseline and scene is not None:
             out["cpu_baseline"] = cpu_baseline(args, *scene)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]

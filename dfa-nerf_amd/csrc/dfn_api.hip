@@ -247,6 +247,7 @@ static int render_fwd_impl(int tier, const DfnFrame* frame, const void* packed_h
     A.z_out = z_vals;
     A.out_u8 = out_u8;
     A.samples_out = nullptr;
+    A.ranks_out = nullptr;
     A.act_T[0] = A.act_T[1] = nullptr;
     A.masks[0] = A.masks[1] = nullptr;
     A.NP = 0;
@@ -359,25 +360,30 @@ int dfn_train_prepare(int tier, const float* params, const float* signal_head, c
     return DFN_OK;
 }
 
-int dfn_train_fwd(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
-                  const float* bias_head, const float* bias_torso, const float* bg_f32, const uint8_t* bg_u8,
-                  const int32_t* pix_index, float* rgb_head, float* rgb_com, float* samples, void* act_head,
-                  uint32_t* masks_head, void* act_torso, uint32_t* masks_torso, void* stream) {
+static int train_fwd_impl(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
+                          const float* bias_head, const float* bias_torso, const float* bg_f32, const uint8_t* bg_u8,
+                          const int32_t* pix_index, float* rgb_head, float* rgb_com, float* samples, void* act_head,
+                          uint32_t* masks_head, void* act_torso, uint32_t* masks_torso, float* z_all, uint8_t* ranks,
+                          bool hier, void* stream) {
+    const char* who = hier ? "dfn_train_fwd_hier" : "dfn_train_fwd";
     if (!train_tier_ok(tier) || !frame || !packed_head || !packed_torso || !bias_head || !bias_torso || !rgb_head ||
-        !rgb_com || !samples || !act_head || !masks_head || !act_torso || !masks_torso)
-        return fail(DFN_E_ARG, "dfn_train_fwd: bad argument");
+        !rgb_com || !samples || !act_head || !masks_head || !act_torso || !masks_torso || (hier && (!z_all || !ranks)))
+        return fail(DFN_E_ARG, std::string(who) + ": bad argument");
     const DfnFrame& F = *frame;
-    if (F.n_coarse != 64 || F.n_fine != 0 || F.fields != 2)
-        return fail(DFN_E_ARG, "dfn_train_fwd: the training step is coarse-only (64 samples), two fields (MAIN:855-899)");
-    if (!bg_f32 && !bg_u8) return fail(DFN_E_ARG, "dfn_train_fwd: no background given");
+    if (!hier && (F.n_coarse != 64 || F.n_fine != 0 || F.fields != 2))
+        return fail(DFN_E_ARG, "dfn_train_fwd: the training step is coarse-only (64 samples), two fields (MAIN:855-899); "
+                               "dfn_train_fwd_hier is the hierarchical variant");
+    if (hier && (F.n_coarse != 64 || (F.n_fine != 64 && F.n_fine != 128) || F.fields != 2))
+        return fail(DFN_E_ARG, "dfn_train_fwd_hier: 64 coarse + 64 or 128 fine samples, two fields");
+    if (!bg_f32 && !bg_u8) return fail(DFN_E_ARG, std::string(who) + ": no background given");
     if (F.ray_count <= 0) return DFN_OK;
-    const long NP = (long)F.ray_count * 64;
-    if (dfn_train_rows(1, 0) * NP >= (1L << 32)) return fail(DFN_E_ARG, "dfn_train_fwd: too many rays per call");
+    const long NP = (long)F.ray_count * (64 + F.n_fine);
+    if (dfn_train_rows(1, 0) * NP >= (1L << 32)) return fail(DFN_E_ARG, std::string(who) + ": too many rays per call");
     ProgramInfo ph, pt;
     program_info(tier, FIELD_HEAD, &ph);
     program_info(tier, FIELD_TORSO, &pt);
     if (bias_torso != bias_head + ph.n_bias)
-        return fail(DFN_E_ARG, "dfn_train_fwd: bias_torso must directly follow bias_head in memory");
+        return fail(DFN_E_ARG, std::string(who) + ": bias_torso must directly follow bias_head in memory");
     RenderArgs A;
     A.frame = F;
     A.out_u8 = 0;
@@ -391,8 +397,10 @@ int dfn_train_fwd(int tier, const DfnFrame* frame, const void* packed_head, cons
     A.pix_index = pix_index;
     A.rgb_head = rgb_head;
     A.rgb_com = rgb_com;
-    A.w_head = A.w_com = A.z_out = nullptr;
+    A.w_head = A.w_com = nullptr;
+    A.z_out = hier ? z_all : nullptr;
     A.samples_out = samples;
+    A.ranks_out = hier ? ranks : nullptr;
     A.act_T[0] = act_head;
     A.act_T[1] = act_torso;
     A.masks[0] = masks_head;
@@ -402,6 +410,23 @@ int dfn_train_fwd(int tier, const DfnFrame* frame, const void* packed_head, cons
     hipError_t err = launch_render(tier, A, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "render_kernel(train)");
     return DFN_OK;
+}
+
+int dfn_train_fwd(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
+                  const float* bias_head, const float* bias_torso, const float* bg_f32, const uint8_t* bg_u8,
+                  const int32_t* pix_index, float* rgb_head, float* rgb_com, float* samples, void* act_head,
+                  uint32_t* masks_head, void* act_torso, uint32_t* masks_torso, void* stream) {
+    return train_fwd_impl(tier, frame, packed_head, packed_torso, bias_head, bias_torso, bg_f32, bg_u8, pix_index, rgb_head,
+                          rgb_com, samples, act_head, masks_head, act_torso, masks_torso, nullptr, nullptr, false, stream);
+}
+
+int dfn_train_fwd_hier(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
+                       const float* bias_head, const float* bias_torso, const float* bg_f32, const uint8_t* bg_u8,
+                       const int32_t* pix_index, float* rgb_head, float* rgb_com, float* samples, void* act_head,
+                       uint32_t* masks_head, void* act_torso, uint32_t* masks_torso, float* z_all, uint8_t* ranks,
+                       void* stream) {
+    return train_fwd_impl(tier, frame, packed_head, packed_torso, bias_head, bias_torso, bg_f32, bg_u8, pix_index, rgb_head,
+                          rgb_com, samples, act_head, masks_head, act_torso, masks_torso, z_all, ranks, true, stream);
 }
 
 int dfn_sample_pixels(int H, int W, int n, int rect_num, const int32_t* rect, uint64_t seed, uint64_t counter,
@@ -441,8 +466,34 @@ int dfn_composite_bwd(const DfnFrame* frame, const int32_t* pix_index, const flo
     A.d_rgb_head = d_rgb_head;
     A.d_rgb_com = d_rgb_com;
     A.dsamples = dsamples;
+    A.z_all = nullptr;
+    A.ranks = nullptr;
     hipError_t err = launch_composite_bwd(A, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "composite_bwd_kernel");
+    return DFN_OK;
+}
+
+int dfn_composite_bwd_hier(const DfnFrame* frame, const int32_t* pix_index, const float* bg_f32, const uint8_t* bg_u8,
+                           const float* samples, const float* z_all, const uint8_t* ranks, const float* d_rgb_head,
+                           const float* d_rgb_com, float* dsamples, void* stream) {
+    if (!frame || !samples || !z_all || !ranks || !d_rgb_head || !dsamples || (!bg_f32 && !bg_u8))
+        return fail(DFN_E_ARG, "dfn_composite_bwd_hier: bad argument");
+    if (frame->n_coarse != 64 || (frame->n_fine != 64 && frame->n_fine != 128))
+        return fail(DFN_E_ARG, "dfn_composite_bwd_hier: 64 coarse + 64 or 128 fine samples");
+    if (frame->ray_count <= 0) return DFN_OK;
+    CompositeBwdArgs A;
+    A.frame = *frame;
+    A.pix_index = pix_index;
+    A.bg_f32 = bg_f32;
+    A.bg_u8 = bg_u8;
+    A.samples = samples;
+    A.d_rgb_head = d_rgb_head;
+    A.d_rgb_com = d_rgb_com;
+    A.dsamples = dsamples;
+    A.z_all = z_all;
+    A.ranks = ranks;
+    hipError_t err = launch_composite_bwd_hier(A, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "composite_bwd_hier_kernel");
     return DFN_OK;
 }
 

@@ -21,7 +21,8 @@ struct RenderArgs {
     float* z_out;
     int out_u8;                 // rgb_head / rgb_com point at uint8 [ray_count,3]: to8b in the epilogue (HELP:17)
     // training recorder (all null for inference): per-sample raw outputs and per-field activations / ReLU masks
-    float* samples_out;         // [ray_count][n_coarse][8]
+    float* samples_out;         // [ray_count][n_coarse + n_fine][8], evaluation order (coarse points, then the fine ones)
+    unsigned char* ranks_out;   // hierarchical training: [ray_count][n_coarse + n_fine] merged rank of every evaluated point
     void* act_T[2];
     unsigned* masks[2];
     long NP;

@@ -133,7 +133,12 @@ template <int TIER, bool TWO = false> struct KernelLds {
 // second time: head on the fine tiles, compositing of the head image over the merged samples, torso on the fine
 // tiles, compositing of the two-field image.  Every sample's (sigma, rgb) is bit-identical to what a pass over
 // all 64 + n_fine merged points gives (an MFMA column depends on its own point only).
-template <int TIER, bool TWO, bool TRAIN>
+// TRAIN: 0 = inference; 1 = the training forward of the reference's step (MAIN:855-899: coarse samples only, recorder on);
+// 2 = the hierarchical training forward (row H under autograd: the fine depths are constants - no gradient through
+// sample_pdf, as in the NeRF lineage - and the loss sees the merged 64 + n_fine samples: every point is evaluated ONCE with
+// the recorder on, the coarse points in the coarse pass, the fine points in the fine passes, recorded in evaluation
+// order; the backward gets the merged depths and each point's merged rank to composite them in depth order)
+template <int TIER, bool TWO, int TRAIN>
 __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 256) void render_kernel(
     const RenderArgs A) {
     using C = TierCfg<TIER>;
@@ -151,10 +156,10 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
 #ifndef DFN_PIPE
 #define DFN_PIPE 1
 #endif
-    typedef CtxT<TRAIN, !TRAIN, TRAIN, (DFN_PIPE != 0) && !TRAIN && !TWO> CtxK;
+    typedef CtxT<TRAIN != 0, TRAIN == 0, TRAIN != 0, (DFN_PIPE != 0) && TRAIN == 0 && !TWO> CtxK;
     CtxK ctx = {lds, wave, lane, lane >> 5, {}};
     constexpr bool two = TWO;
-    const int NF = TRAIN ? 0 : F.n_fine;          // the training forward is the reference's coarse renderer
+    const int NF = TRAIN == 1 ? 0 : F.n_fine;     // TRAIN == 1: the training forward is the reference's coarse renderer
     const bool hier = NF > 0;
     const int KF = NF / 32;                        // fine tiles
     const int S = 64 + NF;
@@ -308,9 +313,11 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
             float p[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) p[k] = add_(st[RS_OH + k], mul_(st[RS_DH + k], z));
-            if constexpr (TRAIN) {      // idle waves (ray >= ray_count) record into the last ray's slots: same values
+            if constexpr (TRAIN != 0) {      // idle waves (ray >= ray_count) record into the last ray's slots: same values
+                // tiles of a ray in evaluation order: coarse 0, 1, then the fine tiles
                 const long rr = valid ? r_raw : F.ray_count - 1;
-                ctx.rec = {A.act_T[0], A.masks[0], RecMap::H_ROWS, rr * 2 + tile, RecMap::H_MDWORDS};
+                ctx.rec = {A.act_T[0], A.masks[0], RecMap::H_ROWS, rr * (S / 32) + (phase == PH_COARSE ? tile : 2 + tile),
+                           RecMap::H_MDWORDS};
             }
 #ifdef DFN_TIMING
             const unsigned long long tm0 = __builtin_readcyclecounter();
@@ -324,17 +331,18 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
             float p[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) p[k] = add_(st[RS_OT + k], mul_(st[RS_DT + k], z));
-            if constexpr (TRAIN) {
+            if constexpr (TRAIN != 0) {
                 const long rr = valid ? r_raw : F.ray_count - 1;
-                ctx.rec = {A.act_T[1], A.masks[1], RecMap::S_ROWS, rr * 2 + tile, RecMap::S_MDWORDS};
+                ctx.rec = {A.act_T[1], A.masks[1], RecMap::S_ROWS, rr * (S / 32) + (phase == PH_COARSE ? tile : 2 + tile),
+                           RecMap::S_MDWORDS};
             }
             b = mlp_torso<TIER>(p, dref_t, bias_t, s, ctx);
         }
 
         if (phase == PH_COARSE) {
             const int si = idx;
-            if (TRAIN && valid && lane < 32) {
-                float* so = A.samples_out + ((size_t)r_raw * 64 + si) * 8;
+            if (TRAIN != 0 && valid && lane < 32) {      // raw outputs, evaluation order: [ray][64 coarse | n_fine fine][8]
+                float* so = A.samples_out + ((size_t)r_raw * S + si) * 8;
                 so[0] = a.sigma; so[1] = a.r; so[2] = a.g; so[3] = a.b;
                 so[4] = b.sigma; so[5] = b.r; so[6] = b.g; so[7] = b.b;
             }
@@ -478,6 +486,15 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
                 }
 #pragma unroll
             for (int q = 0; q < 4; ++q) M[q * L::M_STRIDE + rank_c] = keep_h[q];
+            if constexpr (TRAIN == 2) {      // merged rank of every evaluated point, for the compositing backward
+                if (valid) {
+                    unsigned char* ro = A.ranks_out + (size_t)r_raw * S;
+                    ro[lane] = (unsigned char)rank_c;
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+                        if (m < NF / 64) ro[64 + lane + 64 * m] = (unsigned char)rank_f[m];
+                }
+            }
             if (lane == 0) {                 // the merged compositing starts from scratch
                 st[RS_TH] = 1.0f;
                 st[RS_TC] = 1.0f;
@@ -491,6 +508,10 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
             phase = PH_FINE_H;
             tile = 0;
         } else if (phase == PH_FINE_H) {
+            if (TRAIN == 2 && valid && lane < 32) {
+                float* so = A.samples_out + ((size_t)r_raw * S + 64 + idx) * 8;
+                so[0] = a.sigma; so[1] = a.r; so[2] = a.g; so[3] = a.b;
+            }
             if (lane < 32) {
                 M[ri] = a.sigma;
                 M[L::M_STRIDE + ri] = a.r;
@@ -504,6 +525,10 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
             phase = PH_FINE_T;
             tile = 0;
         } else {
+            if (TRAIN == 2 && valid && lane < 32) {
+                float* so = A.samples_out + ((size_t)r_raw * S + 64 + idx) * 8;
+                so[4] = b.sigma; so[5] = b.r; so[6] = b.g; so[7] = b.b;
+            }
             if (lane < 32) {                 // the sample's head outputs are in M: replace them by the two-field mix
                 const volatile lds_f32* Mv = M;
                 const float sg_h = Mv[ri];
@@ -638,7 +663,7 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
 template <typename K> static hipError_t set_lds(K kernel, int lds) {
     return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
-template <int TIER, bool TWO, bool TRAIN = false> static hipError_t launch_render_t(const RenderArgs& A, hipStream_t st) {
+template <int TIER, bool TWO, int TRAIN = 0> static hipError_t launch_render_t(const RenderArgs& A, hipStream_t st) {
     using C = TierCfg<TIER>;
     const int lds = KernelLds<TIER, TWO>::TOTAL;
     static bool attr_done = false;
@@ -669,8 +694,9 @@ template <int TIER, bool TORSO, bool REC = false> static hipError_t launch_decod
 // all launches of one tier; TRAINABLE: the tier has a training forward (recorder on)
 template <int TIER, bool TRAINABLE> static hipError_t launch_render_tier(const RenderArgs& A, hipStream_t st) {
     const bool two = A.frame.fields == 2;
-    if (A.samples_out) {     // training step: two fields, coarse only, recorder on
-        if constexpr (TRAINABLE) return launch_render_t<TIER, true, true>(A, st);
+    if (A.samples_out) {     // training step: two fields, recorder on; coarse only (MAIN:855-899) or hierarchical (row H)
+        if constexpr (TRAINABLE)
+            return A.frame.n_fine > 0 ? launch_render_t<TIER, true, 2>(A, st) : launch_render_t<TIER, true, 1>(A, st);
         else return hipErrorInvalidValue;
     }
     return two ? launch_render_t<TIER, true>(A, st) : launch_render_t<TIER, false>(A, st);

@@ -21,10 +21,13 @@ struct CompositeBwdArgs {
     const int* pix_index;
     const float* bg_f32;
     const unsigned char* bg_u8;
-    const float* samples;       // [rays][64][8]
+    const float* samples;       // [rays][S][8], S = 64 + n_fine, evaluation order
     const float* d_rgb_head;    // [rays][3]
     const float* d_rgb_com;     // [rays][3] or null
-    float* dsamples;            // out [rays][64][8]
+    float* dsamples;            // out [rays][S][8]
+    // hierarchical step only (launch_composite_bwd_hier): what the forward left about the merge
+    const float* z_all;         // [rays][S] merged, sorted depths
+    const unsigned char* ranks; // [rays][S] merged rank of evaluated point i
 };
 
 struct WOp {                    // one weight-gradient GEMM: C[M x N] = dy_T[a_row.., :] * act_T[b_row.., :]^T
@@ -36,6 +39,7 @@ hipError_t launch_mlp_bwd(int tier, int field, const MlpBwdArgs& A, hipStream_t 
 hipError_t launch_mlp_bwd_bf16(bool torso, const MlpBwdArgs& A, hipStream_t st);     // dfn_bwd_bf16.hip
 void bwd_program_info(int tier, int field, ProgramInfo* out);
 hipError_t launch_composite_bwd(const CompositeBwdArgs& A, hipStream_t st);
+hipError_t launch_composite_bwd_hier(const CompositeBwdArgs& A, hipStream_t st);      // n_fine in {64, 128}
 // Split-K partials: C [ksplit][c_stride] and dbias [ksplit][n_bias], one writer per element and slice (no atomics);
 // launch_reduce_scatter / launch_reduce_bias add the slices in index order (bit-reproducible gradients).
 hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, const int* prefix_dev, int total_items,

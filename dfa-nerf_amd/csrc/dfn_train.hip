@@ -172,6 +172,179 @@ hipError_t launch_composite_bwd(const CompositeBwdArgs& A, hipStream_t st) {
 }
 
 // ================================================================================================
+// compositing backward over the MERGED samples of the hierarchical training step (SURVEY.md 8(a) row H under autograd)
+// ================================================================================================
+// One wave per ray, S = 64 K merged samples (K = 2: 64 + 64, K = 3: 64 + 128): lane l owns the K consecutive merged
+// positions l K .. l K + K - 1.  The forward left every evaluated point's raw outputs in EVALUATION order (coarse points,
+// then the fine ones: the order of the recorded activations, which is what the dX chain walks), its merged rank, and the
+// merged depths; the fine depths are constants (no gradient through sample_pdf), so this is the same differentiation as
+// composite_bwd_kernel with run-time depths and the scans carried across a lane's K positions.
+template <int K>
+__global__ __launch_bounds__(256) void composite_bwd_hier_kernel(const CompositeBwdArgs A) {
+    constexpr int S = 64 * K;
+    __shared__ unsigned char inv_s[4][S];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long ray = (long)blockIdx.x * 4 + wv;
+    if (ray >= A.frame.ray_count) return;
+    const DfnFrame& F = A.frame;
+    const int pix = A.pix_index ? A.pix_index[ray] : F.ray_begin + (int)ray;
+    const int y = pix / F.W, x = pix - y * F.W;
+    const float dx = __fdiv_rn(__fsub_rn((float)x, F.cx), F.focal), dy = __fdiv_rn(-__fsub_rn((float)y, F.cy), F.focal);
+    float nrm[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const float* P = b ? F.pose_body : F.pose;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, P[4 * k]), __fmul_rn(dy, P[4 * k + 1])),
+                                      __fmul_rn(-1.0f, P[4 * k + 2]));
+            acc = __fadd_rn(acc, __fmul_rn(d, d));
+        }
+        nrm[b] = sqrtf(acc);
+    }
+    // inverse of the rank map: merged position -> evaluation index
+    unsigned char* inv = inv_s[wv];
+#pragma unroll
+    for (int m = 0; m < K; ++m) inv[A.ranks[ray * S + lane + 64 * m]] = (unsigned char)(lane + 64 * m);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool cbg = F.concate_bg != 0, two = F.fields == 2;
+    float Gh[3], Gc[3], bgc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        Gh[k] = A.d_rgb_head[ray * 3 + k];
+        Gc[k] = A.d_rgb_com ? A.d_rgb_com[ray * 3 + k] : 0.f;
+        bgc[k] = A.bg_u8 ? __fdiv_rn((float)A.bg_u8[(size_t)pix * 3 + k], 255.0f) : A.bg_f32[(size_t)pix * 3 + k];
+    }
+    // per owned position: everything the two images' backward needs
+    int ev[K];
+    float dz[K], sg_h[K], sg_t[K], ch[K][3], ct[K][3];
+    bool lastp[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int i = lane * K + k;
+        ev[k] = inv[i];
+        lastp[k] = i == S - 1;
+        const float z = A.z_all[ray * S + i];
+        dz[k] = lastp[k] ? F.last_dist : __fsub_rn(A.z_all[ray * S + i + 1], z);
+        const float4* sm = (const float4*)(A.samples + ((size_t)ray * S + ev[k]) * 8);
+        const float4 q0 = sm[0], q1 = sm[1];
+        sg_h[k] = q0.x; ch[k][0] = q0.y; ch[k][1] = q0.z; ch[k][2] = q0.w;
+        sg_t[k] = q1.x; ct[k][0] = q1.y; ct[k][1] = q1.z; ct[k][2] = q1.w;
+        if (cbg && lastp[k]) { ch[k][0] = bgc[0]; ch[k][1] = bgc[1]; ch[k][2] = bgc[2]; }
+    }
+    // weights + d/d(sigma) of one image over the merged samples: s (effective sigma), dist, q = colour . G per position
+    auto image_bwd = [&](const float (&s)[K], const float (&dist)[K], const float (&q)[K], float (&w)[K], float (&ds)[K]) {
+        float e[K], a[K], v[K], pre[K];
+        float prod = 1.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            e[k] = expf(-((fmaxf(s[k], 0.f) + 1e-6f) * dist[k]));
+            a[k] = 1.0f - e[k];
+            v[k] = 1.0f - a[k] + 1e-10f;
+            pre[k] = prod;                       // product of this lane's earlier positions
+            prod *= v[k];
+        }
+        const float T0 = wave_excl_prod(prod, lane);          // transmittance in front of this lane's first position
+        float wq_sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            w[k] = a[k] * (T0 * pre[k]);
+            wq_sum += w[k] * q[k];
+        }
+        const float suf0 = wave_suffix_sum_excl(wq_sum, lane);     // sum of w q over the later lanes
+        float later = 0.f;                                         // ... plus this lane's later positions
+#pragma unroll
+        for (int k = K - 1; k >= 0; --k) {
+            const float da = (T0 * pre[k]) * q[k] - (suf0 + later) / v[k];
+            ds[k] = da * dist[k] * e[k];
+            later += w[k] * q[k];
+        }
+    };
+    float d_sg_h[K], d_sg_t[K], d_ch[K][3], d_ct[K][3];
+    {   // head-only image
+        float s1[K], dist[K], q[K], w[K], ds[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float sh = fmaxf(sg_h[k], 0.f);
+            s1[k] = (cbg && lastp[k]) ? sh + 1e-6f : sh;
+            dist[k] = dz[k] * nrm[0];
+            q[k] = ch[k][0] * Gh[0] + ch[k][1] * Gh[1] + ch[k][2] * Gh[2];
+        }
+        image_bwd(s1, dist, q, w, ds);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool h_is_bg = cbg && lastp[k];
+            d_sg_h[k] = sg_h[k] > 0.f ? ds[k] : 0.f;
+            d_sg_t[k] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                d_ch[k][c] = h_is_bg ? 0.f : w[k] * Gh[c];
+                d_ct[k][c] = 0.f;
+            }
+        }
+    }
+    if (two) {   // composite image (run_nerf_com_trainExpLater.py:146-166)
+        float ss[K], dist[K], q[K], w[K], ds[K], sh[K], stt[K], den[K], wh[K], wt[K];
+        bool zero[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float sgt = (cbg && lastp[k]) ? 0.f : sg_t[k];
+            sh[k] = fmaxf(sg_h[k], 0.f);
+            stt[k] = fmaxf(sgt, 0.f);
+            if (cbg && lastp[k]) stt[k] += 1e-6f;
+            ss[k] = sh[k] + stt[k];
+            zero[k] = ss[k] == 0.f;
+            den[k] = zero[k] ? 1e-4f : ss[k];
+            wh[k] = sh[k] / den[k];
+            wt[k] = stt[k] / den[k];
+            dist[k] = dz[k] * nrm[1];
+            float cm[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) cm[c] = ch[k][c] * wh[k] + ct[k][c] * wt[k];
+            q[k] = cm[0] * Gc[0] + cm[1] * Gc[1] + cm[2] * Gc[2];
+        }
+        image_bwd(ss, dist, q, w, ds);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool h_is_bg = cbg && lastp[k];
+            const float gch = ch[k][0] * Gc[0] + ch[k][1] * Gc[1] + ch[k][2] * Gc[2];
+            const float gct = ct[k][0] * Gc[0] + ct[k][1] * Gc[1] + ct[k][2] * Gc[2];
+            const float dwh = w[k] * gch, dwt = w[k] * gct;
+            float dsh = ds[k] + dwh / den[k], dst = ds[k] + dwt / den[k];
+            if (!zero[k]) {
+                const float common = (dwh * sh[k] + dwt * stt[k]) / (den[k] * den[k]);
+                dsh -= common;
+                dst -= common;
+            }
+            if (sg_h[k] > 0.f) d_sg_h[k] += dsh;
+            if (sg_t[k] > 0.f && !(cbg && lastp[k])) d_sg_t[k] += dst;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (!h_is_bg) d_ch[k][c] += w[k] * Gc[c] * wh[k];
+                d_ct[k][c] += w[k] * Gc[c] * wt[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float4* out = (float4*)(A.dsamples + ((size_t)ray * S + ev[k]) * 8);
+        out[0] = make_float4(d_sg_h[k], d_ch[k][0], d_ch[k][1], d_ch[k][2]);
+        out[1] = make_float4(d_sg_t[k], d_ct[k][0], d_ct[k][1], d_ct[k][2]);
+    }
+}
+hipError_t launch_composite_bwd_hier(const CompositeBwdArgs& A, hipStream_t st) {
+    const int blocks = (A.frame.ray_count + 3) / 4;
+    const int K = (64 + A.frame.n_fine) / 64;
+    if (K == 2) hipLaunchKernelGGL(composite_bwd_hier_kernel<2>, dim3(blocks), dim3(256), 0, st, A);
+    else if (K == 3) hipLaunchKernelGGL(composite_bwd_hier_kernel<3>, dim3(blocks), dim3(256), 0, st, A);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ================================================================================================
 // weight gradients: C[M x N] += A[M x NP] * B[N x NP]^T, contraction over the sample points, split-K + atomics
 // ================================================================================================
 // One wave = one macro-tile of up to WG_MT x WG_NT 32x32 output tiles over a slice of the sample points: per

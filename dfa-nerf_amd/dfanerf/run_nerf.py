@@ -477,8 +477,9 @@ def train_step_loss_hip(nets, dataset, itr_obj, img_i, sel_yx, target_head, targ
         if d.get('_pose_torso_key') != key:
             d['_pose_torso_host'], d['_pose_torso_key'] = pose_torso.detach().cpu().numpy(), key
         pose_torso = d['_pose_torso_host']
+    # --hierarchical (build-side flag): the step differentiates row H (64 + N_importance samples, fine depths detached)
     frame = engine.make_frame(H, W, focal, cx, cy, d['_poses_host'][img_i], pose_torso, d['near'], d['far'],
-                              args.last_dist, 0, pix.numel(), args.N_samples, 0, 2, args.concate_bg)
+                              args.last_dist, 0, pix.numel(), args.N_samples, buf.n_fine, 2, args.concate_bg)
     bg = dataset[itr_obj]['bc_img'].reshape(-1, 3)
     zs = z_shape[0, itr_obj * 2:itr_obj * 2 + 2]
     za = z_app[0, itr_obj * 2:itr_obj * 2 + 2]
@@ -660,7 +661,8 @@ def train():
     from . import training
     # the 16-bit training tier is bf16 (f16, the inference throughput tier, has too little exponent range for gradients)
     tier = getattr(args, "hip_tier", "f32")
-    train_buf = training.TrainBuffers("bf16" if tier == "f16" else tier, args.N_rand, dev)
+    train_buf = training.TrainBuffers("bf16" if tier == "f16" else tier, args.N_rand, dev,
+                                      n_fine=args.N_importance if getattr(args, "hierarchical", False) else 0)
     if "PoseAttNet" in nets and _hip_signals_ok(args):
         train_buf.signal_trainer = training.SignalTrainer(nets["AudNet"], nets["ExpNet"], nets["AudAttNet"],
                                                           nets["PoseAttNet"], ds['auds'], ds['exp'], ds['poses'])

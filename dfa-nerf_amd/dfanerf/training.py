@@ -94,16 +94,20 @@ class PinnedUpload:
 
 
 class TrainBuffers:
-    """Device buffers of one training step, sized for `n_rays` (reused across steps)."""
+    """Device buffers of one training step, sized for `n_rays` rays of 64 + n_fine samples (reused across steps).
+    n_fine = 0: the reference's coarse step (MAIN:855-899); 64 / 128: the hierarchical variant (dfn_train_fwd_hier)."""
 
-    def __init__(self, tier, n_rays, device):
+    def __init__(self, tier, n_rays, device, n_fine=0):
         self.flat = None            # [955242] f32 copy of the decoder parameters (state_dict order), see bind()
         self.flat_views = None
         self.tier = TIERS[tier]
         if self.tier not in (0, 1):
             raise ValueError("the training step runs in the f32 or the bf16 tier (f16 is the inference tier: gradients "
                              "underflow its exponent range)")
-        self.n_rays, self.NP = n_rays, n_rays * 64
+        if n_fine not in (0, 64, 128):
+            raise ValueError("TrainBuffers: n_fine must be 0, 64 or 128")
+        self.n_fine, self.S = int(n_fine), 64 + int(n_fine)
+        self.n_rays, self.NP = n_rays, n_rays * self.S
         assert self.NP % 512 == 0, "N_rand must be a multiple of 8"
         dt = torch.bfloat16 if self.tier == 1 else torch.float32
         rows = lambda f, w: check(lib.dfn_train_rows(f, w), "dfn_train_rows")
@@ -114,6 +118,9 @@ class TrainBuffers:
         self.ws_sig = [torch.empty(rows(f, 5), dtype=torch.float32, device=device) for f in (0, 1)]
         self.samples = torch.empty(self.NP, 8, dtype=torch.float32, device=device)
         self.dsamples = torch.empty(self.NP, 8, dtype=torch.float32, device=device)
+        # hierarchical step: what the forward tells the compositing backward about the merge (depths, ranks)
+        self.z_all = torch.empty(n_rays, self.S, dtype=torch.float32, device=device) if n_fine else None
+        self.ranks = torch.empty(n_rays, self.S, dtype=torch.uint8, device=device) if n_fine else None
         self.packed = [torch.empty(check(lib.dfn_packed_bytes(self.tier, f), "packed"), dtype=torch.uint8, device=device)
                        for f in (0, 1)]
         self.packed_T = [torch.empty(check(lib.dfn_packed_bwd_bytes(self.tier, f), "packed_T"), dtype=torch.uint8,
@@ -162,10 +169,16 @@ class FusedTrainFn(torch.autograd.Function):
         rgb_c = torch.empty(n, 3, dtype=torch.float32, device=dev)
         bg_f32 = bg if bg.dtype == torch.float32 else None
         bg_u8 = bg if bg.dtype == torch.uint8 else None
-        check(lib.dfn_train_fwd(t, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias), bias_t,
-                                _ptr(bg_f32), _ptr(bg_u8), _ptr(pix_index), _ptr(rgb_h), _ptr(rgb_c),
-                                _ptr(buf.samples), _ptr(buf.act[0]), _ptr(buf.masks[0]), _ptr(buf.act[1]),
-                                _ptr(buf.masks[1]), st), "dfn_train_fwd")
+        if buf.n_fine:
+            check(lib.dfn_train_fwd_hier(t, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias), bias_t,
+                                         _ptr(bg_f32), _ptr(bg_u8), _ptr(pix_index), _ptr(rgb_h), _ptr(rgb_c),
+                                         _ptr(buf.samples), _ptr(buf.act[0]), _ptr(buf.masks[0]), _ptr(buf.act[1]),
+                                         _ptr(buf.masks[1]), _ptr(buf.z_all), _ptr(buf.ranks), st), "dfn_train_fwd_hier")
+        else:
+            check(lib.dfn_train_fwd(t, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias), bias_t,
+                                    _ptr(bg_f32), _ptr(bg_u8), _ptr(pix_index), _ptr(rgb_h), _ptr(rgb_c),
+                                    _ptr(buf.samples), _ptr(buf.act[0]), _ptr(buf.masks[0]), _ptr(buf.act[1]),
+                                    _ptr(buf.masks[1]), st), "dfn_train_fwd")
         ctx.buf, ctx.frame, ctx.bg, ctx.pix = buf, frame, bg, pix_index
         ctx.keep = (sh, stt, zs, za)
         ctx.sig_shapes = (sig_head.shape, sig_torso.shape)
@@ -180,8 +193,13 @@ class FusedTrainFn(torch.autograd.Function):
         d_c = d_c.contiguous().float()
         bg_f32 = bg if bg.dtype == torch.float32 else None
         bg_u8 = bg if bg.dtype == torch.uint8 else None
-        check(lib.dfn_composite_bwd(C.byref(frame), _ptr(ctx.pix), _ptr(bg_f32), _ptr(bg_u8), _ptr(buf.samples),
-                                    _ptr(d_h), _ptr(d_c), _ptr(buf.dsamples), st), "dfn_composite_bwd")
+        if buf.n_fine:
+            check(lib.dfn_composite_bwd_hier(C.byref(frame), _ptr(ctx.pix), _ptr(bg_f32), _ptr(bg_u8), _ptr(buf.samples),
+                                             _ptr(buf.z_all), _ptr(buf.ranks), _ptr(d_h), _ptr(d_c), _ptr(buf.dsamples), st),
+                  "dfn_composite_bwd_hier")
+        else:
+            check(lib.dfn_composite_bwd(C.byref(frame), _ptr(ctx.pix), _ptr(bg_f32), _ptr(bg_u8), _ptr(buf.samples),
+                                        _ptr(d_h), _ptr(d_c), _ptr(buf.dsamples), st), "dfn_composite_bwd")
         g_bias = torch.empty(buf.nb[0] + buf.nb[1], dtype=torch.float32, device=dev)
         main = torch.cuda.current_stream(dev)
         # (with more than one rank RCCL brings its own stream: the head field's weight gradients stay on the main stream then,
@@ -521,14 +539,18 @@ class _SignalFn(torch.autograd.Function):
 
 
 def render_train(dec, buf, frame, bg, pix_index, sig_head, sig_torso, z_shape, z_app, signal_trainer=None):
-    """Differentiable (w.r.t. the decoder parameters and the two signals) coarse two-field render of the
-    pixels `pix_index` [n] (int32, y*W+x).  Returns rgb_head, rgb_com [n,3].  Fold and its backward run in HIP, the
+    """Differentiable (w.r.t. the decoder parameters and the two signals) two-field render of the
+    pixels `pix_index` [n] (int32, y*W+x): coarse (frame.n_fine == 0, the reference's step) or hierarchical (64 / 128
+    fine samples at detached depths; buf = TrainBuffers(..., n_fine=...)).  Returns rgb_head, rgb_com [n,3].  Fold and its backward run in HIP, the
     decoder gradients are deposited into .grad by the backward (FusedTrainFn).  One forward per backward: the recorded
     activations live in `buf` and the next forward overwrites them.  signal_trainer: the SignalTrainer whose encode()
     produced BOTH signals for this call (None otherwise): d(signal) then stays on its streams (FusedTrainFn.backward)."""
     if frame.ray_count != buf.n_rays or (pix_index is not None and pix_index.numel() != buf.n_rays):
         raise ValueError(f"render_train: the buffers were sized for {buf.n_rays} rays, the frame has {frame.ray_count}"
                          f" (pix_index {None if pix_index is None else pix_index.numel()})")
+    if frame.n_fine != buf.n_fine or frame.fields != 2:
+        raise ValueError(f"render_train: the buffers were sized for n_fine = {buf.n_fine}, the frame asks for "
+                         f"{frame.n_fine} (fields {frame.fields}: the training step renders both fields)")
     buf.bind(dec)
     if not sig_head.requires_grad:      # keep the Function in the graph even when no conditioning net trains
         sig_head = sig_head.detach().requires_grad_(True)

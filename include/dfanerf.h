@@ -154,6 +154,22 @@ int dfn_train_fwd(int tier, const DfnFrame* frame, const void* packed_head, cons
                   const float* bias_head, const float* bias_torso, const float* bg_f32, const uint8_t* bg_u8,
                   const int32_t* pix_index, float* rgb_head, float* rgb_com, float* samples, void* act_head,
                   uint32_t* masks_head, void* act_torso, uint32_t* masks_torso, void* stream);
+/* The hierarchical variant of the training forward (SURVEY.md 8(a) row H under autograd; 8(d) "report also the hierarchical
+ * variant"; the composition of MAIN:119-124 `N_importance` + HELP:537-581 sample_pdf in the NeRF lineage): frame->n_fine = 64
+ * or 128.  The fine depths are constants (sample_pdf's output is detached, as the lineage does), the loss sees the images
+ * composited over the merged 64 + n_fine samples.  Every point is evaluated once with the recorder on, in EVALUATION order
+ * (per ray: the 64 coarse points, then the n_fine fine ones): NP = (64 + n_fine) * ray_count for samples / act / masks /
+ * dy_T.  Two more outputs feed dfn_composite_bwd_hier: z_all f32 [ray_count][64 + n_fine] (merged, sorted depths) and
+ * ranks u8 [ray_count][64 + n_fine] (merged rank of evaluated point i).  dfn_mlp_bwd / dfn_weight_bias_grad / ... are
+ * the same calls with that NP. */
+int dfn_train_fwd_hier(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
+                       const float* bias_head, const float* bias_torso, const float* bg_f32, const uint8_t* bg_u8,
+                       const int32_t* pix_index, float* rgb_head, float* rgb_com, float* samples, void* act_head,
+                       uint32_t* masks_head, void* act_torso, uint32_t* masks_torso, float* z_all, uint8_t* ranks,
+                       void* stream);
+int dfn_composite_bwd_hier(const DfnFrame* frame, const int32_t* pix_index, const float* bg_f32, const uint8_t* bg_u8,
+                           const float* samples, const float* z_all, const uint8_t* ranks, const float* d_rgb_head,
+                           const float* d_rgb_com, float* dsamples, void* stream);
 /* The pixel draw of a training step in one launch: replaces MAIN:786-820 (np.random.choice(replace=False) over the image,
  * or over (face rect | lower half) and its complement with --sample_rate > 0).  pix_index [n] receives n DISTINCT pixel
  * ids y*W+x, uniform over the subsets, in random order; with rect_num > 0 the first rect_num lie inside (rect | lower

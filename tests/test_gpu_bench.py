@@ -1,0 +1,61 @@
+"""bench.py as the driver runs it: one JSON line with the contract's keys - and the multi-rank forms on a one-GPU box
+(DFN_BENCH_ONE_GPU=1: every rank on GPU 0 over gloo; functional, not a measurement): a plain `python bench.py --gpus 2`
+launches its own ranks (the driver's N = 1 command shape with N > 1), the torchrun form keeps working."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+FAST = ["--steps", "3", "--warmup", "1", "--sustain-seconds", "0", "--no-extra", "--no-cpu-baseline"]
+
+
+def _line(cmd, env=None, timeout=900):
+    r = subprocess.run(cmd, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_and_the_parity_binding():
+    out = _line([sys.executable, BENCH] + FAST)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["dtype"] == "f16" and "workload" in out["config"]
+    assert 0.0 < out["roofline"]["frac"] < 1.0 and out["roofline"]["bound"] == "mfma"
+    # 64 rays of the last timed frame against the oracle, in the timed tier (f16: the 49.4 dB clause of DESIGN.md 3)
+    pc = out["parity_check"]
+    assert "error" not in pc, pc
+    assert pc["rays"] == 64 and pc["psnr_db"] >= 49.4 and pc["max_abs_rgb"] < 2e-2, pc
+
+
+@pytest.mark.parametrize("workload", ["c2", "c5", "c4"])
+def test_plain_python_launches_its_own_ranks(workload):
+    """`python bench.py --gpus 2` with no torchrun environment: two ranks, async double-buffered gather (c2), one gather
+    per 8-frame batch (c5), the gradient bucket (c4)."""
+    env = {"DFN_BENCH_ONE_GPU": "1"}
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    out = _line([sys.executable, BENCH, "--gpus", "2", "--workload", workload] + FAST, env=env)
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["backend"] == "gloo"
+    assert len(out["per_rank"]["ms_per_step"]) == 2 and all(v > 0 for v in out["per_rank"]["ms_per_step"])
+    if workload != "c4":
+        assert out["gather"]["async"] and out["gather"]["ms_alone"] > 0
+        assert out["config"]["frames_per_step"] == (8 if workload == "c5" else 1)
+        assert out["scaling"] == "strong"
+    else:
+        assert out["scaling"] == "weak"
+
+
+def test_torchrun_form_still_works():
+    from conftest import free_port
+    out = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                 "127.0.0.1", "--master-port", str(free_port()), BENCH, "--gpus", "2", "--workload", "c3"] + FAST,
+                env={"DFN_BENCH_ONE_GPU": "1"})
+    assert out["n_gpus"] == 2 and out["config"]["fields"] == 2 and len(out["per_rank"]["render_kernel_ms"]) == 2
