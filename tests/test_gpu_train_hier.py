@@ -10,7 +10,6 @@ import pytest
 import torch
 
 import dfa_oracle as O
-from dfanerf import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -73,9 +72,21 @@ def test_composite_backward_hier_vs_autograd(scene, n_fine):
     np.testing.assert_allclose(got, ref, atol=2e-5 * np.abs(ref).max(), rtol=2e-4)
 
 
+def _signals(states, scene):
+    """the conditioning signals of frame 3 as the reference's encoders produce them (the inputs golden G8 trains on: the
+    regime the bf16 tier's tolerances are stated for - with arbitrary large signals the step's gradient is ill-conditioned
+    and bf16 operands move it by tens of percent, coarse and hierarchical alike: tools/diag_train_tiers.py)"""
+    onets = {k: O.params_to_torch(v) for k, v in states.items() if k != "decoder"}
+    with torch.no_grad():
+        sh = O.encode_signal(onets, t(scene["aud"]), t(scene["exp"]), 3, 0, 300000, 4, 8)[0].reshape(1, 96)
+        st = O.encode_signal_torso(onets, t(scene["poses"]), 3, 0, 300000, 8, 8).reshape(42)
+    return sh.clone(), st.clone()
+
+
 def _hier_step(states, scene, latents, tier, n_fine, n, seed=0):
     """one hierarchical forward + backward on n rays -> (rgb_head, rgb_com, z_all, ranks, sig grads, decoder grads)"""
     from dfanerf import engine, training
+    sig_h, sig_t = _signals(states, scene)
     dev = torch.device("cuda")
     H, W = scene["H"], scene["W"]
     zs, za = [t(v).to(dev) for v in latents]
@@ -85,8 +96,8 @@ def _hier_step(states, scene, latents, tier, n_fine, n, seed=0):
                               0.9, 1e10, 0, n, 64, n_fine, 2, True)
     tgt = torch.rand(n, 3, generator=torch.Generator().manual_seed(5))
     dec = _decoder(states, dev)
-    sh = t(synth.synth_tensor(0, "g3/sig", (1, 96), 0.8)).to(dev).requires_grad_(True)
-    st = t(synth.synth_tensor(0, "g3/sigt", (42,), 0.8)).to(dev).requires_grad_(True)
+    sh = sig_h.to(dev).requires_grad_(True)
+    st = sig_t.to(dev).requires_grad_(True)
     buf = training.TrainBuffers(tier, n, dev, n_fine=n_fine)
     rh, rc = training.render_train(dec, buf, frame, bg, pix.to(dev, torch.int32), sh, st, zs[0, :2], za[0, :2])
     loss = ((rh - tgt.to(dev)) ** 2).mean() + ((rc - tgt.to(dev)) ** 2).mean()
@@ -194,8 +205,7 @@ def test_hierarchical_step_is_bit_reproducible_and_trains(states, scene, latents
     dec = _decoder(states, dev)
     opt = run_nerf.make_adam(dec.parameters(), 5e-4)
     buf = training.TrainBuffers("bf16", n, dev, n_fine=128)
-    sh = t(synth.synth_tensor(0, "g3/sig", (1, 96), 0.8)).to(dev)
-    st = t(synth.synth_tensor(0, "g3/sigt", (42,), 0.8)).to(dev)
+    sh, st = [x.to(dev) for x in _signals(states, scene)]
     losses = []
     for _ in range(10):
         rh, rc = training.render_train(dec, buf, frame, bg, pix, sh, st, zs[0, :2], za[0, :2])
