@@ -272,33 +272,60 @@ class FrameRenderer:
             return eng.render_u8(pk, bias, fr, self.bg, pix_index=pix_index, out_head=oh, out_com=oc)
         return eng.render(pk, bias, fr, self.bg, pix_index=pix_index, out_head=oh, out_com=oc)
 
-    def render_image(self, pose, pose_body, signal, signal_torso, fields=2, out_u8=False):
-        """Whole frame, sharded over the ranks when torch.distributed is initialised -> [H,W,3] images
-        (float32, or uint8 with out_u8: 76 KB instead of 304 KB per rank in the gather).  ONE collective per frame:
-        the kernel writes both images into one padded [n_img, per, 3] shard, all_gather_into_tensor moves it."""
+    def render_image_begin(self, pose, pose_body, signal, signal_torso, fields=2, out_u8=False):
+        """Start a whole frame: render this rank's ray shard and ISSUE the gather (async_op=True: it runs on the backend's
+        own stream) -> a handle for render_image_end().  Two sets of shard / gather buffers alternate, so the gather of
+        frame k runs underneath the render of frame k + 1: call begin(k + 1) before end(k).  ONE
+        collective per frame: the kernel writes both images into one padded [n_img, per, 3] shard."""
         import torch.distributed as dist
         R = self.H * self.W
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            world = dist.get_world_size()
-            begin, count, per = parallel.shard_range(R, world, dist.get_rank())
-            n_img = 2 if fields == 2 else 1
-            key = (n_img, per, out_u8, world)
-            if getattr(self, "_shard_key", None) != key:
-                dt = torch.uint8 if out_u8 else torch.float32
-                self._shard = torch.zeros(n_img, per, 3, dtype=dt, device=self.bg.device)
-                self._gathered = torch.empty(world, n_img, per, 3, dtype=dt, device=self.bg.device)
-                self._shard_key = key
-            out = (self._shard[0, :count], self._shard[1, :count] if fields == 2 else None)
-            if count:
-                self.render(pose, pose_body, signal, signal_torso, begin, count, fields=fields, out_u8=out_u8, out=out)
-            # the output as the CONCATENATION of the shards along dim 0 (the stacked [world, ...] form is an NCCL / RCCL
-            # extension that gloo rejects)
-            dist.all_gather_into_tensor(self._gathered.view(world * n_img, per, 3), self._shard)
-            g = self._gathered.permute(1, 0, 2, 3).reshape(n_img, world * per, 3)[:, :R]
-            rh, rc = g[0], (g[1] if fields == 2 else None)
-        else:
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
             rh, rc = self.render(pose, pose_body, signal, signal_torso, fields=fields, out_u8=out_u8)
+            return {"images": (rh, rc)}
+        world = dist.get_world_size()
+        begin, count, per = parallel.shard_range(R, world, dist.get_rank())
+        n_img = 2 if fields == 2 else 1
+        key = (n_img, per, out_u8, world)
+        if getattr(self, "_shard_key", None) != key:
+            dt = torch.uint8 if out_u8 else torch.float32
+            self._slots = [{"shard": torch.zeros(n_img, per, 3, dtype=dt, device=self.bg.device),
+                            "gathered": torch.empty(world, n_img, per, 3, dtype=dt, device=self.bg.device), "work": None}
+                           for _ in range(2)]
+            self._flip, self._shard_key = 0, key
+        self._flip ^= 1
+        slot = self._slots[self._flip]
+        if slot["work"] is not None:                   # the frame that used these buffers two frames ago was never finished
+            slot["work"].wait()
+            slot["work"] = None
+        shard = slot["shard"]
+        out = (shard[0, :count], shard[1, :count] if fields == 2 else None)
+        if count:
+            self.render(pose, pose_body, signal, signal_torso, begin, count, fields=fields, out_u8=out_u8, out=out)
+        # the output as the CONCATENATION of the shards along dim 0 (the stacked [world, ...] form is an NCCL / RCCL
+        # extension that gloo rejects)
+        slot["work"] = dist.all_gather_into_tensor(slot["gathered"].view(world * n_img, per, 3), shard, async_op=True)
+        return {"slot": slot, "n_img": n_img, "per": per, "world": world, "fields": fields}
+
+    def render_image_end(self, h):
+        """Finish a frame started by render_image_begin: order the current stream behind its gather -> [H,W,3] images
+        (views of the gather buffer: valid until the second render_image_begin after this frame's)."""
+        R = self.H * self.W
+        if "images" in h:
+            rh, rc = h["images"]
+        else:
+            slot = h["slot"]
+            if slot["work"] is not None:
+                slot["work"].wait()
+                slot["work"] = None
+            g = slot["gathered"].permute(1, 0, 2, 3).reshape(h["n_img"], h["world"] * h["per"], 3)[:, :R]
+            rh, rc = g[0], (g[1] if h["fields"] == 2 else None)
         return rh.reshape(self.H, self.W, 3), (rc.reshape(self.H, self.W, 3) if rc is not None else None)
+
+    def render_image(self, pose, pose_body, signal, signal_torso, fields=2, out_u8=False):
+        """Whole frame, sharded over the ranks when torch.distributed is initialised -> [H,W,3] images
+        (float32, or uint8 with out_u8: 76 KB instead of 304 KB per rank in the gather).  begin + end in one call; the
+        frame loops call the two halves themselves to overlap a frame's gather with the next frame's render."""
+        return self.render_image_end(self.render_image_begin(pose, pose_body, signal, signal_torso, fields, out_u8))
 
 
 def run_network(inputs, viewdirs, decoder, z_shape, z_app, signal, head_or_torso='head'):
@@ -623,6 +650,14 @@ def train():
             enc = engine.SignalEncoder(nets["AudNet"], nets["ExpNet"], nets["AudAttNet"], nets["PoseAttNet"],
                                        ds['auds'], ds['exp'], ds['poses'])
         smoothed = global_step >= args.nosmo_iters
+        def finish(handle, img_i):
+            rgb8_head, rgb8 = renderer.render_image_end(handle)
+            if rank == 0:
+                writer.submit([rgb8, rgb8_head],
+                              [os.path.join(outdir_com, tag.format(img_i)),
+                               os.path.join(outdir_head, tag.format(img_i)) if outdir_head else None], keep=rgbs)
+                print('Saved test img at {}'.format(os.path.join(outdir_com, tag.format(img_i))))
+        pending = None
         for img_i in frame_ids:
             with torch.no_grad():
                 if enc is not None:
@@ -634,13 +669,14 @@ def train():
                                            nets["AudAttNet"], global_step, args, len_sig, embed_fn=embed_fn)
                     signal_torso = encode_signal_torso(datasets, itr_obj, img_i, nets.get("PoseAttNet"), global_step,
                                                        args, len_sig, embed_fn=embed_fn)
-                # uint8 straight from the kernel epilogue (to8b fused), gathered as uint8 across the ranks
-                rgb8_head, rgb8 = renderer.render_image(poses_host[img_i], body_host, signal, signal_torso, out_u8=True)
-            if rank == 0:
-                writer.submit([rgb8, rgb8_head],
-                              [os.path.join(outdir_com, tag.format(img_i)),
-                               os.path.join(outdir_head, tag.format(img_i)) if outdir_head else None], keep=rgbs)
-                print('Saved test img at {}'.format(os.path.join(outdir_com, tag.format(img_i))))
+                # uint8 straight from the kernel epilogue (to8b fused), gathered as uint8 across the ranks; pipelined by one
+                # frame: this frame's render is enqueued BEFORE the previous frame's gather is waited for
+                handle = renderer.render_image_begin(poses_host[img_i], body_host, signal, signal_torso, out_u8=True)
+                if pending is not None:
+                    finish(*pending)
+                pending = (handle, img_i)
+        if pending is not None:
+            finish(*pending)
         writer.drain()
         return rgbs
 

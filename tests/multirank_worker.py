@@ -55,6 +55,16 @@ def main():
         fh, fc = R.render(pose, pose_body, sig, sigt, fields=2, out_u8=out_u8)                # this rank alone, all rays
         ok_img &= bool(torch.equal(rh.reshape(-1, 3), fh.reshape(-1, 3)) and torch.equal(rc.reshape(-1, 3), fc.reshape(-1, 3)))
 
+    # the two halves as the frame loops use them: frame k + 1 is begun (rendered, its gather issued) BEFORE frame k is
+    # finished - two gathers in flight on the two buffer sets - and a third frame reuses the first set
+    hs = [R.render_image_begin(sc["poses"][f], pose_body, sig, sigt, fields=2, out_u8=True) for f in (0, 2)]
+    got = [tuple(x.clone() for x in R.render_image_end(hs[0]))]
+    hs.append(R.render_image_begin(sc["poses"][3], pose_body, sig, sigt, fields=2, out_u8=True))
+    got += [tuple(x.clone() for x in R.render_image_end(h)) for h in hs[1:]]
+    for f, (gh, gc) in zip((0, 2, 3), got):
+        fh, fc = R.render(sc["poses"][f], pose_body, sig, sigt, fields=2, out_u8=True)
+        ok_img &= bool(torch.equal(gh.reshape(-1, 3), fh) and torch.equal(gc.reshape(-1, 3), fc))
+
     # ---- training: replicas that start DIFFERENT, broadcast, three data-parallel steps on different frames ---------------
     mods = modules(rank)                                   # rank 1 starts from other values
     opts = {k: run_nerf.make_adam(m.parameters(), 5e-4) for k, m in mods.items()}
