@@ -1,17 +1,28 @@
 #!/bin/bash
 # Build libdfanerf.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+#   build.sh          incremental: an object is rebuilt when the HASH of what it is made from changes
+#   build.sh --clean  from scratch
+# An object's stamp = sha256 of its own source, every header of csrc/ and include/, the compiler flags and hipcc's version.
+# (Timestamps would reuse a stale object whenever a checkout puts an older header next to a newer .o: the objects travel
+# with the tree to the GPU box, the file times do not mean anything there.)
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 SRC="$HERE/csrc"
 OUT="$HERE/dfanerf/libdfanerf.so"
 OBJ="$HERE/build"
+if [ "$1" = "--clean" ]; then rm -rf "$OBJ" "$OUT"; fi
 mkdir -p "$OBJ"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -I$SRC -I$HERE/../include"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -I$SRC -I$HERE/../include $DFN_EXTRA_FLAGS"
+HDR_HASH="$( (cat "$SRC"/*.h "$HERE"/../include/*.h; echo "$FLAGS" | sed "s#$HERE#.#g"; hipcc --version 2>/dev/null | head -2) | sha256sum | cut -d' ' -f1)"
+UNITS="dfn_render dfn_render_f32 dfn_render_bf16 dfn_render_f16 dfn_misc dfn_api dfn_train dfn_bwd_bf16 dfn_wgrad_bf16 dfn_signal"
 pids=()
-for f in dfn_render dfn_render_f32 dfn_render_bf16 dfn_render_f16 dfn_misc dfn_api dfn_train dfn_bwd_bf16 dfn_wgrad_bf16 dfn_signal; do
-  ( if [ ! -f "$OBJ/$f.o" ] || [ -n "$(find "$SRC" "$HERE/../include" -newer "$OBJ/$f.o" \( -name '*.h' -o -name "$f.hip" \) -print -quit)" ]; then
+for f in $UNITS; do
+  ( want="$HDR_HASH $(sha256sum < "$SRC/$f.hip" | cut -d' ' -f1)"
+    if [ ! -f "$OBJ/$f.o" ] || [ "$(cat "$OBJ/$f.stamp" 2>/dev/null)" != "$want" ]; then
+      rm -f "$OBJ/$f.stamp"
       EXTRA=""; case "$f" in dfn_render_*) EXTRA="--save-temps=obj";; esac     # keep the ISA of the render kernels for the checks below
       hipcc $FLAGS $EXTRA -c "$SRC/$f.hip" -o "$OBJ/$f.o"
+      echo "$want" > "$OBJ/$f.stamp"
     fi ) &
   pids+=($!)
 done
@@ -27,5 +38,6 @@ for t in bf16 f16; do
   fi
 done
 rm -f "$OBJ"/*-hip-amdgcn-*.o "$OBJ"/*.hipi "$OBJ"/*.bc "$OBJ"/*.out "$OBJ"/*.resolution.txt "$OBJ"/*.hipfb "$OBJ"/*-host-*.s      # --save-temps leftovers (the device ISA stays)
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/dfn_render.o "$OBJ"/dfn_render_f32.o "$OBJ"/dfn_render_bf16.o "$OBJ"/dfn_render_f16.o "$OBJ"/dfn_misc.o "$OBJ"/dfn_api.o "$OBJ"/dfn_train.o "$OBJ"/dfn_bwd_bf16.o "$OBJ"/dfn_wgrad_bf16.o "$OBJ"/dfn_signal.o "$OBJ"/dfn_plan.o
+OBJS=""; for f in $UNITS; do OBJS="$OBJS $OBJ/$f.o"; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" $OBJS "$OBJ/dfn_plan.o"
 echo "built $OUT"

@@ -90,9 +90,16 @@ int wgrad_ksplit_bf16() {              // slices of the points per GEMM, bf16 ti
 }
 
 template <typename T> hipError_t upload(T** dev, const T* host, size_t n) {
-    hipError_t e = hipMalloc((void**)dev, n * sizeof(T));
+    T* d = nullptr;
+    hipError_t e = hipMalloc((void**)&d, n * sizeof(T));
     if (e != hipSuccess) return e;
-    return hipMemcpy(*dev, host, n * sizeof(T), hipMemcpyHostToDevice);
+    e = hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {          // never publish a table that was not filled
+        (void)hipFree(d);
+        return e;
+    }
+    *dev = d;
+    return hipSuccess;
 }
 WgradEntry& wgrad_of(int field) {
     std::lock_guard<std::mutex> lk(g_plan_mu);
@@ -549,16 +556,29 @@ static int weight_grad_impl(int tier, int field, const void* dy_T, const void* a
             std::vector<WOp> ops(w.ops.size());
             for (size_t i = 0; i < ops.size(); ++i)
                 ops[i] = WOp{w.ops[i].a_row, w.ops[i].M, w.ops[i].b_row, w.ops[i].N, w.ops[i].c_off, w.ops[i].bias_owner};
-            hipError_t e = upload(&w.ops_dev, ops.data(), ops.size());
-            if (e == hipSuccess) e = upload(&w.map_dev, w.map.data(), w.map.size());
-            if (e == hipSuccess) e = upload(&w.prefix_dev, w.prefix.data(), w.prefix.size());
-            if (e == hipSuccess && !w.rows_dev) e = upload(&w.rows_dev, w.bias_rows.data(), w.bias_rows.size());
             std::vector<int> order(ops.size());
             for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
             std::stable_sort(order.begin(), order.end(),
                              [&](int a, int b) { return ops[a].M + ops[a].N > ops[b].M + ops[b].N; });
-            if (e == hipSuccess) e = upload(&w.order_dev, order.data(), order.size());
-            if (e != hipSuccess) return hip_fail(e, "upload(wgrad plan)");
+            // upload into temporaries and publish every pointer only after ALL uploads succeeded: the guard above is keyed on
+            // ops_dev, and a later call must never launch with a table that is still null
+            WOp* d_ops = nullptr;
+            int32_t *d_map = nullptr, *d_rows = nullptr;
+            int *d_prefix = nullptr, *d_order = nullptr;
+            hipError_t e = upload(&d_ops, ops.data(), ops.size());
+            if (e == hipSuccess) e = upload(&d_map, w.map.data(), w.map.size());
+            if (e == hipSuccess) e = upload(&d_prefix, w.prefix.data(), w.prefix.size());
+            if (e == hipSuccess && !w.rows_dev) e = upload(&d_rows, w.bias_rows.data(), w.bias_rows.size());
+            if (e == hipSuccess) e = upload(&d_order, order.data(), order.size());
+            if (e != hipSuccess) {
+                (void)hipFree(d_ops); (void)hipFree(d_map); (void)hipFree(d_prefix); (void)hipFree(d_rows); (void)hipFree(d_order);
+                return hip_fail(e, "upload(wgrad plan)");
+            }
+            w.map_dev = d_map;
+            w.prefix_dev = d_prefix;
+            if (d_rows) w.rows_dev = d_rows;
+            w.order_dev = d_order;
+            w.ops_dev = d_ops;
         }
     }
     // Split-K without atomics: every (GEMM, slice of the points) writes its own slice of the partial arrays in the
@@ -653,10 +673,16 @@ int dfn_signal_grad(int tier, int field, const float* params, const void* dy_T, 
                 rows[i] = w.bias_rows[elems[i]];
                 if (rows[i] < 0 || n % 64) return fail(DFN_E_ARG, "internal: a signal-term bias element without a gradient row");
             }
-            hipError_t e = upload(&w.sig_rows_dev, rows.data(), rows.size());
-            if (e == hipSuccess) e = upload(&w.sig_elems_dev, el.data(), el.size());
-            if (e != hipSuccess) return hip_fail(e, "upload(signal rows)");
+            int32_t *d_rows = nullptr, *d_el = nullptr;      // published together, after both uploads succeeded
+            hipError_t e = upload(&d_rows, rows.data(), rows.size());
+            if (e == hipSuccess) e = upload(&d_el, el.data(), el.size());
+            if (e != hipSuccess) {
+                (void)hipFree(d_rows); (void)hipFree(d_el);
+                return hip_fail(e, "upload(signal rows)");
+            }
             w.n_sig = n;
+            w.sig_elems_dev = d_el;
+            w.sig_rows_dev = d_rows;
         }
     }
     float* parts = workspace;

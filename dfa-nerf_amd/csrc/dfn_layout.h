@@ -13,7 +13,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define DFN_HD __host__ __device__ inline
 #else
 #define DFN_HD inline

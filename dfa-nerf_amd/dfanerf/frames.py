@@ -143,12 +143,15 @@ class PixelSampler:
         if not self.on_gpu or HW >= (1 << 18) or self.n > self.CANDIDATES // 2:
             return False
         frac = 1.0 - np.exp(-self.CANDIDATES / HW)               # expected share of a class's pixels among the candidates
+        # the distinct candidates that land in a class are (nearly) Poisson with mean m = area * frac: ask for six standard
+        # deviations of head-room, so that a shortfall (the kernel would leave output slots unwritten) is a < 1e-9 event
+        enough = lambda m, need: m - 6.0 * np.sqrt(max(m, 0.0)) >= need
         if self.rect_num == 0:
-            return HW * frac >= 1.25 * self.n
+            return enough(HW * frac, self.n)
         if rect_host is None:
             return False
         a_in = self._inside_area(rect_host)
-        return a_in * frac >= 1.25 * self.rect_num and (HW - a_in) * frac >= 1.25 * (self.n - self.rect_num)
+        return enough(a_in * frac, self.rect_num) and enough((HW - a_in) * frac, self.n - self.rect_num)
 
     # ---- the torch path (CPU tests, tiny images) ----------------------------------------------------------------------
     def _draw_torch(self, rect):
@@ -192,7 +195,7 @@ class PixelSampler:
         main = torch.cuda.current_stream()
         if self.pipeline and (self.rect_num == 0 or frame is not None):
             if self._ring is None:
-                self._ring = [torch.empty_like(self.out) for _ in range(3)]
+                self._ring = [torch.zeros_like(self.out) for _ in range(3)]      # (a valid pixel id even if a slot were ever left unwritten)
                 if self._side is None:
                     self._side = torch.cuda.Stream(device=self.device)
                 self._side.wait_stream(main)
@@ -206,7 +209,7 @@ class PixelSampler:
                 self._side.wait_event(self._done[k])
             out, stream = self._ring[k], self._side
         else:
-            out, stream = torch.empty_like(self.out), main          # a fresh tensor per draw: the previous one may still be in use
+            out, stream = torch.zeros_like(self.out), main          # a fresh tensor per draw: the previous one may still be in use
         check(lib.dfn_sample_pixels(self.H, self.W, self.n, self.rect_num, rect_ptr, C.c_uint64(self.seed),
                                     C.c_uint64(self.counter), C.c_void_p(out.data_ptr()), None,
                                     C.c_void_p(stream.cuda_stream)), "dfn_sample_pixels")

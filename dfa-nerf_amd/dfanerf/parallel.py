@@ -67,7 +67,9 @@ def broadcast_replicas(nets, opts, extra=(), src=0, group=None):
             for t in list(nets[k].parameters()) + list(nets[k].buffers()):
                 dist.broadcast(t.data, src=src, group=group)
         for k in sorted(opts):
-            sd = [opts[k].state_dict()] if dist.get_rank(group) == src else [None]
+            # through the HOST: a pickled device tensor unpickles onto the SOURCE rank's device on every receiver (each rank
+            # would open a context and allocate on GPU `src`); load_state_dict casts to the parameters' device
+            sd = [_to_device(opts[k].state_dict(), "cpu")] if dist.get_rank(group) == src else [None]
             dist.broadcast_object_list(sd, src=src, group=group)
             if dist.get_rank(group) != src:
                 dev = next(iter(nets[k].parameters())).device if k in nets else None

@@ -143,10 +143,20 @@ def _need_device(name, *tensors):
         raise RuntimeError(f"{name} runs the HIP kernel and needs device tensors (there is no CPU fallback)")
 
 
+def _forward_only(name, *tensors):
+    """These stand-alone building blocks are forward-only HIP launches.  Under autograd a silently detached result would
+    give a graph-less loss (an opaque 'does not require grad' at backward(), or a dropped gradient term): say so here."""
+    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
+        raise RuntimeError(f"{name} is forward only (a HIP launch outside autograd): an input requires grad.  The "
+                           "differentiable renderer is training.render_train (fused forward + backward); wrap inference "
+                           "calls in torch.no_grad()")
+
+
 def composite_function(sigma, feat):
     """sigma [K,B,R,S], feat [K,B,R,S,3] -> sigma_sum [B,R,S], feat_weighted [B,R,S,3]  (dfn_composite; forward only:
     the differentiable compositing of the training step is inside the fused renderer, training.FusedTrainFn)."""
     _need_device("composite_function", sigma, feat)
+    _forward_only("composite_function", sigma, feat)
     from . import engine
     return engine.composite(sigma.detach(), feat.detach())
 
@@ -154,6 +164,7 @@ def composite_function(sigma, feat):
 def calc_volume_weights(z_vals, ray_vector, sigma, last_dist=1e10):
     """z [B,R,S], ray_vector [B,R,3], sigma [B,R,S] -> weights [B,R,S]  (dfn_volume_weights; forward only)."""
     _need_device("calc_volume_weights", z_vals, ray_vector, sigma)
+    _forward_only("calc_volume_weights", z_vals, ray_vector, sigma)
     from . import engine
     return engine.volume_weights(z_vals.detach(), ray_vector.detach(), sigma.detach(), last_dist)
 
@@ -166,6 +177,10 @@ def render_rays(decoder, p_i, r_i, z_shape_i, z_app_i, signal, head_or_torso, ba
     HIP launch: dfn_decoder_fwd, dfn_composite, dfn_volume_weights); the training step differentiates the fused
     renderer instead (training.render_train)."""
     S = args.N_samples + (args.N_importance if coarse_or_fine == 'fine' else 0)
+    # a reference-style training loop hands in signals that carry a graph (AudNet / AudAttNet outputs): refuse instead of
+    # returning a graph-less image whose loss fails - or silently drops this term - at backward()
+    _forward_only("render_rays", p_i, r_i, z_shape_i, z_app_i, bc_rgb, view_dir, z_vals,
+                  *(signal if isinstance(signal, (list, tuple)) else [signal]))
     with torch.no_grad():
         feat_i, sigma_i = decoder(p_i, r_i, z_shape_i, z_app_i, signal, head_or_torso)
         sigma_i = sigma_i.reshape(batch_size, -1, S)
@@ -720,6 +735,10 @@ def train():
     sampler = frames.PixelSampler(H, W, args.N_rand, args.sample_rate, dev, seed=1234 + rank,
                                   rects=ds['sample_rects'] if args.sample_rate > 0 else None, pipeline=True,
                                   stream=getattr(getattr(train_buf, "signal_trainer", None), "pose_stream", lambda: None)())
+    # the draw is a function of (seed, counter): continue the stream where the checkpoint left it, so that a resumed run
+    # (scripts/train_obama.sh always resumes from 280000.tar) does not replay the pixel sequence of the run before it -
+    # upstream draws from the unseeded global np.random.  Nothing extra is stored in the checkpoint.
+    sampler.counter = int(global_step)
     from tqdm import trange, tqdm
     for i in trange(global_step + 1, args.N_iters + 1, disable=rank != 0):
         img_i = rng.choice(i_train)
