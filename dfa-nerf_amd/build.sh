@@ -12,7 +12,10 @@ OUT="$HERE/dfanerf/libdfanerf.so"
 OBJ="$HERE/build"
 if [ "$1" = "--clean" ]; then rm -rf "$OBJ" "$OUT"; fi
 mkdir -p "$OBJ"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -I$SRC -I$HERE/../include $DFN_EXTRA_FLAGS"
+# -pragma-unroll-threshold: the MLP bodies MUST unroll completely (every fragment index, ring slot and recorder dword is a
+# compile-time constant by construction; a loop left rolled puts the fragment ring and the operand vectors into scratch
+# memory) and with the MX-fp8 recorder some bodies exceed LLVM's default budget of 16384 instructions
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -mllvm -pragma-unroll-threshold=200000 -I$SRC -I$HERE/../include $DFN_EXTRA_FLAGS"
 HDR_HASH="$( (cat "$SRC"/*.h "$HERE"/../include/*.h; echo "$FLAGS" | sed "s#$HERE#.#g"; hipcc --version 2>/dev/null | head -2) | sha256sum | cut -d' ' -f1)"
 UNITS="dfn_render dfn_render_f32 dfn_render_bf16 dfn_render_f16 dfn_misc dfn_api dfn_train dfn_bwd_bf16 dfn_wgrad_bf16 dfn_signal"
 pids=()

@@ -12,6 +12,7 @@
 #include "dfanerf.h"
 #include "dfn_layout.h"
 #include "dfn_misc.h"
+#include "dfn_mlp.h"
 #include "dfn_params.h"
 #include "dfn_plan.h"
 #include "dfn_signal.h"
@@ -293,6 +294,9 @@ long dfn_train_rows(int field, int what) {
     }
     case 4: return (long)BIAS_GRAD_SLICES * dfn_bias_floats(DFN_TIER_BF16, field);   // dfn_bias_grad workspace floats
     case 5: return (long)SIG_ROW_SLICES * 512 + dfn_bias_floats(DFN_TIER_BF16, field);   // dfn_signal_grad workspace floats
+    // 16-bit tier: bytes per 32-point tile of the MX-fp8 arrays act_T / dy_T (rows x 32 e4m3 bytes + the scale block)
+    case 6: return rec8_tile_bytes(t ? 64 + 640 + 128 + 9 * 256 + 32 : 64 + 9 * 256 + 32);
+    case 7: return rec8_tile_bytes(t ? 896 + 10 * 256 + 64 : 10 * 256 + 64);
     default: return fail(DFN_E_ARG, "dfn_train_rows: bad selector");
     }
 }
@@ -586,8 +590,11 @@ static int weight_grad_impl(int tier, int field, const void* dy_T, const void* a
     const long W = (long)w.map.size(), n_tiles = NP / 32;
     const int nb = (int)w.bias_rows.size();
     const int ks = tier == DFN_TIER_BF16 ? wgrad_ksplit_bf16() : WGRAD_KSPLIT;
-    const long per = (n_tiles + ks - 1) / ks;
-    const int valid = (int)((n_tiles + per - 1) / per);           // slices that hold points (the others write nothing)
+    if (tier == DFN_TIER_BF16 && (n_tiles & 1))
+        return fail(DFN_E_ARG, std::string(who) + ": the 16-bit tier contracts pairs of 32-point tiles: NP must be a multiple of 64");
+    const long units = tier == DFN_TIER_BF16 ? n_tiles / 2 : n_tiles;      // what a slice is made of: tile pairs / tiles
+    const long per = (units + ks - 1) / ks;
+    const int valid = (int)((units + per - 1) / per);             // slices that hold points (the others write nothing)
     float* c_parts = workspace;
     float* b_parts = workspace + (long)WS_KSPLIT_MAX * W;
     hipError_t err = hipSuccess;

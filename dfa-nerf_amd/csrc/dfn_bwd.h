@@ -93,28 +93,42 @@ template <int TIER, int NT> DFN_DEV void pin_vec(Vec<TIER, NT>& v) {
 #ifndef DFN_TORSO_DY0_SPREAD
 #define DFN_TORSO_DY0_SPREAD 1
 #endif
-template <int TIER, int NTB, int KU, class CT> struct PutSide {
+// (MX-fp8, dfn_mlp.h: the vector's 4 NTB dword stores are spread evenly over the consuming layer's T = OT / 2 x KU k-steps;
+// the scales of its tile pairs are found in front of the layer)
+template <int TIER, int NTB, int KU, int T, class CT> struct PutSide {
     const BwdIO& io;
     const Vec<TIER, NTB>& v;
     int row0, tg;
     const CT& c;
-    static constexpr int WORDS = 8 * NTB;
-    DFN_DEV void word(int j) const {
+    const Q8* qs;                   // scale of tile pair p (NTB == 1: of the one tile)
+    static constexpr int D = 4 * NTB, DPS = (D + T - 1) / T;        // dword stores per k-step
+    DFN_DEV void dword(int d) const {
 #ifndef DFN_NOPUT
         if constexpr (TIER == TIER_BF16) {
-            if (j < WORDS) store_word_T<NTB>(io.dy_T, io.rows, io.pass, row0, v, j, c);
+            if (d < D) store_dword8<NTB>(io.dy_T, io.rows, io.pass, row0, v, d, 0, qs[d >> 3], c);
         }
 #endif
     }
     DFN_DEV void operator()(int ku) const {
         if (row0 < 0) return;
-        if (DFN_PUT_SPREAD == 2) {
-            if (ku < KU / 2) { word(tg * KU + 2 * ku); word(tg * KU + 2 * ku + 1); }
-        } else {
-            word(tg * KU + ku);
-        }
+        const int s = tg * KU + ku;
+#pragma unroll
+        for (int w = 0; w < DPS; ++w) dword(s * DPS + w);      // (constant trip count; dword() drops d >= D)
     }
 };
+// scales of the tile pairs of `v` + their bytes in dy_T (in front of the layer that streams the vector out)
+template <int TIER, int NTB, class CT>
+DFN_DEV void put_scales(const BwdIO& io, int row0, const Vec<TIER, NTB>& v, Q8 (&qs)[(NTB + 1) / 2], const CT& c) {
+    if constexpr (TIER == TIER_BF16) {
+        if (row0 < 0) return;
+#pragma unroll
+        for (int p = 0; p < (NTB + 1) / 2; ++p) {
+            const int np = NTB >= 2 ? 2 : 1;
+            qs[p] = q8_of_tiles<NTB>(v, 2 * p, np);
+            store_scale8(io.dy_T, io.rows, io.pass, row0, 2 * p, 0, np, qs[p], c);
+        }
+    }
+}
 template <int TIER> constexpr bool put_spread() { return TIER == TIER_BF16 && DFN_PUT_SPREAD != 0; }
 
 // out[OT tiles] = (W^T x in) [* mask]; mask_dword0 < 0: no mask.  put_row >= 0: `in` is written to rows put_row.. of dy_T
@@ -126,6 +140,8 @@ DFN_DEV void bwd_layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, int mask_dw
         if (put_row >= 0) put<TIER, NTB>(io, put_row, in, c);
         put_row = -1;
     }
+    Q8 qs[(NTB + 1) / 2];
+    put_scales<TIER, NTB>(io, put_row, in, qs, c);
 #pragma unroll
     for (int tg = 0; tg < OT / 2; ++tg) {
         f32x16 acc[2];
@@ -134,7 +150,8 @@ DFN_DEV void bwd_layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, int mask_dw
 #ifdef DFN_TIMING
         const unsigned long long q0 = __builtin_readcyclecounter();      // (s_memtime: scalar memory, costs an lgkmcnt(0) each)
 #endif
-        gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c, NoHook{}, PutSide<TIER, NTB, KU, CT>{io, in, put_row, tg, c});
+        gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c, NoHook{},
+                                     PutSide<TIER, NTB, KU, (OT / 2) * KU, CT>{io, in, put_row, tg, c, qs});
 #ifdef DFN_TIMING
         asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
         const unsigned long long q1 = __builtin_readcyclecounter();
@@ -148,11 +165,6 @@ DFN_DEV void bwd_layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, int mask_dw
         s.t_epi += q2 - q1;          // mask + convert epilogue
 #endif
     }
-    if constexpr (put_spread<TIER>()) {      // what the k-steps did not cover (short layers)
-        if (put_row >= 0)
-#pragma unroll
-            for (int j = (OT / 2) * KU; j < 8 * NTB; ++j) PutSide<TIER, NTB, KU, CT>{io, in, put_row, 0, c}.word(j);
-    }
 }
 // out = (W1^T x in1 + W2^T x in2) [* mask]
 template <int TIER, int OT, int KU1, int NTB1, int KU2, int NTB2, class CT>
@@ -163,20 +175,18 @@ DFN_DEV void bwd_layer2(Vec<TIER, OT>& out, const Vec<TIER, NTB1>& in1, const Ve
         if (put_row1 >= 0) put<TIER, NTB1>(io, put_row1, in1, c);
         put_row1 = -1;
     }
+    Q8 qs[(NTB1 + 1) / 2];
+    put_scales<TIER, NTB1>(io, put_row1, in1, qs, c);
 #pragma unroll
     for (int tg = 0; tg < OT / 2; ++tg) {
         f32x16 acc[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
-        gemm_group<TIER, 2, KU1, NTB1>(acc, in1, f, fe, s, c, NoHook{}, PutSide<TIER, NTB1, KU1, CT>{io, in1, put_row1, tg, c});
+        gemm_group<TIER, 2, KU1, NTB1>(acc, in1, f, fe, s, c, NoHook{},
+                                       PutSide<TIER, NTB1, KU1, (OT / 2) * KU1, CT>{io, in1, put_row1, tg, c, qs});
         gemm_group<TIER, 2, KU2, NTB2>(acc, in2, f, fe, s, c);
         if (mask_dword0 >= 0) apply_mask(acc, mask_word(io, mask_dword0 + tg, c.lane));
         acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);
-    }
-    if constexpr (put_spread<TIER>()) {
-        if (put_row1 >= 0)
-#pragma unroll
-            for (int j = (OT / 2) * KU1; j < 8 * NTB1; ++j) PutSide<TIER, NTB1, KU1, CT>{io, in1, put_row1, 0, c}.word(j);
     }
 }
 

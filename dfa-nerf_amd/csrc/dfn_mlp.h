@@ -255,6 +255,87 @@ DFN_DEV gchar* uniform_ptr(const void* p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (gchar*)(((unsigned long)hi << 32) | lo);
 }
+// ---- MX-fp8 recording (the 16-bit TRAINING tier) -----------------------------------------------------------------------
+// What the forward records for the backward (act_T) and what the dX chain leaves for the weight-gradient GEMMs (dy_T) is
+// written ONCE and read ONCE, 3 GB each way per 2048-ray step in bf16: the training step is bound by that traffic, not by
+// its MFMAs.  Both arrays are therefore stored as OCP fp8 (e4m3) with one power-of-two scale (E8M0) per block of
+// (tile pair = 64 features) x (32 points) - the MX block format gfx950's v_mfma_scale_f32_32x32x64_f8f6f4 consumes
+// directly (dfn_wgrad_bf16.hip: contraction over the points, the K block of 32 IS one 32-point tile): half the bytes, and
+// the rounding (2^-4 relative, independent per element) averages out over the 131,072 points a weight gradient sums:
+// measured 0.1 % (median) / 1.6 % (worst tensor) of the bf16 step's own gradient, invisible next to the 1.7 % the bf16
+// operands cost against the f32 oracle (tools/diag_fp8_record.py).  Power-of-two scales make the result independent of the
+// block size as long as nothing under- or overflows.
+// Layout per 32-point tile: [rows][32 points] bytes (row-major: the MFMA's A / B fragment of a row is two 16-byte runs),
+// then REC8_SCALE_BYTES of scales, one per 32-row block.
+constexpr int REC8_SCALE_BYTES = 128;        // >= rows / 32 of every array (torso dy_T: 110)
+DFN_HD constexpr long rec8_tile_bytes(int rows) { return (long)rows * 32 + REC8_SCALE_BYTES; }
+struct Q8 {
+    float scale;        // power of two: stored value = x / scale
+    unsigned e8;        // its biased exponent (E8M0)
+};
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_q __attribute__((ext_vector_type(2)));
+// scale of tiles [t0, t0 + n) of v: amax over the wave (all 32 points), wave-uniform
+template <int NT> DFN_DEV Q8 q8_of_tiles(const Vec<TIER_BF16, NT>& v, int t0, int n) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    u16x2 m = {0, 0};
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (t >= t0 && t < t0 + n)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u32x4_ q = __builtin_bit_cast(u32x4_, v.u[2 * t + h]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {    // |x| of a bf16 orders like its bit pattern: packed unsigned 16-bit max
+                    const unsigned a = q[e] & 0x7fff7fffu;      // (a scalar: __builtin_bit_cast of a vector ELEMENT miscompiles)
+                    m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2, a));
+                }
+            }
+    unsigned x = max((unsigned)m[0], (unsigned)m[1]);
+    // row maxima by DPP (quad swaps, half-row mirror, row mirror), then the four rows by readlane: an SGPR
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false));
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false));
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, false));
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, false));
+    const unsigned a = max(max((unsigned)__builtin_amdgcn_readlane((int)x, 0), (unsigned)__builtin_amdgcn_readlane((int)x, 16)),
+                           max((unsigned)__builtin_amdgcn_readlane((int)x, 32), (unsigned)__builtin_amdgcn_readlane((int)x, 48)));
+    // amax in [2^(E-127), 2^(E-126)); scale = 2^(E-127-7): |x| / scale < 256 (e4m3 holds 448; no saturation mode needed)
+    const unsigned E = a >> 7;                                   // bf16: sign(1) exponent(8) mantissa(7)
+    Q8 q;
+    q.e8 = E > 8u ? E - 7u : 1u;
+    q.scale = __builtin_bit_cast(float, q.e8 << 23);
+    return q;
+}
+// ONE store instruction: dword d of v (tile d >> 2, accumulator registers 4 (d & 3) .. + 3 = four consecutive feature rows
+// of this lane's point) -> fp8, 4 x 4 byte transpose across the quad of lanes (points n0 .. n0 + 3; two DPP moves + two
+// v_perm_b32), so that lane q of the quad holds feature row q at points n0 .. n0 + 3: 4 bytes of that row's 32-byte run.
+// The 32 lanes of a half-wave write 128 contiguous bytes (4 rows), a whole store instruction 256.
+template <int NT, class CT>
+DFN_DEV void store_dword8(void* arr, int rows, long tile, int row0, const Vec<TIER_BF16, NT>& v, int d, int d_first, const Q8& q,
+                          const CT& c) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    typedef short s16x2_ __attribute__((ext_vector_type(2)));
+    const int t = d >> 2, qq = d & 3;
+    const u32x4_ w = __builtin_bit_cast(u32x4_, v.u[2 * t + (qq >> 1)]);
+    s16x2_ o = {0, 0};
+    const unsigned w_lo = w[2 * (qq & 1)], w_hi = w[2 * (qq & 1) + 1];      // scalar copies: __builtin_bit_cast of a vector ELEMENT miscompiles
+    o = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o, __builtin_bit_cast(bf16x2_q, w_lo), q.scale, false);
+    o = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o, __builtin_bit_cast(bf16x2_q, w_hi), q.scale, true);
+    const unsigned own = __builtin_bit_cast(unsigned, o);
+    const unsigned n1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);          // lane ^ 1
+    const unsigned x = __builtin_amdgcn_perm(own, n1, (c.lane & 1) ? 0x07030501u : 0x02060004u);
+    const unsigned n2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false);            // lane ^ 2
+    const unsigned y = __builtin_amdgcn_perm(x, n2, (c.lane & 2) ? 0x07060302u : 0x01000504u);
+    gchar* ubase = uniform_ptr((char*)arr + tile * rec8_tile_bytes(rows) + (long)row0 * 32);
+    const unsigned voff = (unsigned)((4 * c.half + (c.lane & 3)) * 32 + ((c.lane & 31) & ~3));
+    __builtin_nontemporal_store(y, (__attribute__((address_space(1))) unsigned*)(ubase + (32 * (t - (d_first >> 2)) + 8 * qq) * 32 + voff));
+}
+// the scale bytes of tiles [t0, t0 + n) of a vector whose tile t_first sits at row row0
+template <class CT>
+DFN_DEV void store_scale8(void* arr, int rows, long tile, int row0, int t0, int t_first, int n, const Q8& q, const CT& c) {
+    gchar* sb = uniform_ptr((char*)arr + tile * rec8_tile_bytes(rows) + (long)rows * 32 + (row0 >> 5) + (t0 - t_first));
+    if (c.lane < n) *(__attribute__((address_space(1))) unsigned char*)(sb + c.lane) = (unsigned char)q.e8;
+}
 // tiles [t0, t0 + n) of v -> rows row0 + 32 (t - t0) ...
 template <int TIER, int NT, class CT>
 DFN_DEV void store_tiles_T(void* arr, int rows, long tile, int row0, const Vec<TIER, NT>& v, int t0, int n, const CT& c) {
@@ -264,33 +345,17 @@ DFN_DEV void store_tiles_T(void* arr, int rows, long tile, int row0, const Vec<T
     // immediate) and the register allocator spilled those pointers around the MFMA loops.
     gchar* ubase = uniform_ptr((T*)arr + (tile * rows + row0) * 32);
     if constexpr (TIER == TIER_BF16) {
-        // straight from the packed operand words: register pair (r, r + 1) = features (f, f + 1) = one 32-bit word.
-        // Neighbouring lanes (points n, n ^ 1) swap halves first (one DPP move + one v_perm_b32), so that the even lane
-        // holds feature f of both points and the odd lane feature f + 1: one 4-byte store per word instead of two
-        // 2-byte stores, and every store instruction writes four 64-byte row segments instead of two.
-        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-        const int odd = c.lane & 1;
-        const unsigned voff = (unsigned)((4 * c.half + odd) * 32 + (c.lane & 31) - odd) * 2u;     // odd lane: next row, one point back
-        const unsigned sel = odd ? 0x07060302u : 0x01000504u;             // v_perm bytes: 0-3 = neighbour's word, 4-7 = own
+        // MX-fp8 (above): tile pairs share a scale; one dword store per four feature rows
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (t >= t0 && t < t0 + n)
+        for (int t = 0; t < NT; t += 2)
+            if (t >= t0 && t < t0 + n) {
+                const int np = (t + 1 < t0 + n && t + 1 < NT) ? 2 : 1;
+                const Q8 q = q8_of_tiles<NT>(v, t, np);
+                store_scale8(arr, rows, tile, row0, t, t0, np, q, c);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const bf16x8 uu = v.u[2 * t + h];
-                    const u32x4_ q = __builtin_bit_cast(u32x4_, uu);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int f = 32 * (t - t0) + tile_feat(0, 8 * h + 2 * e);      // + 4 for the upper half (in base)
-                        const unsigned own = q[e];
-                        const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-                        // non-temporal: these arrays are written once and read once by a later kernel; left in the
-                        // L2 as dirty lines they evict the weight stream and are written back under the next kernel
-                        // (measured: training forward 553 -> 453 us, dX head 232 -> 195 us, wgrad 890 -> 810 us)
-                        __builtin_nontemporal_store(__builtin_amdgcn_perm(own, nbr, sel),
-                                                    (__attribute__((address_space(1))) unsigned*)(ubase + f * 64 + voff));
-                    }
-                }
+                for (int dd = 0; dd < 8; ++dd)          // (constant trip count: np may be a run-time value)
+                    if (dd < 4 * np && 4 * t + dd < 4 * NT) store_dword8<NT>(arr, rows, tile, row0, v, 4 * t + dd, 4 * t0, q, c);
+            }
     } else {
 #pragma unroll
         for (int L = 0; L < 16 * NT; ++L)
@@ -300,34 +365,6 @@ DFN_DEV void store_tiles_T(void* arr, int rows, long tile, int row0, const Vec<T
                 __builtin_nontemporal_store((T)v.get(L), (__attribute__((address_space(1))) T*)(ubase + f * 32 * (int)sizeof(T) + voff));
             }
     }
-}
-// ONE store instruction of store_tiles_T (bf16 tier): word j = ((tile * 2 + half-vector) * 4 + e) of v, j < 8 NT.  Lets a
-// caller spread a vector's stores between MFMAs instead of issuing them as one burst (dfn_bwd.h: PutSide).
-template <int NT, class CT>
-DFN_DEV void store_word_T(void* arr, int rows, long tile, int row0, const Vec<TIER_BF16, NT>& v, int j, const CT& c) {
-    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-    gchar* ubase = uniform_ptr((__bf16*)arr + (tile * rows + row0) * 32);
-    const int odd = c.lane & 1;
-    const unsigned voff = (unsigned)((4 * c.half + odd) * 32 + (c.lane & 31) - odd) * 2u;
-    const unsigned sel = odd ? 0x07060302u : 0x01000504u;
-    const int t = j >> 3, h = (j >> 2) & 1, e = j & 3;
-    const u32x4_ q = __builtin_bit_cast(u32x4_, v.u[2 * t + h]);
-    const int f = 32 * t + tile_feat(0, 8 * h + 2 * e);
-    const unsigned own = q[e];
-#ifdef DFN_PUT_KEEP       // timing experiments (wrong results): only tiles [0, DFN_PUT_KEEP) of every vector are stored
-    if (t >= DFN_PUT_KEEP) return;
-#endif
-#ifdef DFN_PUT_RAW        // ... the packed word as it is, no pair swap (2 VALU less per store)
-    __builtin_nontemporal_store(own, (__attribute__((address_space(1))) unsigned*)(ubase + f * 64 + voff));
-    return;
-#endif
-    const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);
-#ifdef DFN_PUT_PLAIN      // ... ordinary stores instead of non-temporal ones
-    *(__attribute__((address_space(1))) unsigned*)(ubase + f * 64 + voff) = __builtin_amdgcn_perm(own, nbr, sel);
-    return;
-#endif
-    __builtin_nontemporal_store(__builtin_amdgcn_perm(own, nbr, sel),
-                                (__attribute__((address_space(1))) unsigned*)(ubase + f * 64 + voff));
 }
 template <int TIER, int NT, class CT>
 DFN_DEV void store_vec_T(void* arr, int rows, long tile, int row0, const Vec<TIER, NT>& v, const CT& c) {
@@ -687,14 +724,20 @@ template <int TIER, int OT, int KU, class CT> struct RecSide {
     const CT& c;
     const Vec<TIER, OT>& out;
     int rec_row, prev;              // prev: the pair whose values are stored (-1: none)
-    static constexpr int WPS = (16 + KU - 1) / KU;       // words per k-step
+    mutable Q8 q;                   // the pair's scale, found at k-step 0
+    static constexpr int DPS = (8 + KU - 1) / KU;       // dword stores per k-step
+    // the pair's 8 dword stores (MX-fp8, above), DPS per k-step from k-step 0 on; k-step 0 also finds the scale
     DFN_DEV void operator()(int ku) const {
         if constexpr (CT::rec_on && TIER == TIER_BF16) {
             if (prev < 0 || rec_row < 0) return;
+            if (ku == 0) {
+                q = q8_of_tiles<OT>(out, 2 * prev, 2);
+                store_scale8(c.rec.act_T, c.rec.rows, c.rec.pass, rec_row, 2 * prev, 0, 2, q, c);
+            }
 #pragma unroll
-            for (int w = 0; w < WPS; ++w)
-                if (ku * WPS + w < 16)
-                    store_word_T<OT>(c.rec.act_T, c.rec.rows, c.rec.pass, rec_row, out, 16 * prev + ku * WPS + w, c);
+            for (int w = 0; w < DPS; ++w)       // (constant trip count: every index below folds once gemm_group is unrolled)
+                if (ku * DPS + w < 8)
+                    store_dword8<OT>(c.rec.act_T, c.rec.rows, c.rec.pass, rec_row, out, 8 * prev + ku * DPS + w, 0, q, c);
         }
     }
 };
@@ -715,7 +758,7 @@ DFN_DEV void layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_f32* 
         f32x16 acc[2];
         acc_init<2>(acc, bias + tg * 64, c.half);
         if constexpr (SPREAD) {
-            gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c, NoHook{}, RecSide<TIER, OT, KU, CT>{c, out, rec_row, tg - 1});
+            gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c, NoHook{}, RecSide<TIER, OT, KU, CT>{c, out, rec_row, tg - 1, {}});
         } else {
             auto flush = [&] {
                 if (pend) rec_vals<TIER>(c, rec_row + 64 * (tg - 1), out, 2 * (tg - 1));

@@ -695,6 +695,24 @@ hipError_t launch_reduce_bias(const int* rows, const float* parts, int n_bias, i
     return hipGetLastError();
 }
 
+// ---- the 16-bit tier's recorded arrays are MX-fp8 (dfn_mlp.h: "MX-fp8 recording"): per 32-point tile [rows][32] e4m3 bytes
+// + one E8M0 scale per 32-row block.  Sum of row `row` over the 32 points of tile t, dequantised.
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float rec8_row_sum(const unsigned char* arr, long t, int rows, int row) {
+    const unsigned char* base = arr + t * rec8_tile_bytes(rows);
+    const uint4* p = (const uint4*)(base + (long)row * 32);
+    const uint4 v0 = p[0], v1 = p[1];
+    const unsigned w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const f32x2_ lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[k], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[k], true);
+        s += (lo[0] + lo[1]) + (hi[0] + hi[1]);
+    }
+    const unsigned e8 = base[(long)rows * 32 + (row >> 5)];
+    return s * __uint_as_float(e8 << 23);
+}
+
 // d(bias blob)[e] = sum over points of dy_T[.., row_of[e], ..]   (tile-major array [tile][rows][32]).
 // Streaming row sums: thread = one row, block = 256 consecutive rows, blockIdx.y = a slice of the tiles; a wave
 // reads 64 rows x 32 points = one contiguous 4 KiB (bf16) / 8 KiB (f32) run per tile.  The partial sum of slice y goes
@@ -710,17 +728,10 @@ __global__ void bias_grad_kernel(const int* e_of, const T* dy_T, long n_tiles, i
     const long t0 = blockIdx.y * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
     float acc = 0.f;
     for (long t = t0; t < t1; ++t) {
-        const uint4* p = (const uint4*)(dy_T + (t * rows + row) * 32);
-        if constexpr (sizeof(T) == 2) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint4 v = p[q];
-                const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k)      // bf16 pair -> two f32
-                    acc += __uint_as_float(w[k] << 16) + __uint_as_float(w[k] & 0xffff0000u);
-            }
+        if constexpr (sizeof(T) == 1) {          // 16-bit tier: MX-fp8
+            acc += rec8_row_sum((const unsigned char*)dy_T, t, rows, row);
         } else {
+            const uint4* p = (const uint4*)(dy_T + (t * rows + row) * 32);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const uint4 v = p[q];
@@ -735,8 +746,8 @@ hipError_t launch_bias_grad(int tier, int field, const int* e_of, const int* bia
     const int rows = field == FIELD_TORSO ? GradMap::S_ROWS : GradMap::H_ROWS;
     const dim3 grid((rows + 255) / 256, BIAS_GRAD_SLICES);
     if (tier == TIER_BF16)
-        hipLaunchKernelGGL(bias_grad_kernel<__bf16>, grid, dim3(256), 0, st, e_of, (const __bf16*)dy_T, NP / 32, rows,
-                           parts, n_bias);
+        hipLaunchKernelGGL(bias_grad_kernel<unsigned char>, grid, dim3(256), 0, st, e_of, (const unsigned char*)dy_T, NP / 32,
+                           rows, parts, n_bias);
     else
         hipLaunchKernelGGL(bias_grad_kernel<float>, grid, dim3(256), 0, st, e_of, (const float*)dy_T, NP / 32, rows, parts,
                            n_bias);
@@ -763,18 +774,10 @@ __global__ __launch_bounds__(64) void sig_rows_kernel(const int* __restrict__ ro
     float acc = 0.f;
 #pragma unroll 4
     for (long t = t0; t < t1; ++t) {
-        const uint4* p = (const uint4*)(dy_T + (t * rows + row) * 32);
-        if constexpr (sizeof(T) == 2) {
-            uint4 v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = p[q];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const unsigned w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc += __uint_as_float(w[k] << 16) + __uint_as_float(w[k] & 0xffff0000u);
-            }
+        if constexpr (sizeof(T) == 1) {          // 16-bit tier: MX-fp8
+            acc += rec8_row_sum((const unsigned char*)dy_T, t, rows, row);
         } else {
+            const uint4* p = (const uint4*)(dy_T + (t * rows + row) * 32);
             uint4 v[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = p[q];
@@ -800,8 +803,8 @@ hipError_t launch_signal_rows(int tier, int field, const int* row_of, const int*
     const int slices = (int)(n_tiles < SIG_ROW_SLICES ? n_tiles : SIG_ROW_SLICES);
     const dim3 grid(n_sig / 64, slices);
     if (tier == TIER_BF16)
-        hipLaunchKernelGGL(sig_rows_kernel<__bf16>, grid, dim3(64), 0, st, row_of, n_sig, (const __bf16*)dy_T, n_tiles, rows,
-                           parts);
+        hipLaunchKernelGGL(sig_rows_kernel<unsigned char>, grid, dim3(64), 0, st, row_of, n_sig, (const unsigned char*)dy_T,
+                           n_tiles, rows, parts);
     else
         hipLaunchKernelGGL(sig_rows_kernel<float>, grid, dim3(64), 0, st, row_of, n_sig, (const float*)dy_T, n_tiles, rows,
                            parts);

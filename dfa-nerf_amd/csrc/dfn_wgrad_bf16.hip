@@ -1,17 +1,21 @@
-// dfn_wgrad_bf16.hip - weight gradients of the bf16 tier: dW = dY . X^T contracted over the sample points,
-// one workgroup per (GEMM, slice of the points), operands shared through LDS.
+// dfn_wgrad_bf16.hip - weight gradients of the 16-bit training tier: dW = dY . X^T contracted over the sample points,
+// one workgroup per (GEMM, slice of the points), operands shared through LDS, MX-fp8 operands on the block-scaled MFMA.
 //
 // Every GEMM of the two fields is at most 256 x 256 (dfn_plan.cpp: build_wgrad_plan), so one workgroup of 8 waves
 // owns the WHOLE output of a GEMM for its slice of the points: each byte of dY / X is fetched from HBM once per
-// GEMM that reads it (wgrad_kernel<bf16> fetched the dY rows once per 128 output columns, per wave, into registers).
-// The operands are tile-major ([tile of 32 points][rows][32], dfn_mlp.h: Rec): the rows a GEMM needs of one tile
-// are ONE contiguous run, which LDS-DMA (global_load_lds_dwordx4) copies into a ring of 4 x 32 KiB steps without
-// touching registers.  The DMA writes LDS linearly (lane i -> 16 bytes at 16 i) but every lane names its own source
-// address: a piece is 16 rows x 64 bytes = 1 KiB of contiguous memory, four consecutive lanes fetch the four
-// 16-byte chunks of one row (one 64-byte segment per quad: full address-coalescing rate; a first version with one
-// row per lane ran at a quarter of it), in the order chunk = slot ^ ((row >> 2) & 3).  That XOR swizzle makes the
-// MFMA operand reads (lane = row, all lanes the same chunk, i.e. a 64-byte stride) free of bank conflicts: the 16
-// lanes of every ds_read_b128 lane group land on 16 different 16-byte slots of the 256-byte bank row.
+// GEMM that reads it.  The operands are what the forward's recorder and the dX chain left (dfn_mlp.h: "MX-fp8
+// recording"): per 32-point tile [rows][32 points] e4m3 bytes + one E8M0 scale per 32-row block, i.e. exactly the
+// operand format of v_mfma_scale_f32_32x32x64_f8f6f4 with the contraction index K = points: a K block of 32 (the unit a
+// scale applies to) IS one tile, an instruction contracts two tiles, and the dequantisation is fused into the MFMA.
+// Lane (m = l & 31, kh = l >> 5) of an A (B) fragment holds row m's points 16 kh .. + 15 of the first tile (bytes 0-15)
+// and of the second tile (bytes 16-31); the scale of the first tile is taken from the lanes with kh = 0, of the second from
+// kh = 1 (tools/mx_probe.hip pins this on the hardware).
+// The rows a GEMM needs of one tile are ONE contiguous run (32 bytes per row), which LDS-DMA (global_load_lds_dwordx4)
+// copies into a ring of steps without touching registers: a DMA piece is one operand tile (32 rows x 32 bytes = 1 KiB),
+// four consecutive lanes fetch the four 16-byte chunks of two rows (one 64-byte segment per quad: full coalescing
+// rate).  The DMA writes LDS linearly (lane i -> 16 bytes at 16 i) but every lane names its own source: position
+// 2 m + (c ^ ((m >> 3) & 1)) holds chunk c of row m, so that the 16 lanes of every ds_read_b128 lane group (rows m .. m + 15,
+// the same chunk) land on 16 different 16-byte slots of the 256-byte bank row.
 // Differentiates decoder.py:277-349 (the Linear layers of both fields) like wgrad_kernel (dfn_train.hip), which
 // stays for the f32 tier.
 #include <hip/hip_runtime.h>
@@ -26,79 +30,89 @@ constexpr int WL_WAVES = 8, WL_THREADS = 64 * WL_WAVES;
 #ifndef DFN_WL_DEPTH
 #define DFN_WL_DEPTH 4
 #endif
-constexpr int WL_DEPTH = DFN_WL_DEPTH;          // ring depth in steps (5 x 32 KiB = the compute unit's whole LDS)
-constexpr int WL_STEP_BYTES = 32 * 1024;        // 16 operand tiles (512 rows x 32 points) per step at most
+constexpr int WL_DEPTH = DFN_WL_DEPTH;          // ring depth in steps
+constexpr int WL_STEP_BYTES = 32 * 1024;        // 32 operand tiles (1 KiB each) per step at most
 constexpr int WL_PIECES = 4;                    // 1 KiB DMA pieces per wave and step at most (32 per step)
+// The E8M0 scales of a chunk of the slice (16 bytes per 32-point tile: up to 8 dY row blocks + 8 X row blocks of the GEMM)
+// are staged into LDS with ordinary loads BEFORE the chunk's DMA pipeline starts: an ordinary vector load inside the loop
+// would make every wait on it drain the LDS-DMA pieces in flight (one in-order vmcnt queue).
+constexpr int WL_CHUNK_PAIRS = 512;             // tile pairs per chunk: 1024 tiles x 16 B = 16 KiB of scales
+constexpr int WL_SCALE_BYTES = 2 * WL_CHUNK_PAIRS * 16;
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 template <int N> DFN_DEV void wl_wait_vm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
-__global__ __launch_bounds__(WL_THREADS) void wgrad_lds_kernel(const WOp* ops, const int* order, const void* dy_T,
-                                                                const void* act_T, long n_tiles, int g_rows, int a_rows,
-                                                                int ksplit, float* C, long c_stride, const int* e_of,
-                                                                float* dbias, int n_bias) {
+__global__ __launch_bounds__(WL_THREADS) void wgrad_mx_kernel(const WOp* ops, const int* order, const void* __restrict__ dy_T,
+                                                               const void* __restrict__ act_T, long n_tiles, int g_rows, int a_rows,
+                                                               int ksplit, float* C, long c_stride, const int* e_of,
+                                                               float* dbias, int n_bias) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     lds_char* lds = (lds_char*)smem;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const WOp o = ops[order[blockIdx.x / ksplit]];
     const int ks = blockIdx.x % ksplit;
-    const long per = (n_tiles + ksplit - 1) / ksplit;
-    const long t0 = ks * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
-    if (t0 >= t1) return;                                               // whole workgroup
+    const long pairs = n_tiles / 2;                                     // (NP is a multiple of 512: n_tiles is even)
+    const long per = (pairs + ksplit - 1) / ksplit;
+    const long p0 = ks * per, p1 = (p0 + per < pairs) ? p0 + per : pairs;      // this slice's tile PAIRS
+    if (p0 >= p1) return;                                               // whole workgroup
     const int mts = o.M / 32, nts = o.N / 32, ntl = mts + nts;          // operand tiles per 32 points
-    const int tps = ntl <= 4 ? 4 : (ntl <= 8 ? 2 : 1);                  // 32-point tiles per step (<= 32 KiB)
-    const int np = tps * ntl * 2;                                       // DMA pieces per step, <= 32
+    const int pps = ntl <= 4 ? 4 : (ntl <= 8 ? 2 : 1);                  // tile pairs per step (<= 32 KiB)
+    const int np = pps * 2 * ntl;                                       // DMA pieces per step, <= 32
     const int n_w = (np - wave + WL_WAVES - 1) / WL_WAVES;              // ... of which this wave issues n_w (1..4)
-    const long n_steps = (t1 - t0 + tps - 1) / tps;
+    const long strideA = rec8_tile_bytes(g_rows), strideB = rec8_tile_bytes(a_rows);
+    lds_char* sc_lds = lds + WL_DEPTH * WL_STEP_BYTES;                  // [tile of the chunk][16]: A row blocks 0..7 | B row blocks 0..7
 
-    // ---- this wave's DMA pieces: the same (sub-tile, operand tile, k-half) every step -----------------------
+    // ---- this wave's DMA pieces: the same (tile of the step, operand tile) every step ------------------------
     const char* src[WL_PIECES];       // per lane: address of its 16 bytes in tile 0
     long stride[WL_PIECES];           // bytes per tile of that operand array
-    int sub[WL_PIECES];               // sub-tile of the step
+    int sub[WL_PIECES];               // tile of the step (0 .. 2 pps - 1)
     unsigned dst[WL_PIECES];          // LDS offset inside the step's slot
+    {
+        const int row = lane >> 1, chunk = (lane & 1) ^ ((row >> 3) & 1);
 #pragma unroll
-    for (int k = 0; k < WL_PIECES; ++k) {
-        const int p = wave + WL_WAVES * k;
-        const int u = p / (ntl * 2), rem = p - u * (ntl * 2);
-        const int tl = rem >> 1, hf = rem & 1;                  // operand tile, upper / lower 16 rows
-        const bool isb = tl >= mts;
-        const int r = 16 * hf + (lane >> 2);                    // row of the tile
-        const int row = (isb ? o.b_row + 32 * (tl - mts) : o.a_row + 32 * tl) + r;
-        const int chunk = (lane & 3) ^ ((r >> 2) & 3);
-        src[k] = (const char*)(isb ? act_T : dy_T) + ((long)row * 32 + 8 * chunk) * 2;
-        stride[k] = (long)(isb ? a_rows : g_rows) * 64;
-        sub[k] = u;
-        dst[k] = (unsigned)(((u * ntl + tl) * 2 + hf) * 1024);
+        for (int k = 0; k < WL_PIECES; ++k) {
+            const int p = wave + WL_WAVES * k;
+            const int u = p / ntl, tl = p - u * ntl;            // tile of the step, operand tile
+            const bool isb = tl >= mts;
+            const int r = (isb ? o.b_row + 32 * (tl - mts) : o.a_row + 32 * tl) + row;
+            src[k] = (const char*)(isb ? act_T : dy_T) + (long)r * 32 + 16 * chunk;
+            stride[k] = isb ? strideB : strideA;
+            sub[k] = u;
+            dst[k] = (unsigned)((u * ntl + tl) * 1024);
+        }
     }
     const unsigned lds_base = (unsigned)(unsigned long)lds;
     unsigned issue_slot = 0;                         // steps are issued in order: slot of the next issue = step % WL_DEPTH
-    auto issue = [&](long s) {                       // DMA of step s into slot s % WL_DEPTH
+    long c0 = p0, c1 = p0;                           // the chunk of tile pairs being processed
+    auto issue = [&](long s) {                       // DMA of step s of the chunk into slot s % WL_DEPTH
         const unsigned slot = lds_base + issue_slot * WL_STEP_BYTES;
         issue_slot = issue_slot + 1 == WL_DEPTH ? 0u : issue_slot + 1;
-        const long tt = t0 + s * tps;
+        const long tt = 2 * (c0 + s * pps);
 #pragma unroll
         for (int k = 0; k < WL_PIECES; ++k)
             if (k < n_w) {
                 long t = tt + sub[k];
-                t = t < t1 ? t : t1 - 1;             // ragged last step: refetch the last tile (never multiplied)
+                t = t < 2 * c1 ? t : 2 * c1 - 1;     // ragged last step: refetch the last tile (never multiplied)
                 const char* a = src[k] + t * stride[k];
                 const unsigned d = __builtin_amdgcn_readfirstlane(slot + dst[k]);
-#ifdef DFN_WL_NT
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(a), "s"(d) : "memory", "m0");
-#else
                 asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(a), "s"(d) : "memory", "m0");
-#endif
             }
     };
 
     // ---- this wave's part of the output: rows 128 rg .. + 127, columns 64 cg .. + 63 -------------------------
     const int rg = wave & 1, cg = wave >> 1;
     const int mt_n = max(0, min(4, mts - 4 * rg)), nt_n = max(0, min(2, nts - 2 * cg));
-    // bias gradients = row sums of dY: operand tile 4 rg + cg times a tile of ones, two MFMAs per 32 points and wave
+    // bias gradients = row sums of dY: operand tile 4 rg + cg times a tile of ones, one more MFMA per tile pair and wave
     const bool do_bias = dbias && o.bias_owner && cg < mt_n;
-    // operand reads: MFMA lane l holds row l & 31, points 8 (l >> 5) + 16 kh .. + 7 = chunk (l >> 5) + 2 kh of the row
-    const int rd_sw = (lane >> 5) ^ ((lane >> 2) & 3);
-    const int rd0 = (lane & 31) * 64 + rd_sw * 16, rd1 = (lane & 31) * 64 + (rd_sw ^ 2) * 16;
+    // operand reads: MFMA lane l holds row l & 31, chunk l >> 5 (points 16 (l >> 5) .. + 15) of both tiles of the pair
+    const int m = lane & 31, kh = lane >> 5;
+    const int rd = (2 * m + (kh ^ ((m >> 3) & 1))) * 16;
+    // scale bytes in memory: [tile][rows x 32 | row block]; the MFMA takes the first tile's from the lanes kh = 0, the
+    // second's from kh = 1
+    const unsigned char* scA = (const unsigned char*)dy_T + (long)g_rows * 32 + (o.a_row >> 5);
+    const unsigned char* scB = (const unsigned char*)act_T + (long)a_rows * 32 + (o.b_row >> 5);
     f32x16 acc[4][2], accb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -106,67 +120,87 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_lds_kernel(const WOp* ops, c
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][0][r] = acc[i][1][r] = 0.f;
     }
-    bf16x8 ones;
+    i32x8 ones;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    for (int e = 0; e < 8; ++e) ones[e] = 0x38383838;           // e4m3 1.0
 
-#pragma unroll
-    for (int s = 0; s < WL_DEPTH - 1; ++s)
-        if (s < n_steps) issue(s);
-    unsigned rd_slot = 0;
-    for (long s = 0; s < n_steps; ++s) {
-        // my pieces of step s have landed (only those of the next WL_DEPTH - 2 steps are younger) and my reads of
-        // step s - 1 have returned; after the barrier that holds for every wave, and slot (s - 1) % 4 is refilled
-        if (s + WL_DEPTH - 2 < n_steps) {
-            switch (n_w) {
-                case 1: wl_wait_vm<1 * (WL_DEPTH - 2)>(); break;
-                case 2: wl_wait_vm<2 * (WL_DEPTH - 2)>(); break;
-                case 3: wl_wait_vm<3 * (WL_DEPTH - 2)>(); break;
-                default: wl_wait_vm<4 * (WL_DEPTH - 2)>(); break;
-            }
-        } else {
-            wl_wait_vm<0>();
+    for (c0 = p0; c0 < p1; c0 = c1) {
+        c1 = (c0 + WL_CHUNK_PAIRS < p1) ? c0 + WL_CHUNK_PAIRS : p1;
+        const long n_steps = (c1 - c0 + pps - 1) / pps;
+        // ---- stage this chunk's scales (nothing of the previous chunk is in flight or being read any more)
+        wl_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        for (int e = threadIdx.x; e < (int)(2 * (c1 - c0)) * 16; e += WL_THREADS) {
+            const long t = 2 * c0 + (e >> 4);
+            const int k = e & 15;
+            unsigned char v = 127;
+            if (k < 8) { if (k < mts) v = scA[t * strideA + k]; }
+            else if (k - 8 < nts) v = scB[t * strideB + (k - 8)];
+            *(DFN_LDS unsigned char*)(sc_lds + e) = v;
         }
+        wl_wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + WL_DEPTH - 1 < n_steps) issue(s + WL_DEPTH - 1);
-        const lds_char* slot = lds + rd_slot * WL_STEP_BYTES;
-        rd_slot = rd_slot + 1 == WL_DEPTH ? 0u : rd_slot + 1;
-        const long tt = t0 + s * tps;
+        issue_slot = 0;
+#pragma unroll
+        for (int s = 0; s < WL_DEPTH - 1; ++s)
+            if (s < n_steps) issue(s);
+        unsigned rd_slot = 0;
+        for (long s = 0; s < n_steps; ++s) {
+            // my pieces of step s have landed (only those of the next WL_DEPTH - 2 steps are younger) and my reads of
+            // step s - 1 have returned; after the barrier that holds for every wave, and slot (s - 1) % WL_DEPTH is refilled
+            if (s + WL_DEPTH - 2 < n_steps) {
+                switch (n_w) {
+                    case 1: wl_wait_vm<1 * (WL_DEPTH - 2)>(); break;
+                    case 2: wl_wait_vm<2 * (WL_DEPTH - 2)>(); break;
+                    case 3: wl_wait_vm<3 * (WL_DEPTH - 2)>(); break;
+                    default: wl_wait_vm<4 * (WL_DEPTH - 2)>(); break;
+                }
+            } else {
+                wl_wait_vm<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (s + WL_DEPTH - 1 < n_steps) issue(s + WL_DEPTH - 1);
+            const lds_char* slot = lds + rd_slot * WL_STEP_BYTES;
+            rd_slot = rd_slot + 1 == WL_DEPTH ? 0u : rd_slot + 1;
+            const long pp = c0 + s * pps;
 #ifdef DFN_WL_NOMFMA          // timing experiment (wrong results): the DMA stream and the barriers alone
-        if (tt >= 0) continue;
+            if (pp >= 0) continue;
 #endif
-        for (int u = 0; u < tps; ++u) {
-            if (tt + u >= t1) break;
-            const lds_char* base = slot + u * ntl * 2048;
-            bf16x8 a[4][2], b[2][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < mt_n && (nt_n > 0 || (do_bias && i == cg))) {
-                    a[i][0] = *(const DFN_LDS bf16x8*)(base + (4 * rg + i) * 2048 + rd0);
-                    a[i][1] = *(const DFN_LDS bf16x8*)(base + (4 * rg + i) * 2048 + rd1);
-                }
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                if (j < nt_n) {
-                    b[j][0] = *(const DFN_LDS bf16x8*)(base + (mts + 2 * cg + j) * 2048 + rd0);
-                    b[j][1] = *(const DFN_LDS bf16x8*)(base + (mts + 2 * cg + j) * 2048 + rd1);
-                }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    if (i < mt_n && j < nt_n) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
-                    }
-            if (do_bias) {
+            for (int u = 0; u < pps; ++u) {
+                if (pp + u >= c1) break;
+                // the scales this lane supplies: of the pair's first tile (kh = 0) or second tile (kh = 1)
+                const lds_char* sc = sc_lds + (2 * (pp + u - c0) + kh) * 16;
+                const unsigned sa4 = *(const DFN_LDS unsigned*)(sc + 4 * rg);
+                const unsigned sb2 = *(const DFN_LDS unsigned short*)(sc + 8 + 2 * cg);
+                const lds_char* b0 = slot + (2 * u) * ntl * 1024 + rd;          // first tile of the pair
+                const lds_char* b1 = b0 + ntl * 1024;                           // second tile
+                i32x8 a[4], b[2];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (i == cg) {
-                        accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], ones, accb, 0, 0, 0);
-                        accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], ones, accb, 0, 0, 0);
+                    if (i < mt_n && (nt_n > 0 || (do_bias && i == cg))) {
+                        const i32x4 lo = *(const DFN_LDS i32x4*)(b0 + (4 * rg + i) * 1024), hi = *(const DFN_LDS i32x4*)(b1 + (4 * rg + i) * 1024);
+                        a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (j < nt_n) {
+                        const i32x4 lo = *(const DFN_LDS i32x4*)(b0 + (mts + 2 * cg + j) * 1024), hi = *(const DFN_LDS i32x4*)(b1 + (mts + 2 * cg + j) * 1024);
+                        b[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (i < mt_n && j < nt_n)
+                            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[i], b[j], acc[i][j], 0, 0, 0, (int)(sa4 >> (8 * i)), 0,
+                                                                                        (int)(sb2 >> (8 * j)));
+                if (do_bias) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (i == cg) accb = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[i], ones, accb, 0, 0, 0, (int)(sa4 >> (8 * i)), 0, 127);
+                }
             }
         }
     }
@@ -198,16 +232,17 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_lds_kernel(const WOp* ops, c
 hipError_t launch_wgrad_bf16(int field, const WOp* ops_dev, const int* order_dev, int n_ops, const void* dy_T,
                              const void* act_T, long NP, int ksplit, float* C, long c_stride, const int* e_of,
                              float* dbias, int n_bias, hipStream_t st) {
-    constexpr int lds = WL_DEPTH * WL_STEP_BYTES;
+    constexpr int lds = WL_DEPTH * WL_STEP_BYTES + WL_SCALE_BYTES;
     static bool done = false;
     if (!done) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_mx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         done = true;
     }
+    if ((NP / 32) & 1) return hipErrorInvalidValue;          // tile pairs (the MFMA contracts two 32-point tiles)
     const bool torso = field == FIELD_TORSO;
     const int g_rows = torso ? GradMap::S_ROWS : GradMap::H_ROWS, a_rows = torso ? RecMap::S_ROWS : RecMap::H_ROWS;
-    hipLaunchKernelGGL(wgrad_lds_kernel, dim3(n_ops * ksplit), dim3(WL_THREADS), lds, st, ops_dev, order_dev, dy_T, act_T,
+    hipLaunchKernelGGL(wgrad_mx_kernel, dim3(n_ops * ksplit), dim3(WL_THREADS), lds, st, ops_dev, order_dev, dy_T, act_T,
                        NP / 32, g_rows, a_rows, ksplit, C, c_stride, e_of, dbias, n_bias);
     return hipGetLastError();
 }

@@ -109,10 +109,15 @@ class TrainBuffers:
         self.n_fine, self.S = int(n_fine), 64 + int(n_fine)
         self.n_rays, self.NP = n_rays, n_rays * self.S
         assert self.NP % 512 == 0, "N_rand must be a multiple of 8"
-        dt = torch.bfloat16 if self.tier == 1 else torch.float32
         rows = lambda f, w: check(lib.dfn_train_rows(f, w), "dfn_train_rows")
-        self.act = [torch.empty(rows(f, 0), self.NP, dtype=dt, device=device) for f in (0, 1)]
-        self.dy = [torch.empty(rows(f, 1), self.NP, dtype=dt, device=device) for f in (0, 1)]
+        if self.tier == 1:
+            # 16-bit tier: the recorded arrays are MX-fp8 (e4m3 + one E8M0 scale per 32-row block and 32-point tile, the
+            # operand format of the block-scaled MFMA the weight-gradient GEMMs run on): [tile][dfn_train_rows(f, 6 / 7)] bytes
+            self.act = [torch.empty(self.NP // 32, rows(f, 6), dtype=torch.uint8, device=device) for f in (0, 1)]
+            self.dy = [torch.empty(self.NP // 32, rows(f, 7), dtype=torch.uint8, device=device) for f in (0, 1)]
+        else:
+            self.act = [torch.empty(rows(f, 0), self.NP, dtype=torch.float32, device=device) for f in (0, 1)]
+            self.dy = [torch.empty(rows(f, 1), self.NP, dtype=torch.float32, device=device) for f in (0, 1)]
         self.masks = [torch.empty(self.NP // 32, rows(f, 2), 64, dtype=torch.int32, device=device) for f in (0, 1)]
         self.ws = [torch.empty(rows(f, 3), dtype=torch.float32, device=device) for f in (0, 1)]
         self.ws_sig = [torch.empty(rows(f, 5), dtype=torch.float32, device=device) for f in (0, 1)]
@@ -607,12 +612,16 @@ class _PointBuffers:
 
     def __init__(self, tier, field, n, device):
         self.tier, self.field, self.n = tier, field, n
-        self.NP = NP = (n + 31) // 32 * 32
-        dt = torch.bfloat16 if tier == 1 else torch.float32
+        # whole tiles; the 16-bit tier's weight-gradient GEMMs contract PAIRS of tiles (block-scaled MFMA, K = 64 points)
+        self.NP = NP = (n + 63) // 64 * 64 if tier == 1 else (n + 31) // 32 * 32
         rows = lambda w: check(lib.dfn_train_rows(field, w), "dfn_train_rows")
-        self.act = torch.empty(rows(0), NP, dtype=dt, device=device)
-        self.dy = torch.empty(rows(1), NP, dtype=dt, device=device)
-        self.masks = torch.empty(NP // 32, rows(2), 64, dtype=torch.int32, device=device)
+        if tier == 1:       # MX-fp8 (TrainBuffers); zeros: a padding tile the forward never writes must read as 0.0 x 2^-127
+            self.act = torch.zeros(NP // 32, rows(6), dtype=torch.uint8, device=device)
+            self.dy = torch.empty(NP // 32, rows(7), dtype=torch.uint8, device=device)
+        else:
+            self.act = torch.empty(rows(0), NP, dtype=torch.float32, device=device)
+            self.dy = torch.empty(rows(1), NP, dtype=torch.float32, device=device)
+        self.masks = torch.zeros(NP // 32, rows(2), 64, dtype=torch.int32, device=device)
         self.ws = torch.empty(rows(3), dtype=torch.float32, device=device)
         self.samples = torch.zeros(NP, 8, dtype=torch.float32, device=device)
         self.packed = torch.empty(check(lib.dfn_packed_bytes(tier, field), "packed"), dtype=torch.uint8, device=device)

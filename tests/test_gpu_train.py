@@ -229,9 +229,10 @@ def test_training_step_full_size_vs_oracle_autograd(states, scene, latents, tier
 def test_bf16_training_tracks_f32_over_200_steps(states, scene, latents):
     """200 optimisation steps (all five networks, gated Adams, the production input stage: device pixel draws, uint8
     ground-truth frames) in the f32 tier and in the bf16 tier from the same start on the same data: both descend and the bf16
-    loss curve ends on the f32 one - mean of the last 20 losses within 2 %, every step of the second half within 2 %.  (The
+    loss curve ends on the f32 one - mean of the last 20 losses within 2 %, every step of the second half within 5 %.  (The
     first ~40 steps are Adam's chaotic transient at lr 5e-4 - the loss overshoots and recovers - where two trajectories that
-    differ by rounding are not comparable step by step; measured: 0.13 % at the end, <= 0.35 % from step 40 on.)"""
+    differ by rounding are not comparable step by step; measured with the MX-fp8 recorder: 0.5 % at the end, <= 2.5 % per step
+    in the second half; with bf16 recording it was 0.13 % / 0.35 %.)"""
     from dfanerf import frames, nets, run_nerf, training
     dev = torch.device("cuda")
     n, n_steps = 1024, 200
@@ -278,7 +279,7 @@ def test_bf16_training_tracks_f32_over_200_steps(states, scene, latents):
     worst = float(np.max((np.abs(b - a) / a)[n_steps // 2:]))
     print(f"bf16 vs f32 over {n_steps} steps: final-loss difference {final:.3%}, worst step of the second half {worst:.3%}; "
           f"loss {a[0]:.4f} -> {a[-1]:.4f}")
-    assert final <= 0.02 and worst <= 0.02, (final, worst)
+    assert final <= 0.02 and worst <= 0.05, (final, worst)
 
 
 def test_fused_fold_backward_matches_torch_fold(states, scene, latents):
@@ -334,9 +335,20 @@ def test_signal_grad_shortcut_matches_the_fold_backward(states, tier):
     p = lambda x: C.c_void_p(x.data_ptr())
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     gen = torch.Generator(device=dev).manual_seed(11)
+    def fill(arr, mean, std):
+        """random contents for a recorded array: f32 tier [rows, NP] floats; 16-bit tier MX-fp8 [tile][rows x 32 e4m3 | 128
+        scale bytes] (dfn_mlp.h "MX-fp8 recording"): e4m3 values with a random power-of-two scale per 32-row block"""
+        if arr.dtype != torch.uint8:
+            arr.copy_(torch.randn(arr.shape, device=dev, generator=gen) * std + mean)
+            return
+        nt, nb = arr.shape
+        rows = (nb - 128) // 32
+        v = (torch.randn(nt, rows * 32, device=dev, generator=gen) * std + mean) * 64.0
+        arr[:, :rows * 32] = v.to(torch.float8_e4m3fn).view(torch.uint8)
+        arr[:, rows * 32:] = torch.randint(118, 124, (nt, 128), device=dev, generator=gen, dtype=torch.uint8)      # x 2^-9 .. 2^-4
     for f, n in ((0, 96), (1, 42)):
-        buf.dy[f].copy_(torch.randn(buf.dy[f].shape, device=dev, generator=gen) * 0.05 + 0.01)
-        buf.act[f].copy_(torch.randn(buf.act[f].shape, device=dev, generator=gen) * 0.1)
+        fill(buf.dy[f], 0.01, 0.05)
+        fill(buf.act[f], 0.0, 0.1)
         sig = torch.randn(n, device=dev, generator=gen)
         z = torch.randn(2, 256, device=dev, generator=gen)
         g_flat, g_bias = torch.zeros_like(flat), torch.zeros(buf.nb[f], device=dev)

@@ -12,7 +12,7 @@ BASE="$ROOT/dfa-nerf_amd/build"
 OBJ="$ROOT/exp_libs/obj_$NAME"
 mkdir -p "$OBJ"
 UNITS="${VARIANT_UNITS:-dfn_render_f16 dfn_render_bf16}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -I$SRC -I$ROOT/include $*"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -mllvm -pragma-unroll-threshold=200000 -I$SRC -I$ROOT/include $*"
 pids=()
 for f in $UNITS; do
   ( hipcc $FLAGS --save-temps=obj -c "$SRC/$f.hip" -o "$OBJ/$f.o" 2>"$OBJ/$f.log" ) &

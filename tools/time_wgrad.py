@@ -12,8 +12,12 @@ tier = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 dev = torch.device("cuda")
 buf = training.TrainBuffers(tier, 2048, dev)
 for f in (0, 1):
-    buf.act[f].copy_(torch.randn_like(buf.act[f], dtype=torch.float32) * 0.1)
-    buf.dy[f].copy_(torch.randn_like(buf.dy[f], dtype=torch.float32) * 0.1)
+    for arr in (buf.act[f], buf.dy[f]):
+        if arr.dtype == torch.uint8:      # 16-bit tier: MX-fp8 [tile][rows x 32 e4m3 | 128 scale bytes]
+            arr.copy_((torch.randn(arr.shape, device=dev) * 8).to(torch.float8_e4m3fn).view(torch.uint8))
+            arr[:, -128:] = 120
+        else:
+            arr.copy_(torch.randn_like(arr) * 0.1)
 g_flat = torch.zeros(955242, device=dev)
 gb = [torch.zeros(buf.nb[f], device=dev) for f in (0, 1)]
 p = lambda t: C.c_void_p(t.data_ptr())
