@@ -38,7 +38,7 @@ DFN_DEV void apply_mask(f32x16 (&acc)[2], unsigned bits) {
 #ifndef DFN_NOMASK
 #pragma unroll
     for (int b = 0; b < 32; ++b) {      // bit b sign-extended to a word (v_bfe_i32), ANDed onto the value: 2 ops per value
-        const unsigned keep = (unsigned)__builtin_amdgcn_sbfe((int)bits, b, 1);
+        const unsigned keep = (unsigned)__builtin_amdgcn_sbfe((int)bits, mask_pos(b), 1);
         const float x = acc[b >> 4][b & 15];          // a scalar copy: __builtin_bit_cast of a vector ELEMENT miscompiles
         acc[b >> 4][b & 15] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & keep);
     }
@@ -258,7 +258,7 @@ DFN_DEV void bwd_trunk(const BwdIn& in, Vec<TIER, 8>& dy0, Vec<TIER, 4>& gpd_ski
         const unsigned bits = mask_word(io, m_trunk + RecMap::TM_A4R + w, c.lane);
 #pragma unroll
         for (int b = 0; b < 32; ++b)
-            if (!((bits >> b) & 1u)) cur.set(32 * w + b, 0.f);
+            if (!((bits >> mask_pos(b)) & 1u)) cur.set(32 * w + b, 0.f);
     }
     // blocks[3..0]^T -> dy3 .. dy0; layer l writes its input: dy4 (l = 3), then dy3 .. dy1
     if constexpr (TIER == TIER_F32) {
@@ -336,8 +336,8 @@ DFN_DEV void bwd_torso(const BwdIn& in, const BwdIO& io, Stream& s, const CT& c)
         const unsigned be = mask_word(io, RecMap::S_MD0 + 6, c.lane), bs = mask_word(io, RecMap::S_MD0 + 7, c.lane);
 #pragma unroll
         for (int b = 0; b < 32; ++b) {
-            if (!((be >> b) & 1u)) ge.set(b, 0.f);
-            if (!((bs >> b) & 1u)) gs.set(b, 0.f);
+            if (!((be >> mask_pos(b)) & 1u)) ge.set(b, 0.f);
+            if (!((bs >> mask_pos(b)) & 1u)) gs.set(b, 0.f);
         }
     }
     put<TIER, 2>(io, GradMap::S_DE3, ge, c);

@@ -276,9 +276,12 @@ struct Q8 {
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_q __attribute__((ext_vector_type(2)));
 // scale of tiles [t0, t0 + n) of v: amax over the wave (all 32 points), wave-uniform
-template <int NT> DFN_DEV Q8 q8_of_tiles(const Vec<TIER_BF16, NT>& v, int t0, int n) {
+// NONNEG: the values are ReLU outputs (no sign bits to clear)
+template <int NT, bool NONNEG = false> DFN_DEV Q8 q8_of_tiles(const Vec<TIER_BF16, NT>& v, int t0, int n) {
     typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-    u16x2 m = {0, 0};
+    // a TREE of packed maxima (four independent chains, then their maximum): as one chain the 15 dependent v_pk_max_u16 of a
+    // tile pair sit in front of everything the wave issues next (in-order issue), MFMAs included
+    u16x2 m4[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
 #pragma unroll
     for (int t = 0; t < NT; ++t)
         if (t >= t0 && t < t0 + n)
@@ -287,16 +290,18 @@ template <int NT> DFN_DEV Q8 q8_of_tiles(const Vec<TIER_BF16, NT>& v, int t0, in
                 const u32x4_ q = __builtin_bit_cast(u32x4_, v.u[2 * t + h]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {    // |x| of a bf16 orders like its bit pattern: packed unsigned 16-bit max
-                    const unsigned a = q[e] & 0x7fff7fffu;      // (a scalar: __builtin_bit_cast of a vector ELEMENT miscompiles)
-                    m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2, a));
+                    const unsigned a = NONNEG ? q[e] : q[e] & 0x7fff7fffu;      // (a scalar: __builtin_bit_cast of a vector ELEMENT miscompiles)
+                    m4[e] = __builtin_elementwise_max(m4[e], __builtin_bit_cast(u16x2, a));
                 }
             }
+    const u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(m4[0], m4[1]), __builtin_elementwise_max(m4[2], m4[3]));
     unsigned x = max((unsigned)m[0], (unsigned)m[1]);
-    // row maxima by DPP (quad swaps, half-row mirror, row mirror), then the four rows by readlane: an SGPR
-    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false));
-    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false));
-    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, false));
-    x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, false));
+    // row maxima by DPP (quad swaps, half-row mirror, row mirror; `old` = the source: every lane is written, and a separate
+    // old operand would cost a v_mov per step), then the four rows by readlane: an SGPR
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false));
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false));
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false));
+    x = max(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false));
     const unsigned a = max(max((unsigned)__builtin_amdgcn_readlane((int)x, 0), (unsigned)__builtin_amdgcn_readlane((int)x, 16)),
                            max((unsigned)__builtin_amdgcn_readlane((int)x, 32), (unsigned)__builtin_amdgcn_readlane((int)x, 48)));
     // amax in [2^(E-127), 2^(E-126)); scale = 2^(E-127-7): |x| / scale < 256 (e4m3 holds 448; no saturation mode needed)
@@ -322,9 +327,9 @@ DFN_DEV void store_dword8(void* arr, int rows, long tile, int row0, const Vec<TI
     o = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o, __builtin_bit_cast(bf16x2_q, w_lo), q.scale, false);
     o = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o, __builtin_bit_cast(bf16x2_q, w_hi), q.scale, true);
     const unsigned own = __builtin_bit_cast(unsigned, o);
-    const unsigned n1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);          // lane ^ 1
+    const unsigned n1 = (unsigned)__builtin_amdgcn_update_dpp((int)own, (int)own, 0xB1, 0xf, 0xf, false);          // lane ^ 1
     const unsigned x = __builtin_amdgcn_perm(own, n1, (c.lane & 1) ? 0x07030501u : 0x02060004u);
-    const unsigned n2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false);            // lane ^ 2
+    const unsigned n2 = (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false);            // lane ^ 2
     const unsigned y = __builtin_amdgcn_perm(x, n2, (c.lane & 2) ? 0x07060302u : 0x01000504u);
     gchar* ubase = uniform_ptr((char*)arr + tile * rec8_tile_bytes(rows) + (long)row0 * 32);
     const unsigned voff = (unsigned)((4 * c.half + (c.lane & 3)) * 32 + ((c.lane & 31) & ~3));
@@ -375,21 +380,6 @@ DFN_DEV void rec_vec(const CT& c, int row0, const Vec<TIER, NT>& v) {
     if constexpr (!CT::rec_on) return;
     else store_vec_T<TIER, NT>(c.rec.act_T, c.rec.rows, c.rec.pass, row0, v, c);
 }
-// ReLU mask bits of a vector (bit L of this lane's words = local slot L is positive)
-template <int TIER, int NT, class CT>
-DFN_DEV void rec_mask(const CT& c, int dword0, const Vec<TIER, NT>& v) {
-    if constexpr (CT::rec_on)
-#pragma unroll
-    for (int w = 0; w < (NT + 1) / 2; ++w) {
-        unsigned bits = 0;
-#pragma unroll
-        for (int b = 0; b < 32; ++b)
-            if (32 * w + b < 16 * NT) bits |= (v.get(32 * w + b) > 0.f) ? (1u << b) : 0u;
-        gchar* mb = uniform_ptr(c.rec.masks + ((long)c.rec.pass * c.rec.mask_dwords + dword0 + w) * 64);
-        *(__attribute__((address_space(1))) unsigned*)(mb + (unsigned)c.lane * 4u) = bits;      // (ordinary: the dX kernels read these next)
-    }
-}
-
 
 // The A-fragment stream of a pass is strictly sequential (fragment f lives in slab f/32 at position f%32),
 // so fragments are prefetched PF_DEPTH ahead into a small register ring that is carried across ops and
@@ -638,15 +628,45 @@ DFN_DEV void rec_vals(const CT& c, int row0, const Vec<TIER, NT>& out, int t0) {
     if constexpr (CT::rec_on)
         if (row0 >= 0) store_tiles_T<TIER, NT>(c.rec.act_T, c.rec.rows, c.rec.pass, row0, out, t0, 2, c);
 }
+// ReLU bit of value b (= 16 g + r: tile g of the pair, accumulator register r) of a tile pair inside its mask dword: value b
+// lives in the (b & 1) half of packed operand word b >> 1, and the 16-bit tiers build the dword FROM those words (below)
+DFN_HD constexpr int mask_pos(int b) { return ((b & 1) << 4) | (b >> 1); }
 template <class CT>
 DFN_DEV void rec_mask_pair(const CT& c, int mask_dword, const f32x16 (&acc)[2]) {
     if constexpr (CT::rec_on) {
         if (mask_dword >= 0) {
             unsigned bits = 0;
 #pragma unroll
-            for (int b = 0; b < 32; ++b) bits |= (acc[b >> 4][b & 15] > 0.f) ? (1u << b) : 0u;
+            for (int b = 0; b < 32; ++b) bits |= (acc[b >> 4][b & 15] > 0.f) ? (1u << mask_pos(b)) : 0u;
             gchar* mb = uniform_ptr(c.rec.masks + ((long)c.rec.pass * c.rec.mask_dwords + mask_dword) * 64);
             *(__attribute__((address_space(1))) unsigned*)(mb + (unsigned)c.lane * 4u) = bits;      // (ordinary: the dX kernels read these next)
+        }
+    }
+}
+
+// The same dword from the pair's packed, ReLU'd operand words (16-bit tiers): a positive bf16 / f16 is a non-zero 16-bit
+// pattern >= 1, so v_pk_min_u16(word, 0x00010001) is (bit of the low half) | (bit of the high half) << 16 and one
+// v_lshl_or_b32 drops both at mask_pos: 1 VALU per value instead of the 3 (compare, select, or) of the f32 route - a
+// quarter of the training forward's vector instructions were mask bits.
+template <int TIER, int NT, class CT>
+DFN_DEV void rec_mask_pair_packed(const CT& c, int mask_dword, const Vec<TIER, NT>& out, int t0) {
+    if constexpr (CT::rec_on && tier_is16(TIER)) {
+        if (mask_dword >= 0) {
+            typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+            const u16x2 one = {1, 1};
+            unsigned bits = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32x4_ q = __builtin_bit_cast(u32x4_, out.u[2 * t0 + k]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned w = q[e];          // (a scalar: __builtin_bit_cast of a vector ELEMENT miscompiles)
+                    const unsigned t = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, w), one));
+                    bits |= t << (4 * k + e);
+                }
+            }
+            gchar* mb = uniform_ptr(c.rec.masks + ((long)c.rec.pass * c.rec.mask_dwords + mask_dword) * 64);
+            *(__attribute__((address_space(1))) unsigned*)(mb + (unsigned)c.lane * 4u) = bits;
         }
     }
 }
@@ -720,7 +740,7 @@ DFN_DEV void layer_pipe(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_
 #ifndef DFN_REC_SPREAD
 #define DFN_REC_SPREAD 1
 #endif
-template <int TIER, int OT, int KU, class CT> struct RecSide {
+template <int TIER, int OT, int KU, class CT, bool NONNEG> struct RecSide {
     const CT& c;
     const Vec<TIER, OT>& out;
     int rec_row, prev;              // prev: the pair whose values are stored (-1: none)
@@ -731,7 +751,7 @@ template <int TIER, int OT, int KU, class CT> struct RecSide {
         if constexpr (CT::rec_on && TIER == TIER_BF16) {
             if (prev < 0 || rec_row < 0) return;
             if (ku == 0) {
-                q = q8_of_tiles<OT>(out, 2 * prev, 2);
+                q = q8_of_tiles<OT, NONNEG>(out, 2 * prev, 2);
                 store_scale8(c.rec.act_T, c.rec.rows, c.rec.pass, rec_row, 2 * prev, 0, 2, q, c);
             }
 #pragma unroll
@@ -758,7 +778,7 @@ DFN_DEV void layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_f32* 
         f32x16 acc[2];
         acc_init<2>(acc, bias + tg * 64, c.half);
         if constexpr (SPREAD) {
-            gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c, NoHook{}, RecSide<TIER, OT, KU, CT>{c, out, rec_row, tg - 1, {}});
+            gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c, NoHook{}, RecSide<TIER, OT, KU, CT, RELU>{c, out, rec_row, tg - 1, {}});
         } else {
             auto flush = [&] {
                 if (pend) rec_vals<TIER>(c, rec_row + 64 * (tg - 1), out, 2 * (tg - 1));
@@ -768,7 +788,8 @@ DFN_DEV void layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_f32* 
             flush();                // no hand-over inside this group
         }
         acc_to_vec<TIER, 2, OT, RELU>(acc, out, 2 * tg);
-        rec_mask_pair(c, rec_mask < 0 ? -1 : rec_mask + tg, acc);
+        if constexpr (RELU && tier_is16(TIER)) rec_mask_pair_packed<TIER, OT>(c, rec_mask < 0 ? -1 : rec_mask + tg, out, 2 * tg);
+        else rec_mask_pair(c, rec_mask < 0 ? -1 : rec_mask + tg, acc);
         pend = CT::rec_on && rec_row >= 0;
     }
     if (pend) rec_vals<TIER>(c, rec_row + 64 * (OT / 2 - 1), out, OT - 2);
@@ -978,7 +999,8 @@ DFN_DEV MlpOut mlp_trunk(Vec<TIER, 8>& act, const Vec<TIER, NTP>& pvec, const Dh
             gemm_group<TIER, 2, P::KU_VIEW, 1>(acc, vview, f, fe, s, c, flush);
             flush();
             acc_to_vec<TIER, 2, 8, true>(acc, hid, 2 * tg);
-            rec_mask_pair(c, m_trunk + RecMap::TM_H + tg, acc);
+            if constexpr (tier_is16(TIER)) rec_mask_pair_packed<TIER, 8>(c, m_trunk + RecMap::TM_H + tg, hid, 2 * tg);
+            else rec_mask_pair(c, m_trunk + RecMap::TM_H + tg, acc);
             pend = CT::rec_on;
             ptg = tg;
         }
