@@ -265,15 +265,29 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
         # next to the ALGORITHMIC bytes of the step (pixel ids, targets, background, the four weight streams, the parameter
         # read of the pack, the gradient write): the ratio is the traffic the recorded design adds.
         from dfanerf._lib import lib as _l
-        esz = 2 if tier == "bf16" else 4
         NP = S * N_RAND
-        act_b = sum(_l.dfn_train_rows(f, 0) for f in (0, 1)) * NP * esz
-        dy_b = sum(_l.dfn_train_rows(f, 1) for f in (0, 1)) * NP * esz
+        if tier == "bf16":       # MX-fp8 recording: [tile][rows x 32 e4m3 bytes + scale block]
+            act_b = sum(_l.dfn_train_rows(f, 6) for f in (0, 1)) * (NP // 32)
+            dy_b = sum(_l.dfn_train_rows(f, 7) for f in (0, 1)) * (NP // 32)
+        else:
+            act_b = sum(_l.dfn_train_rows(f, 0) for f in (0, 1)) * NP * 4
+            dy_b = sum(_l.dfn_train_rows(f, 1) for f in (0, 1)) * NP * 4
         step_bytes = 2 * (act_b + dy_b)          # recorded activations and pre-activation gradients: written once, read once (wgrad)
         t_id = 1 if tier == "bf16" else 0
         streams = sum(_l.dfn_packed_bytes(t_id, f) + _l.dfn_packed_bwd_bytes(t_id, f) for f in (0, 1))
         alg_bytes = N_RAND * (4 + 3 + 3 + 3 + 24) + 2 * streams + 2 * 4 * 1138656
-        gbs = step_bytes * world * steps / dt / 1e9
+        # measured HBM bytes per step (rocprofv3 PMC passes of this command, profiles/traffic.json), when a pass was committed
+        traffic, traffic_src = step_bytes, ("design bytes per step and GPU: recorded activations + pre-activation gradients, "
+                                            "written once and read once")
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                tr = json.load(f).get(f"{workload}_{tier}")
+            if tr and world == 1:
+                traffic = tr["hbm_bytes_per_launch"]
+                traffic_src = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per kernel, summed over the step's launches)"
+        except OSError:
+            pass
+        gbs = traffic * world * steps / dt / 1e9
         peak = PEAK_TFLOPS[tier] * world
         out = {
             "metric": f"training rays/sec (whole node), N_rand={N_RAND} per GPU, {S} samples, 2 fields, fwd+bwd+Adam",
@@ -285,9 +299,8 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
                        "fields": 2, "parallelism": f"dp{world}, one flat-bucket all_reduce (1,138,656 floats)"},
             "roofline": {"bound": "mfma", "kernel": "whole step (render_kernel<train>, mlp_bwd, wgrad_lds)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "flop_per_ray": flop_ray,
-                         "traffic": step_bytes, "traffic_source": "design bytes per step and GPU: recorded activations + "
-                                                                  "pre-activation gradients, written once and read once",
-                         "algorithmic_bytes": alg_bytes, "traffic_over_algorithmic": step_bytes / alg_bytes,
+                         "traffic": traffic, "traffic_source": traffic_src, "recorded_bytes_per_step": step_bytes,
+                         "algorithmic_bytes": alg_bytes, "traffic_over_algorithmic": traffic / alg_bytes,
                          "hbm": {"achieved_gbs": gbs, "peak_gbs": 8000.0 * world, "frac": gbs / (8000.0 * world)}},
             "per_rank": {"ms_per_step": rank_ms}}
         if sus:

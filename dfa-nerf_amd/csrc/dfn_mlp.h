@@ -307,6 +307,11 @@ template <int NT, bool NONNEG = false> DFN_DEV Q8 q8_of_tiles(const Vec<TIER_BF1
     // amax in [2^(E-127), 2^(E-126)); scale = 2^(E-127-7): |x| / scale < 256 (e4m3 holds 448; no saturation mode needed)
     const unsigned E = a >> 7;                                   // bf16: sign(1) exponent(8) mantissa(7)
     Q8 q;
+#ifdef DFN_REC8_NOAMAX        // timing experiment (wrong results): a fixed scale, no amax
+    q.e8 = 120u;
+    q.scale = __builtin_bit_cast(float, q.e8 << 23);
+    return q;
+#endif
     q.e8 = E > 8u ? E - 7u : 1u;
     q.scale = __builtin_bit_cast(float, q.e8 << 23);
     return q;
@@ -327,10 +332,18 @@ DFN_DEV void store_dword8(void* arr, int rows, long tile, int row0, const Vec<TI
     o = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o, __builtin_bit_cast(bf16x2_q, w_lo), q.scale, false);
     o = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o, __builtin_bit_cast(bf16x2_q, w_hi), q.scale, true);
     const unsigned own = __builtin_bit_cast(unsigned, o);
+#ifdef DFN_REC8_NOXPOSE       // timing experiment (wrong results): what do the quad transposes cost?
+    const unsigned y = own;
+#else
     const unsigned n1 = (unsigned)__builtin_amdgcn_update_dpp((int)own, (int)own, 0xB1, 0xf, 0xf, false);          // lane ^ 1
     const unsigned x = __builtin_amdgcn_perm(own, n1, (c.lane & 1) ? 0x07030501u : 0x02060004u);
     const unsigned n2 = (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false);            // lane ^ 2
     const unsigned y = __builtin_amdgcn_perm(x, n2, (c.lane & 2) ? 0x07060302u : 0x01000504u);
+#endif
+#ifdef DFN_REC8_NOSTORE       // timing experiment (wrong results): everything but the store instruction
+    asm volatile("" ::"v"(y));
+    return;
+#endif
     gchar* ubase = uniform_ptr((char*)arr + tile * rec8_tile_bytes(rows) + (long)row0 * 32);
     const unsigned voff = (unsigned)((4 * c.half + (c.lane & 3)) * 32 + ((c.lane & 31) & ~3));
     __builtin_nontemporal_store(y, (__attribute__((address_space(1))) unsigned*)(ubase + (32 * (t - (d_first >> 2)) + 8 * qq) * 32 + voff));
