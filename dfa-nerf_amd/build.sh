@@ -18,6 +18,11 @@ mkdir -p "$OBJ"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -mllvm -pragma-unroll-threshold=200000 -I$SRC -I$HERE/../include $DFN_EXTRA_FLAGS"
 HDR_HASH="$( (cat "$SRC"/*.h "$HERE"/../include/*.h; echo "$FLAGS" | sed "s#$HERE#.#g"; hipcc --version 2>/dev/null | head -2) | sha256sum | cut -d' ' -f1)"
 UNITS="dfn_render dfn_render_f32 dfn_render_bf16 dfn_render_f16 dfn_misc dfn_api dfn_train dfn_bwd_bf16 dfn_wgrad_bf16 dfn_signal"
+# the library's own stamp (next to the .so: it travels with it to the GPU box, the object directory does not): everything it
+# is made from, hashed - an up-to-date library is not rebuilt
+LIB_HASH="$( (echo "$HDR_HASH"; cat "$SRC"/*.hip "$SRC"/*.cpp) | sha256sum | cut -d' ' -f1)"
+if [ -f "$OUT" ] && [ "$(cat "$OUT.stamp" 2>/dev/null)" = "$LIB_HASH" ]; then echo "up to date: $OUT"; exit 0; fi
+rm -f "$OUT.stamp"
 pids=()
 for f in $UNITS; do
   ( want="$HDR_HASH $(sha256sum < "$SRC/$f.hip" | cut -d' ' -f1)"
@@ -43,4 +48,5 @@ done
 rm -f "$OBJ"/*-hip-amdgcn-*.o "$OBJ"/*.hipi "$OBJ"/*.bc "$OBJ"/*.out "$OBJ"/*.resolution.txt "$OBJ"/*.hipfb "$OBJ"/*-host-*.s      # --save-temps leftovers (the device ISA stays)
 OBJS=""; for f in $UNITS; do OBJS="$OBJS $OBJ/$f.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" $OBJS "$OBJ/dfn_plan.o"
+echo "$LIB_HASH" > "$OUT.stamp"
 echo "built $OUT"
