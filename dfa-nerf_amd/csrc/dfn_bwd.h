@@ -93,27 +93,31 @@ template <int TIER, int NT> DFN_DEV void pin_vec(Vec<TIER, NT>& v) {
 #ifndef DFN_TORSO_DY0_SPREAD
 #define DFN_TORSO_DY0_SPREAD 1
 #endif
-// (MX-fp8, dfn_mlp.h: the vector's 4 NTB dword stores are spread evenly over the consuming layer's T = OT / 2 x KU k-steps;
-// the scales of its tile pairs are found in front of the layer)
+// (MX-fp8, dfn_mlp.h: the vector's NTB 16-byte tile stores are spread evenly over the consuming layer's T = OT / 2 x KU
+// k-steps; the scales of its tile pairs are found in front of the layer)
 template <int TIER, int NTB, int KU, int T, class CT> struct PutSide {
     const BwdIO& io;
     const Vec<TIER, NTB>& v;
     int row0, tg;
     const CT& c;
     const Q8* qs;                   // scale of tile pair p (NTB == 1: of the one tile)
-    static constexpr int D = 4 * NTB, DPS = (D + T - 1) / T;        // dword stores per k-step
-    DFN_DEV void dword(int d) const {
+    static constexpr int STRIDE = T >= NTB ? T / NTB : 1, PER = T >= NTB ? 1 : (NTB + T - 1) / T;      // k-steps per tile / tiles per k-step
+    DFN_DEV void tile(int t) const {
 #ifndef DFN_NOPUT
         if constexpr (TIER == TIER_BF16) {
-            if (d < D) store_dword8<NTB>(io.dy_T, io.rows, io.pass, row0, v, d, 0, qs[d >> 3], c);
+            if (t < NTB) store_tile8<NTB>(io.dy_T, io.rows, io.pass, row0, v, t, 0, qs[t >> 1], c);
         }
 #endif
     }
     DFN_DEV void operator()(int ku) const {
         if (row0 < 0) return;
         const int s = tg * KU + ku;
+        if constexpr (T >= NTB) {
+            if (s % STRIDE == 0) tile(s / STRIDE);
+        } else {
 #pragma unroll
-        for (int w = 0; w < DPS; ++w) dword(s * DPS + w);      // (constant trip count; dword() drops d >= D)
+            for (int w = 0; w < PER; ++w) tile(s * PER + w);
+        }
     }
 };
 // scales of the tile pairs of `v` + their bytes in dy_T (in front of the layer that streams the vector out)

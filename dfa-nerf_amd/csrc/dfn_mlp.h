@@ -265,8 +265,14 @@ DFN_DEV gchar* uniform_ptr(const void* p) {
 // measured 0.1 % (median) / 1.6 % (worst tensor) of the bf16 step's own gradient, invisible next to the 1.7 % the bf16
 // operands cost against the f32 oracle (tools/diag_fp8_record.py).  Power-of-two scales make the result independent of the
 // block size as long as nothing under- or overflows.
-// Layout per 32-point tile: [rows][32 points] bytes (row-major: the MFMA's A / B fragment of a row is two 16-byte runs),
-// then REC8_SCALE_BYTES of scales, one per 32-row block.
+// Layout per 32-point tile: one 1-KiB block per 32-row (feature) block, then REC8_SCALE_BYTES of scales, one per block.
+// Inside a block the bytes are POINT-major, [point n][half h][accumulator register r] = feature tile_feat(h, r) of point n:
+// exactly the 16 bytes lane (n, h) holds of the block after the conversion, so a block is written by ONE 16-byte store
+// per lane (1 KiB contiguous per instruction) with no cross-lane traffic.  The weight-gradient GEMMs need the transpose
+// (lane = feature row, registers = points): they get it from the LDS transpose read ds_read_b64_tr_b8 (dfn_wgrad_bf16.hip;
+// tools/tr8_probe.hip pins its semantics).  Round 3's first version transposed 4 x 4 bytes across lane quads in the
+// producers (two DPP moves + two v_perm_b32 per dword, four dword stores per block): the transposes cost 13 us and the
+// store instructions most of 56 us of the 430-us training forward.
 constexpr int REC8_SCALE_BYTES = 128;        // >= rows / 32 of every array (torso dy_T: 110)
 DFN_HD constexpr long rec8_tile_bytes(int rows) { return (long)rows * 32 + REC8_SCALE_BYTES; }
 struct Q8 {
@@ -316,37 +322,30 @@ template <int NT, bool NONNEG = false> DFN_DEV Q8 q8_of_tiles(const Vec<TIER_BF1
     q.scale = __builtin_bit_cast(float, q.e8 << 23);
     return q;
 }
-// ONE store instruction: dword d of v (tile d >> 2, accumulator registers 4 (d & 3) .. + 3 = four consecutive feature rows
-// of this lane's point) -> fp8, 4 x 4 byte transpose across the quad of lanes (points n0 .. n0 + 3; two DPP moves + two
-// v_perm_b32), so that lane q of the quad holds feature row q at points n0 .. n0 + 3: 4 bytes of that row's 32-byte run.
-// The 32 lanes of a half-wave write 128 contiguous bytes (4 rows), a whole store instruction 256.
+// ONE store instruction: tile t of v (this lane's 16 features of the 32-row block, one point) -> 16 fp8 bytes at
+// [point][half] of the block; 8 conversions, no cross-lane traffic.
 template <int NT, class CT>
-DFN_DEV void store_dword8(void* arr, int rows, long tile, int row0, const Vec<TIER_BF16, NT>& v, int d, int d_first, const Q8& q,
-                          const CT& c) {
+DFN_DEV void store_tile8(void* arr, int rows, long tile, int row0, const Vec<TIER_BF16, NT>& v, int t, int t_first, const Q8& q,
+                         const CT& c) {
     typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
     typedef short s16x2_ __attribute__((ext_vector_type(2)));
-    const int t = d >> 2, qq = d & 3;
-    const u32x4_ w = __builtin_bit_cast(u32x4_, v.u[2 * t + (qq >> 1)]);
-    s16x2_ o = {0, 0};
-    const unsigned w_lo = w[2 * (qq & 1)], w_hi = w[2 * (qq & 1) + 1];      // scalar copies: __builtin_bit_cast of a vector ELEMENT miscompiles
-    o = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o, __builtin_bit_cast(bf16x2_q, w_lo), q.scale, false);
-    o = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o, __builtin_bit_cast(bf16x2_q, w_hi), q.scale, true);
-    const unsigned own = __builtin_bit_cast(unsigned, o);
-#ifdef DFN_REC8_NOXPOSE       // timing experiment (wrong results): what do the quad transposes cost?
-    const unsigned y = own;
-#else
-    const unsigned n1 = (unsigned)__builtin_amdgcn_update_dpp((int)own, (int)own, 0xB1, 0xf, 0xf, false);          // lane ^ 1
-    const unsigned x = __builtin_amdgcn_perm(own, n1, (c.lane & 1) ? 0x07030501u : 0x02060004u);
-    const unsigned n2 = (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false);            // lane ^ 2
-    const unsigned y = __builtin_amdgcn_perm(x, n2, (c.lane & 2) ? 0x07060302u : 0x01000504u);
-#endif
+    u32x4_ out;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {            // registers 4 k .. 4 k + 3 -> dword k
+        const u32x4_ w = __builtin_bit_cast(u32x4_, v.u[2 * t + (k >> 1)]);
+        const unsigned w_lo = w[2 * (k & 1)], w_hi = w[2 * (k & 1) + 1];      // scalar copies: __builtin_bit_cast of a vector ELEMENT miscompiles
+        s16x2_ o = {0, 0};
+        o = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o, __builtin_bit_cast(bf16x2_q, w_lo), q.scale, false);
+        o = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o, __builtin_bit_cast(bf16x2_q, w_hi), q.scale, true);
+        out[k] = __builtin_bit_cast(unsigned, o);
+    }
 #ifdef DFN_REC8_NOSTORE       // timing experiment (wrong results): everything but the store instruction
-    asm volatile("" ::"v"(y));
+    asm volatile("" ::"v"(out));
     return;
 #endif
     gchar* ubase = uniform_ptr((char*)arr + tile * rec8_tile_bytes(rows) + (long)row0 * 32);
-    const unsigned voff = (unsigned)((4 * c.half + (c.lane & 3)) * 32 + ((c.lane & 31) & ~3));
-    __builtin_nontemporal_store(y, (__attribute__((address_space(1))) unsigned*)(ubase + (32 * (t - (d_first >> 2)) + 8 * qq) * 32 + voff));
+    const unsigned voff = (unsigned)((c.lane & 31) * 32 + c.half * 16);
+    __builtin_nontemporal_store(out, (__attribute__((address_space(1))) u32x4_*)(ubase + (t - t_first) * 1024 + voff));
 }
 // the scale bytes of tiles [t0, t0 + n) of a vector whose tile t_first sits at row row0
 template <class CT>
@@ -363,7 +362,7 @@ DFN_DEV void store_tiles_T(void* arr, int rows, long tile, int row0, const Vec<T
     // immediate) and the register allocator spilled those pointers around the MFMA loops.
     gchar* ubase = uniform_ptr((T*)arr + (tile * rows + row0) * 32);
     if constexpr (TIER == TIER_BF16) {
-        // MX-fp8 (above): tile pairs share a scale; one dword store per four feature rows
+        // MX-fp8 (above): tile pairs share a scale; one 16-byte store per tile
 #pragma unroll
         for (int t = 0; t < NT; t += 2)
             if (t >= t0 && t < t0 + n) {
@@ -371,8 +370,8 @@ DFN_DEV void store_tiles_T(void* arr, int rows, long tile, int row0, const Vec<T
                 const Q8 q = q8_of_tiles<NT>(v, t, np);
                 store_scale8(arr, rows, tile, row0, t, t0, np, q, c);
 #pragma unroll
-                for (int dd = 0; dd < 8; ++dd)          // (constant trip count: np may be a run-time value)
-                    if (dd < 4 * np && 4 * t + dd < 4 * NT) store_dword8<NT>(arr, rows, tile, row0, v, 4 * t + dd, 4 * t0, q, c);
+                for (int k = 0; k < 2; ++k)             // (constant trip count: np may be a run-time value)
+                    if (k < np && t + k < NT) store_tile8<NT>(arr, rows, tile, row0, v, t + k, t0, q, c);
             }
     } else {
 #pragma unroll
@@ -758,8 +757,8 @@ template <int TIER, int OT, int KU, class CT, bool NONNEG> struct RecSide {
     const Vec<TIER, OT>& out;
     int rec_row, prev;              // prev: the pair whose values are stored (-1: none)
     mutable Q8 q;                   // the pair's scale, found at k-step 0
-    static constexpr int DPS = (8 + KU - 1) / KU;       // dword stores per k-step
-    // the pair's 8 dword stores (MX-fp8, above), DPS per k-step from k-step 0 on; k-step 0 also finds the scale
+    // k-step 0 finds the pair's scale; its two 16-byte tile stores (MX-fp8, above) go out at k-steps S0 and S1
+    static constexpr int S0 = KU > 1 ? 1 : 0, S1 = KU > 2 ? 1 + (KU - 1) / 2 : S0;
     DFN_DEV void operator()(int ku) const {
         if constexpr (CT::rec_on && TIER == TIER_BF16) {
             if (prev < 0 || rec_row < 0) return;
@@ -767,10 +766,8 @@ template <int TIER, int OT, int KU, class CT, bool NONNEG> struct RecSide {
                 q = q8_of_tiles<OT, NONNEG>(out, 2 * prev, 2);
                 store_scale8(c.rec.act_T, c.rec.rows, c.rec.pass, rec_row, 2 * prev, 0, 2, q, c);
             }
-#pragma unroll
-            for (int w = 0; w < DPS; ++w)       // (constant trip count: every index below folds once gemm_group is unrolled)
-                if (ku * DPS + w < 8)
-                    store_dword8<OT>(c.rec.act_T, c.rec.rows, c.rec.pass, rec_row, out, 8 * prev + ku * DPS + w, 0, q, c);
+            if (ku == S0) store_tile8<OT>(c.rec.act_T, c.rec.rows, c.rec.pass, rec_row, out, 2 * prev, 0, q, c);
+            if (ku == S1) store_tile8<OT>(c.rec.act_T, c.rec.rows, c.rec.pass, rec_row, out, 2 * prev + 1, 0, q, c);
         }
     }
 };

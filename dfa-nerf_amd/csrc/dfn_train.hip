@@ -695,20 +695,18 @@ hipError_t launch_reduce_bias(const int* rows, const float* parts, int n_bias, i
     return hipGetLastError();
 }
 
-// ---- the 16-bit tier's recorded arrays are MX-fp8 (dfn_mlp.h: "MX-fp8 recording"): per 32-point tile [rows][32] e4m3 bytes
-// + one E8M0 scale per 32-row block.  Sum of row `row` over the 32 points of tile t, dequantised.
-typedef float f32x2_ __attribute__((ext_vector_type(2)));
+// ---- the 16-bit tier's recorded arrays are MX-fp8 (dfn_mlp.h: "MX-fp8 recording"): per 32-point tile one KiB per 32-row
+// block, point-major ([point][half h][register r] = feature tile_feat(h, r)), + one E8M0 scale per block.  Sum of row `row`
+// over the 32 points of tile t, dequantised: the row's byte of every point's 32-byte record.
 __device__ __forceinline__ float rec8_row_sum(const unsigned char* arr, long t, int rows, int row) {
     const unsigned char* base = arr + t * rec8_tile_bytes(rows);
-    const uint4* p = (const uint4*)(base + (long)row * 32);
-    const uint4 v0 = p[0], v1 = p[1];
-    const unsigned w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    int h, r;
+    tile_feat_inv(row & 31, &h, &r);
+    const unsigned* p = (const unsigned*)(base + (long)(row >> 5) * 1024 + h * 16 + (r & ~3));
+    const int sh = 8 * (r & 3);
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const f32x2_ lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[k], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[k], true);
-        s += (lo[0] + lo[1]) + (hi[0] + hi[1]);
-    }
+    for (int n = 0; n < 32; ++n) s += __builtin_amdgcn_cvt_f32_fp8((int)(p[n * 8] >> sh), 0);
     const unsigned e8 = base[(long)rows * 32 + (row >> 5)];
     return s * __uint_as_float(e8 << 23);
 }

@@ -10,12 +10,13 @@
 // Lane (m = l & 31, kh = l >> 5) of an A (B) fragment holds row m's points 16 kh .. + 15 of the first tile (bytes 0-15)
 // and of the second tile (bytes 16-31); the scale of the first tile is taken from the lanes with kh = 0, of the second from
 // kh = 1 (tools/mx_probe.hip pins this on the hardware).
-// The rows a GEMM needs of one tile are ONE contiguous run (32 bytes per row), which LDS-DMA (global_load_lds_dwordx4)
-// copies into a ring of steps without touching registers: a DMA piece is one operand tile (32 rows x 32 bytes = 1 KiB),
-// four consecutive lanes fetch the four 16-byte chunks of two rows (one 64-byte segment per quad: full coalescing
-// rate).  The DMA writes LDS linearly (lane i -> 16 bytes at 16 i) but every lane names its own source: position
-// 2 m + (c ^ ((m >> 3) & 1)) holds chunk c of row m, so that the 16 lanes of every ds_read_b128 lane group (rows m .. m + 15,
-// the same chunk) land on 16 different 16-byte slots of the 256-byte bank row.
+// A 32-row block of one tile is ONE contiguous KiB, POINT-major ([point n][half h][register r], what the producers' lanes
+// hold), which LDS-DMA (global_load_lds_dwordx4) copies linearly into a ring of steps without touching registers.  The
+// transpose to the MFMA's operand layout is the LDS read: ds_read_b64_tr_b8 hands lane i of a 16-lane group byte i & 7 of
+// the eight 8-byte rows named by the group's lanes of parity i >> 3 (tools/tr8_probe.hip).  Lane i names (point 16 kh + 8 q
+// + (i >> 1), byte block i & 1 of half h = group & 1): lanes 0-7 of the group then receive registers 0-7, lanes 8-15
+// registers 8-15 of eight points - MFMA row m = 16 h + r is feature tile_feat(h, r), a relabelling of the rows inside a
+// 32-row block that the epilogue undoes.  Four reads (q = 0, 1 of both tiles) make a fragment.
 // Differentiates decoder.py:277-349 (the Linear layers of both fields) like wgrad_kernel (dfn_train.hip), which
 // stays for the f32 tier.
 #include <hip/hip_runtime.h>
@@ -41,6 +42,15 @@ constexpr int WL_SCALE_BYTES = 2 * WL_CHUNK_PAIRS * 16;
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+// one MFMA fragment (8 dwords) of a 32-row block from its point-major LDS images of two tiles: p0 / p1 = this lane's
+// transpose-read address in the first / second tile for q = 0 (see the header)
+DFN_DEV i32x8 frag_tr8(const lds_char* p0, const lds_char* p1) {
+    const i32x2 a = __builtin_amdgcn_ds_read_tr8_b64_v2i32((DFN_LDS i32x2*)p0), b = __builtin_amdgcn_ds_read_tr8_b64_v2i32((DFN_LDS i32x2*)(p0 + 256));
+    const i32x2 c = __builtin_amdgcn_ds_read_tr8_b64_v2i32((DFN_LDS i32x2*)p1), d = __builtin_amdgcn_ds_read_tr8_b64_v2i32((DFN_LDS i32x2*)(p1 + 256));
+    const i32x8 f = {a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+    return f;
+}
 template <int N> DFN_DEV void wl_wait_vm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
 __global__ __launch_bounds__(WL_THREADS) void wgrad_mx_kernel(const WOp* ops, const int* order, const void* __restrict__ dy_T,
@@ -70,14 +80,13 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_mx_kernel(const WOp* ops, co
     int sub[WL_PIECES];               // tile of the step (0 .. 2 pps - 1)
     unsigned dst[WL_PIECES];          // LDS offset inside the step's slot
     {
-        const int row = lane >> 1, chunk = (lane & 1) ^ ((row >> 3) & 1);
 #pragma unroll
         for (int k = 0; k < WL_PIECES; ++k) {
             const int p = wave + WL_WAVES * k;
             const int u = p / ntl, tl = p - u * ntl;            // tile of the step, operand tile
             const bool isb = tl >= mts;
-            const int r = (isb ? o.b_row + 32 * (tl - mts) : o.a_row + 32 * tl) + row;
-            src[k] = (const char*)(isb ? act_T : dy_T) + (long)r * 32 + 16 * chunk;
+            const int r = isb ? o.b_row + 32 * (tl - mts) : o.a_row + 32 * tl;       // first row of the block: 1 KiB, copied linearly
+            src[k] = (const char*)(isb ? act_T : dy_T) + (long)r * 32 + 16 * lane;
             stride[k] = isb ? strideB : strideA;
             sub[k] = u;
             dst[k] = (unsigned)((u * ntl + tl) * 1024);
@@ -106,9 +115,9 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_mx_kernel(const WOp* ops, co
     const int mt_n = max(0, min(4, mts - 4 * rg)), nt_n = max(0, min(2, nts - 2 * cg));
     // bias gradients = row sums of dY: operand tile 4 rg + cg times a tile of ones, one more MFMA per tile pair and wave
     const bool do_bias = dbias && o.bias_owner && cg < mt_n;
-    // operand reads: MFMA lane l holds row l & 31, chunk l >> 5 (points 16 (l >> 5) .. + 15) of both tiles of the pair
-    const int m = lane & 31, kh = lane >> 5;
-    const int rd = (2 * m + (kh ^ ((m >> 3) & 1))) * 16;
+    // operand reads (transpose reads, header): this lane names point 16 kh + 8 q + (i >> 1), half h, byte block i & 1
+    const int kh = lane >> 5, hh = (lane >> 4) & 1, li = lane & 15;
+    const int rd = (16 * kh + (li >> 1)) * 32 + hh * 16 + (li & 1) * 8;         // q = 0; q = 1: + 8 points = + 256 bytes
     // scale bytes in memory: [tile][rows x 32 | row block]; the MFMA takes the first tile's from the lanes kh = 0, the
     // second's from kh = 1
     const unsigned char* scA = (const unsigned char*)dy_T + (long)g_rows * 32 + (o.a_row >> 5);
@@ -179,16 +188,10 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_mx_kernel(const WOp* ops, co
                 i32x8 a[4], b[2];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (i < mt_n && (nt_n > 0 || (do_bias && i == cg))) {
-                        const i32x4 lo = *(const DFN_LDS i32x4*)(b0 + (4 * rg + i) * 1024), hi = *(const DFN_LDS i32x4*)(b1 + (4 * rg + i) * 1024);
-                        a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    }
+                    if (i < mt_n && (nt_n > 0 || (do_bias && i == cg))) a[i] = frag_tr8(b0 + (4 * rg + i) * 1024, b1 + (4 * rg + i) * 1024);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    if (j < nt_n) {
-                        const i32x4 lo = *(const DFN_LDS i32x4*)(b0 + (mts + 2 * cg + j) * 1024), hi = *(const DFN_LDS i32x4*)(b1 + (mts + 2 * cg + j) * 1024);
-                        b[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    }
+                    if (j < nt_n) b[j] = frag_tr8(b0 + (mts + 2 * cg + j) * 1024, b1 + (mts + 2 * cg + j) * 1024);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -208,10 +211,12 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_mx_kernel(const WOp* ops, co
     // Split-K WITHOUT atomics: this workgroup owns slice `ks` of the partial arrays (C: [ksplit][c_stride], dbias:
     // [ksplit][n_bias]); every element of a slice has exactly one writer, and reduce_scatter_kernel / reduce_bias_kernel
     // add the slices in index order - the gradients are bit-reproducible run to run (float atomicAdd was not).
+    // MFMA row / column m of a 32-row block = 16 h + r  <->  feature tile_feat(h, r) (the transpose reads' relabelling)
+    auto feat_of = [](int m) { return tile_feat(m >> 4, m & 15); };
     if (do_bias && (lane & 31) == 0) {          // every column of accb holds the row sums: take column 0
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int e = e_of[o.a_row + 32 * (4 * rg + cg) + tile_feat(lane >> 5, r)];
+            const int e = e_of[o.a_row + 32 * (4 * rg + cg) + feat_of(tile_feat(lane >> 5, r))];
             if (e >= 0) dbias[(long)ks * n_bias + e] = accb[r];
         }
     }
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_mx_kernel(const WOp* ops, co
             if (i < mt_n && j < nt_n) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = 32 * (4 * rg + i) + tile_feat(lane >> 5, r), col = 32 * (2 * cg + j) + (lane & 31);
+                    const int row = 32 * (4 * rg + i) + feat_of(tile_feat(lane >> 5, r)), col = 32 * (2 * cg + j) + feat_of(lane & 31);
                     c[(long)row * o.N + col] = acc[i][j][r];
                 }
             }

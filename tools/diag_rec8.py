@@ -24,7 +24,13 @@ dirs = torch.randn(n, 3, generator=g).to(dev)
 
 def decode(arr, rows):
     nt = arr.shape[0]
-    data = arr[:, :rows * 32].view(torch.float8_e4m3fn).float().view(nt, rows, 32)
+    # per 32-row block: [point n][half h][register r] bytes, feature = (r & 3) + 8 (r >> 2) + 4 h
+    raw = arr[:, :rows * 32].view(torch.float8_e4m3fn).float().view(nt, rows // 32, 32, 2, 16)
+    r = torch.arange(16)
+    feat = torch.stack([(r & 3) + 8 * (r >> 2) + 4 * h for h in (0, 1)])            # [2, 16]
+    data = torch.empty(nt, rows // 32, 32, 32, device=arr.device)                  # [tile, block, feature, point]
+    data[:, :, feat.reshape(-1).to(arr.device), :] = raw.permute(0, 1, 3, 4, 2).reshape(nt, rows // 32, 32, 32)
+    data = data.reshape(nt, rows, 32)
     sc = torch.exp2(arr[:, rows * 32:rows * 32 + (rows + 31) // 32].float() - 127.0)           # [nt, rows/32]
     sc = sc.repeat_interleave(32, dim=1)[:, :rows]
     return (data * sc[..., None]).permute(1, 0, 2).reshape(rows, nt * 32)                      # [rows, NP]
