@@ -404,6 +404,22 @@ def test_full_frame_psnr_16bit_tiers_vs_f32_tier(eng, packed, scene, latents, go
             assert whole >= PSNR_GATE[tier], (tier, name, whole)
             if tier == "f16":
                 assert worst >= PSNR_CLAUSE_DB, (tier, name, worst)
+                # the clause itself, MEASURED instead of derived: "PSNR within 0.05 dB of reference" is a statement about the
+                # PSNR a user computes against ground truth.  Ground truth here = the exact tier's frame plus what a trained
+                # model still misses (independent noise at 30 dB, three seeds); the f16 frame's PSNR against it may be at most
+                # 0.05 dB below the f32 frame's - on the whole frame and on every 2,500-ray block
+                for seed in range(3):
+                    rs = np.random.RandomState(seed)
+                    gt = ref + rs.randn(*ref.shape) * 10 ** (-30 / 20)
+                    loss = psnr(ref, gt) - psnr(img, gt)
+                    e_ref = ((ref - gt) ** 2).reshape(-1, 2500, 3).mean((1, 2))
+                    e_img = ((img - gt) ** 2).reshape(-1, 2500, 3).mean((1, 2))
+                    loss_blk = float((10.0 * np.log10(e_img / e_ref)).max())
+                    if seed == 0:
+                        print(f"    measured PSNR loss of the f16 frame against a 30-dB ground truth: whole frame {loss:.4f} dB, "
+                              f"worst block {loss_blk:.4f} dB (clause: 0.05)")
+                    # (a block's 7,500 values leave a +-0.01 dB sampling term of the noise / error cross product)
+                    assert loss <= 0.05 and loss_blk <= 0.05 + 0.015, (name, seed, loss, loss_blk)
         # the u8 image a user sees: identical up to +-1 LSB except where the sampler's switch moved a depth
         d = np.abs(O.to8b(out[tier][0]).astype(int) - O.to8b(out["f32"][0]).astype(int))
         print(f"  u8 head image {tier}: {(d > 0).mean() * 100:.2f} % of values differ, max {d.max()} LSB")
