@@ -35,8 +35,22 @@ def _multi_rank():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
-def _side_stream(device, high=False):
-    return torch.cuda.Stream(device=device, priority=-1 if (high and _SIG_PRIO) else 0)
+_STREAMS = {}
+
+
+def _side_stream(device, high=False, role=None):
+    """A side stream by ROLE ("wgrad", "sig_a", "sig_p"), one per device and role for the whole process: the device runs four
+    hardware queues, and every further stream shares one with another stream and serialises with it - a second
+    TrainBuffers / SignalTrainer in the same process (bench.py's other workloads, a second model) must reuse the first
+    one's streams instead of creating four more."""
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), role,
+           bool(high and _SIG_PRIO))
+    if role is None:
+        return torch.cuda.Stream(device=device, priority=-1 if (high and _SIG_PRIO) else 0)
+    s = _STREAMS.get(key)
+    if s is None:
+        s = _STREAMS[key] = torch.cuda.Stream(device=device, priority=-1 if (high and _SIG_PRIO) else 0)
+    return s
 
 
 def _sync_flat(params, views):
@@ -212,14 +226,14 @@ class FusedTrainFn(torch.autograd.Function):
         # with it: 1.77 -> 2.39 ms per step)
         over = _OVERLAP and _WGRAD_SIDE and not _multi_rank()
         if over and getattr(buf, "_side", None) is None:
-            buf._side = _side_stream(dev)
+            buf._side = _side_stream(dev, role="wgrad")
         side = buf._side if over else None
         # zeroed HERE, on the main stream: a many-workgroup fill on a side stream starves behind the dX chain's workgroups
         # (measured: 340 us for this 4-MB fill, and the head field's weight gradients queue behind it)
         g_flat = _grad_buffer(buf.net, "_g_flat", flat, buf.params)
         if _OVERLAP:
             if getattr(buf, "_sig_streams", None) is None:
-                buf._sig_streams = (_side_stream(dev, True), _side_stream(dev, True))
+                buf._sig_streams = (_side_stream(dev, True, "sig_a"), _side_stream(dev, True, "sig_p"))
             tr = ctx.defer
             s_a, s_p = (tr.audio_stream(), tr.pose_stream()) if tr is not None else buf._sig_streams
             # dfn_signal_grad overwrites its half.  Deferred to a SignalTrainer the buffer is the trainer's own: its readers
@@ -400,7 +414,7 @@ class SignalTrainer:
         if not _OVERLAP:
             return None, None
         if getattr(self, "_side", None) is None:
-            self._side = (_side_stream(self.device, True), _side_stream(self.device, True))
+            self._side = (_side_stream(self.device, True, "sig_a"), _side_stream(self.device, True, "sig_p"))
         return self._side
 
     def adopt_optimizers(self, opts):
