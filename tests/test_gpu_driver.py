@@ -180,6 +180,14 @@ def test_training_cli_writes_reference_checkpoint(dataset):
     assert np.asarray(Image.open(tdir / "test_000.png")).shape == (H, 2 * W, 3)
     log = open(base / "loss.txt").read().strip().split("\n")
     assert log[-1].startswith("[TEST] Iter: 280002 Object: 0_person PSNR: ")
+    # the hierarchical training variant through the CLI (--hierarchical: the step differentiates row H, 64 + 128 samples, in
+    # the 16-bit tier with its MX-fp8 recorder); three steps, finite losses, a checkpoint
+    _run(root, "--N_rand=256 --N_iters=280005 --i_weights=280005 --i_print=1 --hierarchical --N_importance 128 --hip_tier bf16 "
+               "--expname hier_train")
+    hb = root / "dataset" / "train_together" / "hier_train"
+    hl = [ln for ln in open(hb / "loss.txt").read().strip().split("\n") if ln.startswith("[TRAIN]")]
+    assert len(hl) >= 3 and all(np.isfinite(float(ln.split("Com Loss: ")[1].split()[0])) for ln in hl), hl[-3:]
+    assert (hb / "280005.tar").exists()
 
 
 def test_cli_with_two_ranks_on_one_gpu(dataset):
