@@ -133,11 +133,16 @@ int dfn_render_fwd_u8(int tier, const DfnFrame* frame, const void* packed_head, 
  * streams, writes every pre-activation gradient feature-major), dfn_weight_grad (gradient GEMMs over the sample
  * points, scattered into a flat buffer laid out like `params`), dfn_bias_grad (gradient of the folded bias blob;
  * the caller chains it into fc_z / fc_z_skips / fc_z_view / the signal columns / the conditioning networks).
- * Buffers (element type = tier: bf16 or f32), NP = 64 * ray_count:
+ * Buffers, NP = 64 * ray_count (a multiple of 64 in the 16-bit tier):
  *   samples, dsamples  f32 [NP][8]  (sigma_h, rgb_h[3], sigma_t, rgb_t[3]) and their gradients
- *   act_<field>        [dfn_train_rows(field,0)][NP]   inputs of every GEMM, feature-major
+ *   act_<field>        inputs of every GEMM.   f32 tier: f32 [NP/32][dfn_train_rows(field,0)][32] (feature-major per 32-point
+ *                      tile).  16-bit tier (DFN_TIER_BF16): MX-fp8, u8 [NP/32][dfn_train_rows(field,6)]: per tile one 1-KiB
+ *                      block per 32 feature rows, e4m3, point-major ([point][half][register]: feature = the MFMA C/D map), then
+ *                      a 128-byte block of E8M0 scales, one per 32-row block - the operand format of
+ *                      v_mfma_scale_f32_32x32x64_f8f6f4, which the weight-gradient GEMMs run on
  *   masks_<field>      u32 [NP/32][dfn_train_rows(field,2)][64]   ReLU bits
- *   dy_T               [dfn_train_rows(field,1)][NP]   pre-activation gradients, feature-major
+ *   dy_T               pre-activation gradients, like act_<field>: rows dfn_train_rows(field,1) / bytes per tile
+ *                      dfn_train_rows(field,7)
  *   workspace          f32 [dfn_train_rows(field,3)]  split-K partial slices; the reduction adds them in a fixed
  *                      order (no float atomics): the gradients are bit-reproducible run to run                      */
 long dfn_train_rows(int field, int what);
