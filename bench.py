@@ -201,7 +201,7 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
         for o in opts.values():
             o.zero_grad()
         t2 = c()
-        loss.backward()
+        training.backward(loss, buf)             # loss.backward() started with the buffers' unit gradient, as run_nerf.train does
         t3 = c()
         if bucket is not None:
             bucket.all_reduce_()

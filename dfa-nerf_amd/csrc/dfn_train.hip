@@ -628,6 +628,7 @@ __global__ __launch_bounds__(1024) void mse_loss_kernel(const float* __restrict_
     if (t == 0) {
         losses[0] = __fdiv_rn(red[0][0], (float)total);      // img2mse(rgb_head, target_head)
         losses[1] = __fdiv_rn(red[1][0], (float)total);      // img2mse(rgb_com, target_com)
+        losses[2] = __fadd_rn(losses[1], losses[0]);          // the step's loss (MAIN:902-907: loss_com + loss_head)
     }
 }
 hipError_t launch_mse_loss(const float* rgb_head, const float* rgb_com, const unsigned char* img_head,

@@ -525,8 +525,13 @@ def train_step_loss_hip(nets, dataset, itr_obj, img_i, sel_yx, target_head, targ
     bg = dataset[itr_obj]['bc_img'].reshape(-1, 3)
     zs = z_shape[0, itr_obj * 2:itr_obj * 2 + 2]
     za = z_app[0, itr_obj * 2:itr_obj * 2 + 2]
-    rgb_head, rgb_com = training.render_train(dec, buf, frame, bg, pix, signal[0], signal_torso, zs, za,
-                                              signal_trainer=sig_tr if (sig_tr is not None and itr_obj == 0) else None)
+    tr_arg = sig_tr if (sig_tr is not None and itr_obj == 0) else None
+    if target_head.dtype == torch.uint8 and not args.use_L1:
+        # the production step: forward + both losses + their sum as ONE autograd node (training.FusedTrainLossFn; start its
+        # backward with training.backward(loss, buf) and no ATen kernel runs between the forward and the dX chain)
+        return training.render_train_loss(dec, buf, frame, bg, pix, signal[0], signal_torso, zs, za, target_head, target_com,
+                                          signal_trainer=tr_arg)
+    rgb_head, rgb_com = training.render_train(dec, buf, frame, bg, pix, signal[0], signal_torso, zs, za, signal_trainer=tr_arg)
     if target_head.dtype == torch.uint8:
         # whole uint8 ground-truth frames [H*W,3] resident on the device (frames.DeviceFrameCache): the targets are gathered
         # inside the loss kernel (dfn_mse_loss_u8: MAIN:791-800 + 902-907 + their autograd in one launch)
@@ -749,7 +754,7 @@ def train():
                                                         len(i_train), embed_fn, ds['poses'][0, :3, :4], train_buf)
         for o in opts.values():
             o.zero_grad()
-        loss.backward()
+        training.backward(loss, train_buf)          # loss.backward() with the buffers' own unit gradient (FusedTrainLossFn)
         if bucket is not None:
             bucket.all_reduce_()
         optimizer_steps(opts, global_step, args)

@@ -79,7 +79,7 @@ def _grad_buffer(owner, name, like, params):
         g = torch.zeros_like(like)
         setattr(owner, name, g)
     else:
-        g.zero_()
+        check(lib.dfn_zero_async(_ptr(g), g.numel() * 4, _stream()), "dfn_zero_async")      # (hipMemsetAsync: no ATen launch)
     return g
 
 
@@ -167,142 +167,150 @@ class FusedTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app, defer=None):
-        # defer: the SignalTrainer whose _SignalFn produced both signals (their backward then picks d(signal) up on its own
-        # streams and the main stream never waits for it), or None
-        ctx.defer = defer if _OVERLAP else None
-        t, st = buf.tier, _stream()
-        flat = buf.flat
-        dev = flat.device
-        sh = sig_head.detach().reshape(-1).float().contiguous()
-        stt = sig_torso.detach().reshape(-1).float().contiguous()
-        zs = z_shape.detach().reshape(2, 256).float().contiguous()
-        za = z_app.detach().reshape(2, 256).float().contiguous()
-        bias = buf.bias
-        bias_t = C.c_void_p(bias.data_ptr() + 4 * buf.nb[0])
-        # both folds and the four packed weight streams in one launch (six launches back to back cost 37 us of the step)
-        check(lib.dfn_train_prepare(t, _ptr(flat), _ptr(sh), _ptr(stt), _ptr(zs), _ptr(za), _ptr(buf.packed[0]),
-                                    _ptr(buf.packed[1]), _ptr(buf.packed_T[0]), _ptr(buf.packed_T[1]), _ptr(bias), bias_t,
-                                    st), "dfn_train_prepare")
-        n = frame.ray_count
-        rgb_h = torch.empty(n, 3, dtype=torch.float32, device=dev)
-        rgb_c = torch.empty(n, 3, dtype=torch.float32, device=dev)
-        bg_f32 = bg if bg.dtype == torch.float32 else None
-        bg_u8 = bg if bg.dtype == torch.uint8 else None
-        if buf.n_fine:
-            check(lib.dfn_train_fwd_hier(t, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias), bias_t,
-                                         _ptr(bg_f32), _ptr(bg_u8), _ptr(pix_index), _ptr(rgb_h), _ptr(rgb_c),
-                                         _ptr(buf.samples), _ptr(buf.act[0]), _ptr(buf.masks[0]), _ptr(buf.act[1]),
-                                         _ptr(buf.masks[1]), _ptr(buf.z_all), _ptr(buf.ranks), st), "dfn_train_fwd_hier")
-        else:
-            check(lib.dfn_train_fwd(t, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias), bias_t,
-                                    _ptr(bg_f32), _ptr(bg_u8), _ptr(pix_index), _ptr(rgb_h), _ptr(rgb_c),
-                                    _ptr(buf.samples), _ptr(buf.act[0]), _ptr(buf.masks[0]), _ptr(buf.act[1]),
-                                    _ptr(buf.masks[1]), st), "dfn_train_fwd")
-        ctx.buf, ctx.frame, ctx.bg, ctx.pix = buf, frame, bg, pix_index
-        ctx.keep = (sh, stt, zs, za)
-        ctx.sig_shapes = (sig_head.shape, sig_torso.shape)
-        return rgb_h, rgb_c
+        return _fused_forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app, defer)
 
     @staticmethod
     def backward(ctx, d_h, d_c):
-        buf, frame, bg, st = ctx.buf, ctx.frame, ctx.bg, _stream()
-        sh, stt, zs, za = ctx.keep
-        flat, dev = buf.flat, buf.flat.device
-        d_h = d_h.contiguous().float()
-        d_c = d_c.contiguous().float()
-        bg_f32 = bg if bg.dtype == torch.float32 else None
-        bg_u8 = bg if bg.dtype == torch.uint8 else None
-        if buf.n_fine:
-            check(lib.dfn_composite_bwd_hier(C.byref(frame), _ptr(ctx.pix), _ptr(bg_f32), _ptr(bg_u8), _ptr(buf.samples),
-                                             _ptr(buf.z_all), _ptr(buf.ranks), _ptr(d_h), _ptr(d_c), _ptr(buf.dsamples), st),
-                  "dfn_composite_bwd_hier")
-        else:
-            check(lib.dfn_composite_bwd(C.byref(frame), _ptr(ctx.pix), _ptr(bg_f32), _ptr(bg_u8), _ptr(buf.samples),
-                                        _ptr(d_h), _ptr(d_c), _ptr(buf.dsamples), st), "dfn_composite_bwd")
-        g_bias = torch.empty(buf.nb[0] + buf.nb[1], dtype=torch.float32, device=dev)
-        main = torch.cuda.current_stream(dev)
-        # (with more than one rank RCCL brings its own stream: the head field's weight gradients stay on the main stream then,
-        # so that the process still runs on four streams - a fifth shares a hardware queue with another one and serialises
-        # with it: 1.77 -> 2.39 ms per step)
-        over = _OVERLAP and _WGRAD_SIDE and not _multi_rank()
-        if over and getattr(buf, "_side", None) is None:
-            buf._side = _side_stream(dev, role="wgrad")
-        side = buf._side if over else None
-        # zeroed HERE, on the main stream: a many-workgroup fill on a side stream starves behind the dX chain's workgroups
-        # (measured: 340 us for this 4-MB fill, and the head field's weight gradients queue behind it)
-        g_flat = _grad_buffer(buf.net, "_g_flat", flat, buf.params)
-        if _OVERLAP:
-            if getattr(buf, "_sig_streams", None) is None:
-                buf._sig_streams = (_side_stream(dev, True, "sig_a"), _side_stream(dev, True, "sig_p"))
-            tr = ctx.defer
-            s_a, s_p = (tr.audio_stream(), tr.pose_stream()) if tr is not None else buf._sig_streams
-            # dfn_signal_grad overwrites its half.  Deferred to a SignalTrainer the buffer is the trainer's own: its readers
-            # run on the trainer's streams and - pipelined - nothing orders the main stream behind them before the next
-            # encode(), so a buffer from the caching allocator would be handed out again (to the next step's pixel upload,
-            # say) while the encoder backward still reads it.  Otherwise a fresh one (autograd may keep it as a .grad); the
-            # waits below order the main stream behind its writers.
-            if tr is not None:
-                if getattr(tr, "_d_sig", None) is None:
-                    tr._d_sig = torch.empty(96 + 42, dtype=torch.float32, device=dev)
-                d_sig = tr._d_sig
-            else:
-                d_sig = torch.empty(96 + 42, dtype=torch.float32, device=dev)
+        return _fused_backward(ctx, d_h, d_c)
+
+
+def _fused_forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app, defer):
+    # defer: the SignalTrainer whose _SignalFn produced both signals (their backward then picks d(signal) up on its own
+    # streams and the main stream never waits for it), or None
+    ctx.defer = defer if _OVERLAP else None
+    t, st = buf.tier, _stream()
+    flat = buf.flat
+    dev = flat.device
+    sh = sig_head.detach().reshape(-1).float().contiguous()
+    stt = sig_torso.detach().reshape(-1).float().contiguous()
+    zs = z_shape.detach().reshape(2, 256).float().contiguous()
+    za = z_app.detach().reshape(2, 256).float().contiguous()
+    bias = buf.bias
+    bias_t = C.c_void_p(bias.data_ptr() + 4 * buf.nb[0])
+    # both folds and the four packed weight streams in one launch (six launches back to back cost 37 us of the step)
+    check(lib.dfn_train_prepare(t, _ptr(flat), _ptr(sh), _ptr(stt), _ptr(zs), _ptr(za), _ptr(buf.packed[0]),
+                                _ptr(buf.packed[1]), _ptr(buf.packed_T[0]), _ptr(buf.packed_T[1]), _ptr(bias), bias_t,
+                                st), "dfn_train_prepare")
+    n = frame.ray_count
+    rgb_h = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    rgb_c = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    bg_f32 = bg if bg.dtype == torch.float32 else None
+    bg_u8 = bg if bg.dtype == torch.uint8 else None
+    if buf.n_fine:
+        check(lib.dfn_train_fwd_hier(t, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias), bias_t,
+                                     _ptr(bg_f32), _ptr(bg_u8), _ptr(pix_index), _ptr(rgb_h), _ptr(rgb_c),
+                                     _ptr(buf.samples), _ptr(buf.act[0]), _ptr(buf.masks[0]), _ptr(buf.act[1]),
+                                     _ptr(buf.masks[1]), _ptr(buf.z_all), _ptr(buf.ranks), st), "dfn_train_fwd_hier")
+    else:
+        check(lib.dfn_train_fwd(t, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias), bias_t,
+                                _ptr(bg_f32), _ptr(bg_u8), _ptr(pix_index), _ptr(rgb_h), _ptr(rgb_c),
+                                _ptr(buf.samples), _ptr(buf.act[0]), _ptr(buf.masks[0]), _ptr(buf.act[1]),
+                                _ptr(buf.masks[1]), st), "dfn_train_fwd")
+    ctx.buf, ctx.frame, ctx.bg, ctx.pix = buf, frame, bg, pix_index
+    ctx.keep = (sh, stt, zs, za)
+    ctx.sig_shapes = (sig_head.shape, sig_torso.shape)
+    return rgb_h, rgb_c
+
+
+def _fused_backward(ctx, d_h, d_c):
+    buf, frame, bg, st = ctx.buf, ctx.frame, ctx.bg, _stream()
+    sh, stt, zs, za = ctx.keep
+    flat, dev = buf.flat, buf.flat.device
+    d_h = d_h.contiguous().float()
+    d_c = d_c.contiguous().float()
+    bg_f32 = bg if bg.dtype == torch.float32 else None
+    bg_u8 = bg if bg.dtype == torch.uint8 else None
+    if buf.n_fine:
+        check(lib.dfn_composite_bwd_hier(C.byref(frame), _ptr(ctx.pix), _ptr(bg_f32), _ptr(bg_u8), _ptr(buf.samples),
+                                         _ptr(buf.z_all), _ptr(buf.ranks), _ptr(d_h), _ptr(d_c), _ptr(buf.dsamples), st),
+              "dfn_composite_bwd_hier")
+    else:
+        check(lib.dfn_composite_bwd(C.byref(frame), _ptr(ctx.pix), _ptr(bg_f32), _ptr(bg_u8), _ptr(buf.samples),
+                                    _ptr(d_h), _ptr(d_c), _ptr(buf.dsamples), st), "dfn_composite_bwd")
+    g_bias = torch.empty(buf.nb[0] + buf.nb[1], dtype=torch.float32, device=dev)
+    main = torch.cuda.current_stream(dev)
+    # (with more than one rank RCCL brings its own stream: the head field's weight gradients stay on the main stream then,
+    # so that the process still runs on four streams - a fifth shares a hardware queue with another one and serialises
+    # with it: 1.77 -> 2.39 ms per step)
+    over = _OVERLAP and _WGRAD_SIDE and not _multi_rank()
+    if over and getattr(buf, "_side", None) is None:
+        buf._side = _side_stream(dev, role="wgrad")
+    side = buf._side if over else None
+    # zeroed HERE, on the main stream: a many-workgroup fill on a side stream starves behind the dX chain's workgroups
+    # (measured: 340 us for this 4-MB fill, and the head field's weight gradients queue behind it)
+    g_flat = _grad_buffer(buf.net, "_g_flat", flat, buf.params)
+    if _OVERLAP:
+        if getattr(buf, "_sig_streams", None) is None:
+            buf._sig_streams = (_side_stream(dev, True, "sig_a"), _side_stream(dev, True, "sig_p"))
+        tr = ctx.defer
+        s_a, s_p = (tr.audio_stream(), tr.pose_stream()) if tr is not None else buf._sig_streams
+        # dfn_signal_grad overwrites its half.  Deferred to a SignalTrainer the buffer is the trainer's own: its readers
+        # run on the trainer's streams and - pipelined - nothing orders the main stream behind them before the next
+        # encode(), so a buffer from the caching allocator would be handed out again (to the next step's pixel upload,
+        # say) while the encoder backward still reads it.  Otherwise a fresh one (autograd may keep it as a .grad); the
+        # waits below order the main stream behind its writers.
+        if tr is not None:
+            if getattr(tr, "_d_sig", None) is None:
+                tr._d_sig = torch.empty(96 + 42, dtype=torch.float32, device=dev)
+            d_sig = tr._d_sig
         else:
             d_sig = torch.empty(96 + 42, dtype=torch.float32, device=dev)
-        def dx(f, stream):
-            check(lib.dfn_mlp_bwd(buf.tier, f, _ptr(buf.packed_T[f]), _ptr(buf.samples), _ptr(buf.dsamples),
-                                  _ptr(buf.masks[f]), buf.NP, _ptr(buf.dy[f]), stream), "dfn_mlp_bwd")
+    else:
+        d_sig = torch.empty(96 + 42, dtype=torch.float32, device=dev)
+    def dx(f, stream):
+        check(lib.dfn_mlp_bwd(buf.tier, f, _ptr(buf.packed_T[f]), _ptr(buf.samples), _ptr(buf.dsamples),
+                              _ptr(buf.masks[f]), buf.NP, _ptr(buf.dy[f]), stream), "dfn_mlp_bwd")
 
-        def dw(f, stream, g, with_sig):
-            gb = C.c_void_p(g_bias.data_ptr() + (4 * buf.nb[0] if f else 0))
-            check(lib.dfn_weight_bias_grad(buf.tier, f, _ptr(buf.dy[f]), _ptr(buf.act[f]), buf.NP, _ptr(buf.ws[f]),
-                                           _ptr(g), gb, stream), "dfn_weight_bias_grad")
-            ds = C.c_void_p(d_sig.data_ptr() + (4 * 96 if f else 0)) if with_sig else None
-            check(lib.dfn_fold_bias_bwd(buf.tier, FIELD_TORSO if f else FIELD_HEAD, _ptr(flat), _ptr(stt if f else sh),
-                                        _ptr(zs[f]), _ptr(za[f]), gb, _ptr(g), ds, stream), "dfn_fold_bias_bwd")
+    def dw(f, stream, g, with_sig):
+        gb = C.c_void_p(g_bias.data_ptr() + (4 * buf.nb[0] if f else 0))
+        check(lib.dfn_weight_bias_grad(buf.tier, f, _ptr(buf.dy[f]), _ptr(buf.act[f]), buf.NP, _ptr(buf.ws[f]),
+                                       _ptr(g), gb, stream), "dfn_weight_bias_grad")
+        ds = C.c_void_p(d_sig.data_ptr() + (4 * 96 if f else 0)) if with_sig else None
+        check(lib.dfn_fold_bias_bwd(buf.tier, FIELD_TORSO if f else FIELD_HEAD, _ptr(flat), _ptr(stt if f else sh),
+                                    _ptr(zs[f]), _ptr(za[f]), gb, _ptr(g), ds, stream), "dfn_fold_bias_bwd")
 
-        def dsig(f, stream):
-            # d(signal) from the row sums of the dy_T rows behind it, without waiting for the weight gradients
-            check(lib.dfn_signal_grad(buf.tier, f, _ptr(flat), _ptr(buf.dy[f]), buf.NP, _ptr(buf.ws_sig[f]),
-                                      C.c_void_p(d_sig.data_ptr() + (4 * 96 if f else 0)), stream), "dfn_signal_grad")
-        if _OVERLAP:
-            # Three chains next to the main one.  (1) the head field's weight gradients (HBM reads) on a side stream
-            # underneath the torso field's dX chain (MFMAs + HBM writes); the main stream waits for that chain before the
-            # torso field's weight gradients, so the two fields accumulate into the one gradient buffer in a fixed order
-            # (bit-reproducible; the side chain ends well before the dX chain it runs under).  (2, 3) d(signal) of each
-            # field as soon as its dX chain is done (dfn_signal_grad) on the conditioning networks' streams: their backward
-            # (single-workgroup latency chains, 0.26 ms) then runs underneath the weight-gradient GEMMs instead of behind
-            # them.  Who consumes d_sig decides whether the main stream has to wait: _SignalFn.backward launches on those
-            # same streams (ctx.defer).
-            dx(0, st)
-            s_a.wait_stream(main)
-            dsig(0, C.c_void_p(s_a.cuda_stream))
-            if over:
-                side.wait_stream(main)
-                dw(0, C.c_void_p(side.cuda_stream), g_flat, False)
-            else:
-                dw(0, st, g_flat, False)
-            dx(1, st)
-            s_p.wait_stream(main)
-            dsig(1, C.c_void_p(s_p.cuda_stream))
-            if over:
-                main.wait_stream(side)
-            dw(1, st, g_flat, False)
-            if tr is None:          # torch autograd consumes d_sig on the main stream
-                main.wait_stream(s_a)
-                main.wait_stream(s_p)
-            else:
-                tr._deferred = True
+    def dsig(f, stream):
+        # d(signal) from the row sums of the dy_T rows behind it, without waiting for the weight gradients
+        check(lib.dfn_signal_grad(buf.tier, f, _ptr(flat), _ptr(buf.dy[f]), buf.NP, _ptr(buf.ws_sig[f]),
+                                  C.c_void_p(d_sig.data_ptr() + (4 * 96 if f else 0)), stream), "dfn_signal_grad")
+    if _OVERLAP:
+        # Three chains next to the main one.  (1) the head field's weight gradients (HBM reads) on a side stream
+        # underneath the torso field's dX chain (MFMAs + HBM writes); the main stream waits for that chain before the
+        # torso field's weight gradients, so the two fields accumulate into the one gradient buffer in a fixed order
+        # (bit-reproducible; the side chain ends well before the dX chain it runs under).  (2, 3) d(signal) of each
+        # field as soon as its dX chain is done (dfn_signal_grad) on the conditioning networks' streams: their backward
+        # (single-workgroup latency chains, 0.26 ms) then runs underneath the weight-gradient GEMMs instead of behind
+        # them.  Who consumes d_sig decides whether the main stream has to wait: _SignalFn.backward launches on those
+        # same streams (ctx.defer).
+        dx(0, st)
+        s_a.wait_stream(main)
+        dsig(0, C.c_void_p(s_a.cuda_stream))
+        if over:
+            side.wait_stream(main)
+            dw(0, C.c_void_p(side.cuda_stream), g_flat, False)
         else:
-            # one stream, the SAME kernels in the same order per buffer (d(signal) through dfn_signal_grad here too): bit for
-            # bit what the overlapped schedule computes - the reference the stream-schedule test holds it against
-            for f in (0, 1):
-                dx(f, st)
-                dsig(f, st)
-                dw(f, st, g_flat, False)
-        buf.net.deposit(g_flat, touched=_decoder_touched(buf.net, (0, 1)))
-        return (d_sig[:96].reshape(ctx.sig_shapes[0]), d_sig[96:].reshape(ctx.sig_shapes[1]), None, None, None, None,
-                None, None, None)
+            dw(0, st, g_flat, False)
+        dx(1, st)
+        s_p.wait_stream(main)
+        dsig(1, C.c_void_p(s_p.cuda_stream))
+        if over:
+            main.wait_stream(side)
+        dw(1, st, g_flat, False)
+        if tr is None:          # torch autograd consumes d_sig on the main stream
+            main.wait_stream(s_a)
+            main.wait_stream(s_p)
+        else:
+            tr._deferred = True
+    else:
+        # one stream, the SAME kernels in the same order per buffer (d(signal) through dfn_signal_grad here too): bit for
+        # bit what the overlapped schedule computes - the reference the stream-schedule test holds it against
+        for f in (0, 1):
+            dx(f, st)
+            dsig(f, st)
+            dw(f, st, g_flat, False)
+    buf.net.deposit(g_flat, touched=_decoder_touched(buf.net, (0, 1)))
+    return (d_sig[:96].reshape(ctx.sig_shapes[0]), d_sig[96:].reshape(ctx.sig_shapes[1]), None, None, None, None,
+            None, None, None)
 
 
 class _FlatNet:
@@ -582,6 +590,24 @@ def render_train(dec, buf, frame, bg, pix_index, sig_head, sig_torso, z_shape, z
     return FusedTrainFn.apply(sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app, signal_trainer)
 
 
+def render_train_loss(dec, buf, frame, bg, pix_index, sig_head, sig_torso, z_shape, z_app, img_head, img_com,
+                      signal_trainer=None):
+    """render_train + the step's loss against uint8 ground-truth frames [H*W,3] resident on the device, as one autograd node
+    (FusedTrainLossFn): -> loss (= loss_com + loss_head), loss_head, loss_com, rgb_head, rgb_com."""
+    if frame.ray_count != buf.n_rays or pix_index is None or pix_index.numel() != buf.n_rays:
+        raise ValueError(f"render_train_loss: the buffers were sized for {buf.n_rays} rays, the frame has {frame.ray_count}")
+    if frame.n_fine != buf.n_fine or frame.fields != 2:
+        raise ValueError(f"render_train_loss: the buffers were sized for n_fine = {buf.n_fine}, the frame asks for {frame.n_fine}")
+    buf.bind(dec)
+    if not sig_head.requires_grad:
+        sig_head = sig_head.detach().requires_grad_(True)
+    if signal_trainer is not None:
+        node = sig_head.grad_fn
+        if node is None or node is not sig_torso.grad_fn or type(node).__name__ != "_SignalFnBackward":
+            signal_trainer = None
+    return FusedTrainLossFn.apply(sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app, signal_trainer, img_head, img_com)
+
+
 # ---- the loss ------------------------------------------------------------------------------------------------------------
 class MseLossFn(torch.autograd.Function):
     """(rgb_head, rgb_com [n,3]) -> losses [2] = (img2mse(rgb_head, target_head), img2mse(rgb_com, target_com)) with the
@@ -595,7 +621,7 @@ class MseLossFn(torch.autograd.Function):
         if img_head.dtype != torch.uint8 or img_com.dtype != torch.uint8 or pix.dtype != torch.int32:
             raise TypeError("MseLossFn: uint8 frames and int32 pixel ids expected")
         rh, rc = rgb_head.detach().contiguous(), rgb_com.detach().contiguous()
-        losses = torch.empty(2, dtype=torch.float32, device=rh.device)
+        losses = torch.empty(3, dtype=torch.float32, device=rh.device)      # (head, com, their sum)
         d_h, d_c = torch.empty_like(rh), torch.empty_like(rc)
         check(lib.dfn_mse_loss_u8(_ptr(rh), _ptr(rc), _ptr(img_head), _ptr(img_com), _ptr(pix), n, _ptr(losses), _ptr(d_h),
                                   _ptr(d_c), _stream()), "dfn_mse_loss_u8")
@@ -613,6 +639,58 @@ class MseLossFn(torch.autograd.Function):
             out = torch._foreach_mul((d_h, d_c), g_h)
             return out[0], out[1], None, None, None
         return (None if g_h is None else d_h * g_h), (None if g_c is None else d_c * g_c), None, None, None
+
+
+class FusedTrainLossFn(torch.autograd.Function):
+    """FusedTrainFn and MseLossFn as ONE autograd node: (sig_head, sig_torso) -> (loss, loss_head, loss_com, rgb_head, rgb_com)
+    with loss = loss_com + loss_head formed inside dfn_mse_loss_u8 (MAIN:902-907).  The loss kernel already leaves
+    d loss / d rgb; when the step's backward is started with the buffers' own unit gradient (training.backward(loss, buf)) the
+    backward goes straight into the compositing backward: no ATen launch between the forward and the dX chain (as two nodes
+    autograd ran an add, a ones fill and a multi-tensor multiply there).  rgb_* are returned for inspection only (not
+    differentiable through this node: a loss on them - --use_L1 - takes the two-node route)."""
+
+    @staticmethod
+    def forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app, defer, img_head, img_com):
+        if img_head.dtype != torch.uint8 or img_com.dtype != torch.uint8 or pix_index.dtype != torch.int32:
+            raise TypeError("FusedTrainLossFn: uint8 frames and int32 pixel ids expected")
+        rgb_h, rgb_c = _fused_forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app, defer)
+        n = rgb_h.shape[0]
+        losses = torch.empty(3, dtype=torch.float32, device=rgb_h.device)
+        if getattr(buf, "_d_rgb", None) is None or buf._d_rgb[0].shape != rgb_h.shape:
+            buf._d_rgb = (torch.empty_like(rgb_h), torch.empty_like(rgb_c))
+        d_h, d_c = buf._d_rgb
+        check(lib.dfn_mse_loss_u8(_ptr(rgb_h), _ptr(rgb_c), _ptr(img_head), _ptr(img_com), _ptr(pix_index), n, _ptr(losses),
+                                  _ptr(d_h), _ptr(d_c), _stream()), "dfn_mse_loss_u8")
+        ctx.d = (d_h, d_c)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(rgb_h, rgb_c)
+        return losses[2], losses[0], losses[1], rgb_h, rgb_c
+
+    @staticmethod
+    def backward(ctx, g_sum, g_h, g_c, _gh, _gc):
+        d_h, d_c = ctx.d
+        unit = unit_gradient(ctx.buf)
+        if not (g_sum is not None and g_h is None and g_c is None and g_sum.data_ptr() == unit.data_ptr()):
+            # any other upstream gradient: scale explicitly (torch ops)
+            zero = torch.zeros((), dtype=torch.float32, device=d_h.device)
+            gs = zero if g_sum is None else g_sum
+            d_h = d_h * (gs + (zero if g_h is None else g_h))
+            d_c = d_c * (gs + (zero if g_c is None else g_c))
+        return _fused_backward(ctx, d_h, d_c) + (None, None)
+
+
+def unit_gradient(buf):
+    """the 0-dim ones tensor of `buf`: hand it to backward() as the loss's gradient (training.backward) and autograd neither
+    fills a fresh one nor does FusedTrainLossFn have to multiply by it"""
+    u = getattr(buf, "_unit", None)
+    if u is None:
+        u = buf._unit = torch.ones((), dtype=torch.float32, device=buf.samples.device)
+    return u
+
+
+def backward(loss, buf):
+    """loss.backward() with the buffers' unit gradient (see FusedTrainLossFn)."""
+    torch.autograd.backward(loss, grad_tensors=unit_gradient(buf))
 
 
 def mse_losses(rgb_head, rgb_com, img_head, img_com, pix):

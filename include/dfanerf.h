@@ -188,7 +188,8 @@ int dfn_sample_pixels(int H, int W, int n, int rect_num, const int32_t* rect, ui
 /* The loss of a training step in one launch: replaces target[select_coords] (MAIN:791-800: the pixels pix_index of the
  * head and the composite ground-truth images, here uint8 [H*W,3] resident on the device, / 255 as LOAD:58-60), the two
  * img2mse (HELP:13; MAIN:902-907) and their autograd:
- *   losses[0] = mean((rgb_head - target_head)^2), losses[1] = mean((rgb_com - target_com)^2)   (means over 3 n values)
+ *   losses [3]: losses[0] = mean((rgb_head - target_head)^2), losses[1] = mean((rgb_com - target_com)^2) (means over 3 n
+ *   values), losses[2] = losses[1] + losses[0] (the step's loss, MAIN:902-907)
  *   d_rgb_head / d_rgb_com [n,3] = 2 (rgb - target) / (3 n)  = d (losses[0] + losses[1]) / d rgb
  * Fixed reduction order (bit-reproducible). */
 int dfn_mse_loss_u8(const float* rgb_head, const float* rgb_com, const uint8_t* img_head, const uint8_t* img_com,
