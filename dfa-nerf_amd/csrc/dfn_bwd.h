@@ -76,14 +76,14 @@ template <int TIER, int NT> DFN_DEV void pin_vec(Vec<TIER, NT>& v) {
 }
 
 // DFN_PUT_SPREAD: how the dy_T stores of a layer's INPUT vector (the previous layer's finished output, alive as this
-// layer's B operand anyway) are issued.  0: one burst of 8 NTB store instructions in front of the layer, all eight waves of
-// the workgroup at once.  1: one store per k-step, between the MFMAs of the whole layer (head 225 -> 213 us, torso 255 ->
-// 240 us: interleaved A/B on one box).  2: two per k-step in the first half of every tile pair (no better than 1).
-// What the stores cost was measured with timing experiments (wrong results): with one tile in eight stored the head kernel
-// takes 139 us - the other 75-85 us are the 0.69 GB of stores, which the same pattern reaches 5.6 TB/s on when nothing
-// else runs (tools/l2_atomic_probe.hip) but only ~3.2 TB/s next to the MFMA chain.  NOT the cause (each ablated, +-3 %): the
-// vmcnt wait of the slab hand-over (vmcnt(63)), the ReLU mask loads or their 2.5 VALU per value, the depth of the
-// fragment prefetch (compiler-sunk ds_reads pinned by sched_barrier), the instruction cache (0.3 % misses).
+// layer's B operand anyway) are issued.  0: one burst in front of the layer, all eight waves of the workgroup at once.
+// 1: spread between the MFMAs of the whole layer (PutSide: one 16-byte MX-fp8 tile store every T / NTB k-steps).
+// History (bf16 recording, round 2): spreading 64 word stores per vector bought 5 % (head 225 -> 213 us); with one tile in
+// eight stored the head kernel took 139 us - the other 75-85 us were the 0.69 GB of stores.  Round 3 (MX-fp8, point-major
+// blocks: 8 store instructions and half the bytes per vector): head 182 us, of which the store instructions 24, the block
+// amax 10, the ReLU mask application 8; without any recording 133 us (ablation builds, tools/time_dx.py).  NOT the cause
+// (each ablated, +-3 %): the vmcnt wait of the slab hand-over (vmcnt(63)), the ReLU mask loads, the depth of the fragment
+// prefetch (compiler-sunk ds_reads pinned by sched_barrier), the instruction cache (0.3 % misses).
 #ifndef DFN_PUT_SPREAD
 #define DFN_PUT_SPREAD 1
 #endif

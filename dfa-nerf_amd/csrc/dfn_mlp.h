@@ -747,8 +747,9 @@ DFN_DEV void layer_pipe(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_
     acc_to_vec<TIER, 2, OT, RELU>(acc[(OT / 2 - 1) & 1], out, OT - 2);        // the last pair: not overlapped
 }
 
-// DFN_REC_SPREAD (training recorder, bf16 tier): 1 = the 16 store instructions of tile pair tg - 1 go out one by one between
-// the MFMAs of pair tg (RecSide), like the dX chain's PutSide (dfn_bwd.h); 0 = as one burst at the next slab hand-over.
+// DFN_REC_SPREAD (training recorder, 16-bit tier): 1 = the scale search and the two 16-byte tile stores of tile pair tg - 1
+// go out between the MFMAs of pair tg (RecSide), like the dX chain's PutSide (dfn_bwd.h); 0 = as one burst at the next slab
+// hand-over.
 #ifndef DFN_REC_SPREAD
 #define DFN_REC_SPREAD 1
 #endif
