@@ -231,7 +231,11 @@ struct Rec {
 // next one are issued between the MFMAs of the pair in between, on a second set of accumulators (+32 registers).
 template <bool REC, bool ASMF = false, bool ASMD = false, bool PIPE = false> struct CtxT {
     static constexpr bool rec_on = REC;
-    static constexpr bool asm_fetch = ASMF && !REC && (DFN_ASM_FETCH != 0);
+#ifndef DFN_TRAIN_ASMF      // 1: the asm fragment fetch in the recording (training forward) kernels too: 413 -> 402 us; tools/check_inflight.py
+                            // (run by build.sh on their ISA as well) proves no spill or copy touches an in-flight destination
+#define DFN_TRAIN_ASMF 1
+#endif
+    static constexpr bool asm_fetch = (ASMF || (REC && DFN_TRAIN_ASMF != 0)) && (!REC || DFN_TRAIN_ASMF != 0) && (DFN_ASM_FETCH != 0);
     static constexpr bool asm_dma = asm_fetch || ASMD;
     static constexpr bool pipe = PIPE && !REC;
     lds_char* ring;
