@@ -408,12 +408,11 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
     shards = [torch.zeros(B, n_img, per, 3, dtype=torch.float32, device=dev) for _ in range(2)]
     gathered = [torch.empty(world, B, n_img, per, 3, dtype=torch.float32, device=dev) if world > 1 else None for _ in range(2)]
     works = [None, None]
-    state = {"bias": None}
     ev = []
 
     # conditioning networks in HIP (dfn_encode_signal / dfn_encode_signal_torso)
     enc = engine.SignalEncoder(aud_net, exp_net, att, patt, ds[0]["auds"], ds[0]["exp"], ds[0]["poses"])
-    fid = [torch.tensor([f], dtype=torch.int32, device=dev) for f in range(F)]
+    prefetch = engine.FramePrefetcher(enc, pk, zs_d, za_d, A.smo_size, A.smo_torse_size, fields=fields)
     probe = torch.zeros(2, dtype=torch.int64, device=dev)
 
     def step(i, timed):
@@ -424,19 +423,20 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
         shard = shards[k]
         for b in range(B):
             f = (i * B + b) % F
-            s2, t2 = enc.encode(fid[f], A.smo_size, A.smo_torse_size)           # 2 launches: [1,96], [1,42]
-            sig, sigt = s2[0], (t2[0] if fields == 2 else None)
-            state["bias"] = pk.fold(sig, sigt, zs_d, za_d, out=state["bias"])
+            # conditioning signals (2 encoder launches) + bias fold of THIS frame were started underneath the previous frame's
+            # render (engine.FramePrefetcher); the next frame's start underneath this one's
+            bias = prefetch.get(f, next_frame=(i * B + b + 1) % F)
             fr = engine.make_frame(H, W, sc["focal"], sc["cx"], sc["cy"], sc["poses"][f], sc["pose_body"], sc["near"],
                                    sc["far"], ray_begin=begin, ray_count=count, n_fine=n_fine, fields=fields)
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            engine.render(pk, state["bias"], fr, bg, out_head=shard[b, 0, :count],
+            engine.render(pk, bias, fr, bg, out_head=shard[b, 0, :count],
                           out_com=shard[b, 1, :count] if fields == 2 else None)
             if timed:
                 e1.record()
                 ev.append((e0, e1))
+            prefetch.done()
         if world > 1:
             # concatenation form (every backend takes it); async: the collective waits for this stream's work so far and
             # the NEXT step's render does not wait for the collective

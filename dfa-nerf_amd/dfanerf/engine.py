@@ -148,6 +148,71 @@ class SignalEncoder:
         return sig, sigt
 
 
+_STREAMS = {}
+
+
+def side_stream(device, high=False, role=None):
+    """A side stream by ROLE ("wgrad", "sig_a", "sig_p"), one per device and role for the whole process: the device runs four
+    hardware queues, and every further stream shares one with another stream and serialises with it - a second
+    TrainBuffers / SignalTrainer / FramePrefetcher in the same process (bench.py's other workloads, the test renders of a
+    training run, a second model) must reuse the first one's streams instead of creating more."""
+    if role is None:
+        return torch.cuda.Stream(device=device, priority=-1 if high else 0)
+    d = torch.device(device)
+    key = (d.index if d.index is not None else torch.cuda.current_device(), role, bool(high))
+    s = _STREAMS.get(key)
+    if s is None:
+        s = _STREAMS[key] = torch.cuda.Stream(device=device, priority=-1 if high else 0)
+    return s
+
+
+class FramePrefetcher:
+    """The per-frame front end (conditioning signals -> folded bias blob: two single-workgroup encoder launches and the fold,
+    ~0.1 ms of latency chains that keep one compute unit busy) ONE FRAME AHEAD on a side stream: while frame k renders, frame
+    k + 1's blob is produced underneath it; the render stream only waits for an event.  At 8 GPUs a rank's share of a frame
+    is 4.4 ms, and the un-pipelined front end was 2.3 % of it (the part of a frame that does not shrink with the ray shard).
+    Two blobs alternate; a blob is rewritten only after the render that read it (an event of the render stream)."""
+
+    def __init__(self, encoder, packed, z_shape, z_app, smo_size, smo_torso_size, fields=2, length=None):
+        self.enc, self.pk, self.zs, self.za = encoder, packed, z_shape, z_app
+        self.smo, self.smo_t, self.fields, self.length = int(smo_size), int(smo_torso_size), int(fields), length
+        self.side = side_stream(packed.device, role="wgrad")      # the process-wide general side stream
+        self.slots = [{"bias": None, "ready": None, "free": None, "frame": None} for _ in range(2)]
+        self.k = 0
+
+    def _produce(self, slot, frame):
+        main = torch.cuda.current_stream(self.pk.device)
+        if slot["bias"] is None:
+            self.side.wait_stream(main)                    # first use: the parameters were written on the main stream
+        if slot["free"] is not None:
+            self.side.wait_event(slot["free"])             # the render that read this blob last
+        with torch.cuda.stream(self.side):
+            s2, t2 = self.enc.encode([int(frame)], self.smo, self.smo_t, length=self.length)
+            slot["bias"] = self.pk.fold(s2[0], t2[0] if self.fields == 2 else None, self.zs, self.za, out=slot["bias"])
+            slot["ready"] = torch.cuda.Event()
+            slot["ready"].record(self.side)
+        slot["frame"] = int(frame)
+
+    def get(self, frame, next_frame=None):
+        """-> the bias blob of `frame`, valid on the current stream (produced now if it was not prefetched).  `next_frame`:
+        the frame to start underneath this one's render.  Call done() once the render that reads the blob is enqueued."""
+        slot = self.slots[self.k]
+        if slot["frame"] != int(frame):
+            self._produce(slot, frame)
+        torch.cuda.current_stream(self.pk.device).wait_event(slot["ready"])
+        self._cur, self._next = slot, next_frame
+        return slot["bias"]
+
+    def done(self):
+        slot = self._cur
+        slot["free"] = torch.cuda.Event()
+        slot["free"].record(torch.cuda.current_stream(self.pk.device))
+        slot["frame"] = None                               # consumed
+        self.k ^= 1
+        if self._next is not None:
+            self._produce(self.slots[self.k], self._next)
+
+
 def make_frame(H, W, focal, cx, cy, pose, pose_body, near, far, last_dist=1e10, ray_begin=0, ray_count=None,
                n_coarse=64, n_fine=0, fields=2, concate_bg=True):
     fr = DfnFrame()

@@ -269,13 +269,15 @@ class FrameRenderer:
         self.n_fine = args.N_importance if getattr(args, "hierarchical", False) else 0
 
     def render(self, pose, pose_body, signal, signal_torso, ray_begin=0, ray_count=None, pix_index=None, fields=2,
-               out_u8=False, out=None):
+               out_u8=False, out=None, bias=None):
         """-> rgb_head [n,3], rgb_com [n,3] (None if fields == 1); out_u8: uint8 images, to8b fused into the kernel;
-        out: (head, com) tensors the kernel writes into (e.g. slices of the shard that is gathered)."""
+        out: (head, com) tensors the kernel writes into (e.g. slices of the shard that is gathered); bias: the frame's folded
+        bias blob if the caller already has it (engine.FramePrefetcher), instead of the two signals."""
         eng = self.engine
         pk = self.decoder.packed(self.tier)
-        bias = pk.fold(signal[0] if isinstance(signal, (list, tuple)) else signal,
-                       signal_torso if fields == 2 else None, self.zs, self.za)
+        if bias is None:
+            bias = pk.fold(signal[0] if isinstance(signal, (list, tuple)) else signal,
+                           signal_torso if fields == 2 else None, self.zs, self.za)
         n = (self.H * self.W - ray_begin) if ray_count is None else ray_count
         if pix_index is not None:
             n = pix_index.numel()
@@ -287,7 +289,7 @@ class FrameRenderer:
             return eng.render_u8(pk, bias, fr, self.bg, pix_index=pix_index, out_head=oh, out_com=oc)
         return eng.render(pk, bias, fr, self.bg, pix_index=pix_index, out_head=oh, out_com=oc)
 
-    def render_image_begin(self, pose, pose_body, signal, signal_torso, fields=2, out_u8=False):
+    def render_image_begin(self, pose, pose_body, signal, signal_torso, fields=2, out_u8=False, bias=None):
         """Start a whole frame: render this rank's ray shard and ISSUE the gather (async_op=True: it runs on the backend's
         own stream) -> a handle for render_image_end().  Two sets of shard / gather buffers alternate, so the gather of
         frame k runs underneath the render of frame k + 1: call begin(k + 1) before end(k).  ONE
@@ -295,7 +297,7 @@ class FrameRenderer:
         import torch.distributed as dist
         R = self.H * self.W
         if not (dist.is_initialized() and dist.get_world_size() > 1):
-            rh, rc = self.render(pose, pose_body, signal, signal_torso, fields=fields, out_u8=out_u8)
+            rh, rc = self.render(pose, pose_body, signal, signal_torso, fields=fields, out_u8=out_u8, bias=bias)
             return {"images": (rh, rc)}
         world = dist.get_world_size()
         begin, count, per = parallel.shard_range(R, world, dist.get_rank())
@@ -315,7 +317,7 @@ class FrameRenderer:
         shard = slot["shard"]
         out = (shard[0, :count], shard[1, :count] if fields == 2 else None)
         if count:
-            self.render(pose, pose_body, signal, signal_torso, begin, count, fields=fields, out_u8=out_u8, out=out)
+            self.render(pose, pose_body, signal, signal_torso, begin, count, fields=fields, out_u8=out_u8, out=out, bias=bias)
         # the output as the CONCATENATION of the shards along dim 0 (the stacked [world, ...] form is an NCCL / RCCL
         # extension that gloo rejects)
         slot["work"] = dist.all_gather_into_tensor(slot["gathered"].view(world * n_img, per, 3), shard, async_op=True)
@@ -678,12 +680,23 @@ def train():
                                os.path.join(outdir_head, tag.format(img_i)) if outdir_head else None], keep=rgbs)
                 print('Saved test img at {}'.format(os.path.join(outdir_com, tag.format(img_i))))
         pending = None
-        for img_i in frame_ids:
+        frame_ids = list(frame_ids)
+        # the per-frame front end (signal encoders + bias fold) one frame ahead on a side stream (engine.FramePrefetcher)
+        pf = None
+        if enc is not None:
+            pf = engine.FramePrefetcher(enc, renderer.decoder.packed(renderer.tier), renderer.zs, renderer.za,
+                                        args.smo_size if smoothed else 0, args.smo_torse_size if smoothed else 0, fields=2,
+                                        length=len_sig)
+        for k, img_i in enumerate(frame_ids):
             with torch.no_grad():
-                if enc is not None:
-                    s2, t2 = enc.encode([img_i], args.smo_size if smoothed else 0,
-                                        args.smo_torse_size if smoothed else 0, length=len_sig)
-                    signal, signal_torso = [s2, None], t2[0]
+                if pf is not None:
+                    bias = pf.get(img_i, frame_ids[k + 1] if k + 1 < len(frame_ids) else None)
+                    handle = renderer.render_image_begin(poses_host[img_i], body_host, None, None, out_u8=True, bias=bias)
+                    pf.done()
+                    if pending is not None:
+                        finish(*pending)
+                    pending = (handle, img_i)
+                    continue
                 else:
                     signal = encode_signal(datasets, itr_obj, img_i, args.dim_aud, nets["AudNet"], nets["ExpNet"],
                                            nets["AudAttNet"], global_step, args, len_sig, embed_fn=embed_fn)

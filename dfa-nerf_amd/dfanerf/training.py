@@ -35,22 +35,9 @@ def _multi_rank():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
-_STREAMS = {}
-
-
 def _side_stream(device, high=False, role=None):
-    """A side stream by ROLE ("wgrad", "sig_a", "sig_p"), one per device and role for the whole process: the device runs four
-    hardware queues, and every further stream shares one with another stream and serialises with it - a second
-    TrainBuffers / SignalTrainer in the same process (bench.py's other workloads, a second model) must reuse the first
-    one's streams instead of creating four more."""
-    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), role,
-           bool(high and _SIG_PRIO))
-    if role is None:
-        return torch.cuda.Stream(device=device, priority=-1 if (high and _SIG_PRIO) else 0)
-    s = _STREAMS.get(key)
-    if s is None:
-        s = _STREAMS[key] = torch.cuda.Stream(device=device, priority=-1 if (high and _SIG_PRIO) else 0)
-    return s
+    """engine.side_stream with the signal streams' priority switch (DFN_TRAIN_SIG_PRIO)."""
+    return engine.side_stream(device, high and _SIG_PRIO, role)
 
 
 def _sync_flat(params, views):
