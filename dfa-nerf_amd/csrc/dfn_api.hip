@@ -679,6 +679,8 @@ int dfn_signal_grad(int tier, int field, const float* params, const void* dy_T, 
             for (int i = 0; i < n; ++i) {
                 rows[i] = w.bias_rows[elems[i]];
                 if (rows[i] < 0 || n % 64) return fail(DFN_E_ARG, "internal: a signal-term bias element without a gradient row");
+                // sig_rows8_kernel: 32 consecutive entries = the rows of one aligned 32-row block
+                if ((rows[i] >> 5) != (rows[i & ~31] >> 5)) return fail(DFN_E_ARG, "internal: signal rows not in whole 32-row blocks");
             }
             int32_t *d_rows = nullptr, *d_el = nullptr;      // published together, after both uploads succeeded
             hipError_t e = upload(&d_rows, rows.data(), rows.size());

@@ -787,13 +787,72 @@ __global__ __launch_bounds__(64) void sig_rows_kernel(const int* __restrict__ ro
     }
     parts[(long)blockIdx.y * n_sig + i] = acc;
 }
-__global__ void sig_reduce_kernel(const int* __restrict__ elem_of, int n_sig, const float* __restrict__ parts, int slices,
-                                  float* __restrict__ dbias) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// MX-fp8 arrays: one wave = one 32-row block of dy_T over a slice of the tiles.  A block of a tile is ONE contiguous KiB,
+// [point n][half h][register r]: lane L takes its 16 bytes (point L >> 1, half L & 1: sixteen features of one point) with
+// one dwordx4 load - 1 KiB per load instruction instead of the 64 useful bytes a row-per-lane walk gets -, dequantises with
+// v_cvt_pk_f32_fp8 and the tile's E8M0 scale (the wave's scale bytes of 64 tiles are fetched by one load, v_readlane per
+// tile), and accumulates sixteen sums; the 32 points are added at the end (five xor steps), fixed order: bit-reproducible.
+// row_of[32 b .. 32 b + 31] must be the rows of ONE aligned block (checked by the launcher's caller: signal rows are whole
+// 64-row vectors); parts[slice][i] as before.
+__global__ __launch_bounds__(64) void sig_rows8_kernel(const int* __restrict__ row_of, int n_sig, const unsigned char* __restrict__ dy_T,
+                                                       long n_tiles, int rows, float* __restrict__ parts) {
+    __shared__ float sums[32];
+    const int lane = threadIdx.x;
+    const int my_row = row_of[blockIdx.x * 32 + (lane & 31)];
+    const int rb = __builtin_amdgcn_readfirstlane(my_row >> 5);
+    const long per = (n_tiles + gridDim.y - 1) / gridDim.y;
+    const long t0 = blockIdx.y * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
+    const long stride = rec8_tile_bytes(rows);
+    const unsigned char* blk = dy_T + (long)rb * 1024 + 16 * lane;
+    const unsigned char* scl = dy_T + (long)rows * 32 + rb;
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    for (long c = t0; c < t1; c += 64) {
+        const int n = (int)((t1 - c < 64) ? t1 - c : 64);
+        const unsigned sc = lane < n ? scl[(c + lane) * stride] : 127u;
+#pragma unroll 8
+        for (int u = 0; u < n; ++u) {
+            const uint4 v = *(const uint4*)(blk + (c + u) * stride);
+            const float scale = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)sc, u) << 23);
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[q], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[q], true);
+                acc[4 * q + 0] = fmaf(lo[0], scale, acc[4 * q + 0]);
+                acc[4 * q + 1] = fmaf(lo[1], scale, acc[4 * q + 1]);
+                acc[4 * q + 2] = fmaf(hi[0], scale, acc[4 * q + 2]);
+                acc[4 * q + 3] = fmaf(hi[1], scale, acc[4 * q + 3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+#pragma unroll
+        for (int m = 2; m < 64; m <<= 1) acc[k] += __shfl_xor(acc[k], m, 64);
+    }
+    if (lane < 2) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sums[lane * 16 + k] = acc[k];
+    }
+    __syncthreads();
+    if (lane < 32) {
+        int h, r;
+        tile_feat_inv(my_row & 31, &h, &r);
+        parts[(long)blockIdx.y * n_sig + blockIdx.x * 32 + lane] = sums[h * 16 + r];
+    }
+}
+// one wave per element: the lanes fetch the slices in parallel, the adds stay in index order inside a lane and in a fixed tree
+// across the lanes (the serial loop was 128 dependent HBM latencies: 62 us on the critical path of the step)
+__global__ __launch_bounds__(256) void sig_reduce_kernel(const int* __restrict__ elem_of, int n_sig, const float* __restrict__ parts, int slices,
+                                                         float* __restrict__ dbias) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n_sig) return;
     float a = 0.f;
-    for (int k = 0; k < slices; ++k) a += parts[(long)k * n_sig + i];
-    dbias[elem_of[i]] = a;
+    for (int k = lane; k < slices; k += 64) a += parts[(long)k * n_sig + i];
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) a += __shfl_xor(a, m, 64);
+    if (lane == 0) dbias[elem_of[i]] = a;
 }
 hipError_t launch_signal_rows(int tier, int field, const int* row_of, const int* elem_of, int n_sig, const void* dy_T, long NP,
                               float* parts, float* dbias, hipStream_t st) {
@@ -802,12 +861,12 @@ hipError_t launch_signal_rows(int tier, int field, const int* row_of, const int*
     const int slices = (int)(n_tiles < SIG_ROW_SLICES ? n_tiles : SIG_ROW_SLICES);
     const dim3 grid(n_sig / 64, slices);
     if (tier == TIER_BF16)
-        hipLaunchKernelGGL(sig_rows_kernel<unsigned char>, grid, dim3(64), 0, st, row_of, n_sig, (const unsigned char*)dy_T,
+        hipLaunchKernelGGL(sig_rows8_kernel, dim3(n_sig / 32, slices), dim3(64), 0, st, row_of, n_sig, (const unsigned char*)dy_T,
                            n_tiles, rows, parts);
     else
         hipLaunchKernelGGL(sig_rows_kernel<float>, grid, dim3(64), 0, st, row_of, n_sig, (const float*)dy_T, n_tiles, rows,
                            parts);
-    hipLaunchKernelGGL(sig_reduce_kernel, dim3((n_sig + 255) / 256), dim3(256), 0, st, elem_of, n_sig, parts, slices, dbias);
+    hipLaunchKernelGGL(sig_reduce_kernel, dim3((n_sig + 3) / 4), dim3(256), 0, st, elem_of, n_sig, parts, slices, dbias);
     return hipGetLastError();
 }
 

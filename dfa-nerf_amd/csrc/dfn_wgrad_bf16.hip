@@ -31,6 +31,19 @@ constexpr int WL_WAVES = 8, WL_THREADS = 64 * WL_WAVES;
 #ifndef DFN_WL_DEPTH
 #define DFN_WL_DEPTH 4
 #endif
+// Cache policy of the operand stream: every byte is read once by one workgroup -> non-temporal (measured, both fields, alone:
+// DMA stream only 339 -> 319 us, whole kernel 448 -> 438 us; sc1 / sc0 sc1: no change).  Also measured and NOT adopted: the
+// arrays laid out [row block][tile] (sequential 1-KiB streams instead of 8-KiB runs at a 77-KB stride): the same 4.4-4.5 TB/s;
+// every other piece through registers instead of LDS-DMA: the same - the stream is bound on the memory side, not by the
+// LDS-DMA path of a compute unit.
+#ifndef DFN_WL_POL
+#define DFN_WL_POL 1
+#endif
+#if DFN_WL_POL == 1
+#define DFN_WL_POLICY " nt"
+#else
+#define DFN_WL_POLICY ""
+#endif
 constexpr int WL_DEPTH = DFN_WL_DEPTH;          // ring depth in steps
 constexpr int WL_STEP_BYTES = 32 * 1024;        // 32 operand tiles (1 KiB each) per step at most
 constexpr int WL_PIECES = 4;                    // 1 KiB DMA pieces per wave and step at most (32 per step)
@@ -106,7 +119,7 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_mx_kernel(const WOp* ops, co
                 t = t < 2 * c1 ? t : 2 * c1 - 1;     // ragged last step: refetch the last tile (never multiplied)
                 const char* a = src[k] + t * stride[k];
                 const unsigned d = __builtin_amdgcn_readfirstlane(slot + dst[k]);
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(a), "s"(d) : "memory", "m0");
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" DFN_WL_POLICY ::"v"(a), "s"(d) : "memory", "m0");
             }
     };
 
