@@ -35,7 +35,10 @@ constexpr int WL_WAVES = 8, WL_THREADS = 64 * WL_WAVES;
 // DMA stream only 339 -> 319 us, whole kernel 448 -> 438 us; sc1 / sc0 sc1: no change).  Also measured and NOT adopted: the
 // arrays laid out [row block][tile] (sequential 1-KiB streams instead of 8-KiB runs at a 77-KB stride): the same 4.4-4.5 TB/s;
 // every other piece through registers instead of LDS-DMA: the same - the stream is bound on the memory side, not by the
-// LDS-DMA path of a compute unit.
+// LDS-DMA path of a compute unit.  Where the kernel's time goes (both fields, alone; timing builds DFN_WL_NOMFMA / DFN_WL_NOLDS):
+// DMA stream + barriers 311 us, + the MFMAs on constant operands 386 us, + the transpose reads = the kernel, 439 us.  A
+// register-double-buffered variant (reads of pair q + 1 under the MFMAs of pair q; needs 4 waves x 128 x 128 outputs to fit
+// the registers) can at best reach the 386-us row: not built.
 #ifndef DFN_WL_POL
 #define DFN_WL_POL 1
 #endif
@@ -199,12 +202,18 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_mx_kernel(const WOp* ops, co
                 const lds_char* b0 = slot + (2 * u) * ntl * 1024 + rd;          // first tile of the pair
                 const lds_char* b1 = b0 + ntl * 1024;                           // second tile
                 i32x8 a[4], b[2];
+#ifdef DFN_WL_NOLDS          // timing experiment (wrong results): the MFMAs on constant operands, no fragment reads
+                for (int i = 0; i < 4; ++i) a[i] = ones;
+                for (int j = 0; j < 2; ++j) b[j] = ones;
+                asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]));
+#else
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (i < mt_n && (nt_n > 0 || (do_bias && i == cg))) a[i] = frag_tr8(b0 + (4 * rg + i) * 1024, b1 + (4 * rg + i) * 1024);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     if (j < nt_n) b[j] = frag_tr8(b0 + (mts + 2 * cg + j) * 1024, b1 + (mts + 2 * cg + j) * 1024);
+#endif
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
