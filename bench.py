@@ -642,15 +642,15 @@ def main():
         # the other BASELINE configs, short runs in the same process (driver-timed, not builder-only numbers); c2_f32 = the
         # exact tier, the one that meets the north star's "within 1e-4 PSNR" clause
         for name, wl, tier, k, w in (("c3", "c3", args.tier, 40, 5), ("c1", "c1", args.tier, 60, 5),
-                                     ("c2_f32", "c2", "f32", 5, 1), ("c4", "c4", args.tier, 150, 20),
-                                     ("c4h", "c4h", args.tier, 60, 10)):
+                                     ("c2_f32", "c2", "f32", 5, 1), ("c5", "c5", args.tier, 4, 1),
+                                     ("c4", "c4", args.tier, 150, 20), ("c4h", "c4h", args.tier, 60, 10)):
             if wl == args.workload and tier == args.tier:
                 continue
             try:
                 r = bench_training(args, wl, k, w, 1, 0, dev) if wl in TRAIN_WORKLOADS else \
                     bench_render(args, wl, tier, k, w, 1, 0, dev, check=(name == "c2_f32" and not args.no_parity_check))
                 r.pop("_scene", None)
-                extra[name] = {kk: r[kk] for kk in ("metric", "value", "unit", "steps", "ms_per_step", "dtype", "roofline",
+                extra[name] = {kk: r[kk] for kk in ("metric", "value", "unit", "steps", "ms_per_step", "ms_per_frame", "dtype", "roofline",
                                                     "parity_check") if kk in r}
                 extra[name]["workload"] = r["config"]["workload"]
             except Exception as e:                      # never lose the headline line to a side measurement

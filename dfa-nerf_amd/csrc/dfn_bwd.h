@@ -44,6 +44,41 @@ DFN_DEV void apply_mask(f32x16 (&acc)[2], unsigned bits) {
     }
 #endif
 }
+// 16-bit tiers: the same on the PACKED operand words of the pair (tiles t0, t0 + 1 of v).  Word j = 8 g + 4 h + e of the pair
+// holds values 2 j (low half) and 2 j + 1 (high half), whose bits sit at j and 16 + j of the mask dword (mask_pos): shifting
+// both halves of the dword left by 15 - j puts each value's bit on its half's sign, an arithmetic shift right by 15 spreads it
+// over the half - v_pk_lshlrev_b16, v_pk_ashrrev_i16, v_and_b32: 3 VALU per word = 1.5 per value.  (The per-value form above
+// compiles to v_and + v_cmp_ne + v_cndmask + a second v_and per VALUE: 40 % of the dX kernels' vector instructions.)  asm: so
+// that it stays that way; a zeroed bf16 half = the zeroed f32 value converted.
+template <int TIER, int NT>
+DFN_DEV void apply_mask_packed(Vec<TIER, NT>& v, int t0, unsigned bits) {
+    static_assert(tier_is16(TIER), "packed operand words");
+#ifndef DFN_NOMASK
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int gh = 0; gh < 4; ++gh) {             // register 2 (t0 + g) + h of v, g = gh >> 1, h = gh & 1: words 4 gh .. 4 gh + 3
+        u32x4_ q = __builtin_bit_cast(u32x4_, v.u[2 * t0 + gh]);
+        unsigned w[4] = {q[0], q[1], q[2], q[3]};          // scalar copies (__builtin_bit_cast of a vector ELEMENT miscompiles)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = 4 * gh + e;
+            // ONE asm per word, tied to the word: as separate statements the scheduler hoisted the sixteen masks of a pair
+            // above its MFMAs (they only depend on the mask dword) and spilled 100 registers
+            unsigned m;
+            if (j < 15)
+                asm("v_pk_lshlrev_b16 %1, %3, %2 op_sel_hi:[0,1]\n\tv_pk_ashrrev_i16 %1, 15, %1 op_sel_hi:[0,1]\n\tv_and_b32 %0, %0, %1"
+                    : "+v"(w[e]), "=&v"(m) : "v"(bits), "n"(15 - j));
+            else
+                asm("v_pk_ashrrev_i16 %1, 15, %2 op_sel_hi:[0,1]\n\tv_and_b32 %0, %0, %1" : "+v"(w[e]), "=&v"(m) : "v"(bits));
+        }
+        const u32x4_ r = {w[0], w[1], w[2], w[3]};
+        v.u[2 * t0 + gh] = __builtin_bit_cast(typename std::remove_reference<decltype(v.u[0])>::type, r);
+    }
+#endif
+}
+#ifndef DFN_PACKED_MASK
+#define DFN_PACKED_MASK 1
+#endif
 DFN_DEV unsigned mask_word(const BwdIO& io, int dword, int lane) {
 #ifdef DFN_EXP_CONSTMASK      // timing experiment (wrong results): no mask LOADS (a value the compiler cannot fold)
     return (unsigned)io.mask_dwords * 0x9E3779B1u + (unsigned)(dword * 64 + lane) * 0x85EBCA6Bu;
@@ -160,8 +195,13 @@ DFN_DEV void bwd_layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, int mask_dw
         asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
         const unsigned long long q1 = __builtin_readcyclecounter();
 #endif
-        if (mask_dword0 >= 0) apply_mask(acc, mask_word(io, mask_dword0 + tg, c.lane));
-        acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);
+        if constexpr (tier_is16(TIER) && DFN_PACKED_MASK) {
+            acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);
+            if (mask_dword0 >= 0) apply_mask_packed<TIER, OT>(out, 2 * tg, mask_word(io, mask_dword0 + tg, c.lane));
+        } else {
+            if (mask_dword0 >= 0) apply_mask(acc, mask_word(io, mask_dword0 + tg, c.lane));
+            acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);
+        }
 #ifdef DFN_TIMING
         asm volatile("" : "+v"(out.u[4 * tg]), "+v"(out.u[4 * tg + 3]));
         const unsigned long long q2 = __builtin_readcyclecounter();
@@ -189,8 +229,13 @@ DFN_DEV void bwd_layer2(Vec<TIER, OT>& out, const Vec<TIER, NTB1>& in1, const Ve
         gemm_group<TIER, 2, KU1, NTB1>(acc, in1, f, fe, s, c, NoHook{},
                                        PutSide<TIER, NTB1, KU1, (OT / 2) * KU1, CT>{io, in1, put_row1, tg, c, qs});
         gemm_group<TIER, 2, KU2, NTB2>(acc, in2, f, fe, s, c);
-        if (mask_dword0 >= 0) apply_mask(acc, mask_word(io, mask_dword0 + tg, c.lane));
-        acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);
+        if constexpr (tier_is16(TIER) && DFN_PACKED_MASK) {
+            acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);
+            if (mask_dword0 >= 0) apply_mask_packed<TIER, OT>(out, 2 * tg, mask_word(io, mask_dword0 + tg, c.lane));
+        } else {
+            if (mask_dword0 >= 0) apply_mask(acc, mask_word(io, mask_dword0 + tg, c.lane));
+            acc_to_vec<TIER, 2, OT, false>(acc, out, 2 * tg);
+        }
     }
 }
 
@@ -260,9 +305,13 @@ DFN_DEV void bwd_trunk(const BwdIn& in, Vec<TIER, 8>& dy0, Vec<TIER, 4>& gpd_ski
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
         const unsigned bits = mask_word(io, m_trunk + RecMap::TM_A4R + w, c.lane);
+        if constexpr (tier_is16(TIER)) {
+            apply_mask_packed<TIER, 8>(cur, 2 * w, bits);
+        } else {
 #pragma unroll
-        for (int b = 0; b < 32; ++b)
-            if (!((bits >> mask_pos(b)) & 1u)) cur.set(32 * w + b, 0.f);
+            for (int b = 0; b < 32; ++b)
+                if (!((bits >> mask_pos(b)) & 1u)) cur.set(32 * w + b, 0.f);
+        }
     }
     // blocks[3..0]^T -> dy3 .. dy0; layer l writes its input: dy4 (l = 3), then dy3 .. dy1
     if constexpr (TIER == TIER_F32) {
@@ -338,10 +387,15 @@ DFN_DEV void bwd_torso(const BwdIn& in, const BwdIO& io, Stream& s, const CT& c)
     put<TIER, 2>(io, GradMap::S_GS3, gs, c);
     {
         const unsigned be = mask_word(io, RecMap::S_MD0 + 6, c.lane), bs = mask_word(io, RecMap::S_MD0 + 7, c.lane);
+        if constexpr (tier_is16(TIER)) {
+            apply_mask_packed<TIER, 2>(ge, 0, be);
+            apply_mask_packed<TIER, 2>(gs, 0, bs);
+        } else {
 #pragma unroll
-        for (int b = 0; b < 32; ++b) {
-            if (!((be >> mask_pos(b)) & 1u)) ge.set(b, 0.f);
-            if (!((bs >> mask_pos(b)) & 1u)) gs.set(b, 0.f);
+            for (int b = 0; b < 32; ++b) {
+                if (!((be >> mask_pos(b)) & 1u)) ge.set(b, 0.f);
+                if (!((bs >> mask_pos(b)) & 1u)) gs.set(b, 0.f);
+            }
         }
     }
     put<TIER, 2>(io, GradMap::S_DE3, ge, c);

@@ -3,6 +3,8 @@
 // built with LLVM's minimum-register scheduler, which cut their spills from ~200 to 17-89 registers; since the
 // operand vectors are converted in register pairs and the ReLU bits applied with bfe + and (dfn_mlp.h: acc_to_vec,
 // dfn_bwd.h: apply_mask) the default scheduler needs no spill at all and is 8 % faster than that build.)
+// Round 3 (MX-fp8 recording, packed mask application): 16 spilled registers in the torso kernel, none in the head kernel.
+#define DFN_DPP_ASM 0           // q8_of_tiles: the builtin DPP steps (dfn_mlp.h)
 #include "dfn_bwd_kernel.h"
 
 namespace dfn {

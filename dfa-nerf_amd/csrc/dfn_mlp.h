@@ -277,6 +277,9 @@ DFN_DEV gchar* uniform_ptr(const void* p) {
 // tools/tr8_probe.hip pins its semantics).  Round 3's first version transposed 4 x 4 bytes across lane quads in the
 // producers (two DPP moves + two v_perm_b32 per dword, four dword stores per block): the transposes cost 13 us and the
 // store instructions most of 56 us of the 430-us training forward.
+#ifndef DFN_DPP_ASM
+#define DFN_DPP_ASM 1
+#endif
 constexpr int REC8_SCALE_BYTES = 128;        // >= rows / 32 of every array (torso dy_T: 110)
 DFN_HD constexpr long rec8_tile_bytes(int rows) { return (long)rows * 32 + REC8_SCALE_BYTES; }
 struct Q8 {
@@ -306,12 +309,22 @@ template <int NT, bool NONNEG = false> DFN_DEV Q8 q8_of_tiles(const Vec<TIER_BF1
             }
     const u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(m4[0], m4[1]), __builtin_elementwise_max(m4[2], m4[3]));
     unsigned x = max((unsigned)m[0], (unsigned)m[1]);
-    // row maxima by DPP (quad swaps, half-row mirror, row mirror; `old` = the source: every lane is written, and a separate
-    // old operand would cost a v_mov per step), then the four rows by readlane: an SGPR
+    // row maxima by DPP (quad swaps, half-row mirror, row mirror), then the four rows by readlane: an SGPR.  As asm: the
+    // update_dpp builtin compiles to v_mov + v_mov_dpp + v_max per step (12 VALU), v_max_u32_dpp with the DPP on its own first
+    // operand is one; dst = src0 = src1, so a lane whose source lane is off keeps its value.  s_nop 1: the two wait states a
+    // DPP read needs behind the VALU write of its operand (the compiler does not see into the asm).
+#if !DFN_DPP_ASM          // (the dX kernels: the asm form costs them 18 more spilled registers and is not faster there)
     x = max(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false));
     x = max(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false));
     x = max(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false));
     x = max(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false));
+#else
+    asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 0"
+        : "+v"(x));
+#endif
     const unsigned a = max(max((unsigned)__builtin_amdgcn_readlane((int)x, 0), (unsigned)__builtin_amdgcn_readlane((int)x, 16)),
                            max((unsigned)__builtin_amdgcn_readlane((int)x, 32), (unsigned)__builtin_amdgcn_readlane((int)x, 48)));
     // amax in [2^(E-127), 2^(E-126)); scale = 2^(E-127-7): |x| / scale < 256 (e4m3 holds 448; no saturation mode needed)
@@ -338,7 +351,7 @@ DFN_DEV void store_tile8(void* arr, int rows, long tile, int row0, const Vec<TIE
     for (int k = 0; k < 4; ++k) {            // registers 4 k .. 4 k + 3 -> dword k
         const u32x4_ w = __builtin_bit_cast(u32x4_, v.u[2 * t + (k >> 1)]);
         const unsigned w_lo = w[2 * (k & 1)], w_hi = w[2 * (k & 1) + 1];      // scalar copies: __builtin_bit_cast of a vector ELEMENT miscompiles
-        s16x2_ o = {0, 0};
+        s16x2_ o;                                // (both halves are written: no v_mov 0 per dword)
         o = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o, __builtin_bit_cast(bf16x2_q, w_lo), q.scale, false);
         o = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(o, __builtin_bit_cast(bf16x2_q, w_hi), q.scale, true);
         out[k] = __builtin_bit_cast(unsigned, o);
@@ -669,18 +682,21 @@ DFN_DEV void rec_mask_pair_packed(const CT& c, int mask_dword, const Vec<TIER, N
     if constexpr (CT::rec_on && tier_is16(TIER)) {
         if (mask_dword >= 0) {
             typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-            const u16x2 one = {1, 1};
-            unsigned bits = 0;
+            unsigned b2[2] = {0, 0};          // two v_lshl_or_b32 chains (the compiler's shift + v_or3 tree: 1.7 VALU per word)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const u32x4_ q = __builtin_bit_cast(u32x4_, out.u[2 * t0 + k]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const unsigned w = q[e];          // (a scalar: __builtin_bit_cast of a vector ELEMENT miscompiles)
-                    const unsigned t = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, w), one));
-                    bits |= t << (4 * k + e);
+                    // asm: LLVM rewrites min(u16x2, {1, 1}) into two 16-bit compares, two selects and a v_perm (5 VALU per
+                    // word; the training forward carried 4,000 of them)
+                    unsigned t;
+                    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(w), "s"(0x00010001u));
+                    asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(b2[e & 1]) : "v"(t), "n"(4 * k + e));
                 }
             }
+            const unsigned bits = b2[0] | b2[1];
             gchar* mb = uniform_ptr(c.rec.masks + ((long)c.rec.pass * c.rec.mask_dwords + mask_dword) * 64);
             *(__attribute__((address_space(1))) unsigned*)(mb + (unsigned)c.lane * 4u) = bits;
         }
