@@ -144,6 +144,38 @@ def test_signal_encoders_single_frame_beyond_sequence_length(states, scene):
     assert not torch.equal(a, b)
 
 
+def test_frame_prefetcher_equals_the_direct_front_end(dropin, states, scene, latents):
+    """engine.FramePrefetcher (signal encoders + bias fold one frame ahead on a side stream, run_nerf.py's render loop and
+    bench.py): the blob it hands out is bit for bit the blob of encode() + fold() on the render stream - with the hinted
+    frame, with a hint that turns out wrong, without a hint, and when a blob's slot comes round again."""
+    from dfanerf import engine, nets
+    M, D = dropin
+    dev = torch.device("cuda")
+    mods = {"AudNet": nets.AudioNet_W2L(), "ExpNet": nets.ExpressionEnc(), "AudAttNet": nets.AudioAttNet(96, 4),
+            "PoseAttNet": nets.AudioAttNet(42, 8)}
+    for k, m in mods.items():
+        m.load_state_dict({kk: t(v) for kk, v in states[k].items()})
+        m.to(dev)
+    dec = D.Decoder(z_dim=256, hidden_size=256, dim_signal=96, use_deformation_field=True)
+    dec.load_state_dict({k: t(v) for k, v in states["decoder"].items()})
+    dec.to(dev)
+    auds, exps, poses = [t(scene[k]).to(dev) for k in ("aud", "exp", "poses")]
+    enc = engine.SignalEncoder(mods["AudNet"], mods["ExpNet"], mods["AudAttNet"], mods["PoseAttNet"], auds, exps, poses)
+    zs, za = [t(v).reshape(-1, 256)[:2].to(dev).float().contiguous() for v in latents]
+    pk = dec.packed("f16")
+    n = auds.shape[0]
+    order = [3, 0, n - 1, n - 1, 2, 5, 1]
+    hints = [0, 4, n - 1, 2, None, 1, None]          # right, WRONG, right (same frame again), right, none, right, none
+    pf = engine.FramePrefetcher(enc, pk, zs, za, 4, 8, fields=2)
+    for f, nxt in zip(order, hints):
+        got = pf.get(f, nxt).clone()
+        pf.done()
+        s2, t2 = enc.encode([f], 4, 8)
+        want = pk.fold(s2[0], t2[0], zs, za)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), f
+
+
 def test_rccl_backend_world1_collectives(scene, states, latents, golden):
     """The collectives of the multi-GPU path on the RCCL backend ("nccl" on ROCm), on the one GPU a gpurun box has
     (world size 1; RCCL refuses two ranks on one device, so a real exchange needs the driver's multi-GPU node): process
