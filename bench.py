@@ -45,6 +45,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "dfa-nerf_amd"))
 
+import dfanerf  # noqa: F401,E402  (before the first GPU call: multi-rank processes ask the runtime for eight hardware queues)
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -174,7 +175,7 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
     buf.signal_trainer = training.SignalTrainer(mods["AudNet"], mods["ExpNet"], mods["AudAttNet"], mods["PoseAttNet"],
                                                 ds[0]["auds"], ds[0]["exp"], ds[0]["poses"])
     buf.signal_trainer.adopt_optimizers(opts)
-    bucket = parallel.FlatGradBucket(list(mods.values())) if world > 1 else None
+    bucket = parallel.FlatGradBucket(list(mods.values())) if world > 1 or parallel.multi_rank_schedule() else None
     rng = np.random.RandomState(100 + rank)
     rng_frame = np.random.RandomState(100) if strong else rng      # strong: ONE frame per step on all ranks (MAIN:779)
     # the training input stage as train() runs it (dfanerf/frames.py): uint8 ground-truth frames resident on the device,
@@ -240,6 +241,7 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
             dt = float(tmax.item())
         assert torch.isfinite(loss)
         state["dt_rank"] = dt_rank
+        state["loss"] = float(loss)
         return dt
     state = {}
     for _ in range(warmup):
@@ -297,7 +299,7 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
             "vs_baseline": None, "dtype": tier, "data": "synthetic",
             "config": {"workload": desc, "H": H, "W": W, "N_rand_per_gpu": N_RAND, "n_coarse": 64, "n_fine": n_fine,
                        "fields": 2, "parallelism": f"dp{world}, one flat-bucket all_reduce (1,138,656 floats)"},
-            "roofline": {"bound": "mfma", "kernel": "whole step (render_kernel<train>, mlp_bwd, wgrad_lds)",
+            "roofline": {"bound": "mfma", "kernel": "whole step (render_kernel<train>, mlp_bwd, wgrad_mx)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "flop_per_ray": flop_ray,
                          "traffic": traffic, "traffic_source": traffic_src, "recorded_bytes_per_step": step_bytes,
                          "algorithmic_bytes": alg_bytes, "traffic_over_algorithmic": traffic / alg_bytes,
@@ -305,6 +307,8 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
             "per_rank": {"ms_per_step": rank_ms}}
         if sus:
             out["sustained"] = sus
+        if os.environ.get("DFN_BENCH_PRINT_LOSS"):      # (tests: the loss of the last timed step, rank 0)
+            out["last_loss"] = state["loss"]
     return out
 
 
@@ -628,6 +632,15 @@ def main():
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)                        # the ranks RCCL actually connected
         rccl_ranks = int(ones.item())
+    # DFN_BENCH_RCCL_WORLD1=1 (developer switch, one GPU): a process group of ONE rank on the real RCCL backend and the
+    # multi-rank training schedule (DFN_FORCE_MULTIRANK: bucket all_reduce through RCCL's own stream, head weight gradients on
+    # the main stream, optimizer streams ordered behind the collective) - what N > 1 runs per rank, minus the exchange.
+    if world == 1 and os.environ.get("DFN_BENCH_RCCL_WORLD1"):
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ["DFN_FORCE_MULTIRANK"] = "1"
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        backend = "nccl (one rank, DFN_BENCH_RCCL_WORLD1)"
     if world != args.gpus and rank == 0:
         print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}; using {world}", file=sys.stderr)
 
@@ -665,7 +678,7 @@ def main():
         if extra:
             out["other_workloads"] = extra
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -112,7 +112,8 @@ class HipAdam(torch.optim.Adam):
         if s is None:
             return self._step(closure, None)
         cur = torch.cuda.current_stream(s.device)
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        from .parallel import multi_rank_schedule
+        if multi_rank_schedule():
             s.wait_stream(cur)
         out = self._step(closure, s)
         if not getattr(self, "dfn_join_later", False):     # the owner of the stream orders its readers itself

@@ -92,11 +92,28 @@ def _to_device(obj, dev):
     return obj
 
 
+def multi_rank_schedule():
+    """True when the training step runs next to a collective: more than one rank - or DFN_FORCE_MULTIRANK=1 with an
+    initialised process group of ONE rank (developer switch: the multi-rank stream schedule and the bucket all_reduce over
+    the real RCCL backend on a box with one GPU; RCCL refuses two ranks on one device)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("DFN_FORCE_MULTIRANK") == "1"
+
+
 class FlatGradBucket:
-    """One flat fp32 buffer for the gradients of several modules -> a single all_reduce per step."""
+    """One flat fp32 buffer for the gradients of several modules -> a single all_reduce per step.
+
+    The HIP training path writes ONE flat gradient buffer per network (training._FlatNet, `.grad` = views of it).  After the
+    first step those buffers ARE slices of the bucket (_adopt): from then on a step's all_reduce runs in place on what the
+    backward kernels wrote - no gather copy, no scaling pass (ReduceOp.AVG on RCCL), no re-pointing of sixty `.grad`s;
+    measured on one MI355X through RCCL (one rank, bench.py DFN_BENCH_RCCL_WORLD1): 95 us of a 1.4-ms step.  Gradients that
+    live anywhere else (torch autograd's own tensors, accumulated gradients) take the general path: two multi-tensor copies
+    around the collective."""
 
     def __init__(self, modules):
-        self.params = [p for m in modules for p in m.parameters()]
+        self.modules = list(modules)
+        self.params = [p for m in self.modules for p in m.parameters()]
         self.numel = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
@@ -104,18 +121,53 @@ class FlatGradBucket:
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self._ptrs = [v.data_ptr() for v in self.views]
+        self._spans, off = [], 0                     # (first element, one past the last, parameters) per module
+        for m in self.modules:
+            ps = list(m.parameters())
+            n = sum(p.numel() for p in ps)
+            self._spans.append((off, off + n, ps))
+            off += n
+
+    def _adopt(self):
+        """The networks' flat gradient buffers become slices of the bucket (modules bound by training._FlatNet whose flat
+        layout is exactly their parameters, in order: all five networks of the training step)."""
+        for m, (a, b, ps) in zip(self.modules, self._spans):
+            fn = m.__dict__.get("_dfn_flat")
+            if fn is not None and fn.flat.numel() == b - a and len(fn.params) == len(ps) and \
+                    all(x is y for x, y in zip(fn.params, ps)):
+                fn._g_flat = self.flat[a:b]
+
+    def _reduce(self, group):
+        world = dist.get_world_size(group)
+        if world > 1 and dist.get_backend(group) == "nccl":
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            if world > 1:
+                self.flat.mul_(1.0 / world)
 
     def all_reduce_(self, group=None):
-        """Average the gradients over the ranks in place (missing grads count as zero).  Two multi-tensor copies and
-        one collective per step: afterwards every parameter's .grad IS its slice of the bucket (no copy back)."""
-        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        """Average the gradients over the ranks in place (missing grads count as zero)."""
+        if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not multi_rank_schedule()):
             return
-        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
+        grads = [p.grad for p in self.params]
+        if any(g is not None for g in grads) and \
+                all(g is None or g.data_ptr() == ptr for g, ptr in zip(grads, self._ptrs)):
+            # in place.  A module NONE of whose parameters has a gradient ran no backward this step: its slice still holds
+            # an older step's values (parameters without a gradient inside a module that ran are zero: the backward zeroed
+            # the module's whole buffer); `.grad = None` stays None.
+            for a, b, ps in self._spans:
+                if all(p.grad is None for p in ps):
+                    self.flat[a:b].zero_()
+            self._reduce(group)
+            return
+        have = [(v, g) for v, g in zip(self.views, grads) if g is not None]
         if len(have) < len(self.params):
             self.flat.zero_()
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        self.flat.mul_(1.0 / dist.get_world_size(group))
+        self._reduce(group)
         for p, v in zip(self.params, self.views):
             p.grad = v
+        self._adopt()

@@ -30,11 +30,6 @@ _WGRAD_SIDE = os.environ.get("DFN_TRAIN_WGRAD_SIDE", "1") == "1"
 _SIG_PRIO = os.environ.get("DFN_TRAIN_SIG_PRIO", "1") == "1"
 
 
-def _multi_rank():
-    import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-
-
 def _side_stream(device, high=False, role=None):
     """engine.side_stream with the signal streams' priority switch (DFN_TRAIN_SIG_PRIO)."""
     return engine.side_stream(device, high and _SIG_PRIO, role)
@@ -216,10 +211,10 @@ def _fused_backward(ctx, d_h, d_c):
                                     _ptr(d_h), _ptr(d_c), _ptr(buf.dsamples), st), "dfn_composite_bwd")
     g_bias = torch.empty(buf.nb[0] + buf.nb[1], dtype=torch.float32, device=dev)
     main = torch.cuda.current_stream(dev)
-    # (with more than one rank RCCL brings its own stream: the head field's weight gradients stay on the main stream then,
-    # so that the process still runs on four streams - a fifth shares a hardware queue with another one and serialises
-    # with it: 1.77 -> 2.39 ms per step)
-    over = _OVERLAP and _WGRAD_SIDE and not _multi_rank()
+    # (with more than one rank RCCL brings a fifth stream; the package asks the runtime for eight hardware queues then
+    # (dfanerf/__init__.py) - on the default four the weight-gradient stream shares the main stream's queue and this overlap
+    # is lost: 1.32 -> 1.36 ms per step through RCCL on one GPU)
+    over = _OVERLAP and _WGRAD_SIDE
     if over and getattr(buf, "_side", None) is None:
         buf._side = _side_stream(dev, role="wgrad")
     side = buf._side if over else None

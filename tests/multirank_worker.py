@@ -81,7 +81,7 @@ def main():
     gt = (torch.randint(0, 256, (H * W, 3), dtype=torch.uint8, device=dev, generator=gen),
           torch.randint(0, 256, (H * W, 3), dtype=torch.uint8, device=dev, generator=gen))
     embed_fn, _ = nets.get_embedder(3, 0)
-    assert training._multi_rank()
+    assert parallel.multi_rank_schedule()
     losses = []
     for k in range(3):
         loss, *_ = run_nerf.train_step_loss_hip(mods, ds, 0, (k + rank) % 4, sampler.draw(), gt[0], gt[1], zs, za, 300000,

@@ -59,3 +59,20 @@ def test_torchrun_form_still_works():
                  "127.0.0.1", "--master-port", str(free_port()), BENCH, "--gpus", "2", "--workload", "c3"] + FAST,
                 env={"DFN_BENCH_ONE_GPU": "1"})
     assert out["n_gpus"] == 2 and out["config"]["fields"] == 2 and len(out["per_rank"]["render_kernel_ms"]) == 2
+
+
+def test_training_step_in_the_multi_rank_schedule_over_rccl():
+    """DFN_BENCH_RCCL_WORLD1: a process group of ONE rank on the real RCCL backend (RCCL refuses two ranks on one device) and
+    the multi-rank training schedule - the gradient bucket reduced IN PLACE through RCCL's own stream, eight hardware queues,
+    the optimizer streams ordered behind the collective: what every rank of an N > 1 run does per step, minus the exchange.
+    The loss after 40 optimisation steps equals the single-rank schedule's (same seeds; averaging over one rank is the
+    identity, and the weight gradients are bit-reproducible)."""
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    args = [sys.executable, BENCH, "--workload", "c4", "--steps", "30", "--warmup", "10", "--sustain-seconds", "0",
+            "--no-extra", "--no-cpu-baseline"]
+    single = _line(args, env={"DFN_BENCH_PRINT_LOSS": "1"})
+    multi = _line(args, env={"DFN_BENCH_PRINT_LOSS": "1", "DFN_BENCH_RCCL_WORLD1": "1"})
+    assert multi["backend"].startswith("nccl") and single["backend"] is None
+    assert multi["ms_per_step"] > 0 and multi["n_gpus"] == 1
+    assert multi["last_loss"] == single["last_loss"], (multi["last_loss"], single["last_loss"])
