@@ -175,7 +175,9 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
     buf.signal_trainer = training.SignalTrainer(mods["AudNet"], mods["ExpNet"], mods["AudAttNet"], mods["PoseAttNet"],
                                                 ds[0]["auds"], ds[0]["exp"], ds[0]["poses"])
     buf.signal_trainer.adopt_optimizers(opts)
-    bucket = parallel.FlatGradBucket(list(mods.values())) if world > 1 or parallel.multi_rank_schedule() else None
+    bucket = parallel.StepReducer(mods, opts, buf.signal_trainer) if world > 1 or parallel.multi_rank_schedule() else None
+    if os.environ.get("DFN_BENCH_ONE_BUCKET"):       # developer switch: the single-collective form
+        bucket = parallel.FlatGradBucket(list(mods.values())) if bucket is not None else None
     rng = np.random.RandomState(100 + rank)
     rng_frame = np.random.RandomState(100) if strong else rng      # strong: ONE frame per step on all ranks (MAIN:779)
     # the training input stage as train() runs it (dfanerf/frames.py): uint8 ground-truth frames resident on the device,
@@ -298,7 +300,7 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": tier, "data": "synthetic",
             "config": {"workload": desc, "H": H, "W": W, "N_rand_per_gpu": N_RAND, "n_coarse": 64, "n_fine": n_fine,
-                       "fields": 2, "parallelism": f"dp{world}, one flat-bucket all_reduce (1,138,656 floats)"},
+                       "fields": 2, "parallelism": f"dp{world}, three in-place all_reduces per step, each on the stream its gradients are produced on: audio-side networks (180,785 floats), PoseAttNet (2,629), decoder (955,242)"},
             "roofline": {"bound": "mfma", "kernel": "whole step (render_kernel<train>, mlp_bwd, wgrad_mx)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "flop_per_ray": flop_ray,
                          "traffic": traffic, "traffic_source": traffic_src, "recorded_bytes_per_step": step_bytes,

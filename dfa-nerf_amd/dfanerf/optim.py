@@ -107,13 +107,14 @@ class HipAdam(torch.optim.Adam):
         the backward, so their update (and the next step's encoder forward behind it) need not queue behind the decoder's
         weight-gradient GEMMs.  The current stream is ordered behind the update (unless `dfn_join_later`: the stream's owner
         does that where the parameters are next read); with more than one rank the side stream first waits for the current
-        one (the gradient all-reduce runs there)."""
+        one (the gradient all-reduce runs there) unless parallel.StepReducer exchanged these gradients on the side stream."""
         s = getattr(self, "dfn_stream", None)
         if s is None:
             return self._step(closure, None)
         cur = torch.cuda.current_stream(s.device)
         from .parallel import multi_rank_schedule
-        if multi_rank_schedule():
+        # (dfn_reduced_on_stream, set per step by parallel.StepReducer: these gradients were exchanged on `s` itself)
+        if multi_rank_schedule() and not self.__dict__.pop("dfn_reduced_on_stream", False):
             s.wait_stream(cur)
         out = self._step(closure, s)
         if not getattr(self, "dfn_join_later", False):     # the owner of the stream orders its readers itself

@@ -171,3 +171,41 @@ class FlatGradBucket:
         for p, v in zip(self.params, self.views):
             p.grad = v
         self._adopt()
+
+
+class StepReducer:
+    """The training step's gradient exchange in THREE collectives, each on the stream its gradients are produced on
+    (training.SignalTrainer): the audio-side networks' 180,785 gradients as soon as their backward is done (under the torso
+    field's dX chain), PoseAttNet's 2,629 after the torso's, the decoder's 955,242 behind its weight-gradient GEMMs on the
+    current stream.  With ONE bucket the conditioning networks' Adam waited for the decoder's last GEMM, and the next step's
+    audio encoder (a 77-us single-workgroup chain the decoder forward needs) was exposed at the start of every step instead
+    of running underneath the previous step's GEMMs.  Every rank issues the collectives in the same order (audio, pose,
+    decoder) - also the order they become ready in -; the backend runs them on its one stream in that order."""
+
+    AUDIO = ("AudNet", "ExpNet", "AudAttNet")
+    POSE = ("PoseAttNet",)
+
+    def __init__(self, nets, opts=None, signal_trainer=None):
+        """nets: dict name -> module as run_nerf.create_nerf returns it ("decoder" + the conditioning networks)."""
+        self.trainer = signal_trainer
+        self.opts = opts or {}
+        early = signal_trainer is not None and getattr(signal_trainer, "_pipelined", False) and \
+            signal_trainer.audio_stream() is not None and all(k in nets for k in self.AUDIO + self.POSE) and \
+            set(nets) == set(self.AUDIO + self.POSE + ("decoder",))
+        if early:
+            self.side = [(self.AUDIO, FlatGradBucket([nets[k] for k in self.AUDIO]), signal_trainer.audio_stream),
+                         (self.POSE, FlatGradBucket([nets[k] for k in self.POSE]), signal_trainer.pose_stream)]
+            self.dec = FlatGradBucket([nets["decoder"]])
+        else:                     # no side streams to run the early collectives on: one bucket, one collective
+            self.side = []
+            self.dec = FlatGradBucket(list(nets.values()))
+
+    def all_reduce_(self, group=None):
+        for names, bucket, stream in self.side:
+            with torch.cuda.stream(stream()):
+                bucket.all_reduce_(group)
+            for k in names:                            # their step() need not wait for the current stream's collective
+                o = self.opts.get(k)
+                if o is not None:
+                    o.dfn_reduced_on_stream = True
+        self.dec.all_reduce_(group)

@@ -736,7 +736,7 @@ def train():
         train_buf.signal_trainer = training.SignalTrainer(nets["AudNet"], nets["ExpNet"], nets["AudAttNet"],
                                                           nets["PoseAttNet"], ds['auds'], ds['exp'], ds['poses'])
         train_buf.signal_trainer.adopt_optimizers(opts)
-    bucket = parallel.FlatGradBucket(list(nets.values())) if world > 1 else None
+    bucket = parallel.StepReducer(nets, opts, getattr(train_buf, "signal_trainer", None)) if world > 1 else None
     rng = np.random.RandomState(1234 + rank) if world > 1 else np.random
     i_train = ds['i_train']
     # training input stage on the device: uint8 ground-truth frames resident in HBM (decoded

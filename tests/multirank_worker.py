@@ -75,7 +75,8 @@ def main():
     buf.signal_trainer = training.SignalTrainer(mods["AudNet"], mods["ExpNet"], mods["AudAttNet"], mods["PoseAttNet"],
                                                 ds[0]["auds"], ds[0]["exp"], ds[0]["poses"])
     buf.signal_trainer.adopt_optimizers(opts)
-    bucket = parallel.FlatGradBucket(list(mods.values()))
+    bucket = parallel.StepReducer(mods, opts, buf.signal_trainer)          # as run_nerf.train() builds it
+    assert len(bucket.side) == 2
     sampler = frames.PixelSampler(H, W, 512, 0, dev, seed=50 + rank, pipeline=True, stream=buf.signal_trainer.pose_stream())
     gen = torch.Generator(device=dev).manual_seed(9 + rank)
     gt = (torch.randint(0, 256, (H * W, 3), dtype=torch.uint8, device=dev, generator=gen),
