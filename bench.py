@@ -421,33 +421,56 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
     prefetch = engine.FramePrefetcher(enc, pk, zs_d, za_d, A.smo_size, A.smo_torse_size, fields=fields)
     probe = torch.zeros(2, dtype=torch.int64, device=dev)
 
+    # N > 1: consecutive FRAMES alternate between two render streams.  A rank's shard is 12.4 rounds of workgroups at 8 ranks:
+    # on one stream the 13th, partial round leaves 64 % of the compute units idle (5 % of the frame); the next frame's
+    # workgroups, launched on the other stream, start on them (tools/shard_scaling.py --two-streams, one GPU: a 1/8 shard
+    # 4.09 -> 3.90 ms per frame, 95.6 % -> 100 % of linear; 1/4: 99.2 -> 100 %).  N == 1: one stream, as profiled.
+    main_stream = torch.cuda.current_stream(dev)
+    if world > 1:
+        rstreams = [engine.side_stream(dev, role="render_a"), engine.side_stream(dev, role="render_b")]
+        for rs in rstreams:
+            rs.wait_stream(main_stream)                  # the set-up above ran on the main stream
+    else:
+        rstreams = [main_stream, main_stream]
+
     def step(i, timed):
         k = i & 1
+        used = sorted({(i * B + b) & 1 for b in range(B)})
         if works[k] is not None:
-            works[k].wait()                              # the gather that last used these buffers (two steps ago)
+            for u in used:                               # the gather that last used these buffers (two steps ago)
+                with torch.cuda.stream(rstreams[u]):
+                    works[k].wait()
             works[k] = None
         shard = shards[k]
         for b in range(B):
-            f = (i * B + b) % F
-            # conditioning signals (2 encoder launches) + bias fold of THIS frame were started underneath the previous frame's
-            # render (engine.FramePrefetcher); the next frame's start underneath this one's
-            bias = prefetch.get(f, next_frame=(i * B + b + 1) % F)
-            fr = engine.make_frame(H, W, sc["focal"], sc["cx"], sc["cy"], sc["poses"][f], sc["pose_body"], sc["near"],
-                                   sc["far"], ray_begin=begin, ray_count=count, n_fine=n_fine, fields=fields)
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            engine.render(pk, bias, fr, bg, out_head=shard[b, 0, :count],
-                          out_com=shard[b, 1, :count] if fields == 2 else None)
-            if timed:
-                e1.record()
-                ev.append((e0, e1))
-            prefetch.done()
+            g = i * B + b
+            f = g % F
+            rs = rstreams[g & 1]
+            with torch.cuda.stream(rs):
+                # conditioning signals (2 encoder launches) + bias fold of THIS frame were started underneath the previous
+                # frame's render (engine.FramePrefetcher); the next frame's start underneath this one's
+                bias = prefetch.get(f, next_frame=(g + 1) % F)
+                fr = engine.make_frame(H, W, sc["focal"], sc["cx"], sc["cy"], sc["poses"][f], sc["pose_body"], sc["near"],
+                                       sc["far"], ray_begin=begin, ray_count=count, n_fine=n_fine, fields=fields)
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(rs)
+                engine.render(pk, bias, fr, bg, out_head=shard[b, 0, :count],
+                              out_com=shard[b, 1, :count] if fields == 2 else None)
+                if timed:
+                    e1.record(rs)
+                    ev.append((e0, e1))
+                prefetch.done()
         if world > 1:
-            # concatenation form (every backend takes it); async: the collective waits for this stream's work so far and
-            # the NEXT step's render does not wait for the collective
-            works[k] = dist.all_gather_into_tensor(gathered[k].view(world * B * n_img, per, 3),
-                                                   shard.view(B * n_img, per, 3), async_op=True)
+            last = rstreams[(i * B + B - 1) & 1]
+            for u in used:                               # (a batch: frames of the step ran on both streams)
+                if rstreams[u] is not last:
+                    last.wait_stream(rstreams[u])
+            with torch.cuda.stream(last):
+                # concatenation form (every backend takes it); async: the collective waits for this stream's work so far and
+                # the NEXT step's render does not wait for the collective
+                works[k] = dist.all_gather_into_tensor(gathered[k].view(world * B * n_img, per, 3),
+                                                       shard.view(B * n_img, per, 3), async_op=True)
             return gathered[k]
         return shard
 
@@ -479,7 +502,25 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         assert torch.isfinite(img).all()
+        state["last"] = (i0 + n - 1, img)
         return dt, (float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")), dt_rank
+
+    state = {}
+
+    def gather_check():
+        """N > 1, rank 0, outside the timed region: the frame the LAST timed step gathered (its last frame, if a batch) against
+        the same frame rendered whole by this rank alone - every rank's shard, as it arrived, bit for bit."""
+        i_last, img = state["last"]
+        f = (i_last * B + B - 1) % F
+        got = img.view(world, B, n_img, per, 3)[:, B - 1].permute(1, 0, 2, 3).reshape(n_img, world * per, 3)[:, :R].clone()
+        s2, t2 = enc.encode([f], A.smo_size, A.smo_torse_size)
+        bias = pk.fold(s2[0], t2[0] if fields == 2 else None, zs_d, za_d)
+        fr = engine.make_frame(H, W, sc["focal"], sc["cx"], sc["cy"], sc["poses"][f], sc["pose_body"], sc["near"], sc["far"],
+                               ray_begin=0, ray_count=R, n_fine=n_fine, fields=fields)
+        whole = torch.empty(n_img, R, 3, dtype=torch.float32, device=dev)
+        engine.render(pk, bias, fr, bg, out_head=whole[0], out_com=whole[1] if fields == 2 else None)
+        torch.cuda.synchronize()
+        return {"frame": f, "identical": bool(torch.equal(got, whole)), "max_abs_diff": float((got - whole).abs().max())}
 
     def clock():
         """effective shader clock of the last launch (GHz), read inside the kernel"""
@@ -503,6 +544,12 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
     # per-rank figures (every rank contributes): its own wall time per step and its render_kernel time per launch
     rank_ms = all_ranks(dt_rank / steps * 1e3, world, dev)
     rank_kern = all_ranks(kern_ms, world, dev)
+    gcheck = None
+    if world > 1 and rank == 0:
+        try:
+            gcheck = gather_check()
+        except Exception as e:                          # never lose the line to the check; the failure is in the line
+            gcheck = {"error": f"{type(e).__name__}: {e}"}
     # the collective alone (nothing to overlap with): 20 gathers of the step's shard, synchronised
     gather_ms = None
     if world > 1:
@@ -562,7 +609,8 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
     }
     if world > 1:
         out["gather"] = {"ms_alone": gather_ms, "bytes_per_rank": int(B * n_img * per * 12), "async": True,
-                         "collective": "all_gather_into_tensor"}
+                         "collective": "all_gather_into_tensor", "render_streams": 2}
+        out["gather_check"] = gcheck
     if sus:
         sus["roofline_frac"] = flop_ray * count / (sus["kernel_ms"] * 1e-3) / 1e12 / peak
         out["sustained"] = sus

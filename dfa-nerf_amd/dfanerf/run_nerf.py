@@ -309,19 +309,30 @@ class FrameRenderer:
                             "gathered": torch.empty(world, n_img, per, 3, dtype=dt, device=self.bg.device), "work": None}
                            for _ in range(2)]
             self._flip, self._shard_key = 0, key
+            # Consecutive frames alternate between TWO render streams (one per buffer set): a rank's shard is 12.4 rounds of
+            # workgroups at 8 ranks, and on one stream the 13th, partial round leaves 64 % of the compute units idle (5 % of
+            # the frame) - the next frame's workgroups, launched on the other stream, start on them (measured on one GPU,
+            # tools/shard_scaling.py --two-streams: a 1/8 shard 4.09 -> 3.90 ms per frame = 95.6 % -> 100 % of linear)
+            self._rstreams = [self.engine.side_stream(self.bg.device, role="render_a"),
+                              self.engine.side_stream(self.bg.device, role="render_b")]
         self._flip ^= 1
         slot = self._slots[self._flip]
-        if slot["work"] is not None:                   # the frame that used these buffers two frames ago was never finished
-            slot["work"].wait()
-            slot["work"] = None
-        shard = slot["shard"]
-        out = (shard[0, :count], shard[1, :count] if fields == 2 else None)
-        if count:
-            self.render(pose, pose_body, signal, signal_torso, begin, count, fields=fields, out_u8=out_u8, out=out, bias=bias)
-        # the output as the CONCATENATION of the shards along dim 0 (the stacked [world, ...] form is an NCCL / RCCL
-        # extension that gloo rejects)
-        slot["work"] = dist.all_gather_into_tensor(slot["gathered"].view(world * n_img, per, 3), shard, async_op=True)
-        return {"slot": slot, "n_img": n_img, "per": per, "world": world, "fields": fields}
+        rs = self._rstreams[self._flip]
+        rs.wait_stream(torch.cuda.current_stream(self.bg.device))      # pose-independent inputs (signals / blob) of the caller
+        with torch.cuda.stream(rs):
+            if slot["work"] is not None:               # the frame that used these buffers two frames ago was never finished
+                slot["work"].wait()
+                slot["work"] = None
+            shard = slot["shard"]
+            out = (shard[0, :count], shard[1, :count] if fields == 2 else None)
+            if count:
+                self.render(pose, pose_body, signal, signal_torso, begin, count, fields=fields, out_u8=out_u8, out=out,
+                            bias=bias)
+            # the output as the CONCATENATION of the shards along dim 0 (the stacked [world, ...] form is an NCCL / RCCL
+            # extension that gloo rejects)
+            slot["work"] = dist.all_gather_into_tensor(slot["gathered"].view(world * n_img, per, 3), shard, async_op=True)
+        # "stream": what read the caller's inputs (engine.FramePrefetcher.done() must record its event there)
+        return {"slot": slot, "n_img": n_img, "per": per, "world": world, "fields": fields, "stream": rs}
 
     def render_image_end(self, h):
         """Finish a frame started by render_image_begin: order the current stream behind its gather -> [H,W,3] images
@@ -692,7 +703,8 @@ def train():
                 if pf is not None:
                     bias = pf.get(img_i, frame_ids[k + 1] if k + 1 < len(frame_ids) else None)
                     handle = renderer.render_image_begin(poses_host[img_i], body_host, None, None, out_u8=True, bias=bias)
-                    pf.done()
+                    with torch.cuda.stream(handle.get("stream") or torch.cuda.current_stream(dev)):
+                        pf.done()                       # (on the stream the render that read the blob runs on)
                     if pending is not None:
                         finish(*pending)
                     pending = (handle, img_i)

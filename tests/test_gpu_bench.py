@@ -47,6 +47,8 @@ def test_plain_python_launches_its_own_ranks(workload):
     assert len(out["per_rank"]["ms_per_step"]) == 2 and all(v > 0 for v in out["per_rank"]["ms_per_step"])
     if workload != "c4":
         assert out["gather"]["async"] and out["gather"]["ms_alone"] > 0
+        # the last timed frame as it was gathered (two render streams, two buffer sets) = the frame rendered whole by one rank
+        assert out["gather_check"].get("identical") is True, out["gather_check"]
         assert out["config"]["frames_per_step"] == (8 if workload == "c5" else 1)
         assert out["scaling"] == "strong"
     else:
@@ -59,6 +61,7 @@ def test_torchrun_form_still_works():
                  "127.0.0.1", "--master-port", str(free_port()), BENCH, "--gpus", "2", "--workload", "c3"] + FAST,
                 env={"DFN_BENCH_ONE_GPU": "1"})
     assert out["n_gpus"] == 2 and out["config"]["fields"] == 2 and len(out["per_rank"]["render_kernel_ms"]) == 2
+    assert out["gather_check"].get("identical") is True, out["gather_check"]
 
 
 def test_training_step_in_the_multi_rank_schedule_over_rccl():

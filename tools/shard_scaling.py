@@ -24,18 +24,22 @@ bg = torch.from_numpy(sc["bg"]).reshape(-1, 3).to(dev)
 H, W = sc["H"], sc["W"]
 R = H * W
 base = None
+# --two-streams: consecutive frames alternate between two streams (each with its own blob and output): the workgroups of
+# frame k + 1 start on the compute units that frame k's last, partial round of workgroups leaves idle
+TWO = "--two-streams" in sys.argv
+streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)] if TWO else [torch.cuda.current_stream(dev)] * 2
 for n in (1, 2, 4, 8):
     per = (R + n - 1) // n
-    out = torch.empty(per, 3, device=dev)
-    bias = None
+    outs = [torch.empty(per, 3, device=dev) for _ in range(2)]
+    biases = [None, None]
     def step(i):
-        global bias
         f = i % F
-        s2, _ = enc.encode(fid[f], 4, 8)
-        bias = pk.fold(s2[0], None, zs, za, out=bias)
-        fr = engine.make_frame(H, W, sc["focal"], sc["cx"], sc["cy"], sc["poses"][f], sc["pose_body"], sc["near"],
-                               sc["far"], ray_begin=0, ray_count=per, n_fine=128, fields=1)
-        engine.render(pk, bias, fr, bg, out_head=out)
+        with torch.cuda.stream(streams[i & 1]):
+            s2, _ = enc.encode(fid[f], 4, 8)
+            biases[i & 1] = pk.fold(s2[0], None, zs, za, out=biases[i & 1])
+            fr = engine.make_frame(H, W, sc["focal"], sc["cx"], sc["cy"], sc["poses"][f], sc["pose_body"], sc["near"],
+                                   sc["far"], ray_begin=0, ray_count=per, n_fine=128, fields=1)
+            engine.render(pk, biases[i & 1], fr, bg, out_head=outs[i & 1])
     for i in range(4):
         step(i)
     torch.cuda.synchronize()
