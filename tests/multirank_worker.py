@@ -65,6 +65,36 @@ def main():
         fh, fc = R.render(sc["poses"][f], pose_body, sig, sigt, fields=2, out_u8=True)
         ok_img &= bool(torch.equal(gh.reshape(-1, 3), fh) and torch.equal(gc.reshape(-1, 3), fc))
 
+    # the render-person loop of run_nerf.train(): the front end one frame ahead (engine.FramePrefetcher), consecutive frames
+    # on the two render streams, the gather of frame k underneath the render of frame k + 1 - 24 frames in a row, every
+    # gathered frame against the frame one rank renders whole from the same blob
+    from dfanerf import engine
+    enc = engine.SignalEncoder(mods["AudNet"], mods["ExpNet"], mods["AudAttNet"], mods["PoseAttNet"], t(sc["aud"]).to(dev),
+                               t(sc["exp"]).to(dev), t(sc["poses"]).to(dev))
+    pk = mods["decoder"].packed(R.tier)
+    refs = []
+    for f in range(4):
+        s2, t2 = enc.encode([f], 4, 8)
+        refs.append(tuple(x.clone() for x in R.render(sc["poses"][f], pose_body, None, None, fields=2, out_u8=True,
+                                                      bias=pk.fold(s2[0], t2[0], R.zs, R.za))))
+    pf = engine.FramePrefetcher(enc, pk, R.zs, R.za, 4, 8, fields=2)
+    order = [(7 * k + (k >> 2)) % 4 for k in range(24)]
+    pending, ok_loop = None, True
+
+    def finish(h, f):
+        gh, gc = R.render_image_end(h)
+        return bool(torch.equal(gh.reshape(-1, 3), refs[f][0]) and torch.equal(gc.reshape(-1, 3), refs[f][1]))
+    for k, f in enumerate(order):
+        bias = pf.get(f, order[k + 1] if k + 1 < len(order) else None)
+        h = R.render_image_begin(sc["poses"][f], pose_body, None, None, out_u8=True, bias=bias)
+        with torch.cuda.stream(h.get("stream") or torch.cuda.current_stream(dev)):
+            pf.done()
+        if pending is not None:
+            ok_loop &= finish(*pending)
+        pending = (h, f)
+    ok_loop &= finish(*pending)
+    ok_img &= ok_loop
+
     # ---- training: replicas that start DIFFERENT, broadcast, three data-parallel steps on different frames ---------------
     mods = modules(rank)                                   # rank 1 starts from other values
     opts = {k: run_nerf.make_adam(m.parameters(), 5e-4) for k, m in mods.items()}
