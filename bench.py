@@ -604,7 +604,11 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
                      "reference_composition": {"decoder_evals_per_ray_per_field": evals_ref,
                                                "flop_per_ray": evals_ref * per_pt, "tflops": ref_comp,
                                                "frac": ref_comp / peak},
-                     "rays_per_launch": count},
+                     "rays_per_launch": count,
+                     # the whole job against the whole node's peak, from the wall clock (N > 1: consecutive frames overlap
+                     # on two streams, so a launch's event time includes its neighbours' head and tail)
+                     "whole_job": {"tflops": flop_ray * R * B * steps / dt / 1e12,
+                                   "frac": flop_ray * R * B * steps / dt / 1e12 / (peak * world)}},
         "per_rank": {"ms_per_step": rank_ms, "render_kernel_ms": rank_kern},
     }
     if world > 1:
