@@ -29,7 +29,10 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 constexpr int WAVES = 8, FRAGS = 32;            // a 32-KiB slab of fragments in LDS, re-read round robin
 
 // LDS2: fragment reads per TWO MFMAs (0, 1, 2); VALU2: vector instructions per two MFMAs
-template <bool F16, int LDS2, int VALU2>
+// MODE (round 3, second series - why do LDS reads and VALU cost more TOGETHER than the sum of each alone?):
+//   0 as above; 1 the LDS reads land in registers the MFMAs do NOT use (operands stay constant); 2 the VALU are plain v_mov_b32;
+//   3 the fragment reads of an iteration are issued as one burst in front of its 32 MFMAs; 4 VALU = v_pk_max_i16 only
+template <bool F16, int LDS2, int VALU2, int MODE = 0>
 __global__ __launch_bounds__(64 * WAVES) void chain(const u32x4* __restrict__ frag_src, const u32x4* __restrict__ b_src,
                                                        int iters, float* out, unsigned long long* clk) {
     extern __shared__ u32x4 slab[];          // 150 KiB requested at launch: ONE workgroup per compute unit, 2 waves per SIMD, like the renderer
@@ -42,12 +45,44 @@ __global__ __launch_bounds__(64 * WAVES) void chain(const u32x4* __restrict__ fr
     u32x4 a0 = slab[lane], a1 = slab[64 + lane];
     unsigned e0 = b[0][0], e1 = b[1][1], e2 = b[2][2], e3 = b[3][3];
     const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    u32x4 d0 = a0, d1 = a1;
+    u32x4 burst[16];
     for (int it = 0; it < iters; ++it) {
+        if constexpr (MODE == 3) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) burst[q] = slab[((q + it) % FRAGS) * 64 + lane];
+        }
+        if constexpr (MODE == 5 || MODE == 6) {          // the iteration's VALU as ONE burst (5: in front of its 32 MFMAs; 6: two bursts of half)
+#pragma unroll
+            for (int v = 0; v < 16 * VALU2 / (MODE == 6 ? 2 : 1); ++v) {
+                unsigned& x = (v & 3) == 0 ? e0 : (v & 3) == 1 ? e1 : (v & 3) == 2 ? e2 : e3;
+                if (v & 1) asm volatile("v_pk_max_i16 %0, %1, %2" : "=v"(x) : "v"(x), "v"(e0 ^ e2));
+                else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(x) : "v"(__builtin_bit_cast(float, x)), "v"(__builtin_bit_cast(float, x ^ 0x3f800000u)));
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 16; ++k) {          // 32 MFMAs per iteration
+            if constexpr (MODE == 6) {
+                if (k == 8) {
+#pragma unroll
+                    for (int v = 0; v < 8 * VALU2; ++v) {
+                        unsigned& x = (v & 3) == 0 ? e0 : (v & 3) == 1 ? e1 : (v & 3) == 2 ? e2 : e3;
+                        if (v & 1) asm volatile("v_pk_max_i16 %0, %1, %2" : "=v"(x) : "v"(x), "v"(e0 ^ e2));
+                        else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(x) : "v"(__builtin_bit_cast(float, x)), "v"(__builtin_bit_cast(float, x ^ 0x3f800000u)));
+                    }
+                }
+            }
             const int f = (2 * k) % FRAGS;
-            if (LDS2 >= 1) a0 = slab[f * 64 + lane];
-            if (LDS2 >= 2) a1 = slab[(f + 1) * 64 + lane];
+            if constexpr (MODE == 1) {
+                if (LDS2 >= 1) { d0 = slab[f * 64 + lane]; asm volatile("" : "+v"(d0)); }
+                if (LDS2 >= 2) { d1 = slab[(f + 1) * 64 + lane]; asm volatile("" : "+v"(d1)); }
+            } else if constexpr (MODE == 3) {
+                a0 = burst[(2 * k) % 16];
+                a1 = burst[(2 * k + 1) % 16];
+            } else {
+                if (LDS2 >= 1) a0 = slab[f * 64 + lane];
+                if (LDS2 >= 2) a1 = slab[(f + 1) * 64 + lane];
+            }
             if constexpr (F16) {
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, b[k & 3]), acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, b[(k + 1) & 3]), acc1, 0, 0, 0);
@@ -57,9 +92,10 @@ __global__ __launch_bounds__(64 * WAVES) void chain(const u32x4* __restrict__ fr
             }
             // the epilogue's instruction mix on registers the MFMAs do not wait for: packed convert + packed max
 #pragma unroll
-            for (int v = 0; v < VALU2; ++v) {
+            for (int v = 0; v < (MODE == 5 || MODE == 6 ? 0 : VALU2); ++v) {
                 unsigned& x = (v & 3) == 0 ? e0 : (v & 3) == 1 ? e1 : (v & 3) == 2 ? e2 : e3;
-                if (v & 1) x = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, x), (s16x2)(short)(k + 1)));
+                if constexpr (MODE == 2) asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(x ^ (unsigned)k));
+                else if ((v & 1) || MODE == 4) asm volatile("v_pk_max_i16 %0, %1, %2" : "=v"(x) : "v"(x), "v"(e0 ^ e2));
                 else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(x) : "v"(__builtin_bit_cast(float, x)), "v"(__builtin_bit_cast(float, x ^ 0x3f800000u)));
             }
         }
@@ -67,25 +103,25 @@ __global__ __launch_bounds__(64 * WAVES) void chain(const u32x4* __restrict__ fr
     const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.f;
     for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s + (float)(e0 ^ e1 ^ e2 ^ e3);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s + (float)(e0 ^ e1 ^ e2 ^ e3 ^ d0[0] ^ d1[1]);
     if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) { clk[0] = c1 - c0; clk[1] = r1 - r0; }
 }
 
-template <bool F16, int LDS2, int VALU2>
+template <bool F16, int LDS2, int VALU2, int MODE = 0>
 void run(const char* label, const u32x4* frag, const u32x4* bsrc, float* out, unsigned long long* clk, int cus, const char* data) {
     const int iters = 4000, blocks = cus * 4;            // 4 rounds of one workgroup per compute unit
     const int lds = 150 * 1024;
-    hipFuncSetAttribute((const void*)chain<F16, LDS2, VALU2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute((const void*)chain<F16, LDS2, VALU2, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL((chain<F16, LDS2, VALU2>), dim3(blocks), dim3(64 * WAVES), lds, 0, frag, bsrc, 200, out, clk);     // warm-up
+    hipLaunchKernelGGL((chain<F16, LDS2, VALU2, MODE>), dim3(blocks), dim3(64 * WAVES), lds, 0, frag, bsrc, 200, out, clk);     // warm-up
     hipDeviceSynchronize();
     float best = 1e30f;
     unsigned long long h[2] = {0, 0};
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((chain<F16, LDS2, VALU2>), dim3(blocks), dim3(64 * WAVES), lds, 0, frag, bsrc, iters, out, clk);
+        hipLaunchKernelGGL((chain<F16, LDS2, VALU2, MODE>), dim3(blocks), dim3(64 * WAVES), lds, 0, frag, bsrc, iters, out, clk);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -97,8 +133,8 @@ void run(const char* label, const u32x4* frag, const u32x4* bsrc, float* out, un
     const double ghz = h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
     // matrix-pipe duty from the measured rate and the measured clock: at duty 1 and 2.4 GHz the chip does 2500 TFLOP/s
     const double duty = ghz > 0 ? tf / (2500.0 * ghz / 2.4) : 0.0;
-    printf("%-5s %-6s LDS %.1f KiB/MFMA  VALU %.1f/MFMA : %7.1f TFLOP/s  frac %.3f  clock %.2f GHz  matrix-pipe duty %.2f\n", label, data,
-           LDS2 / 2.0, VALU2 / 2.0, tf, tf / 2500.0, ghz, duty);
+    printf("%-5s %-6s LDS %.1f KiB/MFMA  VALU %.1f/MFMA mode %d : %7.1f TFLOP/s  frac %.3f  clock %.2f GHz  matrix-pipe duty %.2f\n", label, data,
+           LDS2 / 2.0, VALU2 / 2.0, MODE, tf, tf / 2500.0, ghz, duty);
 }
 
 int main() {
@@ -136,6 +172,12 @@ int main() {
             if (f16) {
                 RUN(true, 0, 0); RUN(true, 1, 0); RUN(true, 2, 0);
                 RUN(true, 0, 4); RUN(true, 2, 2); RUN(true, 2, 4); RUN(true, 2, 6); RUN(true, 1, 4);
+                if (getenv("PROBE_SERIES2")) {
+#define RUNM(L, V, M) run<true, L, V, M>("f16", F, B, out, clk, cus, data)
+                    RUNM(2, 4, 2); RUNM(0, 4, 2); RUNM(2, 4, 4); RUNM(0, 4, 4);
+                    RUNM(2, 2, 5); RUNM(2, 4, 5); RUNM(2, 6, 5); RUNM(0, 4, 5); RUNM(2, 4, 6); RUNM(2, 2, 0); RUNM(2, 4, 0);
+#undef RUNM
+                }
             } else {
                 RUN(false, 0, 0); RUN(false, 2, 0); RUN(false, 2, 4); RUN(false, 1, 4);
             }
