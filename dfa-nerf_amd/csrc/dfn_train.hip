@@ -811,18 +811,24 @@ __global__ __launch_bounds__(64) void sig_rows8_kernel(const int* __restrict__ r
     for (long c = t0; c < t1; c += 64) {
         const int n = (int)((t1 - c < 64) ? t1 - c : 64);
         const unsigned sc = lane < n ? scl[(c + lane) * stride] : 127u;
-#pragma unroll 8
-        for (int u = 0; u < n; ++u) {
-            const uint4 v = *(const uint4*)(blk + (c + u) * stride);
-            const float scale = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)sc, u) << 23);
-            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        for (int u0 = 0; u0 < n; u0 += 8) {              // eight tiles' loads in flight (constant trip counts inside)
+            uint4 v[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[q], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[q], true);
-                acc[4 * q + 0] = fmaf(lo[0], scale, acc[4 * q + 0]);
-                acc[4 * q + 1] = fmaf(lo[1], scale, acc[4 * q + 1]);
-                acc[4 * q + 2] = fmaf(hi[0], scale, acc[4 * q + 2]);
-                acc[4 * q + 3] = fmaf(hi[1], scale, acc[4 * q + 3]);
+            for (int j = 0; j < 8; ++j)
+                if (u0 + j < n) v[j] = *(const uint4*)(blk + (c + u0 + j) * stride);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (u0 + j >= n) break;
+                const float scale = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)sc, u0 + j) << 23);
+                const unsigned w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[q], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[q], true);
+                    acc[4 * q + 0] = fmaf(lo[0], scale, acc[4 * q + 0]);
+                    acc[4 * q + 1] = fmaf(lo[1], scale, acc[4 * q + 1]);
+                    acc[4 * q + 2] = fmaf(hi[0], scale, acc[4 * q + 2]);
+                    acc[4 * q + 3] = fmaf(hi[1], scale, acc[4 * q + 3]);
+                }
             }
         }
     }
