@@ -83,11 +83,14 @@ struct WgradEntry {
 WgradEntry g_wgrad[2];
 constexpr int WGRAD_KSPLIT = 32;
 constexpr int WS_KSPLIT_MAX = 32;       // slices the workspace is sized for (>= every tier's split)
-// 16: the kernel alone takes the same time for 16 ... 32 slices (0.81-0.82 ms for both fields, HBM-bound), the second stage
+// head 16 / torso 18 (round 3, whole step, interleaved A/B over 600 steps x 4: torso 16 / 17 / 18 / 20 = 1.1056 / 1.1021 / 1.0975 /
+// 1.114 ms; head 19: worse).  Round 2: the kernel alone takes the same time for 16 ... 32 slices (0.81-0.82 ms for both fields, HBM-bound), the second stage
 // reads a third less and the whole training step is 1.2 % faster than with 24 (interleaved A/B, bench.py --workload c4)
-int wgrad_ksplit_bf16() {              // slices of the points per GEMM, bf16 tier (DFN_WGRAD_KSPLIT: developer override)
-    static const int v = [] { const char* e = getenv("DFN_WGRAD_KSPLIT"); const int k = e ? atoi(e) : 0; return k > 0 && k <= WS_KSPLIT_MAX ? k : 16; }();
-    return v;
+int wgrad_ksplit_bf16(int field) {     // slices of the points per GEMM, bf16 tier (DFN_WGRAD_KSPLIT[_H|_T]: developer overrides)
+    static const int v[2] = {
+        [] { const char* e = getenv("DFN_WGRAD_KSPLIT_H"); if (!e) e = getenv("DFN_WGRAD_KSPLIT"); const int k = e ? atoi(e) : 0; return k > 0 && k <= WS_KSPLIT_MAX ? k : 16; }(),
+        [] { const char* e = getenv("DFN_WGRAD_KSPLIT_T"); if (!e) e = getenv("DFN_WGRAD_KSPLIT"); const int k = e ? atoi(e) : 0; return k > 0 && k <= WS_KSPLIT_MAX ? k : 18; }()};
+    return v[field == FIELD_TORSO ? 1 : 0];
 }
 
 template <typename T> hipError_t upload(T** dev, const T* host, size_t n) {
@@ -589,7 +592,7 @@ static int weight_grad_impl(int tier, int field, const void* dy_T, const void* a
     // workspace, the reduce kernels add the slices in index order -> bit-reproducible gradients.
     const long W = (long)w.map.size(), n_tiles = NP / 32;
     const int nb = (int)w.bias_rows.size();
-    const int ks = tier == DFN_TIER_BF16 ? wgrad_ksplit_bf16() : WGRAD_KSPLIT;
+    const int ks = tier == DFN_TIER_BF16 ? wgrad_ksplit_bf16(field) : WGRAD_KSPLIT;
     if (tier == DFN_TIER_BF16 && (n_tiles & 1))
         return fail(DFN_E_ARG, std::string(who) + ": the 16-bit tier contracts pairs of 32-point tiles: NP must be a multiple of 64");
     const long units = tier == DFN_TIER_BF16 ? n_tiles / 2 : n_tiles;      // what a slice is made of: tile pairs / tiles
