@@ -38,7 +38,9 @@ constexpr int WL_WAVES = 8, WL_THREADS = 64 * WL_WAVES;
 // LDS-DMA path of a compute unit.  Where the kernel's time goes (both fields, alone; timing builds DFN_WL_NOMFMA / DFN_WL_NOLDS):
 // DMA stream + barriers 311 us, + the MFMAs on constant operands 386 us, + the transpose reads = the kernel, 439 us.  A
 // register-double-buffered variant (reads of pair q + 1 under the MFMAs of pair q; needs 4 waves x 128 x 128 outputs to fit
-// the registers) can at best reach the 386-us row: not built.
+// the registers) can at best reach the 386-us row: not built.  Built and measured out: the two waves of a SIMD out of phase
+// (waves 4-7 multiply the fragments they read for the PREVIOUS pair, then read this one's, so that one wave's transpose reads run
+// under its partner's MFMAs; no second fragment set) - 472 us instead of 444, the step 1.5 % slower.
 #ifndef DFN_WL_POL
 #define DFN_WL_POL 1
 #endif
