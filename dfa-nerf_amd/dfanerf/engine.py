@@ -177,13 +177,29 @@ class FramePrefetcher:
         self.enc, self.pk, self.zs, self.za = encoder, packed, z_shape, z_app
         self.smo, self.smo_t, self.fields, self.length = int(smo_size), int(smo_torso_size), int(fields), length
         self.side = side_stream(packed.device, role="wgrad")      # the process-wide general side stream
-        self.slots = [{"bias": None, "ready": None, "free": None, "frame": None} for _ in range(2)]
+        # The blobs come from the CURRENT (main) stream's allocator pool, here, not from the side stream's inside _produce:
+        # they are read on the render streams, and a block of the side stream's pool would go back to that pool when the
+        # prefetcher is dropped - to be reused by the training step's weight-gradient stream while a render still reads it
+        # (ADVICE r3).  Freed into the main pool the usual rule holds: the next user is ordered behind the main stream.
+        nb = packed.bias_floats(FIELD_HEAD) + (packed.bias_floats(FIELD_TORSO) if self.fields == 2 else 0)
+        self.slots = [{"bias": torch.empty(nb, dtype=torch.float32, device=packed.device), "ready": None, "free": None,
+                       "frame": None} for _ in range(2)]
         self.k = 0
+        self._home = torch.cuda.current_stream(packed.device)
+        self._stale = True                                 # the side stream has not seen the parameters yet
+
+    def parameters_changed(self):
+        """Call after the networks' parameters (or the packed weights / latent codes) were rewritten on the main stream: the
+        next blob is produced behind the main stream's work instead of underneath it.  A prefetcher is otherwise meant to live
+        for ONE render loop over fixed parameters (run_nerf builds one per loop): waiting for the main stream at every frame
+        would serialise the front end with the render it is there to hide under."""
+        self._stale = True
 
     def _produce(self, slot, frame):
         main = torch.cuda.current_stream(self.pk.device)
-        if slot["bias"] is None:
-            self.side.wait_stream(main)                    # first use: the parameters were written on the main stream
+        if self._stale:
+            self.side.wait_stream(main)                    # the parameters were written on the main stream
+            self._stale = False
         if slot["free"] is not None:
             self.side.wait_event(slot["free"])             # the render that read this blob last
         with torch.cuda.stream(self.side):
@@ -199,7 +215,10 @@ class FramePrefetcher:
         slot = self.slots[self.k]
         if slot["frame"] != int(frame):
             self._produce(slot, frame)
-        torch.cuda.current_stream(self.pk.device).wait_event(slot["ready"])
+        cur = torch.cuda.current_stream(self.pk.device)
+        cur.wait_event(slot["ready"])
+        if cur != self._home:
+            slot["bias"].record_stream(cur)                # read on a render stream other than the one it was allocated on
         self._cur, self._next = slot, next_frame
         return slot["bias"]
 

@@ -162,14 +162,22 @@ class FlatGradBucket:
                     self.flat[a:b].zero_()
             self._reduce(group)
             return
-        have = [(v, g) for v, g in zip(self.views, grads) if g is not None]
-        if len(have) < len(self.params):
-            self.flat.zero_()
-        if have:
-            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        # general path.  Some gradients may ALREADY live in the bucket (an adopted network next to torch-autograd ones):
+        # those are left where they are - zeroing the whole bucket here wiped them (the decoder stopped
+        # training from step 2 whenever the conditioning networks' gradients came from torch autograd).  Only the views of
+        # parameters WITHOUT a gradient are zeroed (they count as zero in the average), only foreign gradients are copied.
+        zero = [v for v, g in zip(self.views, grads) if g is None]
+        copy = [(v, g) for v, g, ptr in zip(self.views, grads, self._ptrs) if g is not None and g.data_ptr() != ptr]
+        if zero:
+            torch._foreach_zero_(zero)
+        if copy:
+            torch._foreach_copy_([v for v, _ in copy], [g for _, g in copy])
         self._reduce(group)
-        for p, v in zip(self.params, self.views):
-            p.grad = v
+        # `.grad = None` stays None, as on the in-place path and in single-rank training (Adam skips the parameter; which
+        # parameters carry a gradient is decided by the step gating, identical on every rank)
+        for p, v, g in zip(self.params, self.views, grads):
+            if g is not None:
+                p.grad = v
         self._adopt()
 
 

@@ -99,18 +99,29 @@ _FLAGS = [
 # --image_ext: file type of the rendered frames (upstream writes .jpg, MAIN:722-732; png = the kernel's uint8 output
 # losslessly, which is what the parity tests read back)
 _EXTRA_FLAGS = [("hip_tier", str, 'f32'), ("hierarchical", None, None), ("image_ext", str, 'jpg')]
+_EXTRA_HELP = {
+    "hip_tier": "precision tier of the HIP path: f32 (exact MFMA products, the parity tier; default) | f16 (throughput tier "
+                "for rendering: f16 MFMA operands, f32 accumulation) | bf16.  TRAINING with f16 or bf16 runs the 16-bit "
+                "training tier: bf16 MFMA operands in the forward and the dX chain, and the arrays recorded for the backward "
+                "(layer inputs, pre-activation gradients) in MX-fp8 (e4m3 values + one power-of-two scale per 64 features x "
+                "32 points; the weight-gradient GEMMs run on them: values below amax * 2^-17 of a block flush to zero).  "
+                "Use f32 for a reference-exact training run",
+    "hierarchical": "64 + N_importance samples per ray (coarse pass -> sample_pdf -> the same decoder on the merged depths)",
+    "image_ext": "file type of the rendered frames (jpg as upstream; png keeps the kernel's uint8 output losslessly)",
+}
 
 
 def config_parser():
     parser = ConfigArgParser()
     parser.add_argument('--config', help='config file path')
     for name, typ, default in _FLAGS + _EXTRA_FLAGS:
+        kw = {"help": _EXTRA_HELP[name]} if name in _EXTRA_HELP else {}
         if typ is None:
-            parser.add_argument('--' + name, action='store_true')
+            parser.add_argument('--' + name, action='store_true', **kw)
         elif typ == 'sf':
-            parser.add_argument('--' + name, action='store_false')
+            parser.add_argument('--' + name, action='store_false', **kw)
         else:
-            parser.add_argument('--' + name, type=typ, default=default)
+            parser.add_argument('--' + name, type=typ, default=default, **kw)
     return parser
 
 

@@ -189,6 +189,10 @@ def _fused_forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape,
                                 _ptr(buf.samples), _ptr(buf.act[0]), _ptr(buf.masks[0]), _ptr(buf.act[1]),
                                 _ptr(buf.masks[1]), st), "dfn_train_fwd")
     ctx.buf, ctx.frame, ctx.bg, ctx.pix = buf, frame, bg, pix_index
+    # the recorded arrays (and FusedTrainLossFn's d loss / d rgb) live in `buf` and are overwritten by the next forward
+    # through it: a backward is only valid for the LAST forward (no gradient accumulation over micro-batches through one
+    # TrainBuffers, no retain_graph across forwards) - stamped here, checked in _fused_backward
+    buf._fwd_seq = ctx.seq = getattr(buf, "_fwd_seq", 0) + 1
     ctx.keep = (sh, stt, zs, za)
     ctx.sig_shapes = (sig_head.shape, sig_torso.shape)
     return rgb_h, rgb_c
@@ -196,6 +200,10 @@ def _fused_forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape,
 
 def _fused_backward(ctx, d_h, d_c):
     buf, frame, bg, st = ctx.buf, ctx.frame, ctx.bg, _stream()
+    if buf._fwd_seq != ctx.seq:
+        raise RuntimeError("fused training step: backward of forward #%d, but forward #%d has since overwritten the "
+                           "recorded activations of this TrainBuffers (one forward per backward; use a second TrainBuffers "
+                           "for a second graph)" % (ctx.seq, buf._fwd_seq))
     sh, stt, zs, za = ctx.keep
     flat, dev = buf.flat, buf.flat.device
     d_h = d_h.contiguous().float()

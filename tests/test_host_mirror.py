@@ -199,6 +199,57 @@ def test_select_coords_and_shards():
     assert parallel.shard_range(202500, 8, 7) == (177191, 25309, 25313)
 
 
+class _FakeFlat:
+    """What training._FlatNet is to FlatGradBucket._adopt: one flat gradient buffer per module whose slices are the
+    parameters' .grad (the HIP backward writes `_g_flat`; parameters a forward never used keep .grad = None)."""
+
+    def __init__(self, module):
+        self.params = list(module.parameters())
+        self.flat = torch.zeros(sum(p.numel() for p in self.params))
+        self._g_flat = None
+
+    def backward(self, value, skip_last=True):
+        g = self._g_flat
+        if g is None or any(p.grad is not None for p in self.params):
+            g = torch.zeros_like(self.flat)
+            if not any(p.grad is not None for p in self.params):
+                self._g_flat = g
+        g.zero_()
+        o = 0
+        for i, p in enumerate(self.params):
+            n = p.numel()
+            if not (skip_last and i == len(self.params) - 1):
+                g[o:o + n] = value
+                p.grad = g[o:o + n].view_as(p)
+            o += n
+
+
+def _mixed_bucket_steps(rank, world):
+    """ONE bucket over a network whose gradients live in its own flat buffer (adopted into the bucket after
+    the first all_reduce_, one parameter always without a gradient - the decoder and its listener layers) and networks
+    whose gradients are fresh torch-autograd tensors every step (conditioning networks without a SignalTrainer).  The
+    adopted network's gradients must survive the copy path on every step; parameters without a gradient keep None."""
+    torch.manual_seed(5)
+    dec = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Linear(4, 2, bias=True))
+    cond = torch.nn.Linear(3, 2)
+    idle = torch.nn.Linear(2, 2)                         # a network that runs no backward at all (PoseAttNet, smo_t == 0)
+    fn = dec.__dict__["_dfn_flat"] = _FakeFlat(dec)
+    bk = parallel.FlatGradBucket([dec, cond, idle])
+    out = []
+    for it in range(3):
+        for m in (dec, cond, idle):
+            for p in m.parameters():
+                p.grad = None
+        fn.backward(float(10 * it + rank + 1))
+        cond(torch.full((2, 3), float(rank + 1 + it))).sum().backward()
+        bk.all_reduce_()
+        ps = list(dec.parameters())
+        out.append((float(sum(p.grad.sum() for p in ps[:-1])), ps[-1].grad is None,
+                    float(cond.weight.grad.sum()), all(p.grad is None for p in idle.parameters()),
+                    ps[0].grad.data_ptr() == bk.views[0].data_ptr()))
+    return out
+
+
 def _worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -240,12 +291,14 @@ def _worker(rank, world, port, q):
             o.step()
     rep = np.concatenate([p.detach().numpy().reshape(-1) for k in sorted(nets) for p in nets[k].parameters()] +
                          [lat.numpy().reshape(-1)])
+    mixed = _mixed_bucket_steps(rank, world)
     # strong-scaling split of the training step (bench.py c4s): the reference's 2048 rays split over the ranks
     b0, n0, per0 = parallel.shard_range(2048, world, rank)
     # plain numpy through the queue (tensors would travel as shared-memory file descriptors, which is fragile when
     # the producer exits early)
     q.put((rank, bool(ok_gather), int(bucket.numel), [None if g is None else g.numpy() for g in g_local],
-           [p.grad.detach().clone().numpy() for m in mods for p in m.parameters()], rep, (b0, n0, per0)))
+           [None if p.grad is None else p.grad.detach().clone().numpy() for m in mods for p in m.parameters()], rep,
+           (b0, n0, per0), mixed))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -281,12 +334,22 @@ def test_gloo_world2_gather_and_grad_bucket():
     assert all(r[1] for r in res) and res[0][2] == 5 * 3 + 3 + 3 * 2 + 2
     for k in range(4):
         a, b = res[0][3][k], res[1][3][k]
+        if a is None and b is None:                 # `.grad = None` stays None (single-rank semantics: Adam skips it)
+            assert res[0][4][k] is None and res[1][4][k] is None
+            continue
         z = np.zeros_like(res[0][4][k])
         want = ((a if a is not None else z) + (b if b is not None else z)) / 2
         assert np.allclose(res[0][4][k], want) and np.allclose(res[1][4][k], want)
     # replicas bit-identical after broadcast + 3 data-parallel Adam steps (they used to diverge from step 0)
     assert np.array_equal(res[0][5], res[1][5])
     assert res[0][6] == (0, 1024, 1024) and res[1][6] == (1024, 1024, 1024)
+    # mixed bucket (adopted flat-buffer network + torch-autograd networks), three steps: the adopted network's averaged
+    # gradient is (10 it + 1.5) per element on 3*4 + 4 + 4*2 = 24 elements every step (it was 0 from step 2), the parameter
+    # without a gradient and the idle network keep None, the torch-autograd network averages too
+    for r in (0, 1):
+        for it, (dsum, last_none, csum, idle_none, in_bucket) in enumerate(res[r][7]):
+            assert abs(dsum - 24 * (10 * it + 1.5)) < 1e-4 and last_none and idle_none and in_bucket
+            assert abs(csum - 2 * 2 * 3 * (it + 1.5)) < 1e-4
 
 
 def test_dropin_modules_importable():
