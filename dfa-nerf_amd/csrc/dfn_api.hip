@@ -447,8 +447,8 @@ int dfn_sample_pixels(int H, int W, int n, int rect_num, const int32_t* rect, ui
                       int32_t* pix_index, int32_t* status, void* stream) {
     if (H <= 0 || W <= 0 || n <= 0 || rect_num < 0 || rect_num > n || !pix_index || (rect_num > 0 && !rect))
         return fail(DFN_E_ARG, "dfn_sample_pixels: bad argument");
-    if ((long)H * W >= (1L << 18) || n > SAMPLE_PIXELS_CANDIDATES / 2)
-        return fail(DFN_E_ARG, "dfn_sample_pixels: at most 2^18 pixels and 4096 rays per call");
+    if ((long)H * W > 0x7fffffffL || n > SAMPLE_PIXELS_CANDIDATES / 2)
+        return fail(DFN_E_ARG, "dfn_sample_pixels: at most 2^31 - 1 pixels and 4096 rays per call");
     hipError_t err = launch_sample_pixels(H, W, n, rect_num, rect, seed, counter, pix_index, status, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "sample_pixels_kernel");
     return DFN_OK;
@@ -861,6 +861,26 @@ int dfn_volume_weights(const float* z, const float* ray, const float* sigma, lon
     if (R == 0) return DFN_OK;
     hipError_t err = launch_volume_weights(z, ray, sigma, R, S, last_dist, weights, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "volume_weights_kernel");
+    return DFN_OK;
+}
+
+int dfn_composite_grad(const float* sigma, const float* feat, int K, long N, const float* d_sigma_sum, const float* d_feat_w,
+                       float* d_sigma, float* d_feat, void* stream) {
+    if (!sigma || !feat || !d_sigma || !d_feat || K < 1 || N < 0) return fail(DFN_E_ARG, "dfn_composite_grad: bad argument");
+    if (N == 0) return DFN_OK;
+    hipError_t err = launch_composite_grad(sigma, feat, K, N, d_sigma_sum, d_feat_w, d_sigma, d_feat, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "composite_grad_kernel");
+    return DFN_OK;
+}
+
+int dfn_volume_weights_grad(const float* z, const float* ray, const float* sigma, long R, int S, float last_dist,
+                            const float* d_weights, float* d_sigma, void* stream) {
+    if (!z || !ray || !sigma || !d_weights || !d_sigma || R < 0)
+        return fail(DFN_E_ARG, "dfn_volume_weights_grad: bad argument");
+    if (S < 1 || S > 1024) return fail(DFN_E_ARG, "dfn_volume_weights_grad: need 1 <= S <= 1024");
+    if (R == 0) return DFN_OK;
+    hipError_t err = launch_volume_weights_grad(z, ray, sigma, R, S, last_dist, d_weights, d_sigma, (hipStream_t)stream);
+    if (err != hipSuccess) return hip_fail(err, "volume_weights_grad_kernel");
     return DFN_OK;
 }
 

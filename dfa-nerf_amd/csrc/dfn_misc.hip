@@ -486,6 +486,118 @@ hipError_t launch_volume_weights(const float* z, const float* ray, const float* 
     return hipGetLastError();
 }
 
+// ---- backward of composite_function / calc_volume_weights (the stand-alone building blocks under autograd) ----------------
+// What torch autograd computes through run_nerf_com_trainExpLater.py:146-179 as a reference-shaped training loop calls them
+// (MAIN:888-899).  composite_function: w_k = sigma_k / den with den = sum_k sigma_k, and den := 1e-4 written IN PLACE where the
+// sum is 0 - an index_put_ of a constant, so no gradient reaches sigma through den at those samples.
+__global__ void composite_grad_kernel(const float* sigma, const float* feat, int K, long N, const float* d_ssum,
+                                      const float* d_fw, float* d_sigma, float* d_feat) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float gs = d_ssum ? d_ssum[i] : 0.f;
+    float g[3] = {0.f, 0.f, 0.f};
+    if (d_fw)
+        for (int c = 0; c < 3; ++c) g[c] = d_fw[i * 3 + c];
+    if (K == 1) {
+        d_sigma[i] = gs;
+        for (int c = 0; c < 3; ++c) d_feat[i * 3 + c] = g[c];
+        return;
+    }
+    float tot = 0.f;
+    for (int k = 0; k < K; ++k) tot = __fadd_rn(tot, sigma[k * N + i]);
+    const bool replaced = tot == 0.f;
+    const float den = replaced ? 1e-4f : tot, inv = 1.0f / den;
+    float through_den = 0.f;                      // sum_k <g, feat_k> sigma_k / den^2
+    for (int k = 0; k < K; ++k) {
+        const float* f = feat + (k * N + i) * 3;
+        through_den += (g[0] * f[0] + g[1] * f[1] + g[2] * f[2]) * sigma[k * N + i];
+    }
+    through_den = replaced ? 0.f : through_den * inv * inv;
+    for (int k = 0; k < K; ++k) {
+        const float* f = feat + (k * N + i) * 3;
+        const float w = sigma[k * N + i] * inv;
+        d_sigma[k * N + i] = gs + (g[0] * f[0] + g[1] * f[1] + g[2] * f[2]) * inv - through_den;
+        for (int c = 0; c < 3; ++c) d_feat[(k * N + i) * 3 + c] = w * g[c];
+    }
+}
+hipError_t launch_composite_grad(const float* sigma, const float* feat, int K, long N, const float* d_ssum, const float* d_fw,
+                                 float* d_sigma, float* d_feat, hipStream_t st) {
+    hipLaunchKernelGGL(composite_grad_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, sigma, feat, K, N, d_ssum,
+                       d_fw, d_sigma, d_feat);
+    return hipGetLastError();
+}
+
+// calc_volume_weights: w_s = alpha_s T_s, T_s = prod_{j<s} f_j, f_j = 1 - alpha_j + 1e-10.
+//   d alpha_s = T_s (g_s - G_s),  G_s = sum_{j>s} g_j alpha_j prod_{s<m<j} f_m = b_{s+1} + f_{s+1} G_{s+1}  (b_j = g_j alpha_j)
+// (products of the f BETWEEN s and j only: no division by an f that may be 1e-10).  One wavefront per ray like the forward:
+// each lane owns `per` consecutive samples, the affine maps x -> b + f x are composed inside the lane and scanned across the
+// wave from the far end.  d sigma_s = [sigma_s > 0] d alpha_s dist_s exp(-(relu(sigma_s) + 1e-6) dist_s).
+__global__ void volume_weights_grad_kernel(const float* z, const float* ray, const float* sigma, long R, int S,
+                                           float last_dist, const float* d_w, float* d_sigma) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long r = (long)blockIdx.x * 4 + w;
+    if (r >= R) return;
+    const float dx = ray[r * 3], dy = ray[r * 3 + 1], dzv = ray[r * 3 + 2];
+    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dzv, dzv)));
+    const int per = (S + 63) / 64;
+    const int s0 = lane * per;
+    float alpha[16], pre[16], dist[16], ex[16], gw[16];
+    float prod = 1.0f;
+    for (int k = 0; k < per && k < 16; ++k) {
+        const int s = s0 + k;
+        float a = 0.f, e = 1.f, dd = 0.f, g = 0.f;
+        if (s < S) {
+            const float d = (s == S - 1) ? last_dist : __fsub_rn(z[r * S + s + 1], z[r * S + s]);
+            dd = __fmul_rn(d, nrm);
+            e = expf(-__fmul_rn(__fadd_rn(fmaxf(sigma[r * S + s], 0.f), 1e-6f), dd));
+            a = __fsub_rn(1.0f, e);
+            g = d_w[r * S + s];
+        }
+        alpha[k] = a; dist[k] = dd; ex[k] = e; gw[k] = g;
+        pre[k] = prod;
+        if (s < S) prod = prod * __fadd_rn(__fsub_rn(1.0f, a), 1e-10f);
+    }
+    float inc = prod;                          // T: inclusive scan of the lane products, as in the forward
+    for (int d = 1; d < 64; d <<= 1) {
+        const float up = __shfl_up(inc, d);
+        if (lane >= d) inc *= up;
+    }
+    float exc = __shfl_up(inc, 1);
+    if (lane == 0) exc = 1.0f;
+    // the lane's composed map x -> B + F x over its samples, first sample outermost
+    float F = 1.0f, B = 0.f;
+    for (int k = per < 16 ? per - 1 : 15; k >= 0; --k) {
+        const int s = s0 + k;
+        if (s < S) {
+            const float f = __fadd_rn(__fsub_rn(1.0f, alpha[k]), 1e-10f), b = gw[k] * alpha[k];
+            B = b + f * B;                     // M_s o (F, B)
+            F = f * F;
+        }
+    }
+    float sF = F, sB = B;                      // suffix composition over lanes >= this one
+    for (int d = 1; d < 64; d <<= 1) {
+        const float oF = __shfl_down(sF, d), oB = __shfl_down(sB, d);
+        if (lane + d < 64) { sB = sB + sF * oB; sF = sF * oF; }
+    }
+    float G = __shfl_down(sB, 1);              // G of this lane's LAST sample = (maps of all later lanes)(0)
+    if (lane == 63) G = 0.f;
+    for (int k = per < 16 ? per - 1 : 15; k >= 0; --k) {
+        const int s = s0 + k;
+        if (s < S) {
+            const float T = exc * pre[k];
+            const float d_alpha = T * (gw[k] - G);
+            d_sigma[r * S + s] = sigma[r * S + s] > 0.f ? d_alpha * dist[k] * ex[k] : 0.f;
+            G = gw[k] * alpha[k] + __fadd_rn(__fsub_rn(1.0f, alpha[k]), 1e-10f) * G;
+        }
+    }
+}
+hipError_t launch_volume_weights_grad(const float* z, const float* ray, const float* sigma, long R, int S, float last_dist,
+                                      const float* d_w, float* d_sigma, hipStream_t st) {
+    hipLaunchKernelGGL(volume_weights_grad_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, z, ray, sigma, R, S,
+                       last_dist, d_w, d_sigma);
+    return hipGetLastError();
+}
+
 // ---- to8b ---------------------------------------------------------------------------------------------------------------
 __global__ void to8b_kernel(const float* x, long n, unsigned char* out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

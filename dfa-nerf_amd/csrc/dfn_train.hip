@@ -495,7 +495,11 @@ __global__ __launch_bounds__(SP_THREADS) void sample_pixels_kernel(int H, int W,
                                                                     unsigned long long seed, unsigned long long counter,
                                                                     int* out, int* status) {
     extern __shared__ unsigned sp_lds[];
-    unsigned* table = sp_lds;                    // [SP_TABLE]  (pixel << 13) | smallest candidate index, 0xffffffff = empty
+    // [SP_TABLE]  smallest candidate index of the pixel that claimed the slot, 0xffffffff = empty.  The pixel itself is
+    // cand[entry]: a claimed slot only ever receives candidates of ITS pixel, so that stays valid whatever the timing, and
+    // the frame size is not limited by the entry's bits (round 3 packed (pixel << 13 | index) into the word: H * W < 2^18,
+    // one short of the 512 x 512 frames the reference's preprocessing emits, scripts/process_data.sh:4)
+    unsigned* table = sp_lds;
     unsigned* cand = sp_lds + SP_TABLE;          // [SP_M]
     unsigned* part = cand + SP_M;                // [2][SP_THREADS] per-thread counts, then their exclusive prefix
     const int t = threadIdx.x;
@@ -512,12 +516,12 @@ __global__ __launch_bounds__(SP_THREADS) void sample_pixels_kernel(int H, int W,
 #pragma unroll
     for (int q = 0; q < SP_PER; ++q) {
         const int i = t * SP_PER + q;
-        const unsigned p = cand[i], entry = (p << 13) | (unsigned)i;
+        const unsigned p = cand[i];
         unsigned slot = (p * 2654435761u) >> 18;                         // 14 bits
         for (;;) {
-            const unsigned cur = atomicCAS(&table[slot], 0xffffffffu, entry);
+            const unsigned cur = atomicCAS(&table[slot], 0xffffffffu, (unsigned)i);
             if (cur == 0xffffffffu) break;
-            if ((cur >> 13) == p) { atomicMin(&table[slot], entry); break; }
+            if (cand[cur] == p) { atomicMin(&table[slot], (unsigned)i); break; }
             slot = (slot + 1) & (SP_TABLE - 1);
         }
     }
@@ -531,8 +535,8 @@ __global__ __launch_bounds__(SP_THREADS) void sample_pixels_kernel(int H, int W,
         const int i = t * SP_PER + q;
         const unsigned p = cand[i];
         unsigned slot = (p * 2654435761u) >> 18;
-        while ((table[slot] >> 13) != p) slot = (slot + 1) & (SP_TABLE - 1);
-        const bool first = (table[slot] & 0x1fffu) == (unsigned)i;
+        while (cand[table[slot]] != p) slot = (slot + 1) & (SP_TABLE - 1);
+        const bool first = table[slot] == (unsigned)i;
         const int y = (int)(p / (unsigned)W), x = (int)(p - (unsigned)y * (unsigned)W);
         const bool inside = rect_num > 0 && ((y >= ry0 && y <= ry1 && x >= rx0 && x <= rx1) || 2 * y >= H);
         if (first) {

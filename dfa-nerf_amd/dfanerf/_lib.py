@@ -58,6 +58,8 @@ def _load():
         "dfn_sample_pdf": (i32, [fp, fp, lg, i32, i32, fp, fp, vp]),
         "dfn_composite": (i32, [fp, fp, i32, lg, fp, fp, vp]),
         "dfn_volume_weights": (i32, [fp, fp, fp, lg, i32, C.c_float, fp, vp]),
+        "dfn_composite_grad": (i32, [fp, fp, i32, lg, fp, fp, fp, fp, vp]),
+        "dfn_volume_weights_grad": (i32, [fp, fp, fp, lg, i32, C.c_float, fp, fp, vp]),
         "dfn_to8b": (i32, [fp, lg, vp, vp]),
         "dfn_debug_mfma_layout": (i32, [fp, vp]),
         "dfn_debug_clock_probe": (i32, [vp]),

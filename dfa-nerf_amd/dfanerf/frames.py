@@ -140,7 +140,7 @@ class PixelSampler:
 
     def _kernel_ok(self, rect_host):
         HW = self.H * self.W
-        if not self.on_gpu or HW >= (1 << 18) or self.n > self.CANDIDATES // 2:
+        if not self.on_gpu or HW > 0x7fffffff or self.n > self.CANDIDATES // 2:
             return False
         frac = 1.0 - np.exp(-self.CANDIDATES / HW)               # expected share of a class's pixels among the candidates
         # the distinct candidates that land in a class are (nearly) Poisson with mean m = area * frac: ask for six standard

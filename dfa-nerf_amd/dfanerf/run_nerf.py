@@ -154,29 +154,34 @@ def _need_device(name, *tensors):
         raise RuntimeError(f"{name} runs the HIP kernel and needs device tensors (there is no CPU fallback)")
 
 
-def _forward_only(name, *tensors):
-    """These stand-alone building blocks are forward-only HIP launches.  Under autograd a silently detached result would
-    give a graph-less loss (an opaque 'does not require grad' at backward(), or a dropped gradient term): say so here."""
-    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
-        raise RuntimeError(f"{name} is forward only (a HIP launch outside autograd): an input requires grad.  The "
-                           "differentiable renderer is training.render_train (fused forward + backward); wrap inference "
-                           "calls in torch.no_grad()")
+def _wants_grad(*tensors):
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 
 
 def composite_function(sigma, feat):
-    """sigma [K,B,R,S], feat [K,B,R,S,3] -> sigma_sum [B,R,S], feat_weighted [B,R,S,3]  (dfn_composite; forward only:
-    the differentiable compositing of the training step is inside the fused renderer, training.FusedTrainFn)."""
+    """sigma [K,B,R,S], feat [K,B,R,S,3] -> sigma_sum [B,R,S], feat_weighted [B,R,S,3]  (MAIN:146-166).  dfn_composite; under
+    autograd (a reference-shaped training loop, MAIN:888-889) an autograd node with dfn_composite_grad as its backward.  The
+    production training step differentiates the fused renderer instead (training.FusedTrainFn)."""
     _need_device("composite_function", sigma, feat)
-    _forward_only("composite_function", sigma, feat)
     from . import engine
+    if _wants_grad(sigma, feat):
+        from .training import CompositeFn
+        return CompositeFn.apply(sigma, feat)
     return engine.composite(sigma.detach(), feat.detach())
 
 
 def calc_volume_weights(z_vals, ray_vector, sigma, last_dist=1e10):
-    """z [B,R,S], ray_vector [B,R,3], sigma [B,R,S] -> weights [B,R,S]  (dfn_volume_weights; forward only)."""
+    """z [B,R,S], ray_vector [B,R,3], sigma [B,R,S] -> weights [B,R,S]  (MAIN:169-179).  dfn_volume_weights; under autograd an
+    autograd node with dfn_volume_weights_grad as its backward (gradient of sigma: depths and ray vectors are constants of
+    the training loop, MAIN:838-841 - a gradient request for them is refused rather than silently dropped)."""
     _need_device("calc_volume_weights", z_vals, ray_vector, sigma)
-    _forward_only("calc_volume_weights", z_vals, ray_vector, sigma)
     from . import engine
+    if _wants_grad(z_vals, ray_vector):
+        raise RuntimeError("calc_volume_weights: gradients of z_vals / ray_vector are not implemented (constants of the "
+                           "training loop, MAIN:838-841); detach them")
+    if _wants_grad(sigma):
+        from .training import VolumeWeightsFn
+        return VolumeWeightsFn.apply(z_vals, ray_vector, sigma, last_dist)
     return engine.volume_weights(z_vals.detach(), ray_vector.detach(), sigma.detach(), last_dist)
 
 
@@ -184,15 +189,15 @@ def render_rays(decoder, p_i, r_i, z_shape_i, z_app_i, signal, head_or_torso, ba
                 args, coarse_or_fine='coarse', raw_noise_std=0):
     """One field through decoder -> bg / sigma fix-ups -> composite -> weights -> (rgb, weights)   (MAIN:114-143; dead
     upstream - TypeError at :138 - here with the semantics of the live inline renderer MAIN:653-709 for one field).
-    p_i, r_i [B, R*S, 3]; bc_rgb [B,R,1,3]; view_dir [B,R,3]; z_vals [B,R,S].  Inference entry point (every stage a
-    HIP launch: dfn_decoder_fwd, dfn_composite, dfn_volume_weights); the training step differentiates the fused
-    renderer instead (training.render_train)."""
+    p_i, r_i [B, R*S, 3]; bc_rgb [B,R,1,3]; view_dir [B,R,3]; z_vals [B,R,S].  Every stage is a HIP launch (dfn_decoder_fwd,
+    dfn_composite, dfn_volume_weights); when the decoder's parameters or the signals require grad and grad mode is on, the
+    same stages run as autograd nodes (training.DecoderTrainFn, CompositeFn, VolumeWeightsFn): a reference-shaped loop
+    can back-propagate a loss on the returned rgb.  The production training step is the fused renderer (training.render_train)."""
     S = args.N_samples + (args.N_importance if coarse_or_fine == 'fine' else 0)
-    # a reference-style training loop hands in signals that carry a graph (AudNet / AudAttNet outputs): refuse instead of
-    # returning a graph-less image whose loss fails - or silently drops this term - at backward()
-    _forward_only("render_rays", p_i, r_i, z_shape_i, z_app_i, bc_rgb, view_dir, z_vals,
-                  *(signal if isinstance(signal, (list, tuple)) else [signal]))
-    with torch.no_grad():
+    sigs = [s for s in (signal if isinstance(signal, (list, tuple)) else [signal]) if isinstance(s, torch.Tensor)]
+    grad = torch.is_grad_enabled() and (any(s.requires_grad for s in sigs) or
+                                        any(p.requires_grad for p in decoder.parameters()))
+    with torch.enable_grad() if grad else torch.no_grad():
         feat_i, sigma_i = decoder(p_i, r_i, z_shape_i, z_app_i, signal, head_or_torso)
         sigma_i = sigma_i.reshape(batch_size, -1, S)
         feat_i = feat_i.reshape(batch_size, -1, S, 3)
@@ -200,7 +205,8 @@ def render_rays(decoder, p_i, r_i, z_shape_i, z_app_i, signal, head_or_torso, ba
             feat_i = torch.cat((feat_i[..., :-1, :], bc_rgb.to(feat_i)), dim=-2)          # MAIN:669-671
         sigma = torch.clamp_min(sigma_i, 0.0)                                              # MAIN:688 F.relu
         if args.concate_bg:
-            sigma[..., -1] += 1e-6                                                         # MAIN:692-694
+            # MAIN:692-694, out of place (the in-place form on a ReLU output is rejected by autograd's version check)
+            sigma = torch.cat((sigma[..., :-1], sigma[..., -1:] + 1e-6), dim=-1)
         sigma_sum, feat_weighted = composite_function(sigma.unsqueeze(0), feat_i.unsqueeze(0))
         weights = calc_volume_weights(z_vals, view_dir, sigma_sum, last_dist=args.last_dist)
         rgb = torch.sum(weights.unsqueeze(-1) * feat_weighted, dim=-2).squeeze(0)          # MAIN:706

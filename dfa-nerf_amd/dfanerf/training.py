@@ -688,6 +688,54 @@ def mse_losses(rgb_head, rgb_com, img_head, img_com, pix):
     return MseLossFn.apply(rgb_head, rgb_com, img_head, img_com, pix)
 
 
+# ---- composite_function / calc_volume_weights under autograd ---------------------------------------------------------
+class CompositeFn(torch.autograd.Function):
+    """composite_function (MAIN:146-166) as an autograd node: dfn_composite forward, dfn_composite_grad backward - what a
+    reference-shaped training loop (MAIN:888-889) differentiates through.  sigma [K,...], feat [K,...,3]."""
+
+    @staticmethod
+    def forward(ctx, sigma, feat):
+        s, f = sigma.detach().float().contiguous(), feat.detach().float().contiguous()
+        ctx.save_for_backward(s, f)
+        ctx.set_materialize_grads(False)
+        return engine.composite(s, f)
+
+    @staticmethod
+    def backward(ctx, d_ss, d_fw):
+        s, f = ctx.saved_tensors
+        K = s.shape[0]
+        d_s, d_f = torch.empty_like(s), torch.empty_like(f)
+        d_ss = None if d_ss is None else d_ss.float().contiguous()
+        d_fw = None if d_fw is None else d_fw.float().contiguous()
+        check(lib.dfn_composite_grad(_ptr(s), _ptr(f), K, s.numel() // K, _ptr(d_ss), _ptr(d_fw), _ptr(d_s), _ptr(d_f),
+                                     _stream()), "dfn_composite_grad")
+        return d_s, d_f
+
+
+class VolumeWeightsFn(torch.autograd.Function):
+    """calc_volume_weights (MAIN:169-179) as an autograd node: dfn_volume_weights forward, dfn_volume_weights_grad backward
+    (gradient of sigma; the depths and ray vectors are constants of the training loop, MAIN:838-841)."""
+
+    @staticmethod
+    def forward(ctx, z_vals, ray_vector, sigma, last_dist):
+        S = z_vals.shape[-1]
+        z = z_vals.detach().float().contiguous().reshape(-1, S)
+        r = ray_vector.detach().float().contiguous().reshape(-1, 3)
+        sg = sigma.detach().float().contiguous().reshape(-1, S)
+        ctx.save_for_backward(z, r, sg)
+        ctx.last_dist, ctx.shape = float(last_dist), sigma.shape
+        return engine.volume_weights(z, r, sg, last_dist).reshape(sigma.shape)
+
+    @staticmethod
+    def backward(ctx, d_w):
+        z, r, sg = ctx.saved_tensors
+        d_w = d_w.float().contiguous()
+        d_s = torch.empty_like(sg)
+        check(lib.dfn_volume_weights_grad(_ptr(z), _ptr(r), _ptr(sg), sg.shape[0], sg.shape[1], ctx.last_dist, _ptr(d_w),
+                                          _ptr(d_s), _stream()), "dfn_volume_weights_grad")
+        return None, None, d_s.reshape(ctx.shape), None
+
+
 # ---- Decoder.forward on explicit points under autograd -------------------------------------------------------------
 class _PointBuffers:
     """Device buffers of one decoder-on-points training call (one field), sized for NP = ceil32(n) points."""

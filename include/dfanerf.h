@@ -180,7 +180,7 @@ int dfn_composite_bwd_hier(const DfnFrame* frame, const int32_t* pix_index, cons
  * ids y*W+x, uniform over the subsets, in random order; with rect_num > 0 the first rect_num lie inside (rect | lower
  * half), the rest outside; rect = device int32 [4] = (y0, x0, h, w) of the frame's face rectangle (LOAD:sample_rects).
  * Counter-based generator: (seed, counter) -> the draw (the caller increments counter per step).  8192 candidates are
- * drawn per call: H*W < 2^18, n <= 4096, and every class must contain comfortably more pixels than it is asked for
+ * drawn per call: H*W < 2^31, n <= 4096, and every class must contain comfortably more pixels than it is asked for
  * (status[0..1], optional device int32 [2], returns the distinct candidates found inside / outside). */
 int dfn_sample_pixels(int H, int W, int n, int rect_num, const int32_t* rect, uint64_t seed, uint64_t counter,
                       int32_t* pix_index, int32_t* status, void* stream);
@@ -277,6 +277,18 @@ int dfn_composite(const float* sigma, const float* feat, int K, long N, float* s
 /* calc_volume_weights, MAIN:169-179: z [R,S], ray [R,3], sigma [R,S] -> weights [R,S]. S <= 1024. */
 int dfn_volume_weights(const float* z, const float* ray, const float* sigma, long R, int S,
                        float last_dist, float* weights, void* stream);
+/* Backward of the two building blocks above, for a reference-shaped training loop that differentiates through them
+ * (MAIN:888-899: Decoder.forward -> composite_function -> calc_volume_weights -> sum -> img2mse -> loss.backward()); what
+ * torch autograd computes through MAIN:146-166 / 169-179:
+ *   dfn_composite_grad: (d_sigma_sum [N], d_feat_w [N,3]; either may be NULL = zero) -> d_sigma [K,N], d_feat [K,N,3].  The
+ *     `denom_sigma[denom_sigma == 0] = 1e-4` of MAIN:160 is an in-place constant write: no gradient flows through the
+ *     denominator at those samples.
+ *   dfn_volume_weights_grad: d_weights [R,S] -> d_sigma [R,S] (relu'(sigma) = [sigma > 0]; z and ray are constants of the
+ *     training loop, MAIN:838-841: no gradient is produced for them). */
+int dfn_composite_grad(const float* sigma, const float* feat, int K, long N, const float* d_sigma_sum, const float* d_feat_w,
+                       float* d_sigma, float* d_feat, void* stream);
+int dfn_volume_weights_grad(const float* z, const float* ray, const float* sigma, long R, int S, float last_dist,
+                            const float* d_weights, float* d_sigma, void* stream);
 /* to8b, HELP:17: (255*clip(x,0,1)) truncated to u8. */
 int dfn_to8b(const float* x, long n, uint8_t* out, void* stream);
 

@@ -1,0 +1,262 @@
+"""512 x 512: the frame size the reference's OWN preprocessing emits (scripts/process_data.sh:4 passes --dst_size 512; H and W
+come from bc.jpg, load_audface.py:34-35, 140-142).  H * W = 2^18 exactly - one more than round 3's device pixel sampler could
+address - so every stage is checked at this size: rays bitwise, the renderer against the oracle (exact tier and f16 tier), the
+full frame f16 against f32, one 2048-ray training step against torch CPU autograd through the oracle, and the sampler (no
+ATen route on a 512 x 512 dataset).  Geometry: the 450 x 450 bench scene scaled (same field of view)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dfa_oracle as O
+from dfanerf import synth
+
+pytestmark = pytest.mark.gpu
+
+H512 = W512 = 512
+PSNR_CLAUSE_DB = 49.4                   # see tests/test_gpu_parity.py
+
+
+def t(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+def psnr(a, b):
+    mse = float(((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2).mean())
+    return 99.0 if mse == 0 else -10.0 * np.log10(mse)
+
+
+@pytest.fixture(scope="module")
+def scene512():
+    sc = synth.bench_scene(0, n_frames=8, H=H512, W=W512)
+    sc["focal"] = 1200.0 * 512 / 450
+    return sc
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from dfanerf import engine
+    engine.require_gpu()
+    return engine
+
+
+@pytest.fixture(scope="module")
+def packed(eng, states):
+    flat = eng.flatten_state(states["decoder"], "cuda")
+    return {tier: eng.PackedDecoder(flat, tier, fields=(0, 1)) for tier in ("f32", "f16")}
+
+
+def test_get_rays_bitwise_full_frame_512(eng, scene512):
+    sc = scene512
+    for pose in (sc["poses"][2], sc["pose_body"]):
+        ro, rd = eng.get_rays(H512, W512, sc["focal"], pose[:3, :4], sc["cx"], sc["cy"])
+        oro, ord_ = O.get_rays(H512, W512, sc["focal"], pose[:3, :4], sc["cx"], sc["cy"])
+        assert tuple(rd.shape) == (H512, W512, 3)
+        assert np.array_equal(rd.cpu().numpy(), ord_.numpy()) and np.array_equal(ro.cpu().numpy(), oro.numpy())
+
+
+def _render(eng, pk, sc, latents, sig, sigt, idx, n_fine, fields, **kw):
+    zs, za = latents
+    bias = pk.fold(sig, sigt if fields == 2 else None, zs[0], za[0])
+    fr = eng.make_frame(H512, W512, sc["focal"], sc["cx"], sc["cy"], sc["poses"][2], sc["pose_body"], sc["near"], sc["far"],
+                        ray_count=len(idx), n_fine=n_fine, fields=fields)
+    bg = (t(sc["bg"]).float() / 255.0).reshape(-1, 3).cuda()
+    return eng.render(pk, bias, fr, bg, pix_index=t(np.asarray(idx, np.int32)).cuda(), **kw)
+
+
+def _oracle_inputs(sc, states, latents, idx):
+    P = O.params_to_torch(states["decoder"])
+    zs, za = [t(v) for v in latents]
+    o_h, d_h = O.get_rays(H512, W512, sc["focal"], sc["poses"][2][:3, :4], sc["cx"], sc["cy"])
+    o_t, d_t = O.get_rays(H512, W512, sc["focal"], sc["pose_body"][:3, :4], sc["cx"], sc["cy"])
+    rays = [x.reshape(-1, 3)[idx] for x in (o_h, d_h, o_t, d_t)]
+    bg = (t(sc["bg"]).float() / 255.0).reshape(-1, 3)[idx]
+    return P, zs, za, rays, bg
+
+
+@pytest.mark.parametrize("fields", [1, 2])
+def test_render_512_subset_vs_oracle(eng, packed, scene512, states, latents, golden, fields):
+    """configs[1] / configs[2] on 512 rays spread over the 512 x 512 frame (the last row and column included):
+    exact tier - coarse pass against the oracle's frame loop 2e-5, row H at the kernel's own depths 5e-5 (the staged check of
+    test_render_hierarchical_f32_vs_reference_golden); f16 tier - >= 49.4 dB against the oracle's whole pipeline."""
+    sc = scene512
+    gc = golden("g7_frame_coarse")
+    sig, sigt = gc["signal"][0], gc["signal_torso"].reshape(-1)
+    idx = np.unique(np.concatenate([np.arange(5, H512 * W512, 521)[:500], [0, W512 - 1, H512 * W512 - W512, H512 * W512 - 1,
+                                                                          (1 << 18) - 2, 255 * W512 + 256]]))[:512]
+    P, zs, za, rays, bg = _oracle_inputs(sc, states, latents, idx)
+    signal, signal_t = [t(sig)[None], None], t(sigt)[None]
+    # coarse, exact tier
+    rh, rc = _render(eng, packed["f32"], sc, latents, sig, sigt, idx, 0, fields)
+    with torch.no_grad():
+        oh, oc = O.render_rays_chunk(P, *rays, bg, sc["near"], sc["far"], zs, za, signal, signal_t, 64, 0, fields)
+    np.testing.assert_allclose(rh.cpu().numpy(), oh.numpy(), atol=2e-5, rtol=0)
+    if fields == 2:
+        np.testing.assert_allclose(rc.cpu().numpy(), oc.numpy(), atol=2e-5, rtol=0)
+    # row H, exact tier, at the depths the kernel sampled
+    out = _render(eng, packed["f32"], sc, latents, sig, sigt, idx, 128, fields, want_z=True)
+    rh, rc, z = out[0], out[1], out[-1].cpu()
+    assert (np.diff(z.numpy(), axis=1) >= 0).all()
+    with torch.no_grad():
+        oh, oc = O.render_fixed_samples(P, *rays, bg, z, zs, za, [t(gc["signal"]), None], t(gc["signal_torso"]), fields)
+        ph, pc = O.render_rays_chunk(P, *rays, bg, sc["near"], sc["far"], zs, za, signal, signal_t, 64, 128, fields)
+    np.testing.assert_allclose(rh.cpu().numpy(), oh.numpy(), atol=5e-5, rtol=0)
+    if fields == 2:
+        np.testing.assert_allclose(rc.cpu().numpy(), oc.numpy(), atol=5e-5, rtol=0)
+    # f16 tier against the oracle's own pipeline (its own fine sampler)
+    fh, fc = _render(eng, packed["f16"], sc, latents, sig, sigt, idx, 128, fields)
+    p_h = psnr(fh.cpu().numpy(), ph.numpy())
+    p_c = psnr(fc.cpu().numpy(), pc.numpy()) if fields == 2 else 99.0
+    print(f"512x512 fields={fields}: f16 vs oracle pipeline PSNR head {p_h:.1f} dB, com {p_c:.1f} dB")
+    assert p_h >= PSNR_CLAUSE_DB and p_c >= PSNR_CLAUSE_DB
+
+
+def test_full_frame_512_f16_vs_f32(eng, packed, scene512, latents, golden):
+    """All 262,144 rays of a 512 x 512 frame, 64 + 128 samples, head: f16 (the headline tier) against the exact tier -
+    >= 49.4 dB on the whole frame and on every 4,096-ray block; shard-invariance of the launch (two halves == the whole)."""
+    sc = scene512
+    gc = golden("g7_frame_coarse")
+    zs, za = latents
+    R = H512 * W512
+    bg8 = t(sc["bg"]).reshape(-1, 3).cuda()
+    img = {}
+    for tier in ("f32", "f16"):
+        pk = packed[tier]
+        bias = pk.fold(gc["signal"][0], None, zs[0], za[0])
+        fr = eng.make_frame(H512, W512, sc["focal"], sc["cx"], sc["cy"], sc["poses"][2], sc["pose_body"], sc["near"],
+                            sc["far"], ray_count=R, n_fine=128, fields=1)
+        img[tier] = eng.render(pk, bias, fr, bg8)[0]
+        if tier == "f16":
+            half = R // 2
+            parts = []
+            for b in (0, half):
+                frp = eng.make_frame(H512, W512, sc["focal"], sc["cx"], sc["cy"], sc["poses"][2], sc["pose_body"],
+                                     sc["near"], sc["far"], ray_begin=b, ray_count=half, n_fine=128, fields=1)
+                parts.append(eng.render(pk, bias, frp, bg8)[0])
+            assert torch.equal(torch.cat(parts), img[tier])
+    a, b = [img[k].cpu().numpy().astype(np.float64) for k in ("f16", "f32")]
+    whole = psnr(a, b)
+    worst = -10.0 * np.log10(((a - b) ** 2).reshape(-1, 4096, 3).mean((1, 2)).max())
+    print(f"512x512 full frame f16 vs f32: PSNR {whole:.1f} dB, worst 4096-ray block {worst:.1f} dB")
+    assert whole >= PSNR_CLAUSE_DB and worst >= PSNR_CLAUSE_DB
+    assert np.isfinite(a).all() and a.min() >= 0.0 and a.max() <= 1.0
+
+
+def test_pixel_sampler_512_runs_the_kernel(monkeypatch):
+    """A 512 x 512 dataset draws its pixels with dfn_sample_pixels, never with the ATen top-k route (H * W < 2^18
+    refused exactly this size): distinct, in range up to the LAST pixel, exact class counts, uniform, reproducible."""
+    from dfanerf import frames
+    dev = torch.device("cuda")
+
+    def boom(self, rect):
+        raise AssertionError("_draw_torch called on a 512 x 512 frame")
+    monkeypatch.setattr(frames.PixelSampler, "_draw_torch", boom)
+    HW = H512 * W512
+    s0 = frames.PixelSampler(H512, W512, 2048, 0, dev, seed=11)
+    assert s0._kernel_ok(None)
+    draws = [s0.draw().cpu().numpy() for _ in range(40)]
+    for p in draws:
+        assert p.dtype == np.int32 and len(set(p.tolist())) == 2048 and p.min() >= 0 and p.max() < HW
+    allp = np.concatenate(draws)
+    assert allp.max() >= HW - 64                                             # the top of the range is reached (bit 17 set)
+    assert abs(allp.mean() - (HW - 1) / 2) < 2000
+    hist = np.bincount(allp // (HW // 16), minlength=16)
+    assert hist.min() > 0.9 * hist.mean() and hist.max() < 1.1 * hist.mean()
+    assert np.array_equal(frames.PixelSampler(H512, W512, 2048, 0, dev, seed=11).draw().cpu().numpy(), draws[0])
+    rects = np.array([[120, 140, 170, 180], [10, 10, 40, 40], [340, 0, 100, 511]])
+    s1 = frames.PixelSampler(H512, W512, 2048, 0.95, dev, seed=5, rects=rects, pipeline=True)
+    want = int(2048 * 0.95)
+    for fr in range(3):
+        p = s1.draw(frame=fr).cpu().numpy()
+        y, x = p // W512, p % W512
+        r = rects[fr]
+        inside = ((y >= r[0]) & (y <= r[0] + r[2]) & (x >= r[1]) & (x <= r[1] + r[3])) | (y >= H512 / 2)
+        assert len(set(p.tolist())) == 2048 and int(inside.sum()) == want
+        assert inside[:want].all() and not inside[want:].any()
+    # and larger: 1024 x 1024 (2^20 pixels)
+    big = frames.PixelSampler(1024, 1024, 2048, 0, dev, seed=2)
+    p = np.concatenate([big.draw().cpu().numpy() for _ in range(20)])
+    assert p.max() < 1 << 20 and p.max() > (1 << 20) - 256 and abs(p.mean() - (1 << 19)) < 8000
+    assert all(len(set(q.tolist())) == 2048 for q in p.reshape(20, 2048))
+
+
+@pytest.mark.parametrize("tier", ["f32", "bf16"])
+def test_training_step_512_vs_oracle_autograd(states, scene512, latents, tier, monkeypatch):
+    """One step of the reference's training loop (MAIN:779-907) on a 512 x 512 frame: 2048 pixels drawn by the DEVICE sampler,
+    all five networks, smoothed branch, HIP forward + backward against torch CPU autograd through the oracle (same gates as
+    test_training_step_full_size_vs_oracle_autograd)."""
+    from dfanerf import frames, nets, run_nerf, training
+    sc = scene512
+    dev = torch.device("cuda")
+    step, n = 300000, 2048
+    monkeypatch.setattr(frames.PixelSampler, "_draw_torch",
+                        lambda self, rect: (_ for _ in ()).throw(AssertionError("_draw_torch on 512 x 512")))
+    pix = frames.PixelSampler(H512, W512, n, 0, dev, seed=3).draw().cpu().numpy().astype(np.int64)
+    sel = np.stack([pix // W512, pix % W512], axis=1)
+    tgt_h = t(synth.synth_tensor(0, "g8/th512", (H512, W512, 3), 0.5)) + 0.5
+    tgt_c = t(synth.synth_tensor(0, "g8/tc512", (H512, W512, 3), 0.5)) + 0.5
+    key = "ref512"
+    if key not in _REF:
+        keep = torch.get_num_threads()
+        torch.set_num_threads(min(32, os.cpu_count() or 8))
+        try:
+            zs, za = [t(v) for v in latents]
+            auds, exps, poses = t(sc["aud"]), t(sc["exp"]), t(sc["poses"])
+            allp = {tag: {k: t(v).clone().requires_grad_(True) for k, v in st.items()} for tag, st in states.items()}
+            cnets = {k: v for k, v in allp.items() if k != "decoder"}
+            bg = t(sc["bg"]).float() / 255.0
+            loss, lh, lc = O.train_loss(allp["decoder"], cnets, t(sel), H512, W512, sc["focal"], sc["cx"], sc["cy"], poses[3],
+                                        poses[0], bg, tgt_h, tgt_c, 0.3, 0.9, zs, za, auds, exps, poses, 3, step, 300000, 4, 8,
+                                        auds.shape[0])
+            loss.backward()
+            _REF[key] = ([loss.item(), lh.item(), lc.item()],
+                         {f"{tag}/{k}": (None if v.grad is None else v.grad.clone()) for tag, prm in allp.items()
+                          for k, v in prm.items()})
+        finally:
+            torch.set_num_threads(keep)
+    ref_loss, ref_g = _REF[key]
+    from dfanerf.decoder import Decoder
+    mods = {"decoder": Decoder(z_dim=256, hidden_size=256, dim_signal=96, use_deformation_field=True),
+            "AudNet": nets.AudioNet_W2L(), "ExpNet": nets.ExpressionEnc(), "AudAttNet": nets.AudioAttNet(96, 4),
+            "PoseAttNet": nets.AudioAttNet(42, 8)}
+    for k, m in mods.items():
+        m.load_state_dict({kk: t(v) for kk, v in states[k].items()})
+        m.to(dev)
+    args = run_nerf.config_parser().parse_args(
+        "--expname t --concate_bg --N_rand=2048 --sample_rate=0 --smo_size=4 --smo_torse_size 8 --use_et_embed "
+        "--dim_signal=96 --dim_aud=96 --n_object=1 --use_deformation_field --noexp_iters 400000".split())
+    ds = [{"auds": t(sc["aud"]).to(dev), "exp": t(sc["exp"]).to(dev), "poses": t(sc["poses"]).to(dev),
+           "bc_img": (t(sc["bg"]).float() / 255.0).to(dev), "hwfcxy": [H512, W512, sc["focal"], sc["cx"], sc["cy"]],
+           "near": 0.3, "far": 0.9}]
+    zs, za = [t(v).to(dev) for v in latents]
+    embed_fn, _ = nets.get_embedder(3, 0)
+    buf = training.TrainBuffers(tier, n, dev)
+    buf.signal_trainer = training.SignalTrainer(mods["AudNet"], mods["ExpNet"], mods["AudAttNet"], mods["PoseAttNet"],
+                                                ds[0]["auds"], ds[0]["exp"], ds[0]["poses"])
+    ys, xs = t(sel[:, 0]).to(dev), t(sel[:, 1]).to(dev)
+    loss, lh, lc, _, _ = run_nerf.train_step_loss_hip(mods, ds, 0, 3, sel, tgt_h.to(dev)[ys, xs], tgt_c.to(dev)[ys, xs], zs, za,
+                                                      step, args, sc["aud"].shape[0], embed_fn, ds[0]["poses"][0], buf)
+    np.testing.assert_allclose([loss.item(), lh.item(), lc.item()], ref_loss, rtol=3e-5 if tier == "f32" else 2e-2)
+    loss.backward()
+    torch.cuda.synchronize()
+    rel, rel_dir = (1e-3, 2e-3) if tier == "f32" else (6e-2, 1.5e-1)
+    worst = worst_dir = 0.0
+    for tag, m in mods.items():
+        for k, p in m.named_parameters():
+            ref = ref_g[f"{tag}/{k}"]
+            rn = 0.0 if ref is None else float(ref.double().norm())
+            if rn == 0.0:
+                assert p.grad is None or float(p.grad.abs().max()) <= 1e-12, (tag, k)
+                continue
+            g = p.grad.detach().cpu()
+            gn = float(g.double().norm())
+            worst = max(worst, abs(gn - rn) / rn)
+            assert abs(gn - rn) <= rel * rn + 1e-9, (tag, k, gn, rn)
+            d = float((g - ref).double().norm()) / rn
+            worst_dir = max(worst_dir, d)
+            assert d <= rel_dir, (tag, k, d)
+    print(f"512x512 step {tier}: worst gradient-norm error {worst:.2e}, worst whole-tensor error {worst_dir:.2e}")
+
+
+_REF = {}
