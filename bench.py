@@ -78,7 +78,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)        # 300 frames = ~10 s: a sustained number by default
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["all"],
+                    help="all = the headline (c2) plus short runs of the other configs in `other_workloads` at ANY N: "
+                         "c3, c5, c4, c4s under the process group (N > 1), per-workload error capture")
     ap.add_argument("--tier", default="f16", choices=["f16", "bf16", "f32"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (after the sweep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -377,13 +379,16 @@ def parity_check(sc, st, zs, za, pk, n_fine, fields, frame, dev, tier):
                                                 "`denom < 1e-5` switch moves within one coarse bin)"}}
 
 
-def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_s=0.0, check=False):
+def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_s=0.0, check=False, size=450):
     from dfanerf import engine, nets, synth
     from dfanerf._lib import check as chk, lib
     n_fine, fields, desc = WORKLOADS[workload]
     F = 8                                              # frames of the audio-driven sequence (configs[4] batch)
     B = 8 if workload == "c5" else 1                   # frames per step = frames per gather
-    sc = synth.bench_scene(0, n_frames=F)
+    sc = synth.bench_scene(0, n_frames=F, H=size, W=size)
+    if size != 450:                                    # same field of view as the 450 x 450 scene
+        sc["focal"] = 1200.0 * size / 450
+        desc = desc.replace("450x450", f"{size}x{size}")
     st = synth.synth_all_states(0)
     zs, za = synth.synth_latents(0)
     H, W = sc["H"], sc["W"]
@@ -412,7 +417,8 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
     # waited for when its buffers come round again at step k + 2, so it runs underneath the render of step k + 1.
     n_img = 2 if fields == 2 else 1
     shards = [torch.zeros(B, n_img, per, 3, dtype=torch.float32, device=dev) for _ in range(2)]
-    gathered = [torch.empty(world, B, n_img, per, 3, dtype=torch.float32, device=dev) if world > 1 else None for _ in range(2)]
+    gathered = [torch.empty(world, B, n_img, per, 3, dtype=torch.float32, device=dev) if (world > 1 or dist.is_initialized())
+                else None for _ in range(2)]
     works = [None, None]
     ev = []
 
@@ -426,7 +432,12 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
     # workgroups, launched on the other stream, start on them (tools/shard_scaling.py --two-streams, one GPU: a 1/8 shard
     # 4.09 -> 3.90 ms per frame, 95.6 % -> 100 % of linear; 1/4: 99.2 -> 100 %).  N == 1: one stream, as profiled.
     main_stream = torch.cuda.current_stream(dev)
-    if world > 1:
+    # (DFN_BENCH_RCCL_WORLD1: a process group of ONE rank on the real RCCL backend runs the whole N > 1 schedule - two render
+    # streams, the prefetcher, the asynchronous all_gather_into_tensor on RCCL's own stream, eight hardware queues - on a box
+    # with one GPU: everything a rank of an 8-GPU run does per frame except the wire)
+    from dfanerf import parallel
+    multi = world > 1 or parallel.multi_rank_schedule()
+    if multi:
         rstreams = [engine.side_stream(dev, role="render_a"), engine.side_stream(dev, role="render_b")]
         for rs in rstreams:
             rs.wait_stream(main_stream)                  # the set-up above ran on the main stream
@@ -461,7 +472,7 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
                     e1.record(rs)
                     ev.append((e0, e1))
                 prefetch.done()
-        if world > 1:
+        if multi:
             last = rstreams[(i * B + B - 1) & 1]
             for u in used:                               # (a batch: frames of the step ran on both streams)
                 if rstreams[u] is not last:
@@ -545,14 +556,14 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
     rank_ms = all_ranks(dt_rank / steps * 1e3, world, dev)
     rank_kern = all_ranks(kern_ms, world, dev)
     gcheck = None
-    if world > 1 and rank == 0:
+    if multi and rank == 0:
         try:
             gcheck = gather_check()
         except Exception as e:                          # never lose the line to the check; the failure is in the line
             gcheck = {"error": f"{type(e).__name__}: {e}"}
     # the collective alone (nothing to overlap with): 20 gathers of the step's shard, synchronised
     gather_ms = None
-    if world > 1:
+    if multi:
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
@@ -581,14 +592,14 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             tr = json.load(f).get(f"{'c2' if workload == 'c5' else workload}_{tier}")
-        if tr and world == 1:
+        if tr and world == 1 and size == 450:
             traffic, traffic_src = tr["hbm_bytes_per_launch"], "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
     except OSError:
         pass
     peak = PEAK_TFLOPS[tier]
     out = {
-        "metric": "rays/sec (whole node) at 450x450, 64c+128f samples" if n_fine else
-                  "rays/sec (whole node) at 450x450, 64 coarse samples",
+        "metric": f"rays/sec (whole node) at {H}x{W}, 64c+128f samples" if n_fine else
+                  f"rays/sec (whole node) at {H}x{W}, 64 coarse samples",
         "value": R * B * steps / dt, "unit": "rays/s", "n_gpus": world, "steps": steps,
         "warmup": warmup, "ms_per_step": ms_step, "ms_per_frame": ms_step / B, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": tier, "data": "synthetic",
@@ -611,7 +622,7 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
                                    "frac": flop_ray * R * B * steps / dt / 1e12 / (peak * world)}},
         "per_rank": {"ms_per_step": rank_ms, "render_kernel_ms": rank_kern},
     }
-    if world > 1:
+    if multi:
         out["gather"] = {"ms_alone": gather_ms, "bytes_per_rank": int(B * n_img * per * 12), "async": True,
                          "collective": "all_gather_into_tensor", "render_streams": 2}
         out["gather_check"] = gcheck
@@ -698,30 +709,61 @@ def main():
     if world != args.gpus and rank == 0:
         print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}; using {world}", file=sys.stderr)
 
-    train_wl = args.workload in TRAIN_WORKLOADS
+    run_all = args.workload == "all"
+    headline = "c2" if run_all else args.workload
+    train_wl = headline in TRAIN_WORKLOADS
     if train_wl:
-        out = bench_training(args, args.workload, args.steps, args.warmup, world, rank, dev, args.sustain_seconds)
+        out = bench_training(args, headline, args.steps, args.warmup, world, rank, dev, args.sustain_seconds)
     else:
-        out = bench_render(args, args.workload, args.tier, args.steps, args.warmup, world, rank, dev,
+        out = bench_render(args, headline, args.tier, args.steps, args.warmup, world, rank, dev,
                            args.sustain_seconds, check=not args.no_parity_check)
     extra = {}
-    if world == 1 and not args.no_extra:
+    multi = world > 1 or dist.is_initialized()
+    if (world == 1 and not args.no_extra) or run_all:
         # the other BASELINE configs, short runs in the same process (driver-timed, not builder-only numbers); c2_f32 = the
-        # exact tier, the one that meets the north star's "within 1e-4 PSNR" clause
-        for name, wl, tier, k, w in (("c3", "c3", args.tier, 40, 5), ("c1", "c1", args.tier, 60, 5),
-                                     ("c2_f32", "c2", "f32", 5, 1), ("c5", "c5", args.tier, 4, 1),
-                                     ("c4", "c4", args.tier, 150, 20), ("c4h", "c4h", args.tier, 60, 10)):
-            if wl == args.workload and tier == args.tier:
+        # exact tier, the one that meets the north star's "within 1e-4 PSNR" clause.  Under a process group (--workload all
+        # at N > 1, or DFN_BENCH_RCCL_WORLD1) every rank runs the same list in the same order; a workload that raises on a
+        # rank is recorded in the line (`error`) and, after the ranks have agreed on it, the list goes on.
+        todo = [("c3", "c3", args.tier, 40, 5), ("c1", "c1", args.tier, 60, 5), ("c2_f32", "c2", "f32", 5, 1),
+                ("c5", "c5", args.tier, 4, 1), ("c4", "c4", args.tier, 150, 20), ("c4h", "c4h", args.tier, 60, 10)]
+        if world == 1 and not multi:
+            # 512 x 512: the frame size the reference's own preprocessing emits (scripts/process_data.sh:4)
+            todo.insert(3, ("c2_512", "c2", args.tier, 10, 2))
+        if world > 1:
+            todo = [("c3", "c3", args.tier, 40, 5), ("c5", "c5", args.tier, 4, 1), ("c4", "c4", args.tier, 150, 20),
+                    ("c4s", "c4s", args.tier, 150, 20)]
+        for name, wl, tier, k, w in todo:
+            if wl == headline and tier == args.tier and name != "c2_512":
                 continue
+            r, err = None, None
             try:
-                r = bench_training(args, wl, k, w, 1, 0, dev) if wl in TRAIN_WORKLOADS else \
-                    bench_render(args, wl, tier, k, w, 1, 0, dev, check=(name == "c2_f32" and not args.no_parity_check))
-                r.pop("_scene", None)
-                extra[name] = {kk: r[kk] for kk in ("metric", "value", "unit", "steps", "ms_per_step", "ms_per_frame", "dtype", "roofline",
-                                                    "parity_check") if kk in r}
-                extra[name]["workload"] = r["config"]["workload"]
+                if wl in TRAIN_WORKLOADS:
+                    r = bench_training(args, wl, k, w, world, rank, dev)
+                else:
+                    r = bench_render(args, wl, tier, k, w, world, rank, dev, size=512 if name == "c2_512" else 450,
+                                     check=(name == "c2_f32" and not args.no_parity_check))
             except Exception as e:                      # never lose the headline line to a side measurement
-                extra[name] = {"error": f"{type(e).__name__}: {e}"}
+                err = f"{type(e).__name__}: {e}"
+            if world > 1:
+                try:                                     # agree: a rank that failed marks the workload failed on rank 0's line
+                    bad = torch.tensor([1.0 if err else 0.0], device=dev)
+                    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                    if bad.item() > 0 and err is None:
+                        err = "failed on another rank"
+                except Exception as e:
+                    err = err or f"{type(e).__name__}: {e}"
+            if rank != 0:
+                continue
+            if err or r is None:
+                extra[name] = {"error": err or "no result"}
+                print(f"bench.py: workload {name} failed: {err}", file=sys.stderr)
+                continue
+            r.pop("_scene", None)
+            extra[name] = {kk: r[kk] for kk in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "ms_per_frame", "dtype",
+                                                "scaling", "roofline", "parity_check", "per_rank", "gather", "gather_check")
+                           if kk in r}
+            extra[name]["workload"] = r["config"]["workload"]
+            print(f"bench.py: workload {name}: {r['ms_per_step']:.3f} ms/step", file=sys.stderr)
     if rank == 0:
         scene = out.pop("_scene", None)
         out["rccl_ranks"] = rccl_ranks

@@ -79,3 +79,44 @@ def test_training_step_in_the_multi_rank_schedule_over_rccl():
     assert multi["backend"].startswith("nccl") and single["backend"] is None
     assert multi["ms_per_step"] > 0 and multi["n_gpus"] == 1
     assert multi["last_loss"] == single["last_loss"], (multi["last_loss"], single["last_loss"])
+
+
+@pytest.mark.parametrize("workload", ["c2", "c5"])
+def test_inference_in_the_multi_rank_schedule_over_rccl(workload):
+    """the N > 1 INFERENCE schedule through real RCCL on one GPU (DFN_BENCH_RCCL_WORLD1: a one-rank "nccl" process
+    group): two render streams, the front end one frame ahead (FramePrefetcher), the asynchronous double-buffered
+    all_gather_into_tensor on RCCL's own stream, eight hardware queues - what a rank of an 8-GPU run does per frame, minus the
+    wire.  The gathered frame equals the frame rendered on the plain single-stream path bit for bit."""
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    out = _line([sys.executable, BENCH, "--workload", workload, "--steps", "6", "--warmup", "2", "--sustain-seconds", "0",
+                 "--no-extra", "--no-cpu-baseline"], env={"DFN_BENCH_RCCL_WORLD1": "1"})
+    assert out["backend"].startswith("nccl") and out["n_gpus"] == 1 and out["rccl_ranks"] == 1
+    assert out["gather"]["async"] and out["gather"]["collective"] == "all_gather_into_tensor" and out["gather"]["ms_alone"] > 0
+    assert out["gather"]["render_streams"] == 2
+    assert out["gather_check"].get("identical") is True, out["gather_check"]
+    assert out["per_rank"]["ms_per_step"][0] > 0 and 0.0 < out["roofline"]["whole_job"]["frac"] < 1.0
+    pc = out["parity_check"]                                   # and the timed configuration still matches the oracle
+    assert "error" not in pc and pc["psnr_db"] >= 49.4, pc
+
+
+def test_workload_all_two_ranks_and_fail_fast_without_devices():
+    """`--workload all` at N > 1: ONE call yields the headline (c2) plus c3, c5, c4, c4s under the process group, each with its
+    own error capture; and `--gpus 2` on a box with one GPU (no DFN_BENCH_ONE_GPU) fails fast: rc 2, a clear message."""
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    out = _line([sys.executable, BENCH, "--gpus", "2", "--workload", "all", "--steps", "2", "--warmup", "1",
+                 "--sustain-seconds", "0", "--no-cpu-baseline"], env={"DFN_BENCH_ONE_GPU": "1"}, timeout=1500)
+    assert out["n_gpus"] == 2 and out["config"]["fields"] == 1 and out["gather_check"].get("identical") is True
+    ow = out["other_workloads"]
+    assert set(ow) == {"c3", "c5", "c4", "c4s"}, sorted(ow)
+    for k, v in ow.items():
+        assert "error" not in v, (k, v)
+        assert v["n_gpus"] == 2 and v["ms_per_step"] > 0 and len(v["per_rank"]["ms_per_step"]) == 2
+    assert ow["c3"]["gather_check"]["identical"] and ow["c5"]["gather_check"]["identical"]
+    assert ow["c4"]["scaling"] == "weak" and ow["c4s"]["scaling"] == "strong"
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + FAST, capture_output=True, text=True, timeout=300, cwd=ROOT,
+                           env={k: v for k, v in os.environ.items() if k != "DFN_BENCH_ONE_GPU"})
+        assert r.returncode == 2 and "HIP device" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -445,6 +445,125 @@ def test_decoder_forward_under_grad_is_hip_and_matches_autograd(states, scene, l
         dec(p, d, zs[:, 0], za[:, 0], [None, None], "head")                   # listener layers are not trainable here
 
 
+@pytest.mark.parametrize("step", [0, 300000])
+def test_reference_shaped_loop_trains_through_the_dropin_modules(states, scene, latents, golden, step):
+    """the reference's OWN training loop (MAIN:829-907) written against the drop-in modules - Decoder.forward
+    under grad for both fields, torch glue exactly as upstream (cat / stack / relu / the out-of-place +1e-6), composite_function,
+    calc_volume_weights, torch.sum, img2mse, loss.backward() - no fused renderer.  composite_function / calc_volume_weights are
+    autograd nodes over dfn_composite_grad / dfn_volume_weights_grad; loss and the gradients of all five networks against
+    golden G8 (the same loop through the reference's modules + torch autograd) at the f32 gates (3e-5 / 1e-3)."""
+    import sys
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "NeRFs", "DFANeRF")
+    sys.path.insert(0, d)
+    try:
+        import run_nerf_com_trainExpLater as M
+        import run_nerf_helpers as Hm
+    finally:
+        sys.path.remove(d)
+    g = golden("g8_train_step")
+    dev = torch.device("cuda")
+    mods = _modules(states, dev)
+    dec = mods["decoder"]
+    H, W = scene["H"], scene["W"]
+    ds = [{"auds": t(scene["aud"]).to(dev), "exp": t(scene["exp"]).to(dev), "poses": t(scene["poses"]).to(dev)}]
+
+    class A:
+        nosmo_iters, smo_size, smo_torse_size = 300000, 4, 8
+    n_frames = scene["aud"].shape[0]
+    embed_fn, _ = Hm.get_embedder(3, 0)
+    img_i = 3
+    sig = M.encode_signal(ds, 0, img_i, 96, mods["AudNet"], mods["ExpNet"], mods["AudAttNet"], step, A, n_frames,
+                          embed_fn=embed_fn)
+    sig_t = M.encode_signal_torso(ds, 0, img_i, mods["PoseAttNet"], step, A, n_frames, embed_fn=embed_fn)
+    sel = g["sel_yx"]
+    ys, xs = t(sel[:, 0]).to(dev), t(sel[:, 1]).to(dev)
+    N = sel.shape[0]
+    poses = ds[0]["poses"]
+    ro, rd = Hm.get_rays(H, W, scene["focal"], poses[img_i, :3, :4], scene["cx"], scene["cy"])
+    rot, rdt = Hm.get_rays(H, W, scene["focal"], poses[0, :3, :4], scene["cx"], scene["cy"])
+    ro, rd, rot, rdt = ro[ys, xs], rd[ys, xs], rot[ys, xs], rdt[ys, xs]
+    zt = O.coarse_z(0.3, 0.9, 64).to(dev)[None].expand(N, 64)
+    p_i = (ro[..., None, :] + rd[..., None, :] * zt[..., :, None]).reshape(1, -1, 3)
+    r_i = rd.unsqueeze(1).expand([N, 64, 3]).reshape(1, -1, 3)
+    p_t = (rot[..., None, :] + rdt[..., None, :] * zt[..., :, None]).reshape(1, -1, 3)
+    r_t = rdt.unsqueeze(1).expand([N, 64, 3]).reshape(1, -1, 3)
+    zs, za = [t(v).to(dev) for v in latents]
+    bc_rgb = (t(scene["bg"]).float() / 255.0).to(dev)[ys, xs]
+    tgt_h = (t(synth.synth_tensor(0, "g8/th", (H, W, 3), 0.5)) + 0.5).to(dev)[ys, xs]
+    tgt_c = (t(synth.synth_tensor(0, "g8/tc", (H, W, 3), 0.5)) + 0.5).to(dev)[ys, xs]
+    feat_i, sigma_i = dec(p_i, r_i, zs[:, 0], za[:, 0], sig, 'head')                            # MAIN:861
+    assert feat_i.requires_grad and sigma_i.requires_grad
+    sigma_i = sigma_i.reshape(1, N, 64)
+    feat_i = torch.cat((feat_i.reshape(1, N, 64, -1)[..., :-1, :], bc_rgb.reshape(1, N, 1, 3)), dim=-2)
+    feat_t, sigma_t = dec(p_t, r_t, zs[:, 1], za[:, 1], sig_t, 'torso')                        # MAIN:869
+    sigma_t = sigma_t.reshape(1, N, 64).clone()
+    feat_t = feat_t.reshape(1, N, 64, -1)
+    sigma_t[:, :, -1] = 0
+    bump = torch.zeros(1, 1, 64, device=dev)
+    bump[..., -1] = 1e-6
+    sigma = torch.relu(torch.stack([sigma_i], 0))
+    sigma = torch.cat([sigma[:-1], sigma[-1:] + bump], 0)
+    sigma_to = torch.relu(torch.stack([sigma_i, sigma_t], 0))
+    sigma_to = torch.cat([sigma_to[:-1], sigma_to[-1:] + bump], 0)
+    ssum, fw = M.composite_function(sigma, torch.stack([feat_i], 0))                            # MAIN:888-889
+    ssum_t, fw_t = M.composite_function(sigma_to, torch.stack([feat_i, feat_t], 0))
+    assert ssum_t.requires_grad and fw_t.requires_grad
+    w_h = M.calc_volume_weights(zt[None], rd[None], ssum, last_dist=1e10)                      # MAIN:891-892
+    w_c = M.calc_volume_weights(zt[None], rdt[None], ssum_t, last_dist=1e10)
+    assert w_c.requires_grad
+    rgb_com = torch.sum(w_h.unsqueeze(-1) * fw, dim=-2).squeeze(0)
+    rgb_com_torso = torch.sum(w_c.unsqueeze(-1) * fw_t, dim=-2).squeeze(0)
+    l_h, l_c = Hm.img2mse(rgb_com, tgt_h), Hm.img2mse(rgb_com_torso, tgt_c)
+    loss = l_c + l_h
+    np.testing.assert_allclose([loss.item(), l_h.item(), l_c.item()], g[f"loss_{step}"], rtol=3e-5)
+    loss.backward()
+    worst = 0.0
+    for tag, m in mods.items():
+        for k, p in m.named_parameters():
+            ref = float(g[f"gnorm_{step}/{tag}/{k}"])
+            got = 0.0 if p.grad is None else p.grad.double().norm().item()
+            if ref <= 0:
+                assert got <= 1e-12, (tag, k, got)
+                continue
+            worst = max(worst, abs(got - ref) / ref)
+            assert abs(got - ref) <= 1e-3 * ref + 1e-9, (tag, k, got, ref)
+            gs = p.grad.reshape(-1)
+            rms = ref / np.sqrt(gs.numel())
+            np.testing.assert_allclose(gs[:: max(1, gs.numel() // 8)][:8].cpu().numpy(), g[f"gsamp_{step}/{tag}/{k}"], rtol=2e-2,
+                                       atol=1e-3 * rms + 1e-9)
+    print(f"reference-shaped loop, step {step}: worst relative gradient-norm error {worst:.2e}")
+    # the stand-alone nodes against torch autograd through the twins, incl. the `denom == 0 -> 1e-4` samples and K = 1
+    rs = np.random.RandomState(0)
+    sg = rs.randn(2, 1, 37, 64).astype(np.float32)
+    sg = t(np.where(sg > 0, sg + 0.1, 0.0).astype(np.float32)).to(dev)      # (sums >= 0.1 or exactly 0: 1 / den^2 stays conditioned)
+    sg[:, :, :, 5] = 0.0                                        # both fields empty: the replaced denominator
+    ft = t(rs.rand(2, 1, 37, 64, 3).astype(np.float32)).to(dev)
+    wz = t(rs.rand(1, 37, 64).astype(np.float32)).to(dev)
+    wf = t(rs.rand(1, 37, 64, 3).astype(np.float32)).to(dev)
+    for K in (2, 1):
+        a, b = sg[:K].clone().requires_grad_(True), ft[:K].clone().requires_grad_(True)
+        s1, f1 = M.composite_function(a, b)
+        ((s1 * wz).sum() + (f1 * wf).sum()).backward()
+        a2, b2 = sg[:K].clone().requires_grad_(True), ft[:K].clone().requires_grad_(True)
+        s2, f2 = twins.composite_function_aten(a2, b2)
+        ((s2 * wz).sum() + (f2 * wf).sum()).backward()
+        torch.testing.assert_close(a.grad, a2.grad, rtol=1e-4, atol=2e-5)
+        torch.testing.assert_close(b.grad, b2.grad, rtol=1e-5, atol=1e-6)
+    zz = torch.sort(t(rs.rand(1, 37, 64).astype(np.float32)).to(dev) * 0.6 + 0.3, -1).values
+    rv = t(rs.randn(1, 37, 3).astype(np.float32)).to(dev)
+    for S in (64, 192, 7):
+        sx = t((rs.randn(1, 37, S) * 20).astype(np.float32)).to(dev)
+        z3 = torch.sort(t(rs.rand(1, 37, S).astype(np.float32)).to(dev) * 0.6 + 0.3, -1).values if S != 64 else zz
+        gw = t(rs.randn(1, 37, S).astype(np.float32)).to(dev)
+        a = sx.clone().requires_grad_(True)
+        (M.calc_volume_weights(z3, rv, a, last_dist=1e10) * gw).sum().backward()
+        a2 = sx.clone().requires_grad_(True)
+        (twins.calc_volume_weights_aten(z3, rv, a2, last_dist=1e10) * gw).sum().backward()
+        torch.testing.assert_close(a.grad, a2.grad, rtol=2e-4, atol=1e-6 * float(a2.grad.abs().max()))
+    with pytest.raises(RuntimeError):
+        M.calc_volume_weights(zz.clone().requires_grad_(True), rv, sx[..., :64])
+
+
 def test_stream_schedules_of_the_training_step_agree(states, scene, latents, golden):
     """The training step's kernels are deterministic, so HOW they are spread over streams must not change a bit: 200
     steps (Adam included) with (a) the overlapped schedule (weight gradients of the head field, d(signal) and the
