@@ -74,7 +74,11 @@ struct WgradEntry {
     int32_t* rows_dev = nullptr;
     int32_t* eof_dev = nullptr;      // dy_T row -> bias element
     int* prefix_dev = nullptr;
-    int* order_dev = nullptr;        // GEMMs by decreasing operand rows (bf16 tier: one workgroup per GEMM and k-split)
+    // 16-bit tier: one workgroup per (GEMM, slice of the points), the slice count PER GEMM (balanced split, see wgrad_items)
+    WItem* items_dev = nullptr;
+    int n_items = 0;
+    unsigned char* blk_n_dev = nullptr;    // slices of the GEMM that owns each 256-element block of the dense C array
+    unsigned char* bias_n_dev = nullptr;   // slices of the GEMM that produces each bias element's row sum
     int32_t* sig_rows_dev = nullptr; // dfn_signal_grad: dy_T rows / bias elements behind d(signal)
     int32_t* sig_elems_dev = nullptr;
     int n_sig = 0;
@@ -86,6 +90,50 @@ constexpr int WS_KSPLIT_MAX = 32;       // slices the workspace is sized for (>=
 // head 16 / torso 18 (round 3, whole step, interleaved A/B over 600 steps x 4: torso 16 / 17 / 18 / 20 = 1.1056 / 1.1021 / 1.0975 /
 // 1.114 ms; head 19: worse).  Round 2: the kernel alone takes the same time for 16 ... 32 slices (0.81-0.82 ms for both fields, HBM-bound), the second stage
 // reads a third less and the whole training step is 1.2 % faster than with 24 (interleaved A/B, bench.py --workload c4)
+// Balanced split (round 4).  Round 3 cut every GEMM into the same 16 / 18 slices of the points: the head's 13 GEMMs made 208
+// workgroups on 256 compute units - ONE round, whose length is the 256 x 256 GEMMs' (512 operand bytes per point, 128 steps)
+// while the workgroups of the narrow GEMMs (288-320 bytes per point) finished early and 48 compute units had none.  Now the
+// number of slices of a GEMM is proportional to its operand rows M + N, so that every workgroup streams about the same bytes
+// and the launch fills the chip's compute units once: head 23 slices for a 256 x 256 GEMM (89 steps), 13-14 for the narrow
+// ones.  DFN_WGRAD_KSPLIT[_H|_T] (developer overrides) select a uniform split instead.
+void wgrad_items(const std::vector<WOpHost>& ops, int field, int target_wgs, std::vector<WItem>& items,
+                 std::vector<int>& n_of) {
+    const int uni = [&] {
+        const char* e = getenv(field ? "DFN_WGRAD_KSPLIT_T" : "DFN_WGRAD_KSPLIT_H");
+        if (!e) e = getenv("DFN_WGRAD_KSPLIT");
+        const int k = e ? atoi(e) : 0;
+        return k > 0 && k <= 32 ? k : 0;
+    }();
+    // cost of a GEMM per point: its operand bytes; a floor for the narrow ones (a step of theirs costs a barrier and a DMA
+    // round trip whatever it moves)
+    // (a GEMM with N = 0 only sums the rows of its dY block; it runs the general loop: measured 51 us where a 256 x 256 GEMM
+    // takes 142 - tools/wl_trace.py)
+    auto cost = [](const WOpHost& o) { return o.N == 0 ? 3.0 * o.M : (double)std::max(o.M + o.N, 96); };
+    double total = 0;
+    for (const WOpHost& o : ops) total += cost(o);
+    n_of.assign(ops.size(), 1);
+    int sum = 0;
+    for (size_t i = 0; i < ops.size(); ++i) {
+        n_of[i] = uni ? uni : std::min(32, std::max(1, (int)(target_wgs * cost(ops[i]) / total)));     // (floor: the sum stays <= target)
+        sum += n_of[i];
+    }
+    // hand the workgroups the floor left over to the GEMMs with the most bytes per workgroup
+    while (!uni && sum < target_wgs) {
+        int best = -1;
+        double worst = 0;
+        for (size_t i = 0; i < ops.size(); ++i)
+            if (n_of[i] < 32 && cost(ops[i]) / n_of[i] > worst) worst = cost(ops[i]) / n_of[i], best = (int)i;
+        if (best < 0) break;
+        ++n_of[best];
+        ++sum;
+    }
+    std::vector<int> order(ops.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(ops[a]) / n_of[a] > cost(ops[b]) / n_of[b]; });
+    items.clear();
+    for (int op : order)
+        for (int k = 0; k < n_of[op]; ++k) items.push_back(WItem{op, k, n_of[op], 0});
+}
 int wgrad_ksplit_bf16(int field) {     // slices of the points per GEMM, bf16 tier (DFN_WGRAD_KSPLIT[_H|_T]: developer overrides)
     static const int v[2] = {
         [] { const char* e = getenv("DFN_WGRAD_KSPLIT_H"); if (!e) e = getenv("DFN_WGRAD_KSPLIT"); const int k = e ? atoi(e) : 0; return k > 0 && k <= WS_KSPLIT_MAX ? k : 16; }(),
@@ -563,28 +611,53 @@ static int weight_grad_impl(int tier, int field, const void* dy_T, const void* a
             std::vector<WOp> ops(w.ops.size());
             for (size_t i = 0; i < ops.size(); ++i)
                 ops[i] = WOp{w.ops[i].a_row, w.ops[i].M, w.ops[i].b_row, w.ops[i].N, w.ops[i].c_off, w.ops[i].bias_owner};
-            std::vector<int> order(ops.size());
-            for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-            std::stable_sort(order.begin(), order.end(),
-                             [&](int a, int b) { return ops[a].M + ops[a].N > ops[b].M + ops[b].N; });
+            int cus = 256;
+            {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                    cus = prop.multiProcessorCount;
+            }
+            std::vector<WItem> items;
+            std::vector<int> n_of;
+            wgrad_items(w.ops, field, cus, items, n_of);
+            // slices per 256-element block of C (every GEMM's C region is a multiple of 1024 elements: one GEMM per block) and per
+            // bias element (the GEMM that owns its dy_T row block)
+            std::vector<unsigned char> blk_n((w.map.size() + 255) / 256, 1), bias_n(w.bias_rows.size(), 1);
+            for (size_t i = 0; i < w.ops.size(); ++i) {
+                const WOpHost& o = w.ops[i];
+                if (o.c_off % 256) return fail(DFN_E_ARG, "internal: a GEMM's C region is not block-aligned");
+                for (long b = o.c_off / 256; b < (o.c_off + (long)o.M * o.N + 255) / 256; ++b) blk_n[b] = (unsigned char)n_of[i];
+                if (o.bias_owner)
+                    for (size_t e = 0; e < w.bias_rows.size(); ++e)
+                        if (w.bias_rows[e] >= o.a_row && w.bias_rows[e] < o.a_row + o.M) bias_n[e] = (unsigned char)n_of[i];
+            }
             // upload into temporaries and publish every pointer only after ALL uploads succeeded: the guard above is keyed on
             // ops_dev, and a later call must never launch with a table that is still null
             WOp* d_ops = nullptr;
             int32_t *d_map = nullptr, *d_rows = nullptr;
-            int *d_prefix = nullptr, *d_order = nullptr;
+            int* d_prefix = nullptr;
+            WItem* d_items = nullptr;
+            unsigned char *d_blk = nullptr, *d_bn = nullptr;
             hipError_t e = upload(&d_ops, ops.data(), ops.size());
             if (e == hipSuccess) e = upload(&d_map, w.map.data(), w.map.size());
             if (e == hipSuccess) e = upload(&d_prefix, w.prefix.data(), w.prefix.size());
             if (e == hipSuccess && !w.rows_dev) e = upload(&d_rows, w.bias_rows.data(), w.bias_rows.size());
-            if (e == hipSuccess) e = upload(&d_order, order.data(), order.size());
+            if (e == hipSuccess) e = upload(&d_items, items.data(), items.size());
+            if (e == hipSuccess) e = upload(&d_blk, blk_n.data(), blk_n.size());
+            if (e == hipSuccess) e = upload(&d_bn, bias_n.data(), bias_n.size());
             if (e != hipSuccess) {
-                (void)hipFree(d_ops); (void)hipFree(d_map); (void)hipFree(d_prefix); (void)hipFree(d_rows); (void)hipFree(d_order);
+                (void)hipFree(d_ops); (void)hipFree(d_map); (void)hipFree(d_prefix); (void)hipFree(d_rows); (void)hipFree(d_items);
+                (void)hipFree(d_blk); (void)hipFree(d_bn);
                 return hip_fail(e, "upload(wgrad plan)");
             }
             w.map_dev = d_map;
             w.prefix_dev = d_prefix;
             if (d_rows) w.rows_dev = d_rows;
-            w.order_dev = d_order;
+            w.items_dev = d_items;
+            w.n_items = (int)items.size();
+            w.blk_n_dev = d_blk;
+            w.bias_n_dev = d_bn;
             w.ops_dev = d_ops;
         }
     }
@@ -609,20 +682,27 @@ static int weight_grad_impl(int tier, int field, const void* dy_T, const void* a
     // more, the streaming row-sum kernel is cheaper there (measured).
     const bool fuse = dbias && tier == DFN_TIER_BF16;
     if (tier == DFN_TIER_BF16)
-        err = launch_wgrad_bf16(field, w.ops_dev, w.order_dev, (int)w.ops.size(), dy_T, act_T, NP, ks, c_parts, W,
+        err = launch_wgrad_bf16(field, w.ops_dev, w.items_dev, w.n_items, dy_T, act_T, NP, c_parts, W,
                                 fuse ? w.eof_dev : nullptr, fuse ? b_parts : nullptr, nb, st);
     else
         err = launch_wgrad(tier, field, w.ops_dev, (int)w.ops.size(), w.prefix_dev, w.prefix.back(), dy_T, act_T, NP, ks,
                            c_parts, W, nullptr, nullptr, nb, st);
     if (err != hipSuccess) return hip_fail(err, "wgrad_kernel");
     if (fuse) {
-        err = launch_reduce_both(w.map_dev, c_parts, W, W, valid, grad_flat, w.rows_dev, b_parts, nb, dbias, st);
+        err = launch_reduce_both(w.map_dev, c_parts, W, W, valid, grad_flat, w.rows_dev, b_parts, nb, dbias, w.blk_n_dev,
+                                 w.bias_n_dev, units, st);
         if (err != hipSuccess) return hip_fail(err, "reduce_both_kernel");
         return DFN_OK;
     }
     if (dbias) {
         err = launch_bias_grad(tier, field, w.eof_dev, w.rows_dev, nb, dy_T, NP, b_parts, dbias, st);
         if (err != hipSuccess) return hip_fail(err, "bias_grad_kernel");
+    }
+    if (tier == DFN_TIER_BF16) {          // (weights only) the per-GEMM slice counts of the balanced split
+        err = launch_reduce_both(w.map_dev, c_parts, W, W, valid, grad_flat, nullptr, nullptr, 0, nullptr, w.blk_n_dev, nullptr,
+                                 units, st);
+        if (err != hipSuccess) return hip_fail(err, "reduce_both_kernel");
+        return DFN_OK;
     }
     err = launch_reduce_scatter(w.map_dev, c_parts, W, W, valid, grad_flat, st);
     if (err != hipSuccess) return hip_fail(err, "reduce_scatter_kernel");

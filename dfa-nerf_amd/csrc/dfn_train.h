@@ -47,15 +47,21 @@ hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, cons
                         float* dbias, int n_bias, hipStream_t st);
 // bf16 tier: one workgroup per (GEMM, slice of the points), operands through LDS (dfn_wgrad_bf16.hip); order = GEMMs by
 // decreasing size
-hipError_t launch_wgrad_bf16(int field, const WOp* ops_dev, const int* order_dev, int n_ops, const void* dy_T,
-                             const void* act_T, long NP, int ksplit, float* C, long c_stride, const int* e_of,
-                             float* dbias, int n_bias, hipStream_t st);
+struct WItem {                  // one workgroup of the 16-bit tier's weight-gradient launch: slice `ks` of `n` of GEMM `op`
+    int op, ks, n, pad;
+};
+hipError_t launch_wgrad_bf16(int field, const WOp* ops_dev, const WItem* items_dev, int n_items, const void* dy_T,
+                             const void* act_T, long NP, float* C, long c_stride, const int* e_of, float* dbias, int n_bias,
+                             hipStream_t st);
 // grad_flat[map[i]] += sum over the first `slices` slices of parts[.][i]   (i < n; map[i] < 0: structural padding)
 hipError_t launch_reduce_scatter(const int* map, const float* parts, long n, long stride, int slices, float* grad_flat,
                                  hipStream_t st);
 // launch_reduce_bias + launch_reduce_scatter in one launch (same sums, same order)
+// blk_n / bias_n (may be NULL: `slices` everywhere): slices the GEMM owning a 256-element block of C / a bias element was
+// split into; `units` = tile pairs of the call - a GEMM split n ways over them fills ceil(units / ceil(units / n)) slices
 hipError_t launch_reduce_both(const int* map, const float* parts, long n, long stride, int slices, float* grad_flat,
-                              const int* rows, const float* bparts, int n_bias, float* dbias, hipStream_t st);
+                              const int* rows, const float* bparts, int n_bias, float* dbias, const unsigned char* blk_n,
+                              const unsigned char* bias_n, long units, hipStream_t st);
 // dbias[e] = sum over slices of parts[.][e] for the elements that have a gradient row (rows[e] >= 0), 0 otherwise
 hipError_t launch_reduce_bias(const int* rows, const float* parts, int n_bias, int slices, float* dbias, hipStream_t st);
 constexpr int SAMPLE_PIXELS_CANDIDATES = 8192;

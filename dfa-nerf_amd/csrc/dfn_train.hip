@@ -661,14 +661,21 @@ hipError_t launch_reduce_scatter(const int* map, const float* parts, long n, lon
 }
 // both second stages of the split-K reduction in one launch (bf16 tier: the row sums ride along in the GEMMs): blocks
 // [0, bias_blocks) add the bias slices, the others the weight slices - two dependent 10-25 us launches less per field
+__device__ __forceinline__ int filled_slices(int n, long units) {       // slices of an n-way split that hold points
+    const long per = (units + n - 1) / n;
+    return (int)((units + per - 1) / per);
+}
 __global__ void reduce_both_kernel(const int* map, const float* parts, long n, long stride, int slices, float* grad_flat,
-                                   const int* rows, const float* bparts, int n_bias, float* dbias, int bias_blocks) {
+                                   const int* rows, const float* bparts, int n_bias, float* dbias, int bias_blocks,
+                                   const unsigned char* blk_n, const unsigned char* bias_n, long units) {
     if ((int)blockIdx.x < bias_blocks) {
         const int e = blockIdx.x * blockDim.x + threadIdx.x;
         if (e >= n_bias) return;
         float a = 0.f;
-        if (rows[e] >= 0)
-            for (int k = 0; k < slices; ++k) a += bparts[(long)k * n_bias + e];
+        if (rows[e] >= 0) {
+            const int sl = bias_n ? filled_slices(bias_n[e], units) : slices;
+            for (int k = 0; k < sl; ++k) a += bparts[(long)k * n_bias + e];
+        }
         dbias[e] = a;
         return;
     }
@@ -676,15 +683,17 @@ __global__ void reduce_both_kernel(const int* map, const float* parts, long n, l
     if (i >= n) return;
     const int dst = map[i];
     if (dst < 0) return;
+    const int sl = blk_n ? filled_slices(blk_n[blockIdx.x - bias_blocks], units) : slices;     // (one GEMM per 256-element block)
     float a = 0.f;
-    for (int k = 0; k < slices; ++k) a += parts[(long)k * stride + i];
+    for (int k = 0; k < sl; ++k) a += parts[(long)k * stride + i];
     grad_flat[dst] += a;
 }
 hipError_t launch_reduce_both(const int* map, const float* parts, long n, long stride, int slices, float* grad_flat,
-                              const int* rows, const float* bparts, int n_bias, float* dbias, hipStream_t st) {
+                              const int* rows, const float* bparts, int n_bias, float* dbias, const unsigned char* blk_n,
+                              const unsigned char* bias_n, long units, hipStream_t st) {
     const int bias_blocks = (n_bias + 255) / 256;
     hipLaunchKernelGGL(reduce_both_kernel, dim3((unsigned)(bias_blocks + (n + 255) / 256)), dim3(256), 0, st, map, parts, n,
-                       stride, slices, grad_flat, rows, bparts, n_bias, dbias, bias_blocks);
+                       stride, slices, grad_flat, rows, bparts, n_bias, dbias, bias_blocks, blk_n, bias_n, units);
     return hipGetLastError();
 }
 __global__ void reduce_bias_kernel(const int* rows, const float* parts, int n_bias, int slices, float* dbias) {

@@ -71,20 +71,397 @@ DFN_DEV i32x8 frag_tr8(const lds_char* p0, const lds_char* p1) {
 }
 template <int N> DFN_DEV void wl_wait_vm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
-__global__ __launch_bounds__(WL_THREADS) void wgrad_mx_kernel(const WOp* ops, const int* order, const void* __restrict__ dy_T,
+// ---- the 256 x 256 GEMMs (8 of the ~14-29 GEMMs of a field, 73 % of its operand bytes) -----------------------------------
+// Round 3's loop served every shape with run-time tile counts: per MFMA it executed 19 scalar and 11.6 other vector instructions
+// (every fragment read and every MFMA sat in its own basic block behind a branch; 33 SGPRs spilled to VGPR lanes) and the matrix
+// pipe was 19 % busy (profiles/r03e_c4_bf16_pmc.txt).  For M = N = 256 everything is a constant of the wave: a step is ONE tile
+// pair = 2 x 16 operand blocks = 32 DMA pieces, four per wave - tile u = k >> 1, operand A / B = k & 1, block = the wave's index
+// -; a wave owns 4 x 2 output tiles (row group rg = wave & 1, column group CG = wave >> 1, a template parameter) and the bias
+// row sums of block 4 rg + CG; the E8M0 scales are selected by the MFMA's op_sel (byte i of the dword the lane read) instead
+// of shifted; the DMA pieces are addressed as wave-uniform SGPR base + constant lane offset.
+DFN_DEV void wl_dma(unsigned voff, const char* sbase, unsigned m0v) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" DFN_WL_POLICY ::"v"(voff), "s"(sbase), "s"(m0v) : "memory", "m0");
+}
+// stage the E8M0 scales of tile pairs [c0, c1) into LDS: [tile of the chunk][16] = A row blocks 0..7 | B row blocks 0..7
+DFN_DEV void wl_stage_scales(lds_char* sc_lds, const unsigned char* scA, const unsigned char* scB, long strideA, long strideB,
+                             long c0, long c1, int mts, int nts) {
+    wl_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    for (int e = threadIdx.x; e < (int)(2 * (c1 - c0)) * 16; e += WL_THREADS) {
+        const long t = 2 * c0 + (e >> 4);
+        const int k = e & 15;
+        unsigned char v = 127;
+        if (k < 8) { if (k < mts) v = scA[t * strideA + k]; }
+        else if (k - 8 < nts) v = scB[t * strideB + (k - 8)];
+        *(DFN_LDS unsigned char*)(sc_lds + e) = v;
+    }
+    wl_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+template <int CG>
+DFN_DEV void wl_full(lds_char* lds, const WOp& o, const void* dy_T, const void* act_T, long p0, long p1, int g_rows, int a_rows,
+                     int ks, float* C, long c_stride, const int* e_of, float* dbias, int n_bias, int wave, int lane) {
+    lds_char* sc_lds = lds + WL_DEPTH * WL_STEP_BYTES;
+    const long strideA = rec8_tile_bytes(g_rows), strideB = rec8_tile_bytes(a_rows);
+    const int rg = wave & 1, kh = lane >> 5, hh = (lane >> 4) & 1, li = lane & 15;
+    const bool do_bias = dbias && o.bias_owner;
+    const unsigned char* scA = (const unsigned char*)dy_T + (long)g_rows * 32 + (o.a_row >> 5);
+    const unsigned char* scB = (const unsigned char*)act_T + (long)a_rows * 32 + (o.b_row >> 5);
+    const unsigned lds_base = (unsigned)(unsigned long)lds;
+    const unsigned voffA = (unsigned)((o.a_row + 32 * wave) * 32 + 16 * lane), voffB = (unsigned)((o.b_row + 32 * wave) * 32 + 16 * lane);
+    const unsigned dA = (unsigned)wave * 1024u, dB = (unsigned)(8 + wave) * 1024u;
+    // this lane's transpose-read address (q = 0) in the wave's first A / B block of tile 0 of slot 0
+    const lds_char* rdA = lds + (16 * kh + (li >> 1)) * 32 + hh * 16 + (li & 1) * 8 + 4 * rg * 1024;
+    const lds_char* rdB = rdA + (8 + 2 * CG - 4 * rg) * 1024;
+    f32x16 acc[4][2], accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        accb[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][0][r] = acc[i][1][r] = 0.f;
+    }
+    i32x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = 0x38383838;           // e4m3 1.0
+    for (long c0 = p0, c1; c0 < p1; c0 = c1) {
+        c1 = (c0 + WL_CHUNK_PAIRS < p1) ? c0 + WL_CHUNK_PAIRS : p1;
+        const long n_steps = c1 - c0;                            // one tile pair per step
+        // scales of the chunk: one (tile, operand) = 8 bytes per thread, its eight byte loads in flight together (the general
+        // path's loop, a byte per thread and trip, is eight dependent HBM round trips for a 128-pair slice: ~15 us of ~150)
+        wl_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        for (int e = threadIdx.x; e < (int)(4 * (c1 - c0)); e += WL_THREADS) {
+            const long t = 2 * c0 + (e >> 1);
+            const unsigned char* src = (e & 1) ? scB + t * strideB : scA + t * strideA;
+            unsigned lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                lo |= (unsigned)src[k] << (8 * k);
+                hi |= (unsigned)src[4 + k] << (8 * k);
+            }
+            i32x2 v = {(int)lo, (int)hi};
+            *(DFN_LDS i32x2*)(sc_lds + (e >> 1) * 16 + (e & 1) * 8) = v;
+        }
+        wl_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* gA = (const char*)dy_T + 2 * c0 * strideA;
+        const char* gB = (const char*)act_T + 2 * c0 * strideB;
+        unsigned issue_off = 0;                                  // byte offset of the slot the next issue fills
+        auto issue = [&]() {
+            const unsigned m = lds_base + issue_off;
+            wl_dma(voffA, gA, m + dA);
+            wl_dma(voffB, gB, m + dB);
+            wl_dma(voffA, gA + strideA, m + 16384u + dA);
+            wl_dma(voffB, gB + strideB, m + 16384u + dB);
+            gA += 2 * strideA;
+            gB += 2 * strideB;
+            issue_off = issue_off + WL_STEP_BYTES == WL_DEPTH * WL_STEP_BYTES ? 0u : issue_off + WL_STEP_BYTES;
+        };
+#pragma unroll
+        for (int s = 0; s < WL_DEPTH - 1; ++s)
+            if (s < n_steps) issue();
+        const lds_char* scp = sc_lds + kh * 16;
+        unsigned rd_off = 0;
+        for (long s = 0; s < n_steps; ++s) {
+            if (s + WL_DEPTH - 2 < n_steps) wl_wait_vm<4 * (WL_DEPTH - 2)>();
+            else wl_wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (s + WL_DEPTH - 1 < n_steps) issue();
+            const lds_char* pa = rdA + rd_off;
+            const lds_char* pb = rdB + rd_off;
+            rd_off = rd_off + WL_STEP_BYTES == WL_DEPTH * WL_STEP_BYTES ? 0u : rd_off + WL_STEP_BYTES;
+            const int sa4 = *(const DFN_LDS int*)(scp + 4 * rg);
+            const int sb2 = *(const DFN_LDS unsigned short*)(scp + 8 + 2 * CG);
+            scp += 32;
+            i32x8 a[4], b[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = frag_tr8(pb + j * 1024, pb + j * 1024 + 16384);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = frag_tr8(pa + i * 1024, pa + i * 1024 + 16384);
+#define WL_MM(I)                                                                                                         \
+    acc[I][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[I], b[0], acc[I][0], 0, 0, I, sa4, 0, sb2);             \
+    acc[I][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[I], b[1], acc[I][1], 0, 0, I, sa4, 1, sb2);
+            WL_MM(0) WL_MM(1) WL_MM(2) WL_MM(3)
+#undef WL_MM
+            if (do_bias) accb = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[CG], ones, accb, 0, 0, CG, sa4, 0, 127);
+        }
+    }
+    // epilogue: as the general path (one writer per element and slice; MFMA row m of a block = feature tile_feat(m >> 4, m & 15))
+    auto feat_of = [](int m) { return tile_feat(m >> 4, m & 15); };
+    if (do_bias && (lane & 31) == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int e = e_of[o.a_row + 32 * (4 * rg + CG) + feat_of(tile_feat(lane >> 5, r))];
+            if (e >= 0) dbias[(long)ks * n_bias + e] = accb[r];
+        }
+    }
+    float* c = C + (long)ks * c_stride + o.c_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * (4 * rg + i) + feat_of(tile_feat(lane >> 5, r)), col = 32 * (2 * CG + j) + feat_of(lane & 31);
+                c[(long)row * 256 + col] = acc[i][j][r];
+            }
+        }
+}
+
+// ---- the other fixed shapes: 256 x {128, 64, 32}, 32 x 256, 64 x 64 -------------------------------------------------------------
+// tools/wl_trace.py (round 4, per-workgroup clocks): with the 256 x 256 GEMMs on wl_full (0.91 us per 32-KiB step, the head field at
+// 5.3 TB/s) the launch waited for the shapes the general loop still served - 256 x 64 / 128: 1.06-1.1 us per step; the torso's
+// fifteen 64 x 64 GEMMs of the deformation field: 2.5 us per step, because with 2 x 2 output tiles ONE wave did all the fragment
+// reads and MFMAs of a step's four tile pairs while seven waited at the barrier - 240 of the torso's 432 workgroups, the whole second
+// round of the launch.  Here the eight waves form an RGN x CGN x KWN grid: RGN x CGN over the output tiles (TM x TN per wave) and
+// KWN over the tile PAIRS of a step (64 x 64: 2 x 1 x 4 - every wave one pair and one row tile per step); the KWN partial sums of
+// an output tile are added through LDS at the end, in wave order (fixed: bit-reproducible like everything else here).
+template <int MTS, int NTS, int RGN, int CGN, int KWN>
+DFN_DEV void wl_static(lds_char* lds, const WOp& o, const void* dy_T, const void* act_T, long p0, long p1, int g_rows, int a_rows,
+                       int ks, float* C, long c_stride, const int* e_of, float* dbias, int n_bias, int wave, int lane) {
+    static_assert(RGN * CGN * KWN == WL_WAVES && MTS % RGN == 0 && NTS % CGN == 0, "wave grid");
+    constexpr int TM = MTS / RGN, TN = NTS / CGN, NTL = MTS + NTS;
+    constexpr int PPS = NTL <= 4 ? 4 : (NTL <= 8 ? 2 : 1);              // tile pairs per step (<= 32 KiB)
+    constexpr int NP = PPS * 2 * NTL, NWM = (NP + WL_WAVES - 1) / WL_WAVES;      // DMA pieces per step; per wave at most
+    static_assert(PPS % KWN == 0 && NP <= 32 && TM <= 4 && TN <= 4, "shape");
+    lds_char* sc_lds = lds + WL_DEPTH * WL_STEP_BYTES;
+    const long strideA = rec8_tile_bytes(g_rows), strideB = rec8_tile_bytes(a_rows);
+    const int rg = wave % RGN, cg = (wave / RGN) % CGN, kw = wave / (RGN * CGN);
+    const int kh = lane >> 5, hh = (lane >> 4) & 1, li = lane & 15;
+    const bool do_bias = dbias && o.bias_owner && cg == 0;              // the row sums of a dY block: by the waves of column group 0
+    const unsigned char* scA = (const unsigned char*)dy_T + (long)g_rows * 32 + (o.a_row >> 5);
+    const unsigned char* scB = (const unsigned char*)act_T + (long)a_rows * 32 + (o.b_row >> 5);
+    const unsigned lds_base = (unsigned)(unsigned long)lds;
+    // this wave's DMA pieces: piece p = wave + 8 k of the step = (tile u of the step, operand block tl)
+    unsigned voff[NWM], dst[NWM];
+    int sub[NWM];
+    bool isb[NWM];
+    const int n_w = (NP - wave + WL_WAVES - 1) / WL_WAVES;
+#pragma unroll
+    for (int k = 0; k < NWM; ++k) {
+        const int p = wave + WL_WAVES * k;
+        const int u = p / NTL, tl = p - u * NTL;
+        isb[k] = tl >= MTS;
+        const int r = isb[k] ? o.b_row + 32 * (tl - MTS) : o.a_row + 32 * tl;
+        voff[k] = (unsigned)(r * 32 + 16 * lane);
+        sub[k] = u;
+        dst[k] = (unsigned)((u * NTL + tl) * 1024);
+    }
+    const lds_char* rd0 = lds + (16 * kh + (li >> 1)) * 32 + hh * 16 + (li & 1) * 8;      // transpose-read address, q = 0, block 0
+    f32x16 acc[TM][TN], accb[TM];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            accb[i][r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j][r] = 0.f;
+        }
+    i32x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = 0x38383838;           // e4m3 1.0
+    for (long c0 = p0, c1; c0 < p1; c0 = c1) {
+        c1 = (c0 + WL_CHUNK_PAIRS < p1) ? c0 + WL_CHUNK_PAIRS : p1;
+        const long n_steps = (c1 - c0 + PPS - 1) / PPS;
+        // scales of the chunk: one (tile, operand) per thread, its byte loads in flight together
+        wl_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        for (int e = threadIdx.x; e < (int)(4 * (c1 - c0)); e += WL_THREADS) {
+            const long t = 2 * c0 + (e >> 1);
+            const bool b = e & 1;
+            const unsigned char* src = b ? scB + t * strideB : scA + t * strideA;
+            unsigned lo = 0x7f7f7f7fu, hi = 0x7f7f7f7fu;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < (b ? NTS : MTS)) {
+                    unsigned& w = k < 4 ? lo : hi;
+                    w = (w & ~(0xffu << (8 * (k & 3)))) | ((unsigned)src[k] << (8 * (k & 3)));
+                }
+            i32x2 v = {(int)lo, (int)hi};
+            *(DFN_LDS i32x2*)(sc_lds + (e >> 1) * 16 + (e & 1) * 8) = v;
+        }
+        wl_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        unsigned issue_off = 0;
+        long tt = 2 * c0;                                        // first tile of the next step to issue
+        const long t_last = 2 * c1 - 1;
+        auto issue = [&]() {
+            const unsigned m = lds_base + issue_off;
+#pragma unroll
+            for (int k = 0; k < NWM; ++k)
+                if (k < n_w) {
+                    long t = tt + sub[k];
+                    t = t < t_last ? t : t_last;             // ragged last step: refetch the last tile (never multiplied)
+                    const char* sb = isb[k] ? (const char*)act_T + t * strideB : (const char*)dy_T + t * strideA;
+                    wl_dma(voff[k], sb, m + dst[k]);
+                }
+            tt += 2 * PPS;
+            issue_off = issue_off + WL_STEP_BYTES == WL_DEPTH * WL_STEP_BYTES ? 0u : issue_off + WL_STEP_BYTES;
+        };
+#pragma unroll
+        for (int s = 0; s < WL_DEPTH - 1; ++s)
+            if (s < n_steps) issue();
+        unsigned rd_off = 0;
+        for (long s = 0; s < n_steps; ++s) {
+            if (s + WL_DEPTH - 2 < n_steps) {
+                switch (n_w) {
+                    case 1: wl_wait_vm<1 * (WL_DEPTH - 2)>(); break;
+                    case 2: wl_wait_vm<2 * (WL_DEPTH - 2)>(); break;
+                    case 3: wl_wait_vm<3 * (WL_DEPTH - 2)>(); break;
+                    default: wl_wait_vm<4 * (WL_DEPTH - 2)>(); break;
+                }
+            } else {
+                wl_wait_vm<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (s + WL_DEPTH - 1 < n_steps) issue();
+            const lds_char* slot = rd0 + rd_off;
+            rd_off = rd_off + WL_STEP_BYTES == WL_DEPTH * WL_STEP_BYTES ? 0u : rd_off + WL_STEP_BYTES;
+            const long pp = c0 + s * PPS;
+#pragma unroll
+            for (int uu = 0; uu < PPS / KWN; ++uu) {
+                const int u = kw + KWN * uu;                     // this wave's tile pair of the step
+                if (pp + u >= c1) break;
+                const lds_char* sc = sc_lds + (2 * (pp + u - c0) + kh) * 16;
+                int sa, sb;
+                if constexpr (TM == 1) sa = *(const DFN_LDS unsigned char*)(sc + rg);
+                else if constexpr (TM == 2) sa = *(const DFN_LDS unsigned short*)(sc + 2 * rg);
+                else sa = *(const DFN_LDS int*)(sc + 4 * rg);
+                if constexpr (TN == 1) sb = *(const DFN_LDS unsigned char*)(sc + 8 + cg);
+                else if constexpr (TN == 2) sb = *(const DFN_LDS unsigned short*)(sc + 8 + 2 * cg);
+                else sb = *(const DFN_LDS int*)(sc + 8 + 4 * cg);
+                const lds_char* b0 = slot + (2 * u) * NTL * 1024;       // first tile of the pair
+                const lds_char* b1 = b0 + NTL * 1024;                   // second tile
+                i32x8 a[TM], b[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = frag_tr8(b0 + (MTS + TN * cg + j) * 1024, b1 + (MTS + TN * cg + j) * 1024);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = frag_tr8(b0 + (TM * rg + i) * 1024, b1 + (TM * rg + i) * 1024);
+#define WL_M1(I, J) if constexpr (I < TM && J < TN) acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[I], b[J], acc[I][J], 0, 0, I, sa, J, sb);
+#define WL_MR(I) WL_M1(I, 0) WL_M1(I, 1) WL_M1(I, 2) WL_M1(I, 3)
+                WL_MR(0) WL_MR(1) WL_MR(2) WL_MR(3)
+#undef WL_MR
+#undef WL_M1
+                if (do_bias) {
+#define WL_B1(I) if constexpr (I < TM) accb[I] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[I], ones, accb[I], 0, 0, I, sa, 0, 127);
+                    WL_B1(0) WL_B1(1) WL_B1(2) WL_B1(3)
+#undef WL_B1
+                }
+            }
+        }
+    }
+    auto feat_of = [](int m) { return tile_feat(m >> 4, m & 15); };
+    if constexpr (KWN > 1) {
+        // add the KWN partial sums of every output tile through LDS (the ring is idle: every piece has landed and been read)
+        wl_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        float DFN_LDS* red = (float DFN_LDS*)lds;
+        constexpr int PER_WAVE = (TM * TN + TM) * 16 * 64;               // floats: [tile or bias tile][register][lane]
+        if (kw > 0) {
+            float DFN_LDS* mine = red + (long)wave * PER_WAVE;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mine[((i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[((TM * TN + i) * 16 + r) * 64 + lane] = accb[i][r];
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        if (kw > 0) return;
+#pragma unroll
+        for (int q = 1; q < KWN; ++q) {
+            const float DFN_LDS* other = red + (long)(wave + q * RGN * CGN) * PER_WAVE;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += other[((i * TN + j) * 16 + r) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accb[i][r] += other[((TM * TN + i) * 16 + r) * 64 + lane];
+            }
+        }
+    }
+    if (do_bias && (lane & 31) == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int e = e_of[o.a_row + 32 * (TM * rg + i) + feat_of(tile_feat(lane >> 5, r))];
+                if (e >= 0) dbias[(long)ks * n_bias + e] = accb[i][r];
+            }
+    }
+    float* c = C + (long)ks * c_stride + o.c_off;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * (TM * rg + i) + feat_of(tile_feat(lane >> 5, r)), col = 32 * (TN * cg + j) + feat_of(lane & 31);
+                c[(long)row * (32 * NTS) + col] = acc[i][j][r];
+            }
+}
+
+#ifdef DFN_WL_TRACE          // developer build (tools/build_variant.sh ... -DDFN_WL_TRACE): per-workgroup start / end on the 100-MHz clock
+__device__ unsigned long long* g_wl_trace = nullptr;
+struct WlTraceScope {
+    unsigned long long t0;
+    int op, ks;
+    __device__ WlTraceScope(int op_, int ks_) : t0(__builtin_amdgcn_s_memrealtime()), op(op_), ks(ks_) {}
+    __device__ ~WlTraceScope() {
+        if (g_wl_trace && threadIdx.x == 0) {
+            unsigned long long* r = g_wl_trace + 4 * blockIdx.x;
+            r[0] = t0; r[1] = __builtin_amdgcn_s_memrealtime(); r[2] = (unsigned long long)op; r[3] = (unsigned long long)ks;
+        }
+    }
+};
+#endif
+__global__ __launch_bounds__(WL_THREADS) void wgrad_mx_kernel(const WOp* ops, const WItem* items, const void* __restrict__ dy_T,
                                                                const void* __restrict__ act_T, long n_tiles, int g_rows, int a_rows,
-                                                               int ksplit, float* C, long c_stride, const int* e_of,
+                                                               float* C, long c_stride, const int* e_of,
                                                                float* dbias, int n_bias) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     lds_char* lds = (lds_char*)smem;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const WOp o = ops[order[blockIdx.x / ksplit]];
-    const int ks = blockIdx.x % ksplit;
+    // one workgroup = slice ks of ksplit of one GEMM; the split is PER GEMM, proportional to its operand rows (launch_wgrad_bf16)
+    const WItem it = items[blockIdx.x];
+    const WOp o = ops[it.op];
+    const int ks = it.ks, ksplit = it.n;
+#ifdef DFN_WL_TRACE
+    WlTraceScope trace_scope(it.op, ks);
+#endif
     const long pairs = n_tiles / 2;                                     // (NP is a multiple of 512: n_tiles is even)
     const long per = (pairs + ksplit - 1) / ksplit;
     const long p0 = ks * per, p1 = (p0 + per < pairs) ? p0 + per : pairs;      // this slice's tile PAIRS
     if (p0 >= p1) return;                                               // whole workgroup
+#ifndef DFN_WL_NOFULL
+    if (o.M == 256 && o.N == 256) {                                     // (whole workgroup) the specialised path
+        switch (wave >> 1) {
+            case 0: wl_full<0>(lds, o, dy_T, act_T, p0, p1, g_rows, a_rows, ks, C, c_stride, e_of, dbias, n_bias, wave, lane); break;
+            case 1: wl_full<1>(lds, o, dy_T, act_T, p0, p1, g_rows, a_rows, ks, C, c_stride, e_of, dbias, n_bias, wave, lane); break;
+            case 2: wl_full<2>(lds, o, dy_T, act_T, p0, p1, g_rows, a_rows, ks, C, c_stride, e_of, dbias, n_bias, wave, lane); break;
+            default: wl_full<3>(lds, o, dy_T, act_T, p0, p1, g_rows, a_rows, ks, C, c_stride, e_of, dbias, n_bias, wave, lane); break;
+        }
+        return;
+    }
+#define WL_ARGS lds, o, dy_T, act_T, p0, p1, g_rows, a_rows, ks, C, c_stride, e_of, dbias, n_bias, wave, lane
+    if (o.M == 256 && o.N == 128) { wl_static<8, 4, 4, 2, 1>(WL_ARGS); return; }
+    if (o.M == 256 && o.N == 64) { wl_static<8, 2, 8, 1, 1>(WL_ARGS); return; }
+    if (o.M == 256 && o.N == 32) { wl_static<8, 1, 8, 1, 1>(WL_ARGS); return; }
+    if (o.M == 32 && o.N == 256) { wl_static<1, 8, 1, 8, 1>(WL_ARGS); return; }
+    if (o.M == 64 && o.N == 64) { wl_static<2, 2, 2, 1, 4>(WL_ARGS); return; }
+#undef WL_ARGS
+#endif
     const int mts = o.M / 32, nts = o.N / 32, ntl = mts + nts;          // operand tiles per 32 points
     const int pps = ntl <= 4 ? 4 : (ntl <= 8 ? 2 : 1);                  // tile pairs per step (<= 32 KiB)
     const int np = pps * 2 * ntl;                                       // DMA pieces per step, <= 32
@@ -258,9 +635,9 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_mx_kernel(const WOp* ops, co
             }
 }
 
-hipError_t launch_wgrad_bf16(int field, const WOp* ops_dev, const int* order_dev, int n_ops, const void* dy_T,
-                             const void* act_T, long NP, int ksplit, float* C, long c_stride, const int* e_of,
-                             float* dbias, int n_bias, hipStream_t st) {
+hipError_t launch_wgrad_bf16(int field, const WOp* ops_dev, const WItem* items_dev, int n_items, const void* dy_T,
+                             const void* act_T, long NP, float* C, long c_stride, const int* e_of, float* dbias, int n_bias,
+                             hipStream_t st) {
     constexpr int lds = WL_DEPTH * WL_STEP_BYTES + WL_SCALE_BYTES;
     static bool done = false;
     if (!done) {
@@ -271,9 +648,15 @@ hipError_t launch_wgrad_bf16(int field, const WOp* ops_dev, const int* order_dev
     if ((NP / 32) & 1) return hipErrorInvalidValue;          // tile pairs (the MFMA contracts two 32-point tiles)
     const bool torso = field == FIELD_TORSO;
     const int g_rows = torso ? GradMap::S_ROWS : GradMap::H_ROWS, a_rows = torso ? RecMap::S_ROWS : RecMap::H_ROWS;
-    hipLaunchKernelGGL(wgrad_mx_kernel, dim3(n_ops * ksplit), dim3(WL_THREADS), lds, st, ops_dev, order_dev, dy_T, act_T,
-                       NP / 32, g_rows, a_rows, ksplit, C, c_stride, e_of, dbias, n_bias);
+    hipLaunchKernelGGL(wgrad_mx_kernel, dim3(n_items), dim3(WL_THREADS), lds, st, ops_dev, items_dev, dy_T, act_T, NP / 32,
+                       g_rows, a_rows, C, c_stride, e_of, dbias, n_bias);
     return hipGetLastError();
 }
 
 }  // namespace dfn
+#ifdef DFN_WL_TRACE
+extern "C" int dfn_debug_wl_trace(void* buf) {
+    unsigned long long* p = (unsigned long long*)buf;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(dfn::g_wl_trace), &p, sizeof(p));
+}
+#endif
