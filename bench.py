@@ -190,7 +190,7 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
            torch.randint(0, 256, (H * W, 3), dtype=torch.uint8, device=dev, generator=g8)) for _ in range(8)]
     # (DFN_BENCH_FIFTH_STREAM: developer switch - the pixel draw on a stream of its own, i.e. five streams on four hardware queues)
     sampler = frames.PixelSampler(H, W, N_RAND, 0, dev, seed=100 + rank, pipeline=True,
-                                  stream=None if os.environ.get("DFN_BENCH_FIFTH_STREAM") else buf.signal_trainer.pose_stream())
+                                  stream=None if os.environ.get("DFN_BENCH_FIFTH_STREAM") else run_nerf.draw_stream(buf))
     gstep = 300000                                   # all five optimizers' gates exercised except ExpNet
 
     host_t = [0.0] * 5 if os.environ.get("DFN_BENCH_HOST_TIMING") else None      # developer switch: host time by section

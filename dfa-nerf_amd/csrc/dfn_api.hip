@@ -618,6 +618,14 @@ static int weight_grad_impl(int tier, int field, const void* dy_T, const void* a
                 if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                     cus = prop.multiProcessorCount;
             }
+            // a few compute units are left to the single-workgroup kernels of the conditioning networks' chains (their backward,
+            // Adam, the next step's encoders): a launch of exactly one workgroup per compute unit, 144 KiB of LDS and 2 x 236
+            // registers per SIMD each, leaves them no slot until it ends (DFN_WGRAD_SPARE_CUS: developer override)
+            {
+                const char* e = getenv("DFN_WGRAD_SPARE_CUS");
+                const int spare = e ? atoi(e) : 8;
+                if (spare >= 0 && spare < cus / 2) cus -= spare;
+            }
             std::vector<WItem> items;
             std::vector<int> n_of;
             wgrad_items(w.ops, field, cus, items, n_of);

@@ -581,6 +581,22 @@ def train_step_loss_hip(nets, dataset, itr_obj, img_i, sel_yx, target_head, targ
     return loss, l_head, l_com, rgb_head, rgb_com
 
 
+def draw_stream(train_buf):
+    """The side stream the pipelined pixel draw of the NEXT step runs on (frames.PixelSampler(pipeline=True, stream=...)): one of
+    the process's four (a fifth stream shares a hardware queue with another one).  Round 4: the general side stream - the head
+    field's weight gradients, idle from the middle of the backward on.  Until round 3 it was the pose network's stream, whose
+    chain (backward -> Adam -> the next step's encoder) is the LAST thing a step waits for: the 20-us draw sat in front of the
+    encoder forward the next step's decoder needs (DFN_DRAW_STREAM=pose restores that for A/B)."""
+    import os
+    tr = getattr(train_buf, "signal_trainer", None)
+    if tr is None:
+        return None
+    if os.environ.get("DFN_DRAW_STREAM", "wgrad") == "pose":
+        return tr.pose_stream()
+    from . import engine
+    return engine.side_stream(tr.device, role="wgrad")
+
+
 def _hip_signals_ok(args):
     """The HIP signal encoders (dfn_encode_signal*) cover the reference configuration: 96-wide audio+expression signal,
     even attention windows up to 8 frames.  Anything else goes through the torch modules (nets.encode_signal*)."""
@@ -781,7 +797,7 @@ def train():
             print(f'[dfanerf] {n_pre} ground-truth frame pairs decoded to the device in {time.time() - t0:.1f} s')
     sampler = frames.PixelSampler(H, W, args.N_rand, args.sample_rate, dev, seed=1234 + rank,
                                   rects=ds['sample_rects'] if args.sample_rate > 0 else None, pipeline=True,
-                                  stream=getattr(getattr(train_buf, "signal_trainer", None), "pose_stream", lambda: None)())
+                                  stream=draw_stream(train_buf))
     # the draw is a function of (seed, counter): continue the stream where the checkpoint left it, so that a resumed run
     # (scripts/train_obama.sh always resumes from 280000.tar) does not replay the pixel sequence of the run before it -
     # upstream draws from the unseeded global np.random.  Nothing extra is stored in the checkpoint.

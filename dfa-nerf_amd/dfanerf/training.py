@@ -28,6 +28,10 @@ _OVERLAP = os.environ.get("DFN_TRAIN_OVERLAP", "1") == "1"
 # kernel's workgroup leaves instead of queueing behind its remaining workgroups)
 _WGRAD_SIDE = os.environ.get("DFN_TRAIN_WGRAD_SIDE", "1") == "1"
 _SIG_PRIO = os.environ.get("DFN_TRAIN_SIG_PRIO", "1") == "1"
+# the main stream joins the conditioning networks' streams at the event behind dfn_signal_grad (1) or at their end (0: A/B)
+_EVENT_JOIN = os.environ.get("DFN_TRAIN_EVENT_JOIN", "1") == "1"
+# the torso field's dfn_signal_grad in front of its weight-gradient GEMMs (1) or next to them (0: A/B)
+_SIG_FIRST = os.environ.get("DFN_TRAIN_SIG_FIRST", "1") == "1"
 
 
 def _side_stream(device, high=False, role=None):
@@ -272,9 +276,18 @@ def _fused_backward(ctx, d_h, d_c):
         # (single-workgroup latency chains, 0.26 ms) then runs underneath the weight-gradient GEMMs instead of behind
         # them.  Who consumes d_sig decides whether the main stream has to wait: _SignalFn.backward launches on those
         # same streams (ctx.defer).
+        # (events behind each dfn_signal_grad: its fold backward is the only reader of the DECODER's parameters on the side
+        # streams, so that is all the decoder's Adam has to stay behind - not the conditioning networks' whole backward chains)
+        ev = None
+        if tr is not None:
+            ev = getattr(tr, "_dsig_ev", None)
+            if ev is None:
+                ev = tr._dsig_ev = (torch.cuda.Event(), torch.cuda.Event())
         dx(0, st)
         s_a.wait_stream(main)
         dsig(0, C.c_void_p(s_a.cuda_stream))
+        if ev is not None:
+            ev[0].record(s_a)
         if over:
             side.wait_stream(main)
             dw(0, C.c_void_p(side.cuda_stream), g_flat, False)
@@ -283,6 +296,16 @@ def _fused_backward(ctx, d_h, d_c):
         dx(1, st)
         s_p.wait_stream(main)
         dsig(1, C.c_void_p(s_p.cuda_stream))
+        if ev is not None:
+            ev[1].record(s_p)
+            if _SIG_FIRST:
+                # The torso's d(signal) row sums BEFORE its weight-gradient GEMMs, not next to them: the GEMMs' 256 workgroups
+                # own every compute unit (144 KiB of LDS each) until they finish, so a kernel launched next to them starts
+                # when they end - the pose network's whole backward chain (row sums -> fold backward -> encoder backward ->
+                # Adam -> the next step's encoder forward, ~130 us) then ran BEHIND the GEMMs and the next step's forward
+                # waited for it (timeline: profiles/r04_c4_timeline_before.txt).  30 us of small kernels on the critical
+                # path buy the rest of that chain a place underneath the GEMMs.
+                main.wait_event(ev[1])
         if over:
             main.wait_stream(side)
         dw(1, st, g_flat, False)
@@ -544,8 +567,19 @@ class _SignalFn(torch.autograd.Function):
             # parameters on these streams, and the decoder's Adam (main stream) must not overtake it.  (Leaving the join to
             # the next encode() saved two queue barriers and was a race: with 256 rays the main stream reaches Adam before
             # the starved side kernels have run; the 3000-step bitwise soak of tests/test_gpu_train.py caught it.)
-            main.wait_stream(s_a)
-            main.wait_stream(s_p)
+            # Round 4: when d(signal) was deferred to this trainer, the readers of the decoder's parameters are the two
+            # dfn_signal_grad calls FusedTrainFn.backward issued, and it recorded an event behind each: the main stream waits for
+            # those instead of for the whole chains (the torso side's row sums run next to the torso's weight-gradient GEMMs and
+            # its encoder backward ended 45 us after them: that tail was on the step's critical path for no reason).
+            ev = getattr(tr, "_dsig_ev", None)
+            # (only with adopted optimizers - tr._pipelined -: the conditioning networks' Adam then steps on these streams;
+            # an optimizer on the main stream needs the whole chain behind it, and so does anything that reads their .grad)
+            if deferred and ev is not None and _EVENT_JOIN and getattr(tr, "_pipelined", False):
+                main.wait_event(ev[0])
+                main.wait_event(ev[1])
+            else:
+                main.wait_stream(s_a)
+                main.wait_stream(s_p)
         tr.nets[0].deposit(g[0])
         tr.nets[1].deposit(g[1])
         if smo > 0:
