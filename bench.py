@@ -379,6 +379,51 @@ def parity_check(sc, st, zs, za, pk, n_fine, fields, frame, dev, tier):
                                                 "`denom < 1e-5` switch moves within one coarse bin)"}}
 
 
+def power_ceiling(pk, tier, dev, kernel_tflops):
+    """What the matrix pipe sustains under the chip's power limit on THIS box, measured in-process right after the timed loops
+    (outside the timed region, ~1 s): dfn_debug_mfma_chain = render_kernel's inner loop reduced to its cost drivers, on the
+    renderer's own operand statistics - A fragments = the first 32 KiB of the packed weight stream the timed launches read,
+    B operands = post-ReLU-like activations (half zeros, |N(0,1)| otherwise) in the tier's type.  `bare_chain` = MFMAs only
+    (operands in registers), `renderer_mix` = + one 1-KiB LDS fragment read per MFMA and two convert / max instructions per
+    MFMA (what the decoder's epilogue cannot avoid).  The 2.5 PFLOP/s peak needs 2.4 GHz, which the part only holds when the
+    multipliers do not toggle (tools/vendor_gemm_ceiling.py calibrates the same ceiling with hipBLASLt)."""
+    import ctypes as C
+    from dfanerf._lib import check as chk, lib
+    from dfanerf.engine import TIERS
+    t = TIERS[tier]
+    frags = pk.packed[0][:32768].contiguous()
+    g = torch.Generator(device=dev).manual_seed(5)
+    act = torch.randn(32768, device=dev, generator=g).abs() * (torch.rand(32768, device=dev, generator=g) < 0.5)
+    b = act.to(torch.float16 if tier == "f16" else torch.bfloat16).contiguous()
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    blocks, iters = 4 * cus, 12000
+    out = torch.empty(blocks * 512, dtype=torch.float32, device=dev)
+    clk = torch.zeros(2, dtype=torch.int64, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    res = {}
+    for name, (l, v) in (("bare_chain", (0, 0)), ("renderer_mix", (2, 4))):
+        best = None
+        for rep in range(3):
+            n = 500 if rep == 0 else iters                       # (warm-up first)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            chk(lib.dfn_debug_mfma_chain(t, l, v, C.c_void_p(frags.data_ptr()), C.c_void_p(b.data_ptr()), n, blocks,
+                                         C.c_void_p(out.data_ptr()), C.c_void_p(clk.data_ptr()), st), "dfn_debug_mfma_chain")
+            e1.record()
+            torch.cuda.synchronize()
+            if rep:
+                ms = e0.elapsed_time(e1)
+                c = clk.cpu().numpy()
+                tf = blocks * 8 * n * 32 * 32768.0 / (ms * 1e-3) / 1e12
+                if best is None or tf > best[0]:
+                    best = (tf, float(c[0]) / float(c[1]) * 0.1 if c[1] > 0 else None)
+        res[name] = {"tflops": best[0], "frac_of_peak": best[0] / PEAK_TFLOPS[tier], "clock_ghz": best[1]}
+    res["frac_of_ceiling"] = kernel_tflops / res["bare_chain"]["tflops"]          # the timed kernel against the bare chain
+    res["frac_of_renderer_mix"] = kernel_tflops / res["renderer_mix"]["tflops"]
+    res["operands"] = "A: the packed weight stream's first 32 fragments; B: post-ReLU-like (half zeros, |N(0,1)|), " + tier
+    return res
+
+
 def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_s=0.0, check=False, size=450):
     from dfanerf import engine, nets, synth
     from dfanerf._lib import check as chk, lib
@@ -629,6 +674,12 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
     if sus:
         sus["roofline_frac"] = flop_ray * count / (sus["kernel_ms"] * 1e-3) / 1e12 / peak
         out["sustained"] = sus
+    if check and world == 1 and tier in ("f16", "bf16") and not os.environ.get("DFN_BENCH_NO_CEILING"):
+        try:                                        # after the timed loops; never lose the headline line to it
+            out["roofline"]["power_ceiling"] = power_ceiling(pk, tier, dev, out["sustained"]["roofline_frac"] * peak
+                                                             if sus else achieved)
+        except Exception as e:
+            out["roofline"]["power_ceiling"] = {"error": f"{type(e).__name__}: {e}"}
     if check and world == 1:
         try:
             out["parity_check"] = parity_check(sc, st, zs, za, pk, n_fine, fields, ((warmup + steps) * B - 1) % F, dev, tier)

@@ -33,6 +33,9 @@ hipError_t launch_composite_grad(const float* sigma, const float* feat, int K, l
                                  float* d_sigma, float* d_feat, hipStream_t st);
 hipError_t launch_volume_weights_grad(const float* z, const float* ray, const float* sigma, long R, int S, float last_dist,
                                       const float* d_w, float* d_sigma, hipStream_t st);
+hipError_t launch_zero_words(unsigned* p, long n, hipStream_t st);
+hipError_t launch_mfma_chain(bool f16, int lds2, int valu2, const void* frags, const void* b, int iters, int blocks, float* out,
+                             unsigned long long* clk, hipStream_t st);
 hipError_t launch_to8b(const float* x, long n, unsigned char* out, hipStream_t st);
 hipError_t launch_mfma_probe(float* out, hipStream_t st);
 hipError_t launch_adam_multi(const DfnAdamItem* items, const void* chunks, int n_chunks, float lr, double beta1, double beta2,

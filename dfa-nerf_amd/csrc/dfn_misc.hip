@@ -5,6 +5,7 @@
 // ndc_rays :484-503; sample_pdf :537-581; composite_function run_nerf_com_trainExpLater.py:146-166;
 // calc_volume_weights :169-179; to8b run_nerf_helpers.py:17.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <hip/hip_bf16.h>
 #include "dfn_layout.h"
 #include "dfn_mlp.h"
@@ -596,6 +597,86 @@ hipError_t launch_volume_weights_grad(const float* z, const float* ray, const fl
     hipLaunchKernelGGL(volume_weights_grad_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, z, ray, sigma, R, S,
                        last_dist, d_w, d_sigma);
     return hipGetLastError();
+}
+
+// ---- zero fill (dfn_zero_async) -------------------------------------------------------------------------------------------
+__global__ void zero_words_kernel(unsigned* p, long n) {
+    const long n4 = n >> 2;
+    uint4* q = (uint4*)p;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) q[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = 0;
+}
+hipError_t launch_zero_words(unsigned* p, long n, hipStream_t st) {
+    const long n4 = n >> 2;
+    const int blocks = (int)std::min<long>(1024, std::max<long>(1, (n4 + 255) / 256));
+    hipLaunchKernelGGL(zero_words_kernel, dim3(blocks), dim3(256), 0, st, p, n);
+    return hipGetLastError();
+}
+
+// ---- power-ceiling probe (dfn_debug_mfma_chain) -----------------------------------------------------------------------------
+// render_kernel's inner loop reduced to its cost drivers (tools/mfma_power_probe.hip is the stand-alone original):
+// 8 waves per workgroup, one workgroup per compute unit (150 KiB of LDS requested), every wave issuing the tier's 32x32x16 MFMA
+// on two alternating accumulator sets with LDS2 1-KiB fragment reads and VALU2 convert / max instructions per TWO MFMAs, on the
+// caller's operands.  (0, 0) = the bare chain: what the matrix pipe sustains on those operands under the chip's power limit;
+// (2, 4) = the renderer's instruction mix.
+typedef unsigned pc_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 pc_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pc_f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16, int LDS2, int VALU2>
+__global__ __launch_bounds__(512) void mfma_chain_kernel(const pc_u32x4* __restrict__ frag_src, const pc_u32x4* __restrict__ b_src,
+                                                         int iters, float* out, unsigned long long* clk) {
+    extern __shared__ pc_u32x4 pc_slab[];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 32 * 64; i += 512) pc_slab[i] = frag_src[i];
+    __syncthreads();
+    pc_u32x4 b[4];
+    for (int k = 0; k < 4; ++k) b[k] = b_src[(threadIdx.x * 4 + k) & 4095];
+    f32x16 acc0 = {}, acc1 = {};
+    pc_u32x4 a0 = pc_slab[lane], a1 = pc_slab[64 + lane];
+    unsigned e0 = b[0][0], e1 = b[1][1], e2 = b[2][2], e3 = b[3][3];
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {          // 32 MFMAs per iteration
+            const int f = (2 * k) % 32;
+            if (LDS2 >= 1) a0 = pc_slab[f * 64 + lane];
+            if (LDS2 >= 2) a1 = pc_slab[(f + 1) * 64 + lane];
+            if constexpr (F16) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pc_f16x8, a0), __builtin_bit_cast(pc_f16x8, b[k & 3]), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pc_f16x8, a1), __builtin_bit_cast(pc_f16x8, b[(k + 1) & 3]), acc1, 0, 0, 0);
+            } else {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pc_bf16x8, a0), __builtin_bit_cast(pc_bf16x8, b[k & 3]), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pc_bf16x8, a1), __builtin_bit_cast(pc_bf16x8, b[(k + 1) & 3]), acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int v = 0; v < VALU2; ++v) {
+                unsigned& x = (v & 3) == 0 ? e0 : (v & 3) == 1 ? e1 : (v & 3) == 2 ? e2 : e3;
+                if (v & 1) asm volatile("v_pk_max_i16 %0, %1, %2" : "=v"(x) : "v"(x), "v"(e0 ^ e2));
+                else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(x) : "v"(__builtin_bit_cast(float, x)), "v"(__builtin_bit_cast(float, x ^ 0x3f800000u)));
+            }
+        }
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    float sum = 0.f;
+    for (int r = 0; r < 16; ++r) sum += acc0[r] + acc1[r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = sum + (float)(e0 ^ e1 ^ e2 ^ e3);
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) { clk[0] = c1 - c0; clk[1] = r1 - r0; }
+}
+hipError_t launch_mfma_chain(bool f16, int lds2, int valu2, const void* frags, const void* b, int iters, int blocks, float* out,
+                             unsigned long long* clk, hipStream_t st) {
+    constexpr int lds = 150 * 1024;
+#define PC_GO(F, L, V)                                                                                                        \
+    {                                                                                                                         \
+        hipError_t e = hipFuncSetAttribute((const void*)mfma_chain_kernel<F, L, V>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        if (e != hipSuccess) return e;                                                                                        \
+        hipLaunchKernelGGL((mfma_chain_kernel<F, L, V>), dim3(blocks), dim3(512), lds, st, (const pc_u32x4*)frags,              \
+                           (const pc_u32x4*)b, iters, out, clk);                                                              \
+        return hipGetLastError();                                                                                             \
+    }
+    if (lds2 == 0 && valu2 == 0) { if (f16) PC_GO(true, 0, 0) else PC_GO(false, 0, 0) }
+    if (lds2 == 2 && valu2 == 4) { if (f16) PC_GO(true, 2, 4) else PC_GO(false, 2, 4) }
+#undef PC_GO
+    return hipErrorInvalidValue;
 }
 
 // ---- to8b ---------------------------------------------------------------------------------------------------------------

@@ -63,6 +63,7 @@ def _load():
         "dfn_to8b": (i32, [fp, lg, vp, vp]),
         "dfn_debug_mfma_layout": (i32, [fp, vp]),
         "dfn_debug_clock_probe": (i32, [vp]),
+        "dfn_debug_mfma_chain": (i32, [i32, i32, i32, vp, vp, i32, i32, fp, vp, vp]),
         "dfn_train_rows": (lg, [i32, i32]),
         "dfn_packed_bwd_bytes": (lg, [i32, i32]),
         "dfn_pack_weights_bwd": (i32, [i32, i32, fp, vp, vp]),

@@ -284,28 +284,38 @@ def _fused_backward(ctx, d_h, d_c):
             if ev is None:
                 ev = tr._dsig_ev = (torch.cuda.Event(), torch.cuda.Event())
         dx(0, st)
-        s_a.wait_stream(main)
+        # ONE event behind the head's dX chain for both side chains (every record is a packet in the main queue in front of the
+        # torso's dX chain: two cost 14 us between the two dX kernels)
+        e_dx = getattr(buf, "_ev_dx", None)
+        if e_dx is None:
+            e_dx = buf._ev_dx = torch.cuda.Event()
+        e_dx.record(main)
+        s_a.wait_event(e_dx)
         dsig(0, C.c_void_p(s_a.cuda_stream))
         if ev is not None:
             ev[0].record(s_a)
         if over:
-            side.wait_stream(main)
+            side.wait_event(e_dx)
             dw(0, C.c_void_p(side.cuda_stream), g_flat, False)
         else:
             dw(0, st, g_flat, False)
         dx(1, st)
-        s_p.wait_stream(main)
-        dsig(1, C.c_void_p(s_p.cuda_stream))
-        if ev is not None:
-            ev[1].record(s_p)
-            if _SIG_FIRST:
-                # The torso's d(signal) row sums BEFORE its weight-gradient GEMMs, not next to them: the GEMMs' 256 workgroups
-                # own every compute unit (144 KiB of LDS each) until they finish, so a kernel launched next to them starts
-                # when they end - the pose network's whole backward chain (row sums -> fold backward -> encoder backward ->
-                # Adam -> the next step's encoder forward, ~130 us) then ran BEHIND the GEMMs and the next step's forward
-                # waited for it (timeline: profiles/r04_c4_timeline_before.txt).  30 us of small kernels on the critical
-                # path buy the rest of that chain a place underneath the GEMMs.
-                main.wait_event(ev[1])
+        if ev is not None and _SIG_FIRST:
+            # The torso's d(signal) (row sums, their reduction, the fold backward: three small kernels, ~30 us) ON the main
+            # stream, in front of the torso's weight-gradient GEMMs, not next to them on the pose network's stream: the GEMMs'
+            # workgroups own the compute units (144 KiB of LDS each) until they finish, so a kernel launched next to them
+            # starts when they end - the pose network's whole backward chain (row sums -> fold backward -> encoder backward ->
+            # Adam -> the next step's encoder forward, ~130 us) then ran BEHIND the GEMMs and the next step's forward waited
+            # for it.  On the main stream it also costs no cross-queue hand-over (a wait on another queue's event is 15-20 us:
+            # dX -> pose stream -> main was 59 us between the dX chain and the GEMMs).  The pose stream picks d(signal) up
+            # behind ev[1] (_SignalFn.backward).
+            dsig(1, st)
+            ev[1].record(main)
+        else:
+            s_p.wait_stream(main)
+            dsig(1, C.c_void_p(s_p.cuda_stream))
+            if ev is not None:
+                ev[1].record(s_p)
         if over:
             main.wait_stream(side)
         dw(1, st, g_flat, False)
@@ -538,6 +548,8 @@ class _SignalFn(torch.autograd.Function):
         if s_a is not None and not deferred:
             s_a.wait_stream(main)
             s_p.wait_stream(main)
+        elif s_p is not None and getattr(tr, "_dsig_ev", None) is not None:
+            s_p.wait_event(tr._dsig_ev[1])          # (the torso's d(signal) may have been produced on the main stream: _SIG_FIRST)
         st_a = st if s_a is None else C.c_void_p(s_a.cuda_stream)
         st_t = st if s_p is None else C.c_void_p(s_p.cuda_stream)
         def buffers(side, stream, nets):

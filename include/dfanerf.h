@@ -297,6 +297,14 @@ int dfn_to8b(const float* x, long n, uint8_t* out, void* stream);
  * A = (row,k) / B = (k,col) probes and writes D as the kernels interpret it: out[3][32][32] (bf16, f32, f16).
  * Used by tests to pin the fragment maps. */
 int dfn_debug_mfma_layout(float* out, void* stream);
+/* Power-ceiling probe (bench.py `roofline.power_ceiling`): the renderer's inner loop reduced to its cost drivers - 8 waves per
+ * workgroup, one workgroup per compute unit, the tier's v_mfma_f32_32x32x16 on two alternating accumulator sets with
+ * `lds_reads_per_2` 1-KiB fragment reads from LDS and `valu_per_2` convert / max instructions per TWO MFMAs - on the caller's
+ * operands: fragments = 32 KiB (32 A fragments in the tier's 16-bit type, e.g. a slab of the packed weight stream), operands_b =
+ * 64 KiB.  Variants: (0, 0) the bare chain, (2, 4) the renderer's mix.  Each of the blocks x 8 waves issues 32 x iters MFMAs
+ * (16384 MACs = 32768 FLOP each); out: blocks x 512 floats (sink); clock[0] / clock[1] = shader cycles / 100-MHz ticks of one wave. */
+int dfn_debug_mfma_chain(int tier, int lds_reads_per_2, int valu_per_2, const void* fragments, const void* operands_b, int iters,
+                         int blocks, float* out, uint64_t* clock, void* stream);
 /* Measurement aid (process-global; NULL = off, the default): while set, every dfn_render_fwd* launch makes the workgroup
  * in the middle of its grid write probe[0] = shader cycles (s_memtime) and probe[1] = 100 MHz ticks (s_memrealtime) of
  * its own lifetime into this device array of two uint64: probe[0] / probe[1] x 0.1 GHz = the effective shader clock

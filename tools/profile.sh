@@ -9,10 +9,13 @@ TAG="$1"; shift
 OUT="$REPO/gpurun_out/profiles_$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline --no-extra --sustain-seconds 0 $*"
+# --no-parity-check: the 64-ray oracle launch after the timed loops would sit in every per-kernel average
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-extra --no-parity-check --sustain-seconds 0 $*"
 rm -rf /tmp/rp && mkdir -p /tmp/rp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp/stats -- $BENCH --steps 10 --warmup 2 > "$OUT/bench_under_stats.json" 2> /tmp/rp/stats.err
 cp $(find /tmp/rp/stats -name '*kernel_stats.csv' | head -1) "$OUT/kernel_stats.csv" 2>/dev/null
+# per (kernel, grid size): the full-frame launches on their own row (reproduces bench.py's roofline.kernel_ms directly)
+python "$REPO/tools/kernel_stats_by_grid.py" "$(find /tmp/rp/stats -name '*kernel_trace.csv' | head -1)" > "$OUT/kernel_stats_by_grid.csv" 2>/dev/null
 i=0
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" \
