@@ -303,9 +303,12 @@ class _FrameWriter:
 
     def stats(self):
         wall = (self._time() - self.t0) if self.t0 is not None else 0.0
+        # submit_waited_s: time submit() spent waiting for its slot's previous frame to be written - that wait INCLUDES the
+        # frame's render (the worker first waits for the GPU event), so it is ~wall in a GPU-bound loop; the loop is
+        # output-bound when encoder_utilisation approaches 1
         return {"frames": self.k, "workers": self.workers, "wall_s": wall, "encoder_busy_s": self.busy_s,
                 "encoder_utilisation": self.busy_s / (wall * self.workers) if wall > 0 else 0.0,
-                "submit_blocked_s": self.blocked_s}
+                "submit_waited_s": self.blocked_s}
 
 
 class FrameRenderer:

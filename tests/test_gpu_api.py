@@ -70,6 +70,19 @@ def test_render_rays_dropin_vs_oracle(dropin, states, scene, latents, golden, mo
     rgb, w = M.render_rays(dec, p_i.to(dev), r_i.to(dev), zs[:, 0].to(dev), za[:, 0].to(dev), sig, 'head', 1,
                            bg.reshape(1, R, 1, 3).to(dev), d_h[None].to(dev), z[None].to(dev), args, coarse_or_fine=mode)
     assert tuple(rgb.shape) == (R, 3) and tuple(w.shape) == (1, R, S)
+    # grad mode is on and the decoder's parameters require grad: like the reference's, the result carries a graph (round 4:
+    # Decoder.forward, composite_function and calc_volume_weights are autograd nodes over HIP kernels) - and under no_grad the
+    # same launches give the same bits
+    assert rgb.requires_grad and w.requires_grad
+    with torch.no_grad():
+        rgb0, w0 = M.render_rays(dec, p_i.to(dev), r_i.to(dev), zs[:, 0].to(dev), za[:, 0].to(dev), sig, 'head', 1,
+                                 bg.reshape(1, R, 1, 3).to(dev), d_h[None].to(dev), z[None].to(dev), args, coarse_or_fine=mode)
+    assert not rgb0.requires_grad and torch.equal(rgb0, rgb.detach()) and torch.equal(w0, w.detach())
+    if mode == "coarse":
+        (rgb * torch.linspace(0.5, 1.5, 3, device=dev)).sum().backward()
+        gn = {k: float(p.grad.norm()) for k, p in dec.named_parameters() if p.grad is not None}
+        assert gn["blocks.3.weight"] > 0 and gn["fc_in.weight"] > 0 and "fc_in_torso.weight" not in gn
+    rgb, w = rgb.detach(), w.detach()
     P = O.params_to_torch(states["decoder"])
     with torch.no_grad():
         s_h, f_h, _, _ = O._eval_fields(P, *rays, z, zs, za, [t(gc["signal"]), None], None, 1)
