@@ -346,8 +346,10 @@ long dfn_train_rows(int field, int what) {
     case 4: return (long)BIAS_GRAD_SLICES * dfn_bias_floats(DFN_TIER_BF16, field);   // dfn_bias_grad workspace floats
     case 5: return (long)SIG_ROW_SLICES * 512 + dfn_bias_floats(DFN_TIER_BF16, field);   // dfn_signal_grad workspace floats
     // 16-bit tier: bytes per 32-point tile of the MX-fp8 arrays act_T / dy_T (rows x 32 e4m3 bytes + the scale block)
-    case 6: return rec8_tile_bytes(t ? 64 + 640 + 128 + 9 * 256 + 32 : 64 + 9 * 256 + 32);
+    case 6: return act_tile_bytes(t ? 64 + 640 + 128 + 9 * 256 + 32 : 64 + 9 * 256 + 32, ACT_FP4);      // act_T of the FUSED step (MX-fp4: 16 bytes per row)
     case 7: return rec8_tile_bytes(t ? 896 + 10 * 256 + 64 : 10 * 256 + 64);
+    // act_T of dfn_decoder_train_fwd (Decoder.forward on explicit points under autograd): e4m3, rows x 32 bytes + the scale block
+    case 8: return act_tile_bytes(t ? 64 + 640 + 128 + 9 * 256 + 32 : 64 + 9 * 256 + 32, false);
     default: return fail(DFN_E_ARG, "dfn_train_rows: bad selector");
     }
 }
@@ -598,8 +600,10 @@ static int ensure_eof(WgradEntry& w, int tier, int field) {
     return DFN_OK;
 }
 
-static int weight_grad_impl(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
+static int weight_grad_impl(int tier, int field, int act_format, const void* dy_T, const void* act_T, long NP, float* workspace,
                             float* grad_flat, float* dbias, void* stream, const char* who) {
+    if (act_format != DFN_ACT_E4M3 && act_format != DFN_ACT_E2M1)
+        return fail(DFN_E_ARG, std::string(who) + ": act_format must be DFN_ACT_E4M3 or DFN_ACT_E2M1");
     if (!train_tier_ok(tier) || (field != 0 && field != 1) || !dy_T || !act_T || !workspace || !grad_flat || NP <= 0 ||
         NP % 32)
         return fail(DFN_E_ARG, std::string(who) + ": bad argument (NP must be a multiple of 32)");
@@ -690,7 +694,7 @@ static int weight_grad_impl(int tier, int field, const void* dy_T, const void* a
     // more, the streaming row-sum kernel is cheaper there (measured).
     const bool fuse = dbias && tier == DFN_TIER_BF16;
     if (tier == DFN_TIER_BF16)
-        err = launch_wgrad_bf16(field, w.ops_dev, w.items_dev, w.n_items, dy_T, act_T, NP, c_parts, W,
+        err = launch_wgrad_bf16(field, act_format == DFN_ACT_E2M1, w.ops_dev, w.items_dev, w.n_items, dy_T, act_T, NP, c_parts, W,
                                 fuse ? w.eof_dev : nullptr, fuse ? b_parts : nullptr, nb, st);
     else
         err = launch_wgrad(tier, field, w.ops_dev, (int)w.ops.size(), w.prefix_dev, w.prefix.back(), dy_T, act_T, NP, ks,
@@ -717,15 +721,24 @@ static int weight_grad_impl(int tier, int field, const void* dy_T, const void* a
     return DFN_OK;
 }
 
+// (the two entry points without a format argument consume what the FUSED step records: dfn_train_fwd / dfn_train_fwd_hier)
 int dfn_weight_grad(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
                     float* grad_flat, void* stream) {
-    return weight_grad_impl(tier, field, dy_T, act_T, NP, workspace, grad_flat, nullptr, stream, "dfn_weight_grad");
+    return weight_grad_impl(tier, field, ACT_FP4 ? DFN_ACT_E2M1 : DFN_ACT_E4M3, dy_T, act_T, NP, workspace, grad_flat, nullptr, stream,
+                            "dfn_weight_grad");
 }
 
 int dfn_weight_bias_grad(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
                          float* grad_flat, float* dbias, void* stream) {
     if (!dbias) return fail(DFN_E_ARG, "dfn_weight_bias_grad: dbias is NULL");
-    return weight_grad_impl(tier, field, dy_T, act_T, NP, workspace, grad_flat, dbias, stream, "dfn_weight_bias_grad");
+    return weight_grad_impl(tier, field, ACT_FP4 ? DFN_ACT_E2M1 : DFN_ACT_E4M3, dy_T, act_T, NP, workspace, grad_flat, dbias, stream,
+                            "dfn_weight_bias_grad");
+}
+
+int dfn_weight_bias_grad_fmt(int tier, int field, int act_format, const void* dy_T, const void* act_T, long NP, float* workspace,
+                             float* grad_flat, float* dbias, void* stream) {
+    if (!dbias) return fail(DFN_E_ARG, "dfn_weight_bias_grad_fmt: dbias is NULL");
+    return weight_grad_impl(tier, field, act_format, dy_T, act_T, NP, workspace, grad_flat, dbias, stream, "dfn_weight_bias_grad_fmt");
 }
 
 int dfn_bias_grad(int tier, int field, const void* dy_T, long NP, float* workspace, float* dbias, void* stream) {

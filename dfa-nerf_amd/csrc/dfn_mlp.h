@@ -229,8 +229,9 @@ struct Rec {
 // still in flight - at each use of an ordinary load (a ReLU mask word, a spill reload); without it the waits are counted.
 // PIPE = software-pipelined layers (layer_pipe below): the convert / ReLU epilogue of a tile pair and the bias reads of the
 // next one are issued between the MFMAs of the pair in between, on a second set of accumulators (+32 registers).
-template <bool REC, bool ASMF = false, bool ASMD = false, bool PIPE = false> struct CtxT {
+template <bool REC, bool ASMF = false, bool ASMD = false, bool PIPE = false, bool ACT4 = false> struct CtxT {
     static constexpr bool rec_on = REC;
+    static constexpr bool act_fp4 = ACT4;            // the recorder writes act_T as MX-fp4 (dfn_mlp.h "Round 4")
 #ifndef DFN_TRAIN_ASMF      // 1: the asm fragment fetch in the recording (training forward) kernels too: 413 -> 402 us; tools/check_inflight.py
                             // (run by build.sh on their ISA as well) proves no spill or copy touches an in-flight destination
 #define DFN_TRAIN_ASMF 1
@@ -282,6 +283,27 @@ DFN_DEV gchar* uniform_ptr(const void* p) {
 #endif
 constexpr int REC8_SCALE_BYTES = 128;        // >= rows / 32 of every array (torso dy_T: 110)
 DFN_HD constexpr long rec8_tile_bytes(int rows) { return (long)rows * 32 + REC8_SCALE_BYTES; }
+// Round 4: the recorded ACTIVATIONS (act_T: the GEMM inputs, half of the recorded bytes) are MX-fp4 - e2m1 values (0 .5 1 1.5 2 3 4 6
+// and their negatives) under the same E8M0 scale per (tile pair = 64 features) x (32 points), the narrowest operand format of
+// v_mfma_scale_f32_32x32x64_f8f6f4 (B operand: blgp 4; the pre-activation gradients dy_T stay e4m3: their blocks span too
+// many binades - tools/diag_mx_narrow.py, profiles/r04_mx_narrow_emulation.txt: dy in e2m3 fails the gradient gates, act in
+// e2m1 holds them: worst tensor 7.5 % of 15 %, gradient norms unchanged, the 200-step loss curve 0.05 % off the f32 tier's).
+// A weight gradient sums 131,072 points: the rounding of a 1-mantissa-bit value (up to 25 %, independent per element)
+// averages out like the e4m3 one did.  Layout per 32-point tile: one 512-BYTE block per 32-row block - [point n][half h][8
+// bytes = 16 nibbles, nibble r = accumulator register r = feature tile_feat(h, r)], a lane's two dwords - then the scale
+// bytes.  The consumer transposes with ds_read_b64_tr_b4 (tools/fp4_probe.hip pins the conversion, the operand's K order
+// and the transpose on the hardware).  -DDFN_ACT_FP4=0 restores the e4m3 activations (A/B builds on real data).
+#ifndef DFN_ACT_FP4
+#define DFN_ACT_FP4 1
+#endif
+// WHICH recorder writes MX-fp4: the fused training step's (render_kernel<.., TRAIN>: 131,072+ points per weight gradient).  The
+// decoder-on-points recorder (decoder_kernel<.., REC>: Decoder.forward under autograd, any number of points - a reference-shaped loop,
+// tests with a few thousand points) keeps e4m3: with 4,096 points the e2m1 rounding no longer averages out (whole-tensor
+// error 9.5 % where the gate is 8 %).  The format is a property of the recording context (CtxT<..>::act_fp4) and an argument of the
+// weight-gradient entry points (dfn_weight_bias_grad_fmt).
+constexpr bool ACT_FP4 = DFN_ACT_FP4 != 0;               // format of the FUSED STEP's recorder
+DFN_HD constexpr int act_row_bytes(bool fp4) { return fp4 ? 16 : 32; }          // bytes of one feature row of a 32-point tile
+DFN_HD constexpr long act_tile_bytes(int rows, bool fp4) { return (long)rows * act_row_bytes(fp4) + REC8_SCALE_BYTES; }
 struct Q8 {
     float scale;        // power of two: stored value = x / scale
     unsigned e8;        // its biased exponent (E8M0)
@@ -290,7 +312,8 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_q __attribute__((ext_vector_type(2)));
 // scale of tiles [t0, t0 + n) of v: amax over the wave (all 32 points), wave-uniform
 // NONNEG: the values are ReLU outputs (no sign bits to clear)
-template <int NT, bool NONNEG = false> DFN_DEV Q8 q8_of_tiles(const Vec<TIER_BF16, NT>& v, int t0, int n) {
+// FP4: the scale of an e2m1 block: amax / scale in (3, 6] (6 = the format's largest value: nothing saturates)
+template <int NT, bool NONNEG = false, bool FP4 = false> DFN_DEV Q8 q8_of_tiles(const Vec<TIER_BF16, NT>& v, int t0, int n) {
     typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
     // a TREE of packed maxima (four independent chains, then their maximum): as one chain the 15 dependent v_pk_max_u16 of a
     // tile pair sit in front of everything the wave issues next (in-order issue), MFMAs included
@@ -335,9 +358,46 @@ template <int NT, bool NONNEG = false> DFN_DEV Q8 q8_of_tiles(const Vec<TIER_BF1
     q.scale = __builtin_bit_cast(float, q.e8 << 23);
     return q;
 #endif
-    q.e8 = E > 8u ? E - 7u : 1u;
+    if constexpr (FP4) {
+        // amax = 2^(E-127) (1 + m / 128): m <= 64 -> scale 2^(E-129), amax / scale = 4 (1 + m / 128) in [4, 6]; else 2^(E-128): (3, 4)
+        const unsigned e = E + ((a & 0x7fu) > 64u ? 1u : 0u);
+        q.e8 = e > 3u ? e - 2u : 1u;
+    } else {
+        q.e8 = E > 8u ? E - 7u : 1u;
+    }
     q.scale = __builtin_bit_cast(float, q.e8 << 23);
     return q;
+}
+// tile t of v -> 16 e2m1 nibbles = ONE 8-byte store at [point][half] of the 512-byte block (MX-fp4 activations, above)
+template <int NT, class CT>
+DFN_DEV void store_tile4(void* arr, int rows, long tile, int row0, const Vec<TIER_BF16, NT>& v, int t, int t_first, const Q8& q,
+                         const CT& c) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    u32x2_ out;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {            // registers 8 k .. 8 k + 7 -> dword k, register r in nibble r & 7
+        const u32x4_ w = __builtin_bit_cast(u32x4_, v.u[2 * t + k]);
+        const unsigned w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];      // scalar copies (bit_cast of a vector ELEMENT miscompiles)
+        unsigned o = 0;
+        o = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(o, __builtin_bit_cast(bf16x2_q, w0), q.scale, 0);
+        o = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(o, __builtin_bit_cast(bf16x2_q, w1), q.scale, 1);
+        o = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(o, __builtin_bit_cast(bf16x2_q, w2), q.scale, 2);
+        o = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(o, __builtin_bit_cast(bf16x2_q, w3), q.scale, 3);
+        out[k] = o;
+    }
+    gchar* ubase = uniform_ptr((char*)arr + tile * act_tile_bytes(rows, true) + (long)row0 * 16);
+    const unsigned voff = (unsigned)((c.lane & 31) * 16 + c.half * 8);
+    __builtin_nontemporal_store(out, (__attribute__((address_space(1))) u32x2_*)(ubase + (t - t_first) * 512 + voff));
+}
+// act_T tile store / scale store in the build's activation format
+template <int NT, class CT>
+DFN_DEV void store_tile_act(void* arr, int rows, long tile, int row0, const Vec<TIER_BF16, NT>& v, int t, int t_first, const Q8& q,
+                            const CT& c);
+template <class CT>
+DFN_DEV void store_scale_act(void* arr, int rows, long tile, int row0, int t0, int t_first, int n, const Q8& q, const CT& c) {
+    gchar* sb = uniform_ptr((char*)arr + tile * act_tile_bytes(rows, CT::act_fp4) + (long)rows * act_row_bytes(CT::act_fp4) + (row0 >> 5) + (t0 - t_first));
+    if (c.lane < n) *(__attribute__((address_space(1))) unsigned char*)(sb + c.lane) = (unsigned char)q.e8;
 }
 // ONE store instruction: tile t of v (this lane's 16 features of the 32-row block, one point) -> 16 fp8 bytes at
 // [point][half] of the block; 8 conversions, no cross-lane traffic.
@@ -370,8 +430,14 @@ DFN_DEV void store_scale8(void* arr, int rows, long tile, int row0, int t0, int 
     gchar* sb = uniform_ptr((char*)arr + tile * rec8_tile_bytes(rows) + (long)rows * 32 + (row0 >> 5) + (t0 - t_first));
     if (c.lane < n) *(__attribute__((address_space(1))) unsigned char*)(sb + c.lane) = (unsigned char)q.e8;
 }
-// tiles [t0, t0 + n) of v -> rows row0 + 32 (t - t0) ...
-template <int TIER, int NT, class CT>
+template <int NT, class CT>
+DFN_DEV void store_tile_act(void* arr, int rows, long tile, int row0, const Vec<TIER_BF16, NT>& v, int t, int t_first, const Q8& q,
+                            const CT& c) {
+    if constexpr (CT::act_fp4) store_tile4<NT>(arr, rows, tile, row0, v, t, t_first, q, c);
+    else store_tile8<NT>(arr, rows, tile, row0, v, t, t_first, q, c);
+}
+// tiles [t0, t0 + n) of v -> rows row0 + 32 (t - t0) ...   (ACT: the array is act_T, in the build's activation format)
+template <int TIER, int NT, class CT, bool ACT = false>
 DFN_DEV void store_tiles_T(void* arr, int rows, long tile, int row0, const Vec<TIER, NT>& v, int t0, int n, const CT& c) {
     typedef typename ActT<TIER>::type T;
     // address = wave-uniform base (SGPR pair) + 32-bit per-lane offset + immediate: the "saddr" form of global_store.
@@ -384,11 +450,15 @@ DFN_DEV void store_tiles_T(void* arr, int rows, long tile, int row0, const Vec<T
         for (int t = 0; t < NT; t += 2)
             if (t >= t0 && t < t0 + n) {
                 const int np = (t + 1 < t0 + n && t + 1 < NT) ? 2 : 1;
-                const Q8 q = q8_of_tiles<NT>(v, t, np);
-                store_scale8(arr, rows, tile, row0, t, t0, np, q, c);
+                const Q8 q = q8_of_tiles<NT, false, ACT && CT::act_fp4>(v, t, np);
+                if constexpr (ACT) store_scale_act(arr, rows, tile, row0, t, t0, np, q, c);
+                else store_scale8(arr, rows, tile, row0, t, t0, np, q, c);
 #pragma unroll
                 for (int k = 0; k < 2; ++k)             // (constant trip count: np may be a run-time value)
-                    if (k < np && t + k < NT) store_tile8<NT>(arr, rows, tile, row0, v, t + k, t0, q, c);
+                    if (k < np && t + k < NT) {
+                        if constexpr (ACT) store_tile_act<NT>(arr, rows, tile, row0, v, t + k, t0, q, c);
+                        else store_tile8<NT>(arr, rows, tile, row0, v, t + k, t0, q, c);
+                    }
             }
     } else {
 #pragma unroll
@@ -400,14 +470,14 @@ DFN_DEV void store_tiles_T(void* arr, int rows, long tile, int row0, const Vec<T
             }
     }
 }
-template <int TIER, int NT, class CT>
+template <int TIER, int NT, class CT, bool ACT = false>
 DFN_DEV void store_vec_T(void* arr, int rows, long tile, int row0, const Vec<TIER, NT>& v, const CT& c) {
-    store_tiles_T<TIER, NT>(arr, rows, tile, row0, v, 0, NT, c);
+    store_tiles_T<TIER, NT, CT, ACT>(arr, rows, tile, row0, v, 0, NT, c);
 }
 template <int TIER, int NT, class CT>
 DFN_DEV void rec_vec(const CT& c, int row0, const Vec<TIER, NT>& v) {
     if constexpr (!CT::rec_on) return;
-    else store_vec_T<TIER, NT>(c.rec.act_T, c.rec.rows, c.rec.pass, row0, v, c);
+    else store_vec_T<TIER, NT, CT, true>(c.rec.act_T, c.rec.rows, c.rec.pass, row0, v, c);
 }
 
 // The A-fragment stream of a pass is strictly sequential (fragment f lives in slab f/32 at position f%32),
@@ -655,7 +725,7 @@ DFN_DEV void acc_to_vec(const f32x16 (&acc)[G], Vec<TIER, NT>& v, int t0) {
 template <int TIER, int NT, class CT>
 DFN_DEV void rec_vals(const CT& c, int row0, const Vec<TIER, NT>& out, int t0) {
     if constexpr (CT::rec_on)
-        if (row0 >= 0) store_tiles_T<TIER, NT>(c.rec.act_T, c.rec.rows, c.rec.pass, row0, out, t0, 2, c);
+        if (row0 >= 0) store_tiles_T<TIER, NT, CT, true>(c.rec.act_T, c.rec.rows, c.rec.pass, row0, out, t0, 2, c);
 }
 // ReLU bit of value b (= 16 g + r: tile g of the pair, accumulator register r) of a tile pair inside its mask dword: value b
 // lives in the (b & 1) half of packed operand word b >> 1, and the 16-bit tiers build the dword FROM those words (below)
@@ -784,11 +854,11 @@ template <int TIER, int OT, int KU, class CT, bool NONNEG> struct RecSide {
         if constexpr (CT::rec_on && TIER == TIER_BF16) {
             if (prev < 0 || rec_row < 0) return;
             if (ku == 0) {
-                q = q8_of_tiles<OT, NONNEG>(out, 2 * prev, 2);
-                store_scale8(c.rec.act_T, c.rec.rows, c.rec.pass, rec_row, 2 * prev, 0, 2, q, c);
+                q = q8_of_tiles<OT, NONNEG, CT::act_fp4>(out, 2 * prev, 2);
+                store_scale_act(c.rec.act_T, c.rec.rows, c.rec.pass, rec_row, 2 * prev, 0, 2, q, c);
             }
-            if (ku == S0) store_tile8<OT>(c.rec.act_T, c.rec.rows, c.rec.pass, rec_row, out, 2 * prev, 0, q, c);
-            if (ku == S1) store_tile8<OT>(c.rec.act_T, c.rec.rows, c.rec.pass, rec_row, out, 2 * prev + 1, 0, q, c);
+            if (ku == S0) store_tile_act<OT>(c.rec.act_T, c.rec.rows, c.rec.pass, rec_row, out, 2 * prev, 0, q, c);
+            if (ku == S1) store_tile_act<OT>(c.rec.act_T, c.rec.rows, c.rec.pass, rec_row, out, 2 * prev + 1, 0, q, c);
         }
     }
 };

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
 #ifndef DFN_PIPE
 #define DFN_PIPE 1
 #endif
-    typedef CtxT<TRAIN != 0, TRAIN == 0, TRAIN != 0, (DFN_PIPE != 0) && TRAIN == 0 && !TWO> CtxK;
+    typedef CtxT<TRAIN != 0, TRAIN == 0, TRAIN != 0, (DFN_PIPE != 0) && TRAIN == 0 && !TWO, TRAIN != 0 && ACT_FP4> CtxK;      // (fused step: act_T in MX-fp4)
     CtxK ctx = {lds, wave, lane, lane >> 5, {}};
     constexpr bool two = TWO;
     const int NF = TRAIN == 1 ? 0 : F.n_fine;     // TRAIN == 1: the training forward is the reference's coarse renderer

@@ -50,7 +50,8 @@ hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, cons
 struct WItem {                  // one workgroup of the 16-bit tier's weight-gradient launch: slice `ks` of `n` of GEMM `op`
     int op, ks, n, pad;
 };
-hipError_t launch_wgrad_bf16(int field, const WOp* ops_dev, const WItem* items_dev, int n_items, const void* dy_T,
+// act_fp4: act_T is MX-fp4 (recorded by the fused training step) / MX-fp8 e4m3 (by the decoder-on-points recorder)
+hipError_t launch_wgrad_bf16(int field, bool act_fp4, const WOp* ops_dev, const WItem* items_dev, int n_items, const void* dy_T,
                              const void* act_T, long NP, float* C, long c_stride, const int* e_of, float* dbias, int n_bias,
                              hipStream_t st);
 // grad_flat[map[i]] += sum over the first `slices` slices of parts[.][i]   (i < n; map[i] < 0: structural padding)

@@ -69,6 +69,17 @@ DFN_DEV i32x8 frag_tr8(const lds_char* p0, const lds_char* p1) {
     const i32x8 f = {a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
     return f;
 }
+// B fragment of a 32-row block of MX-fp4 activations (dfn_mlp.h, round 4): the block's LDS image is 512 bytes, [point][half][8
+// bytes = 16 nibbles r = 0..15]; ds_read_b64_tr_b4 hands lane i of a 16-lane group nibble i of the sixteen 8-byte rows named by
+// the group's lanes (tools/fp4_probe.hip): lane j names (point p0 + j, half h = group & 1), so lane i receives feature
+// tile_feat(h, i) of 16 consecutive points - MFMA row m = 16 h + i, the same relabelling as the fp8 A operand's.  An fp4 operand
+// lane (m, kh) holds ALL 32 points of tile kh (nibbles 0..31 = K 0..31 of K block kh): two reads of ONE tile, not one of each.
+// p = this lane's row address for points 0..15 of its tile's block.
+DFN_DEV i32x8 frag_tr4(const lds_char* p) {
+    const i32x2 a = __builtin_amdgcn_ds_read_tr4_b64_v2i32((DFN_LDS i32x2*)p), b = __builtin_amdgcn_ds_read_tr4_b64_v2i32((DFN_LDS i32x2*)(p + 256));
+    const i32x8 f = {a[0], a[1], b[0], b[1], 0, 0, 0, 0};
+    return f;
+}
 template <int N> DFN_DEV void wl_wait_vm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
 // ---- the 256 x 256 GEMMs (8 of the ~14-29 GEMMs of a field, 73 % of its operand bytes) -----------------------------------
@@ -99,21 +110,29 @@ DFN_DEV void wl_stage_scales(lds_char* sc_lds, const unsigned char* scA, const u
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
-template <int CG>
+template <int CG, bool B4>
 DFN_DEV void wl_full(lds_char* lds, const WOp& o, const void* dy_T, const void* act_T, long p0, long p1, int g_rows, int a_rows,
                      int ks, float* C, long c_stride, const int* e_of, float* dbias, int n_bias, int wave, int lane) {
     lds_char* sc_lds = lds + WL_DEPTH * WL_STEP_BYTES;
-    const long strideA = rec8_tile_bytes(g_rows), strideB = rec8_tile_bytes(a_rows);
+    const long strideA = rec8_tile_bytes(g_rows), strideB = act_tile_bytes(a_rows, B4);
     const int rg = wave & 1, kh = lane >> 5, hh = (lane >> 4) & 1, li = lane & 15;
     const bool do_bias = dbias && o.bias_owner;
     const unsigned char* scA = (const unsigned char*)dy_T + (long)g_rows * 32 + (o.a_row >> 5);
-    const unsigned char* scB = (const unsigned char*)act_T + (long)a_rows * 32 + (o.b_row >> 5);
+    const unsigned char* scB = (const unsigned char*)act_T + (long)a_rows * act_row_bytes(B4) + (o.b_row >> 5);
     const unsigned lds_base = (unsigned)(unsigned long)lds;
-    const unsigned voffA = (unsigned)((o.a_row + 32 * wave) * 32 + 16 * lane), voffB = (unsigned)((o.b_row + 32 * wave) * 32 + 16 * lane);
-    const unsigned dA = (unsigned)wave * 1024u, dB = (unsigned)(8 + wave) * 1024u;
+    // DMA pieces (1 KiB each).  dY: block `wave` of both tiles.  Activations, e4m3: block `wave` of both tiles (4 pieces per wave and
+    // step); MX-fp4: a block is 512 bytes, a piece = a PAIR of blocks, 4 per tile - waves 0-3 fetch pair `wave` of tile 0,
+    // waves 4-7 pair `wave - 4` of tile 1 (3 pieces per wave and step).  LDS image of tile u: dY blocks at u * 16 KiB + 1 KiB x
+    // i, activation blocks at u * 16 KiB + 8 KiB + (1 KiB | 512 B) x j.
+    constexpr int NPW = B4 ? 3 : 4;                 // pieces per wave and step
+    const unsigned voffA = (unsigned)((o.a_row + 32 * wave) * 32 + 16 * lane);
+    const unsigned voffB = B4 ? (unsigned)((o.b_row + 64 * (wave & 3)) * 16 + 16 * lane) : (unsigned)((o.b_row + 32 * wave) * 32 + 16 * lane);
+    const unsigned dA = (unsigned)wave * 1024u;
+    const unsigned dB = B4 ? (unsigned)(wave >> 2) * 16384u + 8192u + (unsigned)(wave & 3) * 1024u : (unsigned)(8 + wave) * 1024u;
     // this lane's transpose-read address (q = 0) in the wave's first A / B block of tile 0 of slot 0
     const lds_char* rdA = lds + (16 * kh + (li >> 1)) * 32 + hh * 16 + (li & 1) * 8 + 4 * rg * 1024;
-    const lds_char* rdB = rdA + (8 + 2 * CG - 4 * rg) * 1024;
+    const lds_char* rdB = B4 ? lds + kh * 16384 + 8192 + 2 * CG * 512 + li * 16 + hh * 8        // (tile kh: see frag_tr4)
+                                  : rdA + (8 + 2 * CG - 4 * rg) * 1024;
     f32x16 acc[4][2], accb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -147,14 +166,18 @@ DFN_DEV void wl_full(lds_char* lds, const WOp& o, const void* dy_T, const void* 
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const char* gA = (const char*)dy_T + 2 * c0 * strideA;
-        const char* gB = (const char*)act_T + 2 * c0 * strideB;
+        const char* gB = (const char*)act_T + (2 * c0 + (B4 ? (wave >> 2) : 0)) * strideB;
         unsigned issue_off = 0;                                  // byte offset of the slot the next issue fills
         auto issue = [&]() {
             const unsigned m = lds_base + issue_off;
             wl_dma(voffA, gA, m + dA);
-            wl_dma(voffB, gB, m + dB);
             wl_dma(voffA, gA + strideA, m + 16384u + dA);
-            wl_dma(voffB, gB + strideB, m + 16384u + dB);
+            if constexpr (B4) {
+                wl_dma(voffB, gB, m + dB);               // (gB already points at this wave's tile of the pair)
+            } else {
+                wl_dma(voffB, gB, m + dB);
+                wl_dma(voffB, gB + strideB, m + 16384u + dB);
+            }
             gA += 2 * strideA;
             gB += 2 * strideB;
             issue_off = issue_off + WL_STEP_BYTES == WL_DEPTH * WL_STEP_BYTES ? 0u : issue_off + WL_STEP_BYTES;
@@ -165,7 +188,7 @@ DFN_DEV void wl_full(lds_char* lds, const WOp& o, const void* dy_T, const void* 
         const lds_char* scp = sc_lds + kh * 16;
         unsigned rd_off = 0;
         for (long s = 0; s < n_steps; ++s) {
-            if (s + WL_DEPTH - 2 < n_steps) wl_wait_vm<4 * (WL_DEPTH - 2)>();
+            if (s + WL_DEPTH - 2 < n_steps) wl_wait_vm<NPW * (WL_DEPTH - 2)>();
             else wl_wait_vm<0>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -178,12 +201,15 @@ DFN_DEV void wl_full(lds_char* lds, const WOp& o, const void* dy_T, const void* 
             scp += 32;
             i32x8 a[4], b[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = frag_tr8(pb + j * 1024, pb + j * 1024 + 16384);
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (B4) b[j] = frag_tr4(pb + j * 512);
+                else b[j] = frag_tr8(pb + j * 1024, pb + j * 1024 + 16384);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[i] = frag_tr8(pa + i * 1024, pa + i * 1024 + 16384);
 #define WL_MM(I)                                                                                                         \
-    acc[I][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[I], b[0], acc[I][0], 0, 0, I, sa4, 0, sb2);             \
-    acc[I][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[I], b[1], acc[I][1], 0, 0, I, sa4, 1, sb2);
+    acc[I][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[I], b[0], acc[I][0], 0, (B4 ? 4 : 0), I, sa4, 0, sb2);       \
+    acc[I][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[I], b[1], acc[I][1], 0, (B4 ? 4 : 0), I, sa4, 1, sb2);
             WL_MM(0) WL_MM(1) WL_MM(2) WL_MM(3)
 #undef WL_MM
             if (do_bias) accb = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[CG], ones, accb, 0, 0, CG, sa4, 0, 127);
@@ -219,21 +245,25 @@ DFN_DEV void wl_full(lds_char* lds, const WOp& o, const void* dy_T, const void* 
 // round of the launch.  Here the eight waves form an RGN x CGN x KWN grid: RGN x CGN over the output tiles (TM x TN per wave) and
 // KWN over the tile PAIRS of a step (64 x 64: 2 x 1 x 4 - every wave one pair and one row tile per step); the KWN partial sums of
 // an output tile are added through LDS at the end, in wave order (fixed: bit-reproducible like everything else here).
-template <int MTS, int NTS, int RGN, int CGN, int KWN>
+template <int MTS, int NTS, int RGN, int CGN, int KWN, bool B4>
 DFN_DEV void wl_static(lds_char* lds, const WOp& o, const void* dy_T, const void* act_T, long p0, long p1, int g_rows, int a_rows,
                        int ks, float* C, long c_stride, const int* e_of, float* dbias, int n_bias, int wave, int lane) {
     static_assert(RGN * CGN * KWN == WL_WAVES && MTS % RGN == 0 && NTS % CGN == 0, "wave grid");
-    constexpr int TM = MTS / RGN, TN = NTS / CGN, NTL = MTS + NTS;
+    constexpr int TM = MTS / RGN, TN = NTS / CGN;
+    // 1-KiB pieces per tile: one per dY block; the activation blocks one each (e4m3) or in pairs of 512-byte blocks (MX-fp4; an
+    // odd last block takes the following 512 bytes along - inside the array: TrainBuffers pads act_T by a tile)
+    constexpr int NTB = B4 ? (NTS + 1) / 2 : NTS, NTL = MTS + NTB;
+    constexpr int BBLK = B4 ? 512 : 1024;                          // LDS bytes of an activation block
     constexpr int PPS = NTL <= 4 ? 4 : (NTL <= 8 ? 2 : 1);              // tile pairs per step (<= 32 KiB)
     constexpr int NP = PPS * 2 * NTL, NWM = (NP + WL_WAVES - 1) / WL_WAVES;      // DMA pieces per step; per wave at most
     static_assert(PPS % KWN == 0 && NP <= 32 && TM <= 4 && TN <= 4, "shape");
     lds_char* sc_lds = lds + WL_DEPTH * WL_STEP_BYTES;
-    const long strideA = rec8_tile_bytes(g_rows), strideB = rec8_tile_bytes(a_rows);
+    const long strideA = rec8_tile_bytes(g_rows), strideB = act_tile_bytes(a_rows, B4);
     const int rg = wave % RGN, cg = (wave / RGN) % CGN, kw = wave / (RGN * CGN);
     const int kh = lane >> 5, hh = (lane >> 4) & 1, li = lane & 15;
     const bool do_bias = dbias && o.bias_owner && cg == 0;              // the row sums of a dY block: by the waves of column group 0
     const unsigned char* scA = (const unsigned char*)dy_T + (long)g_rows * 32 + (o.a_row >> 5);
-    const unsigned char* scB = (const unsigned char*)act_T + (long)a_rows * 32 + (o.b_row >> 5);
+    const unsigned char* scB = (const unsigned char*)act_T + (long)a_rows * act_row_bytes(B4) + (o.b_row >> 5);
     const unsigned lds_base = (unsigned)(unsigned long)lds;
     // this wave's DMA pieces: piece p = wave + 8 k of the step = (tile u of the step, operand block tl)
     unsigned voff[NWM], dst[NWM];
@@ -245,12 +275,13 @@ DFN_DEV void wl_static(lds_char* lds, const WOp& o, const void* dy_T, const void
         const int p = wave + WL_WAVES * k;
         const int u = p / NTL, tl = p - u * NTL;
         isb[k] = tl >= MTS;
-        const int r = isb[k] ? o.b_row + 32 * (tl - MTS) : o.a_row + 32 * tl;
-        voff[k] = (unsigned)(r * 32 + 16 * lane);
+        voff[k] = isb[k] ? (unsigned)((o.b_row + (B4 ? 64 : 32) * (tl - MTS)) * act_row_bytes(B4) + 16 * lane)
+                         : (unsigned)((o.a_row + 32 * tl) * 32 + 16 * lane);
         sub[k] = u;
         dst[k] = (unsigned)((u * NTL + tl) * 1024);
     }
     const lds_char* rd0 = lds + (16 * kh + (li >> 1)) * 32 + hh * 16 + (li & 1) * 8;      // transpose-read address, q = 0, block 0
+    const lds_char* rd4 = lds + li * 16 + hh * 8;                                          // ... of an MX-fp4 block (frag_tr4)
     f32x16 acc[TM][TN], accb[TM];
 #pragma unroll
     for (int r = 0; r < 16; ++r)
@@ -321,6 +352,7 @@ DFN_DEV void wl_static(lds_char* lds, const WOp& o, const void* dy_T, const void
             asm volatile("" ::: "memory");
             if (s + WL_DEPTH - 1 < n_steps) issue();
             const lds_char* slot = rd0 + rd_off;
+            const lds_char* slot4 = rd4 + rd_off;
             rd_off = rd_off + WL_STEP_BYTES == WL_DEPTH * WL_STEP_BYTES ? 0u : rd_off + WL_STEP_BYTES;
             const long pp = c0 + s * PPS;
 #pragma unroll
@@ -339,10 +371,15 @@ DFN_DEV void wl_static(lds_char* lds, const WOp& o, const void* dy_T, const void
                 const lds_char* b1 = b0 + NTL * 1024;                   // second tile
                 i32x8 a[TM], b[TN];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = frag_tr8(b0 + (MTS + TN * cg + j) * 1024, b1 + (MTS + TN * cg + j) * 1024);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (B4)          // tile kh of the pair, its activation block TN cg + j
+                        b[j] = frag_tr4(slot4 + (2 * u + kh) * NTL * 1024 + MTS * 1024 + (TN * cg + j) * BBLK);
+                    else
+                        b[j] = frag_tr8(b0 + (MTS + TN * cg + j) * 1024, b1 + (MTS + TN * cg + j) * 1024);
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i) a[i] = frag_tr8(b0 + (TM * rg + i) * 1024, b1 + (TM * rg + i) * 1024);
-#define WL_M1(I, J) if constexpr (I < TM && J < TN) acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[I], b[J], acc[I][J], 0, 0, I, sa, J, sb);
+#define WL_M1(I, J) if constexpr (I < TM && J < TN) acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[I], b[J], acc[I][J], 0, (B4 ? 4 : 0), I, sa, J, sb);
 #define WL_MR(I) WL_M1(I, 0) WL_M1(I, 1) WL_M1(I, 2) WL_M1(I, 3)
                 WL_MR(0) WL_MR(1) WL_MR(2) WL_MR(3)
 #undef WL_MR
@@ -425,6 +462,7 @@ struct WlTraceScope {
     }
 };
 #endif
+template <bool B4>
 __global__ __launch_bounds__(WL_THREADS) void wgrad_mx_kernel(const WOp* ops, const WItem* items, const void* __restrict__ dy_T,
                                                                const void* __restrict__ act_T, long n_tiles, int g_rows, int a_rows,
                                                                float* C, long c_stride, const int* e_of,
@@ -447,26 +485,26 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_mx_kernel(const WOp* ops, co
 #ifndef DFN_WL_NOFULL
     if (o.M == 256 && o.N == 256) {                                     // (whole workgroup) the specialised path
         switch (wave >> 1) {
-            case 0: wl_full<0>(lds, o, dy_T, act_T, p0, p1, g_rows, a_rows, ks, C, c_stride, e_of, dbias, n_bias, wave, lane); break;
-            case 1: wl_full<1>(lds, o, dy_T, act_T, p0, p1, g_rows, a_rows, ks, C, c_stride, e_of, dbias, n_bias, wave, lane); break;
-            case 2: wl_full<2>(lds, o, dy_T, act_T, p0, p1, g_rows, a_rows, ks, C, c_stride, e_of, dbias, n_bias, wave, lane); break;
-            default: wl_full<3>(lds, o, dy_T, act_T, p0, p1, g_rows, a_rows, ks, C, c_stride, e_of, dbias, n_bias, wave, lane); break;
+            case 0: wl_full<0, B4>(lds, o, dy_T, act_T, p0, p1, g_rows, a_rows, ks, C, c_stride, e_of, dbias, n_bias, wave, lane); break;
+            case 1: wl_full<1, B4>(lds, o, dy_T, act_T, p0, p1, g_rows, a_rows, ks, C, c_stride, e_of, dbias, n_bias, wave, lane); break;
+            case 2: wl_full<2, B4>(lds, o, dy_T, act_T, p0, p1, g_rows, a_rows, ks, C, c_stride, e_of, dbias, n_bias, wave, lane); break;
+            default: wl_full<3, B4>(lds, o, dy_T, act_T, p0, p1, g_rows, a_rows, ks, C, c_stride, e_of, dbias, n_bias, wave, lane); break;
         }
         return;
     }
 #define WL_ARGS lds, o, dy_T, act_T, p0, p1, g_rows, a_rows, ks, C, c_stride, e_of, dbias, n_bias, wave, lane
-    if (o.M == 256 && o.N == 128) { wl_static<8, 4, 4, 2, 1>(WL_ARGS); return; }
-    if (o.M == 256 && o.N == 64) { wl_static<8, 2, 8, 1, 1>(WL_ARGS); return; }
-    if (o.M == 256 && o.N == 32) { wl_static<8, 1, 8, 1, 1>(WL_ARGS); return; }
-    if (o.M == 32 && o.N == 256) { wl_static<1, 8, 1, 8, 1>(WL_ARGS); return; }
-    if (o.M == 64 && o.N == 64) { wl_static<2, 2, 2, 1, 4>(WL_ARGS); return; }
+    if (o.M == 256 && o.N == 128) { wl_static<8, 4, 4, 2, 1, B4>(WL_ARGS); return; }
+    if (o.M == 256 && o.N == 64) { wl_static<8, 2, 8, 1, 1, B4>(WL_ARGS); return; }
+    if (o.M == 256 && o.N == 32) { wl_static<8, 1, 8, 1, 1, B4>(WL_ARGS); return; }
+    if (o.M == 32 && o.N == 256) { wl_static<1, 8, 1, 8, 1, B4>(WL_ARGS); return; }
+    if (o.M == 64 && o.N == 64) { wl_static<2, 2, 2, 1, 4, B4>(WL_ARGS); return; }
 #undef WL_ARGS
 #endif
     const int mts = o.M / 32, nts = o.N / 32, ntl = mts + nts;          // operand tiles per 32 points
     const int pps = ntl <= 4 ? 4 : (ntl <= 8 ? 2 : 1);                  // tile pairs per step (<= 32 KiB)
     const int np = pps * 2 * ntl;                                       // DMA pieces per step, <= 32
     const int n_w = (np - wave + WL_WAVES - 1) / WL_WAVES;              // ... of which this wave issues n_w (1..4)
-    const long strideA = rec8_tile_bytes(g_rows), strideB = rec8_tile_bytes(a_rows);
+    const long strideA = rec8_tile_bytes(g_rows), strideB = act_tile_bytes(a_rows, B4);
     lds_char* sc_lds = lds + WL_DEPTH * WL_STEP_BYTES;                  // [tile of the chunk][16]: A row blocks 0..7 | B row blocks 0..7
 
     // ---- this wave's DMA pieces: the same (tile of the step, operand tile) every step ------------------------
@@ -481,7 +519,9 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_mx_kernel(const WOp* ops, co
             const int u = p / ntl, tl = p - u * ntl;            // tile of the step, operand tile
             const bool isb = tl >= mts;
             const int r = isb ? o.b_row + 32 * (tl - mts) : o.a_row + 32 * tl;       // first row of the block: 1 KiB, copied linearly
-            src[k] = (const char*)(isb ? act_T : dy_T) + (long)r * 32 + 16 * lane;
+            // (an MX-fp4 activation block is 512 bytes: this general loop - shapes without a static path - still moves a KiB
+            // per block and takes the following 512 bytes along, inside the array: TrainBuffers pads act_T by a tile)
+            src[k] = (const char*)(isb ? act_T : dy_T) + (long)r * (isb ? act_row_bytes(B4) : 32) + 16 * lane;
             stride[k] = isb ? strideB : strideA;
             sub[k] = u;
             dst[k] = (unsigned)((u * ntl + tl) * 1024);
@@ -516,7 +556,7 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_mx_kernel(const WOp* ops, co
     // scale bytes in memory: [tile][rows x 32 | row block]; the MFMA takes the first tile's from the lanes kh = 0, the
     // second's from kh = 1
     const unsigned char* scA = (const unsigned char*)dy_T + (long)g_rows * 32 + (o.a_row >> 5);
-    const unsigned char* scB = (const unsigned char*)act_T + (long)a_rows * 32 + (o.b_row >> 5);
+    const unsigned char* scB = (const unsigned char*)act_T + (long)a_rows * act_row_bytes(B4) + (o.b_row >> 5);
     f32x16 acc[4][2], accb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -591,14 +631,17 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_mx_kernel(const WOp* ops, co
                     if (i < mt_n && (nt_n > 0 || (do_bias && i == cg))) a[i] = frag_tr8(b0 + (4 * rg + i) * 1024, b1 + (4 * rg + i) * 1024);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    if (j < nt_n) b[j] = frag_tr8(b0 + (mts + 2 * cg + j) * 1024, b1 + (mts + 2 * cg + j) * 1024);
+                    if (j < nt_n) {
+                        if constexpr (B4) b[j] = frag_tr4((kh ? b1 : b0) - rd + (mts + 2 * cg + j) * 1024 + (lane & 15) * 16 + ((lane >> 4) & 1) * 8);
+                        else b[j] = frag_tr8(b0 + (mts + 2 * cg + j) * 1024, b1 + (mts + 2 * cg + j) * 1024);
+                    }
 #endif
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         if (i < mt_n && j < nt_n)
-                            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[i], b[j], acc[i][j], 0, 0, 0, (int)(sa4 >> (8 * i)), 0,
+                            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[i], b[j], acc[i][j], 0, (B4 ? 4 : 0), 0, (int)(sa4 >> (8 * i)), 0,
                                                                                         (int)(sb2 >> (8 * j)));
                 if (do_bias) {
 #pragma unroll
@@ -635,21 +678,26 @@ __global__ __launch_bounds__(WL_THREADS) void wgrad_mx_kernel(const WOp* ops, co
             }
 }
 
-hipError_t launch_wgrad_bf16(int field, const WOp* ops_dev, const WItem* items_dev, int n_items, const void* dy_T,
+hipError_t launch_wgrad_bf16(int field, bool act_fp4, const WOp* ops_dev, const WItem* items_dev, int n_items, const void* dy_T,
                              const void* act_T, long NP, float* C, long c_stride, const int* e_of, float* dbias, int n_bias,
                              hipStream_t st) {
     constexpr int lds = WL_DEPTH * WL_STEP_BYTES + WL_SCALE_BYTES;
     static bool done = false;
     if (!done) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad_mx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_mx_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wgrad_mx_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         done = true;
     }
     if ((NP / 32) & 1) return hipErrorInvalidValue;          // tile pairs (the MFMA contracts two 32-point tiles)
     const bool torso = field == FIELD_TORSO;
     const int g_rows = torso ? GradMap::S_ROWS : GradMap::H_ROWS, a_rows = torso ? RecMap::S_ROWS : RecMap::H_ROWS;
-    hipLaunchKernelGGL(wgrad_mx_kernel, dim3(n_items), dim3(WL_THREADS), lds, st, ops_dev, items_dev, dy_T, act_T, NP / 32,
-                       g_rows, a_rows, C, c_stride, e_of, dbias, n_bias);
+    if (act_fp4)
+        hipLaunchKernelGGL(wgrad_mx_kernel<true>, dim3(n_items), dim3(WL_THREADS), lds, st, ops_dev, items_dev, dy_T, act_T, NP / 32,
+                           g_rows, a_rows, C, c_stride, e_of, dbias, n_bias);
+    else
+        hipLaunchKernelGGL(wgrad_mx_kernel<false>, dim3(n_items), dim3(WL_THREADS), lds, st, ops_dev, items_dev, dy_T, act_T, NP / 32,
+                           g_rows, a_rows, C, c_stride, e_of, dbias, n_bias);
     return hipGetLastError();
 }
 

@@ -77,6 +77,7 @@ def _load():
         "dfn_mlp_bwd": (i32, [i32, i32, vp, fp, fp, vp, lg, vp, vp]),
         "dfn_weight_grad": (i32, [i32, i32, vp, vp, lg, fp, fp, vp]),
         "dfn_weight_bias_grad": (i32, [i32, i32, vp, vp, lg, fp, fp, fp, vp]),
+        "dfn_weight_bias_grad_fmt": (i32, [i32, i32, i32, vp, vp, lg, fp, fp, fp, vp]),
         "dfn_bias_grad": (i32, [i32, i32, vp, lg, fp, fp, vp]),
         "dfn_zero_async": (i32, [vp, lg, vp]),
         "dfn_signal_grad": (i32, [i32, i32, fp, vp, lg, fp, fp, vp]),

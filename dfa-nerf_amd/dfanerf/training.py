@@ -113,7 +113,9 @@ class TrainBuffers:
         if self.tier == 1:
             # 16-bit tier: the recorded arrays are MX-fp8 (e4m3 + one E8M0 scale per 32-row block and 32-point tile, the
             # operand format of the block-scaled MFMA the weight-gradient GEMMs run on): [tile][dfn_train_rows(f, 6 / 7)] bytes
-            self.act = [torch.empty(self.NP // 32, rows(f, 6), dtype=torch.uint8, device=device) for f in (0, 1)]
+            # (act_T: MX-fp4 since round 4, 16 bytes per row and tile; + one tile: the weight-gradient GEMMs' 1-KiB DMA pieces
+            # may take up to 512 bytes behind an odd last 512-byte block along)
+            self.act = [torch.zeros(self.NP // 32 + 1, rows(f, 6), dtype=torch.uint8, device=device) for f in (0, 1)]
             self.dy = [torch.empty(self.NP // 32, rows(f, 7), dtype=torch.uint8, device=device) for f in (0, 1)]
         else:
             self.act = [torch.empty(rows(f, 0), self.NP, dtype=torch.float32, device=device) for f in (0, 1)]
@@ -792,7 +794,8 @@ class _PointBuffers:
         self.NP = NP = (n + 63) // 64 * 64 if tier == 1 else (n + 31) // 32 * 32
         rows = lambda w: check(lib.dfn_train_rows(field, w), "dfn_train_rows")
         if tier == 1:       # MX-fp8 (TrainBuffers); zeros: a padding tile the forward never writes must read as 0.0 x 2^-127
-            self.act = torch.zeros(NP // 32, rows(6), dtype=torch.uint8, device=device)
+            # (selector 8: the decoder-on-points recorder keeps e4m3 activations - dfn_weight_bias_grad_fmt(.., DFN_ACT_E4M3, ..))
+            self.act = torch.zeros(NP // 32, rows(8), dtype=torch.uint8, device=device)
             self.dy = torch.empty(NP // 32, rows(7), dtype=torch.uint8, device=device)
         else:
             self.act = torch.empty(rows(0), NP, dtype=torch.float32, device=device)
@@ -842,8 +845,8 @@ class DecoderTrainFn(torch.autograd.Function):
         g_flat = _grad_buffer(net, "_g_flat", net.flat, net.params)
         g_bias = torch.empty(pb.nb, dtype=torch.float32, device=dev)
         d_sig = torch.zeros(sg.numel(), dtype=torch.float32, device=dev)
-        check(lib.dfn_weight_bias_grad(t, f, _ptr(pb.dy), _ptr(pb.act), pb.NP, _ptr(pb.ws), _ptr(g_flat), _ptr(g_bias),
-                                       st), "dfn_weight_bias_grad")
+        check(lib.dfn_weight_bias_grad_fmt(t, f, 0, _ptr(pb.dy), _ptr(pb.act), pb.NP, _ptr(pb.ws), _ptr(g_flat), _ptr(g_bias),
+                                           st), "dfn_weight_bias_grad_fmt")       # (0 = DFN_ACT_E4M3)
         check(lib.dfn_fold_bias_bwd(t, f, _ptr(net.flat), _ptr(sg), _ptr(zs), _ptr(za), _ptr(g_bias), _ptr(g_flat),
                                     _ptr(d_sig), st), "dfn_fold_bias_bwd")
         net.deposit(g_flat, touched=_decoder_touched(net, (f,)))

@@ -207,6 +207,16 @@ int dfn_bias_grad(int tier, int field, const void* dy_T, long NP, float* workspa
  * tile of ones as well): same outputs, the gradient array is read once less. */
 int dfn_weight_bias_grad(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
                          float* grad_flat, float* dbias, void* stream);
+/* The same with the format of act_T as an argument (16-bit tier; ignored in the f32 tier).  The FUSED step (dfn_train_fwd /
+ * dfn_train_fwd_hier) records its activations as MX-fp4 - e2m1 nibbles, 16 bytes per row and tile: dfn_train_rows(field, 6)
+ * bytes per tile, and the caller allocates one tile more than NP / 32 (1-KiB DMA pieces) - because a weight gradient of that
+ * step sums >= 131,072 points and the rounding averages out.  dfn_decoder_train_fwd (Decoder.forward on
+ * explicit points under autograd: any number of points) records e4m3 - 32 bytes per row and tile, dfn_train_rows(field, 8).
+ * dfn_weight_grad / dfn_weight_bias_grad take the fused step's format. */
+#define DFN_ACT_E4M3 0
+#define DFN_ACT_E2M1 1
+int dfn_weight_bias_grad_fmt(int tier, int field, int act_format, const void* dy_T, const void* act_T, long NP, float* workspace,
+                             float* grad_flat, float* dbias, void* stream);
 /* Backward of dfn_fold_bias (the fold is linear; upstream it is the autograd of DEC:293-295, 311, 318, 332):
  * dbias [dfn_bias_floats] -> grad_flat (+=, layout of `params`: fc_z / fc_z_skips / fc_z_view, the signal columns
  * of fc_in / fc_p_skips / the deformation nets, every bias) and d_signal (+=, [96] head / [42] torso; may be NULL).
