@@ -108,7 +108,15 @@ void wgrad_items(const std::vector<WOpHost>& ops, int field, int target_wgs, std
     // round trip whatever it moves)
     // (a GEMM with N = 0 only sums the rows of its dY block; it runs the general loop: measured 51 us where a 256 x 256 GEMM
     // takes 142 - tools/wl_trace.py)
-    auto cost = [](const WOpHost& o) { return o.N == 0 ? 3.0 * o.M : (double)std::max(o.M + o.N, 96); };
+    // Measured per-workgroup time x slices (tools/wl_trace.py with the MX-fp4 activations, us x slices / 5): a dY row costs 1, an
+    // activation row 1/2 (32 vs 16 bytes per point tile) - 256 x 256: 380, 256 x 128: 326, 256 x 64: 286, 64 x 64: 94 - except
+    // the shapes whose steps are latency- rather than byte-bound: 256 x 32: 244, 32 x 256: 164, N = 0 (M = 64): 180
+    auto cost = [](const WOpHost& o) {
+        if (o.N == 0) return 2.8 * o.M;
+        if (o.M == 256 && o.N == 32) return 245.0;
+        if (o.M == 32 && o.N == 256) return 170.0;
+        return (double)std::max(o.M + o.N / 2, 90);
+    };
     double total = 0;
     for (const WOpHost& o : ops) total += cost(o);
     n_of.assign(ops.size(), 1);
