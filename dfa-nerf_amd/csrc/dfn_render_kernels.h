@@ -156,7 +156,12 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
 #ifndef DFN_PIPE
 #define DFN_PIPE 1
 #endif
-    typedef CtxT<TRAIN != 0, TRAIN == 0, TRAIN != 0, (DFN_PIPE != 0) && TRAIN == 0 && !TWO, TRAIN != 0 && ACT_FP4> CtxK;      // (fused step: act_T in MX-fp4)
+#ifndef DFN_PIPE_TWO         // 1: pipelined layers in the two-field kernel too.  Round 4, measured: 256 VGPRs + 15 spilled (60 B of scratch: the
+                             // build's no-scratch check for the 16-bit inference kernels would refuse it), C3 72.39 -> 71.86 ms (-0.7 %,
+                             // interleaved, three rounds): not adopted
+#define DFN_PIPE_TWO 0
+#endif
+    typedef CtxT<TRAIN != 0, TRAIN == 0, TRAIN != 0, (DFN_PIPE != 0) && TRAIN == 0 && (!TWO || DFN_PIPE_TWO != 0), TRAIN != 0 && ACT_FP4> CtxK;      // (fused step: act_T in MX-fp4)
     CtxK ctx = {lds, wave, lane, lane >> 5, {}};
     constexpr bool two = TWO;
     const int NF = TRAIN == 1 ? 0 : F.n_fine;     // TRAIN == 1: the training forward is the reference's coarse renderer
