@@ -522,9 +522,9 @@ int dfn_mse_loss_u8(const float* rgb_head, const float* rgb_com, const uint8_t* 
     return DFN_OK;
 }
 
-int dfn_composite_bwd(const DfnFrame* frame, const int32_t* pix_index, const float* bg_f32, const uint8_t* bg_u8,
-                      const float* samples, const float* d_rgb_head, const float* d_rgb_com, float* dsamples,
-                      void* stream) {
+static int composite_bwd_impl(const DfnFrame* frame, const int32_t* pix_index, const float* bg_f32, const uint8_t* bg_u8,
+                              const float* samples, const float* d_rgb_head, const float* d_rgb_com, float* dsamples,
+                              float* zero_buf, long zero_floats, void* stream) {
     if (!frame || !samples || !d_rgb_head || !dsamples || (!bg_f32 && !bg_u8))
         return fail(DFN_E_ARG, "dfn_composite_bwd: bad argument");
     if (frame->n_coarse != 64 || frame->n_fine != 0) return fail(DFN_E_ARG, "dfn_composite_bwd: 64 coarse samples only");
@@ -540,14 +540,28 @@ int dfn_composite_bwd(const DfnFrame* frame, const int32_t* pix_index, const flo
     A.dsamples = dsamples;
     A.z_all = nullptr;
     A.ranks = nullptr;
+    A.zero_buf = zero_buf;
+    A.zero_floats = zero_buf ? zero_floats : 0;
     hipError_t err = launch_composite_bwd(A, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "composite_bwd_kernel");
     return DFN_OK;
 }
+int dfn_composite_bwd(const DfnFrame* frame, const int32_t* pix_index, const float* bg_f32, const uint8_t* bg_u8,
+                      const float* samples, const float* d_rgb_head, const float* d_rgb_com, float* dsamples,
+                      void* stream) {
+    return composite_bwd_impl(frame, pix_index, bg_f32, bg_u8, samples, d_rgb_head, d_rgb_com, dsamples, nullptr, 0, stream);
+}
+int dfn_composite_bwd_z(const DfnFrame* frame, const int32_t* pix_index, const float* bg_f32, const uint8_t* bg_u8,
+                        const float* samples, const float* d_rgb_head, const float* d_rgb_com, float* dsamples,
+                        float* zero_buf, long zero_floats, void* stream) {
+    if (zero_buf && (((unsigned long)zero_buf & 15) || zero_floats < 0))
+        return fail(DFN_E_ARG, "dfn_composite_bwd_z: zero_buf must be 16-byte aligned");
+    return composite_bwd_impl(frame, pix_index, bg_f32, bg_u8, samples, d_rgb_head, d_rgb_com, dsamples, zero_buf, zero_floats, stream);
+}
 
-int dfn_composite_bwd_hier(const DfnFrame* frame, const int32_t* pix_index, const float* bg_f32, const uint8_t* bg_u8,
-                           const float* samples, const float* z_all, const uint8_t* ranks, const float* d_rgb_head,
-                           const float* d_rgb_com, float* dsamples, void* stream) {
+static int composite_bwd_hier_impl(const DfnFrame* frame, const int32_t* pix_index, const float* bg_f32, const uint8_t* bg_u8,
+                                   const float* samples, const float* z_all, const uint8_t* ranks, const float* d_rgb_head,
+                                   const float* d_rgb_com, float* dsamples, float* zero_buf, long zero_floats, void* stream) {
     if (!frame || !samples || !z_all || !ranks || !d_rgb_head || !dsamples || (!bg_f32 && !bg_u8))
         return fail(DFN_E_ARG, "dfn_composite_bwd_hier: bad argument");
     if (frame->n_coarse != 64 || (frame->n_fine != 64 && frame->n_fine != 128))
@@ -564,9 +578,25 @@ int dfn_composite_bwd_hier(const DfnFrame* frame, const int32_t* pix_index, cons
     A.dsamples = dsamples;
     A.z_all = z_all;
     A.ranks = ranks;
+    A.zero_buf = zero_buf;
+    A.zero_floats = zero_buf ? zero_floats : 0;
     hipError_t err = launch_composite_bwd_hier(A, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "composite_bwd_hier_kernel");
     return DFN_OK;
+}
+int dfn_composite_bwd_hier(const DfnFrame* frame, const int32_t* pix_index, const float* bg_f32, const uint8_t* bg_u8,
+                           const float* samples, const float* z_all, const uint8_t* ranks, const float* d_rgb_head,
+                           const float* d_rgb_com, float* dsamples, void* stream) {
+    return composite_bwd_hier_impl(frame, pix_index, bg_f32, bg_u8, samples, z_all, ranks, d_rgb_head, d_rgb_com, dsamples, nullptr, 0,
+                                   stream);
+}
+int dfn_composite_bwd_hier_z(const DfnFrame* frame, const int32_t* pix_index, const float* bg_f32, const uint8_t* bg_u8,
+                             const float* samples, const float* z_all, const uint8_t* ranks, const float* d_rgb_head,
+                             const float* d_rgb_com, float* dsamples, float* zero_buf, long zero_floats, void* stream) {
+    if (zero_buf && (((unsigned long)zero_buf & 15) || zero_floats < 0))
+        return fail(DFN_E_ARG, "dfn_composite_bwd_hier_z: zero_buf must be 16-byte aligned");
+    return composite_bwd_hier_impl(frame, pix_index, bg_f32, bg_u8, samples, z_all, ranks, d_rgb_head, d_rgb_com, dsamples, zero_buf,
+                                   zero_floats, stream);
 }
 
 int dfn_mlp_bwd(int tier, int field, const void* packed_T, const float* samples, const float* dsamples,

@@ -28,6 +28,10 @@ struct CompositeBwdArgs {
     // hierarchical step only (launch_composite_bwd_hier): what the forward left about the merge
     const float* z_all;         // [rays][S] merged, sorted depths
     const unsigned char* ranks; // [rays][S] merged rank of evaluated point i
+    // optional: a buffer this launch also fills with zeros (the step's gradient buffer: its own fill launch was 9 us + a gap
+    // between the compositing backward and the dX chain)
+    float* zero_buf;
+    long zero_floats;
 };
 
 struct WOp {                    // one weight-gradient GEMM: C[M x N] = dy_T[a_row.., :] * act_T[b_row.., :]^T

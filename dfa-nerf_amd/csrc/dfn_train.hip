@@ -5,6 +5,7 @@
 // Differentiates run_nerf_com_trainExpLater.py:855-907 (two fields, coarse samples, composite, weights,
 // weighted colour sums) and decoder.py:277-349 / 109-134.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "dfn_bwd_kernel.h"
 
 namespace dfn {
@@ -66,7 +67,15 @@ __device__ __forceinline__ WB weights_bwd(float sigma, float dist, float q, int 
     return r;
 }
 
+__device__ __forceinline__ void composite_zero_fill(const CompositeBwdArgs& A) {
+    if (!A.zero_buf) return;
+    const long n4 = A.zero_floats >> 2, stride = (long)gridDim.x * blockDim.x;
+    float4* q = (float4*)A.zero_buf;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (blockIdx.x == 0 && threadIdx.x < (A.zero_floats & 3)) A.zero_buf[(n4 << 2) + threadIdx.x] = 0.f;
+}
 __global__ void composite_bwd_kernel(const CompositeBwdArgs A) {
+    composite_zero_fill(A);
     const int lane = threadIdx.x & 63;
     const long ray = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= A.frame.ray_count) return;
@@ -183,6 +192,7 @@ template <int K>
 __global__ __launch_bounds__(256) void composite_bwd_hier_kernel(const CompositeBwdArgs A) {
     constexpr int S = 64 * K;
     __shared__ unsigned char inv_s[4][S];
+    composite_zero_fill(A);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long ray = (long)blockIdx.x * 4 + wv;
     if (ray >= A.frame.ray_count) return;
@@ -599,17 +609,23 @@ hipError_t launch_sample_pixels(int H, int W, int n, int rect_num, const int* re
 // run_nerf_com_trainExpLater.py:791-800 (target[select_coords] of the head and the composite image), :902-907
 // (img2mse(rgb_com_torso, target_com) + img2mse(rgb_head, target_head)) and what torch autograd makes of them
 // (d loss / d rgb = 2 (rgb - target) / (3 n)).  Targets are uint8 images resident on the device (/ 255 like LOAD:58-60).
-// One workgroup, fixed reduction order: thread t adds its elements t, t + 1024, ... in sequence, then an LDS tree.
+// Fixed reduction order, several workgroups (round 4; one workgroup walked its six elements per thread through six dependent
+// gathers: 17 us between the forward and the dX chain): block b owns elements [1024 b, 1024 b + 1024), one per thread, an LDS
+// tree per block, and the LAST block to finish (a ticket) adds the blocks' partial sums in block order - the same bits run to run.
+constexpr int MSE_MAX_BLOCKS = 64;
+__device__ float g_mse_part[2][MSE_MAX_BLOCKS];
+__device__ unsigned g_mse_ticket = 0;
 __global__ __launch_bounds__(1024) void mse_loss_kernel(const float* __restrict__ rgb_head, const float* __restrict__ rgb_com,
                                                         const unsigned char* __restrict__ img_head,
                                                         const unsigned char* __restrict__ img_com,
                                                         const int* __restrict__ pix, int n, float* losses, float* d_head,
                                                         float* d_com) {
     __shared__ float red[2][1024];
+    __shared__ bool is_last;
     const int t = threadIdx.x, total = 3 * n;
     const float scale = __fdiv_rn(2.0f, (float)total);
     float sh = 0.f, sc = 0.f;
-    for (int e = t; e < total; e += 1024) {
+    for (int e = blockIdx.x * 1024 + t; e < total; e += gridDim.x * 1024) {      // (one trip unless n > 64 x 1024 / 3)
         const int r = e / 3, c = e - 3 * r;
         const size_t src = (size_t)pix[r] * 3 + c;
         const float dh = __fsub_rn(rgb_head[e], __fdiv_rn((float)img_head[src], 255.0f));
@@ -630,15 +646,30 @@ __global__ __launch_bounds__(1024) void mse_loss_kernel(const float* __restrict_
         __syncthreads();
     }
     if (t == 0) {
-        losses[0] = __fdiv_rn(red[0][0], (float)total);      // img2mse(rgb_head, target_head)
-        losses[1] = __fdiv_rn(red[1][0], (float)total);      // img2mse(rgb_com, target_com)
-        losses[2] = __fadd_rn(losses[1], losses[0]);          // the step's loss (MAIN:902-907: loss_com + loss_head)
+        g_mse_part[0][blockIdx.x] = red[0][0];
+        g_mse_part[1][blockIdx.x] = red[1][0];
+        __threadfence();
+        is_last = atomicAdd(&g_mse_ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (is_last && t == 0) {
+        __threadfence();
+        float a = 0.f, b = 0.f;
+        for (unsigned k = 0; k < gridDim.x; ++k) {          // block order
+            a = __fadd_rn(a, ((volatile float*)g_mse_part[0])[k]);
+            b = __fadd_rn(b, ((volatile float*)g_mse_part[1])[k]);
+        }
+        losses[0] = __fdiv_rn(a, (float)total);      // img2mse(rgb_head, target_head)
+        losses[1] = __fdiv_rn(b, (float)total);      // img2mse(rgb_com, target_com)
+        losses[2] = __fadd_rn(losses[1], losses[0]);  // the step's loss (MAIN:902-907: loss_com + loss_head)
+        g_mse_ticket = 0;                             // (launches on one stream do not overlap: ready for the next one)
     }
 }
 hipError_t launch_mse_loss(const float* rgb_head, const float* rgb_com, const unsigned char* img_head,
                            const unsigned char* img_com, const int* pix, int n, float* losses, float* d_head, float* d_com,
                            hipStream_t st) {
-    hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(1024), 0, st, rgb_head, rgb_com, img_head, img_com, pix, n, losses,
+    const int blocks = std::min(MSE_MAX_BLOCKS, std::max(1, (3 * n + 1023) / 1024));
+    hipLaunchKernelGGL(mse_loss_kernel, dim3(blocks), dim3(1024), 0, st, rgb_head, rgb_com, img_head, img_com, pix, n, losses,
                        d_head, d_com);
     return hipGetLastError();
 }

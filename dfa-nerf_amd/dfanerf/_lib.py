@@ -71,9 +71,11 @@ def _load():
         "dfn_train_fwd": (i32, [i32, C.POINTER(DfnFrame), vp, vp, fp, fp, fp, vp, ip, fp, fp, fp, vp, vp, vp, vp, vp]),
         "dfn_train_fwd_hier": (i32, [i32, C.POINTER(DfnFrame), vp, vp, fp, fp, fp, vp, ip, fp, fp, fp, vp, vp, vp, vp, fp, vp, vp]),
         "dfn_composite_bwd_hier": (i32, [C.POINTER(DfnFrame), ip, fp, vp, fp, fp, vp, fp, fp, fp, vp]),
+        "dfn_composite_bwd_hier_z": (i32, [C.POINTER(DfnFrame), ip, fp, vp, fp, fp, vp, fp, fp, fp, fp, lg, vp]),
         "dfn_sample_pixels": (i32, [i32, i32, i32, i32, ip, C.c_uint64, C.c_uint64, ip, ip, vp]),
         "dfn_mse_loss_u8": (i32, [fp, fp, vp, vp, ip, i32, fp, fp, fp, vp]),
         "dfn_composite_bwd": (i32, [C.POINTER(DfnFrame), ip, fp, vp, fp, fp, fp, fp, vp]),
+        "dfn_composite_bwd_z": (i32, [C.POINTER(DfnFrame), ip, fp, vp, fp, fp, fp, fp, fp, lg, vp]),
         "dfn_mlp_bwd": (i32, [i32, i32, vp, fp, fp, vp, lg, vp, vp]),
         "dfn_weight_grad": (i32, [i32, i32, vp, vp, lg, fp, fp, vp]),
         "dfn_weight_bias_grad": (i32, [i32, i32, vp, vp, lg, fp, fp, fp, vp]),

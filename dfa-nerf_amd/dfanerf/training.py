@@ -216,13 +216,22 @@ def _fused_backward(ctx, d_h, d_c):
     d_c = d_c.contiguous().float()
     bg_f32 = bg if bg.dtype == torch.float32 else None
     bg_u8 = bg if bg.dtype == torch.uint8 else None
+    # the step's flat gradient buffer: the SAME one every step while the parameters' .grad are None when the backward starts
+    # (_grad_buffer) - then the compositing backward's launch zeroes it on the way (dfn_composite_bwd*_z: its own fill was a
+    # 9-us launch + a gap in front of the dX chain); a fresh buffer (gradient accumulation) comes zeroed from the allocator
+    g_flat = getattr(buf.net, "_g_flat", None)
+    reuse = g_flat is not None and g_flat.shape == flat.shape and g_flat.device == dev and \
+        not any(p.grad is not None for p in buf.params)
+    if not reuse:
+        g_flat = _grad_buffer(buf.net, "_g_flat", flat, buf.params)
+    zb, zn = (_ptr(g_flat), g_flat.numel()) if reuse else (None, 0)
     if buf.n_fine:
-        check(lib.dfn_composite_bwd_hier(C.byref(frame), _ptr(ctx.pix), _ptr(bg_f32), _ptr(bg_u8), _ptr(buf.samples),
-                                         _ptr(buf.z_all), _ptr(buf.ranks), _ptr(d_h), _ptr(d_c), _ptr(buf.dsamples), st),
-              "dfn_composite_bwd_hier")
+        check(lib.dfn_composite_bwd_hier_z(C.byref(frame), _ptr(ctx.pix), _ptr(bg_f32), _ptr(bg_u8), _ptr(buf.samples),
+                                           _ptr(buf.z_all), _ptr(buf.ranks), _ptr(d_h), _ptr(d_c), _ptr(buf.dsamples), zb, zn,
+                                           st), "dfn_composite_bwd_hier_z")
     else:
-        check(lib.dfn_composite_bwd(C.byref(frame), _ptr(ctx.pix), _ptr(bg_f32), _ptr(bg_u8), _ptr(buf.samples),
-                                    _ptr(d_h), _ptr(d_c), _ptr(buf.dsamples), st), "dfn_composite_bwd")
+        check(lib.dfn_composite_bwd_z(C.byref(frame), _ptr(ctx.pix), _ptr(bg_f32), _ptr(bg_u8), _ptr(buf.samples),
+                                      _ptr(d_h), _ptr(d_c), _ptr(buf.dsamples), zb, zn, st), "dfn_composite_bwd_z")
     g_bias = torch.empty(buf.nb[0] + buf.nb[1], dtype=torch.float32, device=dev)
     main = torch.cuda.current_stream(dev)
     # (with more than one rank RCCL brings a fifth stream; the package asks the runtime for eight hardware queues then
@@ -232,9 +241,8 @@ def _fused_backward(ctx, d_h, d_c):
     if over and getattr(buf, "_side", None) is None:
         buf._side = _side_stream(dev, role="wgrad")
     side = buf._side if over else None
-    # zeroed HERE, on the main stream: a many-workgroup fill on a side stream starves behind the dX chain's workgroups
-    # (measured: 340 us for this 4-MB fill, and the head field's weight gradients queue behind it)
-    g_flat = _grad_buffer(buf.net, "_g_flat", flat, buf.params)
+    # (g_flat: zeroed above, on the main stream: a many-workgroup fill on a side stream starves behind the dX chain's
+    # workgroups - measured: 340 us for this 4-MB fill, and the head field's weight gradients queue behind it)
     if _OVERLAP:
         if getattr(buf, "_sig_streams", None) is None:
             buf._sig_streams = (_side_stream(dev, True, "sig_a"), _side_stream(dev, True, "sig_p"))

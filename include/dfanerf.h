@@ -197,6 +197,14 @@ int dfn_mse_loss_u8(const float* rgb_head, const float* rgb_com, const uint8_t* 
 int dfn_composite_bwd(const DfnFrame* frame, const int32_t* pix_index, const float* bg_f32, const uint8_t* bg_u8,
                       const float* samples, const float* d_rgb_head, const float* d_rgb_com, float* dsamples,
                       void* stream);
+/* The two compositing backward calls with a buffer the same launch fills with zeros (zero_floats floats at zero_buf, 16-byte
+ * aligned; NULL = none): the step's flat gradient buffer, whose own fill launch sat between this call and the dX chain. */
+int dfn_composite_bwd_z(const DfnFrame* frame, const int32_t* pix_index, const float* bg_f32, const uint8_t* bg_u8,
+                        const float* samples, const float* d_rgb_head, const float* d_rgb_com, float* dsamples,
+                        float* zero_buf, long zero_floats, void* stream);
+int dfn_composite_bwd_hier_z(const DfnFrame* frame, const int32_t* pix_index, const float* bg_f32, const uint8_t* bg_u8,
+                             const float* samples, const float* z_all, const uint8_t* ranks, const float* d_rgb_head,
+                             const float* d_rgb_com, float* dsamples, float* zero_buf, long zero_floats, void* stream);
 int dfn_mlp_bwd(int tier, int field, const void* packed_T, const float* samples, const float* dsamples,
                 const uint32_t* masks, long NP, void* dy_T, void* stream);
 int dfn_weight_grad(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
