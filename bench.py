@@ -251,22 +251,38 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
 
     host_t = [0.0] * 5 if os.environ.get("DFN_BENCH_HOST_TIMING") else None      # developer switch: host time by section
 
+    # DFN_BENCH_GPU_PHASES=1 (developer switch): events on the main stream at the phase boundaries of every step - untraced GPU
+    # time of forward (incl. waiting for the conditioning signals) / backward / optimizer.  NOT free: four timing events per
+    # step took the step from 1.00 to 1.37 ms (an event record in a queue is a barrier packet with a system-scope release:
+    # ~13 us between two kernels, tools/event_cost.py) - read the split, not the sum
+    phases = [] if os.environ.get("DFN_BENCH_GPU_PHASES") else None
+
+    def mark(tag):
+        if phases is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            phases.append((tag, e))
+
     def step():
         c = time.perf_counter
         t0 = c()
+        mark("start")
         img_i = int(rng_frame.randint(0, 8))
         pix = sampler.draw()
         loss, *_ = run_nerf.train_step_loss_hip(mods, ds, 0, img_i, pix, gt[img_i][0], gt[img_i][1], zs, za, gstep, a,
                                                 8, embed_fn, ds[0]["poses"][0], buf)
+        mark("fwd")
         t1 = c()
         for o in opts.values():
             o.zero_grad()
         t2 = c()
         training.backward(loss, buf)             # loss.backward() started with the buffers' unit gradient, as run_nerf.train does
+        mark("bwd")
         t3 = c()
         if bucket is not None:
             bucket.all_reduce_()
         run_nerf.optimizer_steps(opts, gstep, a)
+        mark("opt")
         t4 = c()
         run_nerf.update_lrate(opts, gstep, a)
         if host_t is not None:
@@ -307,7 +323,19 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
     for _ in range(warmup):
         step()
     host_report(max(warmup, 1))
+    if phases is not None:
+        phases.clear()
     dt = timed(steps)
+    if phases is not None and rank == 0:
+        acc, n4 = {}, len(phases) // 4
+        for k in range(1, n4):                       # (skip the first step)
+            (_, e0), (_, e1), (_, e2), (_, e3) = phases[4 * k:4 * k + 4]
+            prev = phases[4 * k - 1][1]
+            for tag, a_, b_ in (("idle before the step's first event", prev, e0), ("draw + signals wait + prepare + forward + loss", e0, e1),
+                                ("backward", e1, e2), ("reduce + Adam", e2, e3)):
+                acc[tag] = acc.get(tag, 0.0) + a_.elapsed_time(b_)
+        print("GPU ms/step on the main stream: " + ", ".join(f"{k_} {v / (n4 - 1):.4f}" for k_, v in acc.items()) +
+              f"  (sum {sum(acc.values()) / (n4 - 1):.4f})", file=sys.stderr)
     rank_ms = all_ranks(state["dt_rank"] / steps * 1e3, world, dev)
     host_report(steps)
     out = None
