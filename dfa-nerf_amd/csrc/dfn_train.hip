@@ -609,31 +609,48 @@ hipError_t launch_sample_pixels(int H, int W, int n, int rect_num, const int* re
 // run_nerf_com_trainExpLater.py:791-800 (target[select_coords] of the head and the composite image), :902-907
 // (img2mse(rgb_com_torso, target_com) + img2mse(rgb_head, target_head)) and what torch autograd makes of them
 // (d loss / d rgb = 2 (rgb - target) / (3 n)).  Targets are uint8 images resident on the device (/ 255 like LOAD:58-60).
-// Fixed reduction order, several workgroups (round 4; one workgroup walked its six elements per thread through six dependent
-// gathers: 17 us between the forward and the dX chain): block b owns elements [1024 b, 1024 b + 1024), one per thread, an LDS
-// tree per block, and the LAST block to finish (a ticket) adds the blocks' partial sums in block order - the same bits run to run.
-constexpr int MSE_MAX_BLOCKS = 64;
-__device__ float g_mse_part[2][MSE_MAX_BLOCKS];
-__device__ unsigned g_mse_ticket = 0;
+// One workgroup, fixed reduction order: thread t adds its elements t, t + 1024, ... in sequence, then an LDS tree.  Round 4:
+// the gathers of eight elements are in flight together (the loop used to walk pix -> image byte -> next element as six
+// DEPENDENT round trips per thread: 17 us between the forward and the dX chain); the additions keep their order, so the
+// results are bit for bit what they were.  (A several-workgroup version with a last-block ticket was 2 us faster and needed a
+// device-global counter: the library keeps no mutable global state, include/dfanerf.h.)
 __global__ __launch_bounds__(1024) void mse_loss_kernel(const float* __restrict__ rgb_head, const float* __restrict__ rgb_com,
                                                         const unsigned char* __restrict__ img_head,
                                                         const unsigned char* __restrict__ img_com,
                                                         const int* __restrict__ pix, int n, float* losses, float* d_head,
                                                         float* d_com) {
     __shared__ float red[2][1024];
-    __shared__ bool is_last;
     const int t = threadIdx.x, total = 3 * n;
     const float scale = __fdiv_rn(2.0f, (float)total);
     float sh = 0.f, sc = 0.f;
-    for (int e = blockIdx.x * 1024 + t; e < total; e += gridDim.x * 1024) {      // (one trip unless n > 64 x 1024 / 3)
-        const int r = e / 3, c = e - 3 * r;
-        const size_t src = (size_t)pix[r] * 3 + c;
-        const float dh = __fsub_rn(rgb_head[e], __fdiv_rn((float)img_head[src], 255.0f));
-        const float dc = __fsub_rn(rgb_com[e], __fdiv_rn((float)img_com[src], 255.0f));
-        sh = __fadd_rn(sh, __fmul_rn(dh, dh));
-        sc = __fadd_rn(sc, __fmul_rn(dc, dc));
-        d_head[e] = __fmul_rn(scale, dh);
-        d_com[e] = __fmul_rn(scale, dc);
+    constexpr int B = 8;
+    for (int e0 = t; e0 < total; e0 += B * 1024) {
+        float rh[B], rc[B];
+        unsigned char th[B], tc[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) {                    // every load of the batch before any use
+            const int e = e0 + k * 1024;
+            if (e < total) {
+                const int r = e / 3, c = e - 3 * r;
+                const size_t src = (size_t)pix[r] * 3 + c;
+                th[k] = img_head[src];
+                tc[k] = img_com[src];
+                rh[k] = rgb_head[e];
+                rc[k] = rgb_com[e];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            const int e = e0 + k * 1024;
+            if (e < total) {
+                const float dh = __fsub_rn(rh[k], __fdiv_rn((float)th[k], 255.0f));
+                const float dc = __fsub_rn(rc[k], __fdiv_rn((float)tc[k], 255.0f));
+                sh = __fadd_rn(sh, __fmul_rn(dh, dh));
+                sc = __fadd_rn(sc, __fmul_rn(dc, dc));
+                d_head[e] = __fmul_rn(scale, dh);
+                d_com[e] = __fmul_rn(scale, dc);
+            }
+        }
     }
     red[0][t] = sh;
     red[1][t] = sc;
@@ -646,30 +663,15 @@ __global__ __launch_bounds__(1024) void mse_loss_kernel(const float* __restrict_
         __syncthreads();
     }
     if (t == 0) {
-        g_mse_part[0][blockIdx.x] = red[0][0];
-        g_mse_part[1][blockIdx.x] = red[1][0];
-        __threadfence();
-        is_last = atomicAdd(&g_mse_ticket, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (is_last && t == 0) {
-        __threadfence();
-        float a = 0.f, b = 0.f;
-        for (unsigned k = 0; k < gridDim.x; ++k) {          // block order
-            a = __fadd_rn(a, ((volatile float*)g_mse_part[0])[k]);
-            b = __fadd_rn(b, ((volatile float*)g_mse_part[1])[k]);
-        }
-        losses[0] = __fdiv_rn(a, (float)total);      // img2mse(rgb_head, target_head)
-        losses[1] = __fdiv_rn(b, (float)total);      // img2mse(rgb_com, target_com)
-        losses[2] = __fadd_rn(losses[1], losses[0]);  // the step's loss (MAIN:902-907: loss_com + loss_head)
-        g_mse_ticket = 0;                             // (launches on one stream do not overlap: ready for the next one)
+        losses[0] = __fdiv_rn(red[0][0], (float)total);      // img2mse(rgb_head, target_head)
+        losses[1] = __fdiv_rn(red[1][0], (float)total);      // img2mse(rgb_com, target_com)
+        losses[2] = __fadd_rn(losses[1], losses[0]);          // the step's loss (MAIN:902-907: loss_com + loss_head)
     }
 }
 hipError_t launch_mse_loss(const float* rgb_head, const float* rgb_com, const unsigned char* img_head,
                            const unsigned char* img_com, const int* pix, int n, float* losses, float* d_head, float* d_com,
                            hipStream_t st) {
-    const int blocks = std::min(MSE_MAX_BLOCKS, std::max(1, (3 * n + 1023) / 1024));
-    hipLaunchKernelGGL(mse_loss_kernel, dim3(blocks), dim3(1024), 0, st, rgb_head, rgb_com, img_head, img_com, pix, n, losses,
+    hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(1024), 0, st, rgb_head, rgb_com, img_head, img_com, pix, n, losses,
                        d_head, d_com);
     return hipGetLastError();
 }

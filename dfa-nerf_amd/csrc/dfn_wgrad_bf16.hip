@@ -399,6 +399,7 @@ DFN_DEV void wl_static(lds_char* lds, const WOp& o, const void* dy_T, const void
         __builtin_amdgcn_s_barrier();
         float DFN_LDS* red = (float DFN_LDS*)lds;
         constexpr int PER_WAVE = (TM * TN + TM) * 16 * 64;               // floats: [tile or bias tile][register][lane]
+        static_assert(PER_WAVE * 4 * WL_WAVES <= WL_DEPTH * WL_STEP_BYTES, "the partial sums fit the (idle) ring");
         if (kw > 0) {
             float DFN_LDS* mine = red + (long)wave * PER_WAVE;
 #pragma unroll
