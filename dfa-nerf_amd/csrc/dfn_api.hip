@@ -881,31 +881,51 @@ int dfn_encode_signal_torso(const float* att_params, const float* poses, int pos
     return DFN_OK;
 }
 
-int dfn_encode_signal_bwd(const float* aud_params, const float* exp_params, const float* att_params, const float* auds,
-                          const float* exps, int n_total, int frame, int smo_size, const float* d_out, float* g_aud,
-                          float* g_exp, float* g_att, void* stream) {
+static int encode_signal_bwd_impl(const float* aud_params, const float* exp_params, const float* att_params, const float* auds,
+                                  const float* exps, int n_total, int frame, int smo_size, const float* d_out, float* g_aud,
+                                  float* g_exp, float* g_att, bool set, void* stream) {
     if (!aud_params || !exp_params || !auds || !exps || !d_out || !g_aud || !g_exp || n_total <= 0)
         return fail(DFN_E_ARG, "dfn_encode_signal_bwd: bad argument");
     if (smo_size < 0 || smo_size > 8 || (smo_size & 1)) return fail(DFN_E_ARG, "dfn_encode_signal_bwd: smo_size must be 0, 2, 4, 6 or 8");
     if (smo_size > 0 && (!att_params || !g_att)) return fail(DFN_E_ARG, "dfn_encode_signal_bwd: attention buffers missing");
     hipError_t err = launch_encode_signal_bwd(aud_params, exp_params, att_params, auds, exps, n_total, frame, smo_size,
-                                              d_out, g_aud, g_exp, g_att, (hipStream_t)stream);
+                                              d_out, g_aud, g_exp, g_att, set, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "encode_signal_bwd_kernel");
     return DFN_OK;
 }
+int dfn_encode_signal_bwd(const float* aud_params, const float* exp_params, const float* att_params, const float* auds,
+                          const float* exps, int n_total, int frame, int smo_size, const float* d_out, float* g_aud,
+                          float* g_exp, float* g_att, void* stream) {
+    return encode_signal_bwd_impl(aud_params, exp_params, att_params, auds, exps, n_total, frame, smo_size, d_out, g_aud, g_exp,
+                                  g_att, false, stream);
+}
+int dfn_encode_signal_bwd_set(const float* aud_params, const float* exp_params, const float* att_params, const float* auds,
+                              const float* exps, int n_total, int frame, int smo_size, const float* d_out, float* g_aud,
+                              float* g_exp, float* g_att, void* stream) {
+    return encode_signal_bwd_impl(aud_params, exp_params, att_params, auds, exps, n_total, frame, smo_size, d_out, g_aud, g_exp,
+                                  g_att, true, stream);
+}
 
-int dfn_encode_signal_torso_bwd(const float* att_params, const float* poses, int pose_stride, int n_total, int frame,
-                                int smo_size, const float* d_out, float* g_att, void* stream) {
+static int encode_signal_torso_bwd_impl(const float* att_params, const float* poses, int pose_stride, int n_total, int frame,
+                                        int smo_size, const float* d_out, float* g_att, bool set, void* stream) {
     if (!poses || !d_out || n_total <= 0 || (pose_stride != 12 && pose_stride != 16))
         return fail(DFN_E_ARG, "dfn_encode_signal_torso_bwd: bad argument");
     if (smo_size < 0 || smo_size > 8 || (smo_size & 1))
         return fail(DFN_E_ARG, "dfn_encode_signal_torso_bwd: smo_size must be 0, 2, 4, 6 or 8");
     if (smo_size == 0) return DFN_OK;          // no parameter takes part before --nosmo_iters
     if (!att_params || !g_att) return fail(DFN_E_ARG, "dfn_encode_signal_torso_bwd: attention buffers missing");
-    hipError_t err = launch_encode_signal_torso_bwd(att_params, poses, pose_stride, n_total, frame, smo_size, d_out, g_att,
+    hipError_t err = launch_encode_signal_torso_bwd(att_params, poses, pose_stride, n_total, frame, smo_size, d_out, g_att, set,
                                                     (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "encode_signal_torso_bwd_kernel");
     return DFN_OK;
+}
+int dfn_encode_signal_torso_bwd(const float* att_params, const float* poses, int pose_stride, int n_total, int frame,
+                                int smo_size, const float* d_out, float* g_att, void* stream) {
+    return encode_signal_torso_bwd_impl(att_params, poses, pose_stride, n_total, frame, smo_size, d_out, g_att, false, stream);
+}
+int dfn_encode_signal_torso_bwd_set(const float* att_params, const float* poses, int pose_stride, int n_total, int frame,
+                                    int smo_size, const float* d_out, float* g_att, void* stream) {
+    return encode_signal_torso_bwd_impl(att_params, poses, pose_stride, n_total, frame, smo_size, d_out, g_att, true, stream);
 }
 
 int dfn_decoder_fwd(int tier, int field, const void* packed, const float* bias, const float* points,

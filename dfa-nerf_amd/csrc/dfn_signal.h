@@ -11,7 +11,7 @@ hipError_t launch_encode_signal_torso(const float* att_params, const float* pose
 namespace dfn {
 hipError_t launch_encode_signal_bwd(const float* aud_params, const float* exp_params, const float* att_params,
                                     const float* auds, const float* exps, int N, int frame, int smo, const float* d_out,
-                                    float* g_aud, float* g_exp, float* g_att, hipStream_t st);
+                                    float* g_aud, float* g_exp, float* g_att, bool set, hipStream_t st);
 hipError_t launch_encode_signal_torso_bwd(const float* att_params, const float* poses, int pose_stride, int N, int frame,
-                                          int smo, const float* d_out, float* g_att, hipStream_t st);
+                                          int smo, const float* d_out, float* g_att, bool set, hipStream_t st);
 }  // namespace dfn

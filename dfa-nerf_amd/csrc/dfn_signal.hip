@@ -250,7 +250,9 @@ __device__ __forceinline__ float dleaky(float post) { return post > 0.f ? 1.0f :
 
 // gradients of y = act(b + W x) over the S rows:  GW[o][k] += sum_t dy[t][o] x[t][k];  Gb[o] += sum_t dy[t][o]
 // (dy already multiplied by act'), and optionally dx[t][k] = sum_o W[o][k] dy[t][o].
-template <int K>
+// SET: the gradients are WRITTEN, not added (every element has exactly one writer per call): the caller's buffers need no
+// zero fill (round 4: three 6-us fills sat in front of the audio chain's 190-us backward, which a training step can end on).
+template <int K, bool SET = false>
 __device__ void linear_rows_bwd(const float* __restrict__ W, float* GW, float* Gb, int M, const float* x, const float* dy,
                                 float* dx, int S) {
     constexpr int KU = (K + 63) / 64;
@@ -262,7 +264,7 @@ __device__ void linear_rows_bwd(const float* __restrict__ W, float* GW, float* G
         for (int r = 0; r < R; ++r) {
             const float* g = GW + (long)(o0 + r) * K;
 #pragma unroll
-            for (int u = 0; u < KU; ++u) old[r][u] = (o0 + r < M && lane + 64 * u < K) ? g[lane + 64 * u] : 0.f;
+            for (int u = 0; u < KU; ++u) old[r][u] = (!SET && o0 + r < M && lane + 64 * u < K) ? g[lane + 64 * u] : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -283,7 +285,7 @@ __device__ void linear_rows_bwd(const float* __restrict__ W, float* GW, float* G
 #pragma unroll
             for (int u = 0; u < KU; ++u)
                 if (lane + 64 * u < K) g[lane + 64 * u] = old[r][u];
-            if (lane == 0) Gb[o] += sb;
+            if (lane == 0) Gb[o] = SET ? sb : Gb[o] + sb;
         }
     }
     if (dx) {
@@ -360,6 +362,7 @@ __device__ void attention_fwd_keep(const float* __restrict__ P, int D, int S, co
     }
     __syncthreads();
 }
+template <bool SET = false>
 __device__ void attention_bwd(const float* __restrict__ P, float* G, int D, int S, const float* feat, const float* d_out,
                               const AttWork& w, float* d_feat /* [S][D], overwritten */) {
     const int chans[6] = {D, 16, 8, 4, 2, 1};
@@ -385,8 +388,8 @@ __device__ void attention_bwd(const float* __restrict__ P, float* G, int D, int 
         for (int j = 0; j < S; ++j) dot = fmaf(w.att[j], w.dz[j], dot);
         for (int i = 0; i < S; ++i) dz[i] = w.att[i] * (w.dz[i] - dot);
         for (int i = 0; i < S; ++i) {
-            GLB[i] += dz[i];
-            for (int j = 0; j < S; ++j) GLW[i * S + j] += dz[i] * c5[j];
+            GLB[i] = SET ? dz[i] : GLB[i] + dz[i];
+            for (int j = 0; j < S; ++j) GLW[i * S + j] = SET ? dz[i] * c5[j] : GLW[i * S + j] + dz[i] * c5[j];
         }
         for (int j = 0; j < S; ++j) {
             float a = 0.f;
@@ -414,12 +417,12 @@ __device__ void attention_bwd(const float* __restrict__ P, float* G, int D, int 
                 const int tt = t + j - 1;
                 if (tt >= 0 && tt < S) a = fmaf(dcur[t * co + o], x[tt * xs + c], a);
             }
-            GW[e] += a;
+            GW[e] = SET ? a : GW[e] + a;
         }
         for (int o = threadIdx.x; o < co; o += blockDim.x) {
             float a = 0.f;
             for (int t = 0; t < S; ++t) a += dcur[t * co + o];
-            GB[o] += a;
+            GB[o] = SET ? a : GB[o] + a;
         }
         float* dnext = (l == 0) ? nullptr : ((dcur == w.dact[0]) ? w.dact[1] : w.dact[0]);
         for (int e = threadIdx.x; e < S * ci; e += blockDim.x) {
@@ -441,6 +444,7 @@ __device__ void attention_bwd(const float* __restrict__ P, float* G, int D, int 
     }
 }
 
+template <bool SET>
 __global__ __launch_bounds__(SIG_THREADS) void encode_signal_bwd_kernel(
     const float* __restrict__ PA, const float* __restrict__ PE, const float* __restrict__ PT, const float* __restrict__ auds,
     const float* __restrict__ exps, int N, int f, int smo, const float* __restrict__ d_out, float* GA, float* GE, float* GT) {
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(SIG_THREADS) void encode_signal_bwd_kernel(
     if (smo > 0) {
         const float* Pl = stage_att(PT, ps, 96, S);
         attention_fwd_keep(Pl, 96, S, ft, w);
-        attention_bwd(Pl, GT, 96, S, ft, dout_s, w, dft);
+        attention_bwd<SET>(Pl, GT, 96, S, ft, dout_s, w, dft);
     } else {
         for (int d = threadIdx.x; d < 96; d += blockDim.x) dft[d] = dout_s[d];
         __syncthreads();
@@ -503,20 +507,21 @@ __global__ __launch_bounds__(SIG_THREADS) void encode_signal_bwd_kernel(
     }
     __syncthreads();
     // ExpressionEnc: e32 = W2 e1 + b2 ; e1 = leaky(W1 xe + b1)      (g1 = d e32; dft reused as d e1)
-    linear_rows_bwd<32>(PE + 2080, GE + 2080, GE + 2080 + 1024, 32, e1, g1, dft, S);
+    linear_rows_bwd<32, SET>(PE + 2080, GE + 2080, GE + 2080 + 1024, 32, e1, g1, dft, S);
     for (int e = threadIdx.x; e < S * 32; e += blockDim.x) dft[e] *= dleaky(e1[e]);
     __syncthreads();
-    linear_rows_bwd<64>(PE, GE, GE + 2048, 32, xe, dft, nullptr, S);
+    linear_rows_bwd<64, SET>(PE, GE, GE + 2048, 32, xe, dft, nullptr, S);
     // AudioNet_W2L: a64 = W3 h2 + b3 ; h2 = leaky(W2 h1 + b2) ; h1 = leaky(W1 xa + b1)      (g0 = d a64)
-    linear_rows_bwd<128>(PA + 164224, GA + 164224, GA + 164224 + 8192, 64, h2, g0, g1, S);       // g1 = d h2
+    linear_rows_bwd<128, SET>(PA + 164224, GA + 164224, GA + 164224 + 8192, 64, h2, g0, g1, S);       // g1 = d h2
     for (int e = threadIdx.x; e < S * 128; e += blockDim.x) g1[e] *= dleaky(h2[e]);
     __syncthreads();
-    linear_rows_bwd<256>(PA + 131328, GA + 131328, GA + 131328 + 32768, 128, h1, g1, g0, S);     // g0 = d h1
+    linear_rows_bwd<256, SET>(PA + 131328, GA + 131328, GA + 131328 + 32768, 128, h1, g1, g0, S);     // g0 = d h1
     for (int e = threadIdx.x; e < S * 256; e += blockDim.x) g0[e] *= dleaky(h1[e]);
     __syncthreads();
-    linear_rows_bwd<512>(PA, GA, GA + 131072, 256, xa, g0, nullptr, S);
+    linear_rows_bwd<512, SET>(PA, GA, GA + 131072, 256, xa, g0, nullptr, S);
 }
 
+template <bool SET>
 __global__ __launch_bounds__(SIG_THREADS) void encode_signal_torso_bwd_kernel(const float* __restrict__ PT,
                                                                               const float* __restrict__ poses, int pose_stride,
                                                                               int N, int f, int smo,
@@ -551,28 +556,38 @@ __global__ __launch_bounds__(SIG_THREADS) void encode_signal_torso_bwd_kernel(co
     w.dact[0] = g0; w.dact[1] = g1;
     const float* Pl = stage_att(PT, ps, 42, S);
     attention_fwd_keep(Pl, 42, S, emb, w);
-    attention_bwd(Pl, GT, 42, S, emb, dout_s, w, demb);
+    attention_bwd<SET>(Pl, GT, 42, S, emb, dout_s, w, demb);
 }
 
 hipError_t launch_encode_signal_bwd(const float* aud_params, const float* exp_params, const float* att_params,
                                     const float* auds, const float* exps, int N, int frame, int smo, const float* d_out,
-                                    float* g_aud, float* g_exp, float* g_att, hipStream_t st) {
+                                    float* g_aud, float* g_exp, float* g_att, bool set, hipStream_t st) {
     const size_t lds = sizeof(float) * (SIG_MAX_WIN * (512 + 256 + 128 + 64 + 32 + 96 + 64 + 32 + 96 + 256 + 256 + 33) + ATT_PARAMS_MAX);
     static bool done = false;
     if (!done) {
-        hipError_t e = hipFuncSetAttribute((const void*)encode_signal_bwd_kernel,
+        hipError_t e = hipFuncSetAttribute((const void*)encode_signal_bwd_kernel<false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)encode_signal_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         done = true;
     }
-    hipLaunchKernelGGL(encode_signal_bwd_kernel, dim3(1), dim3(SIG_THREADS), lds, st, aud_params, exp_params, att_params,
-                       auds, exps, N, frame, smo, d_out, g_aud, g_exp, g_att);
+    if (set)
+        hipLaunchKernelGGL(encode_signal_bwd_kernel<true>, dim3(1), dim3(SIG_THREADS), lds, st, aud_params, exp_params, att_params,
+                           auds, exps, N, frame, smo, d_out, g_aud, g_exp, g_att);
+    else
+        hipLaunchKernelGGL(encode_signal_bwd_kernel<false>, dim3(1), dim3(SIG_THREADS), lds, st, aud_params, exp_params, att_params,
+                           auds, exps, N, frame, smo, d_out, g_aud, g_exp, g_att);
     return hipGetLastError();
 }
 hipError_t launch_encode_signal_torso_bwd(const float* att_params, const float* poses, int pose_stride, int N, int frame,
-                                          int smo, const float* d_out, float* g_att, hipStream_t st) {
-    hipLaunchKernelGGL(encode_signal_torso_bwd_kernel, dim3(1), dim3(SIG_THREADS), 0, st, att_params, poses, pose_stride, N,
-                       frame, smo, d_out, g_att);
+                                          int smo, const float* d_out, float* g_att, bool set, hipStream_t st) {
+    if (set)
+        hipLaunchKernelGGL(encode_signal_torso_bwd_kernel<true>, dim3(1), dim3(SIG_THREADS), 0, st, att_params, poses, pose_stride, N,
+                           frame, smo, d_out, g_att);
+    else
+        hipLaunchKernelGGL(encode_signal_torso_bwd_kernel<false>, dim3(1), dim3(SIG_THREADS), 0, st, att_params, poses, pose_stride, N,
+                           frame, smo, d_out, g_att);
     return hipGetLastError();
 }
 

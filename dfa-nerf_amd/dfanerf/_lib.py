@@ -46,6 +46,8 @@ def _load():
         "dfn_encode_signal_torso": (i32, [fp, fp, i32, i32, ip, i32, i32, fp, vp]),
         "dfn_encode_signal_bwd": (i32, [fp, fp, fp, fp, fp, i32, i32, i32, fp, fp, fp, fp, vp]),
         "dfn_encode_signal_torso_bwd": (i32, [fp, fp, i32, i32, i32, i32, fp, fp, vp]),
+        "dfn_encode_signal_bwd_set": (i32, [fp, fp, fp, fp, fp, i32, i32, i32, fp, fp, fp, fp, vp]),
+        "dfn_encode_signal_torso_bwd_set": (i32, [fp, fp, i32, i32, i32, i32, fp, fp, vp]),
         "dfn_fold_bias": (i32, [i32, i32, fp, fp, fp, fp, fp, vp]),
         "dfn_fold_bias_bwd": (i32, [i32, i32, fp, fp, fp, fp, fp, fp, fp, vp]),
         "dfn_adam_multi": (i32, [vp, vp, i32, C.c_float, C.c_double, C.c_double, C.c_float, C.c_float, C.c_float, vp]),

@@ -32,6 +32,10 @@ _SIG_PRIO = os.environ.get("DFN_TRAIN_SIG_PRIO", "1") == "1"
 _EVENT_JOIN = os.environ.get("DFN_TRAIN_EVENT_JOIN", "1") == "1"
 # the torso field's dfn_signal_grad in front of its weight-gradient GEMMs (1) or next to them (0: A/B)
 _SIG_FIRST = os.environ.get("DFN_TRAIN_SIG_FIRST", "1") == "1"
+# the conditioning networks' backward kernels add their gradients into zero-filled buffers (0) or write them (1: no fill
+# launches in front of them).  Measured (round 4, interleaved, four rounds): writing is SLOWER - c4 0.994 -> 1.014 ms: the
+# single-workgroup kernel's 690 KB of gradient stores go faster into lines the fills just brought into L2 - so 0 stays
+_SIG_SET = os.environ.get("DFN_TRAIN_SIG_SET", "0") == "1"
 
 
 def _side_stream(device, high=False, role=None):
@@ -574,16 +578,21 @@ class _SignalFn(torch.autograd.Function):
                         side.wait_stream(main)      # fresh memory of the main stream's pool: its last user ran there
                     if not any(q.grad is not None for q in n.params):
                         n._g_flat = g
-                check(lib.dfn_zero_async(_ptr(g), g.numel() * 4, stream), "dfn_zero_async")
+                if not _SIG_SET:
+                    check(lib.dfn_zero_async(_ptr(g), g.numel() * 4, stream), "dfn_zero_async")
                 out.append(g)
             return out
         g = buffers(s_a, st_a, tr.nets[:3]) + buffers(s_p, st_t, tr.nets[3:])
         d_sig = d_sig.contiguous().float()
         d_sigt = d_sigt.contiguous().float()
-        check(lib.dfn_encode_signal_torso_bwd(_ptr(p), _ptr(tr.poses), tr.pose_stride, length, frame, smo_t, _ptr(d_sigt),
-                                              _ptr(g[3]), st_t), "dfn_encode_signal_torso_bwd")
-        check(lib.dfn_encode_signal_bwd(_ptr(a), _ptr(e), _ptr(t), _ptr(tr.auds), _ptr(tr.exps), length, frame, smo,
-                                        _ptr(d_sig), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), st_a), "dfn_encode_signal_bwd")
+        # (*_set: the kernels WRITE the gradients - one writer per element and call -: no fill launches in front of them; a
+        # network that takes no part (attention before --nosmo_iters) is not written and not deposited below)
+        bwd_t = lib.dfn_encode_signal_torso_bwd_set if _SIG_SET else lib.dfn_encode_signal_torso_bwd
+        bwd_a = lib.dfn_encode_signal_bwd_set if _SIG_SET else lib.dfn_encode_signal_bwd
+        check(bwd_t(_ptr(p), _ptr(tr.poses), tr.pose_stride, length, frame, smo_t, _ptr(d_sigt), _ptr(g[3]), st_t),
+              "dfn_encode_signal_torso_bwd")
+        check(bwd_a(_ptr(a), _ptr(e), _ptr(t), _ptr(tr.auds), _ptr(tr.exps), length, frame, smo, _ptr(d_sig), _ptr(g[0]),
+                    _ptr(g[1]), _ptr(g[2]), st_a), "dfn_encode_signal_bwd")
         if s_a is not None:
             # Order the main stream behind these chains - ALWAYS: dfn_signal_grad's fold backward reads the DECODER's
             # parameters on these streams, and the decoder's Adam (main stream) must not overtake it.  (Leaving the join to

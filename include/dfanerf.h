@@ -107,6 +107,13 @@ int dfn_encode_signal_bwd(const float* aud_params, const float* exp_params, cons
                           float* g_exp, float* g_att, void* stream);
 int dfn_encode_signal_torso_bwd(const float* att_params, const float* poses, int pose_stride, int n_total, int frame,
                                 int smo_size, const float* d_out, float* g_att, void* stream);
+/* The same, WRITING the gradients instead of adding them (every element of g_aud / g_exp - and of g_att when smo_size > 0 -
+ * has exactly one writer per call): the buffers need no zero fill in front of the call.  smo_size == 0: g_att untouched. */
+int dfn_encode_signal_bwd_set(const float* aud_params, const float* exp_params, const float* att_params, const float* auds,
+                              const float* exps, int n_total, int frame, int smo_size, const float* d_out, float* g_aud,
+                              float* g_exp, float* g_att, void* stream);
+int dfn_encode_signal_torso_bwd_set(const float* att_params, const float* poses, int pose_stride, int n_total, int frame,
+                                    int smo_size, const float* d_out, float* g_att, void* stream);
 
 /* ---- the fused renderer: replaces the frame loop MAIN:611-713 (and its training twin MAIN:829-899) --
  * packed_head/packed_torso, bias_head/bias_torso: from the calls above (torso ones may be NULL when
