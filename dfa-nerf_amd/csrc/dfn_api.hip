@@ -853,19 +853,33 @@ int dfn_signal_grad(int tier, int field, const float* params, const void* dy_T, 
     return DFN_OK;
 }
 
-int dfn_encode_signal(const float* aud_params, const float* exp_params, const float* att_params, const float* auds,
-                      const float* exps, int n_total, const int32_t* frame_ids, int n_frames, int smo_size, float* out,
-                      void* stream) {
+static int encode_signal_impl(const float* aud_params, const float* exp_params, const float* att_params, const float* auds,
+                              const float* exps, int n_total, const int32_t* frame_ids, int n_frames, int smo_size, float* out,
+                              float* keep, void* stream) {
     if (!aud_params || !exp_params || !auds || !exps || !frame_ids || !out || n_total <= 0 || n_frames < 0)
         return fail(DFN_E_ARG, "dfn_encode_signal: bad argument");
+    if (keep && n_frames != 1) return fail(DFN_E_ARG, "dfn_encode_signal_keep: one frame (the training step's)");
     if (smo_size < 0 || smo_size > 8 || (smo_size & 1)) return fail(DFN_E_ARG, "dfn_encode_signal: smo_size must be 0, 2, 4, 6 or 8");
     if (smo_size > 0 && !att_params) return fail(DFN_E_ARG, "dfn_encode_signal: attention parameters missing");
     if (n_frames == 0) return DFN_OK;
     hipError_t err = launch_encode_signal(aud_params, exp_params, att_params, auds, exps, n_total, frame_ids, n_frames,
-                                          smo_size, out, (hipStream_t)stream);
+                                          smo_size, out, keep, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "encode_signal_kernel");
     return DFN_OK;
 }
+int dfn_encode_signal(const float* aud_params, const float* exp_params, const float* att_params, const float* auds,
+                      const float* exps, int n_total, const int32_t* frame_ids, int n_frames, int smo_size, float* out,
+                      void* stream) {
+    return encode_signal_impl(aud_params, exp_params, att_params, auds, exps, n_total, frame_ids, n_frames, smo_size, out, nullptr,
+                              stream);
+}
+int dfn_encode_signal_keep(const float* aud_params, const float* exp_params, const float* att_params, const float* auds,
+                           const float* exps, int n_total, const int32_t* frame_id, int smo_size, float* out, float* keep,
+                           void* stream) {
+    if (!keep) return fail(DFN_E_ARG, "dfn_encode_signal_keep: keep is NULL");
+    return encode_signal_impl(aud_params, exp_params, att_params, auds, exps, n_total, frame_id, 1, smo_size, out, keep, stream);
+}
+long dfn_encode_signal_keep_floats(void) { return SIG_KEEP_FLOATS; }
 
 int dfn_encode_signal_torso(const float* att_params, const float* poses, int pose_stride, int n_total,
                             const int32_t* frame_ids, int n_frames, int smo_size, float* out, void* stream) {
@@ -883,13 +897,13 @@ int dfn_encode_signal_torso(const float* att_params, const float* poses, int pos
 
 static int encode_signal_bwd_impl(const float* aud_params, const float* exp_params, const float* att_params, const float* auds,
                                   const float* exps, int n_total, int frame, int smo_size, const float* d_out, float* g_aud,
-                                  float* g_exp, float* g_att, bool set, void* stream) {
+                                  float* g_exp, float* g_att, bool set, void* stream, const float* kept = nullptr) {
     if (!aud_params || !exp_params || !auds || !exps || !d_out || !g_aud || !g_exp || n_total <= 0)
         return fail(DFN_E_ARG, "dfn_encode_signal_bwd: bad argument");
     if (smo_size < 0 || smo_size > 8 || (smo_size & 1)) return fail(DFN_E_ARG, "dfn_encode_signal_bwd: smo_size must be 0, 2, 4, 6 or 8");
     if (smo_size > 0 && (!att_params || !g_att)) return fail(DFN_E_ARG, "dfn_encode_signal_bwd: attention buffers missing");
     hipError_t err = launch_encode_signal_bwd(aud_params, exp_params, att_params, auds, exps, n_total, frame, smo_size,
-                                              d_out, g_aud, g_exp, g_att, set, (hipStream_t)stream);
+                                              d_out, g_aud, g_exp, g_att, set, kept, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "encode_signal_bwd_kernel");
     return DFN_OK;
 }
@@ -898,6 +912,13 @@ int dfn_encode_signal_bwd(const float* aud_params, const float* exp_params, cons
                           float* g_exp, float* g_att, void* stream) {
     return encode_signal_bwd_impl(aud_params, exp_params, att_params, auds, exps, n_total, frame, smo_size, d_out, g_aud, g_exp,
                                   g_att, false, stream);
+}
+int dfn_encode_signal_bwd_kept(const float* aud_params, const float* exp_params, const float* att_params, const float* auds,
+                               const float* exps, int n_total, int frame, int smo_size, const float* d_out, const float* kept,
+                               float* g_aud, float* g_exp, float* g_att, void* stream) {
+    if (!kept) return fail(DFN_E_ARG, "dfn_encode_signal_bwd_kept: kept is NULL");
+    return encode_signal_bwd_impl(aud_params, exp_params, att_params, auds, exps, n_total, frame, smo_size, d_out, g_aud, g_exp,
+                                  g_att, false, stream, kept);
 }
 int dfn_encode_signal_bwd_set(const float* aud_params, const float* exp_params, const float* att_params, const float* auds,
                               const float* exps, int n_total, int frame, int smo_size, const float* d_out, float* g_aud,

@@ -140,7 +140,8 @@ __device__ void attention(const float* __restrict__ P, int D, int S, const float
 __global__ __launch_bounds__(SIG_THREADS) void encode_signal_kernel(const float* __restrict__ PA, const float* __restrict__ PE,
                                                                     const float* __restrict__ PT, const float* __restrict__ auds,
                                                                     const float* __restrict__ exps, int N,
-                                                                    const int* __restrict__ frame_ids, int smo, float* out) {
+                                                                    const int* __restrict__ frame_ids, int smo, float* out,
+                                                                    float* keep) {
     extern __shared__ float lds[];
     const int S = smo > 0 ? smo : 1, half = smo / 2;
     float* xa = lds;                       // [S][512]
@@ -176,6 +177,14 @@ __global__ __launch_bounds__(SIG_THREADS) void encode_signal_kernel(const float*
         ft[t * 96 + d] = d < 64 ? a64[t * 64 + d] : e32[t * 32 + d - 64];
     }
     __syncthreads();
+    // training (one frame): the activations the backward needs, so that it does not run the three AudioNet layers - 690 KB of
+    // weights through one compute unit - a second time (SIG_KEEP_FLOATS: [h1 S x 256 | h2 S x 128 | e1 S x 32 | ft S x 96])
+    if (keep && blockIdx.x == 0) {
+        for (int e = threadIdx.x; e < S * 256; e += blockDim.x) keep[e] = h1[e];
+        for (int e = threadIdx.x; e < S * 128; e += blockDim.x) keep[SIG_MAX_WIN * 256 + e] = h2[e];
+        for (int e = threadIdx.x; e < S * 32; e += blockDim.x) keep[SIG_MAX_WIN * 384 + e] = e1[e];
+        for (int e = threadIdx.x; e < S * 96; e += blockDim.x) keep[SIG_MAX_WIN * 416 + e] = ft[e];
+    }
     float* o = out + (long)blockIdx.x * 96;
     if (smo > 0) attention(stage_att(PT, ps, 96, S), 96, S, ft, b0, b1, o);
     else
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(SIG_THREADS) void encode_signal_torso_kernel(const 
 
 hipError_t launch_encode_signal(const float* aud_params, const float* exp_params, const float* att_params,
                                 const float* auds, const float* exps, int N, const int* frame_ids, int n_frames, int smo,
-                                float* out, hipStream_t st) {
+                                float* out, float* keep, hipStream_t st) {
     const size_t lds = sizeof(float) * (SIG_MAX_WIN * (512 + 256 + 128 + 64 + 32 + 96 + 16 + 16 + 64 + 32) + ATT_PARAMS_MAX);
     static bool done = false;
     if (!done) {
@@ -227,7 +236,7 @@ hipError_t launch_encode_signal(const float* aud_params, const float* exp_params
         done = true;
     }
     hipLaunchKernelGGL(encode_signal_kernel, dim3(n_frames), dim3(SIG_THREADS), lds, st, aud_params, exp_params,
-                       att_params, auds, exps, N, frame_ids, smo, out);
+                       att_params, auds, exps, N, frame_ids, smo, out, keep);
     return hipGetLastError();
 }
 hipError_t launch_encode_signal_torso(const float* att_params, const float* poses, int pose_stride, int N,
@@ -444,10 +453,11 @@ __device__ void attention_bwd(const float* __restrict__ P, float* G, int D, int 
     }
 }
 
-template <bool SET>
+template <bool SET, bool KEPT>
 __global__ __launch_bounds__(SIG_THREADS) void encode_signal_bwd_kernel(
     const float* __restrict__ PA, const float* __restrict__ PE, const float* __restrict__ PT, const float* __restrict__ auds,
-    const float* __restrict__ exps, int N, int f, int smo, const float* __restrict__ d_out, float* GA, float* GE, float* GT) {
+    const float* __restrict__ exps, int N, int f, int smo, const float* __restrict__ d_out, float* GA, float* GE, float* GT,
+    const float* __restrict__ kept) {
     extern __shared__ float lds[];
     const int S = smo > 0 ? smo : 1, half = smo / 2;
     float* xa = lds;                       // [S][512]
@@ -479,17 +489,26 @@ __global__ __launch_bounds__(SIG_THREADS) void encode_signal_bwd_kernel(
     }
     for (int d = threadIdx.x; d < 96; d += blockDim.x) dout_s[d] = d_out[d];
     __syncthreads();
-    // ---- forward, every activation kept ----
-    linear_rows<512>(PA, PA + 131072, 256, xa, h1, S, true);
-    linear_rows<256>(PA + 131328, PA + 131328 + 32768, 128, h1, h2, S, true);
-    linear_rows<128>(PA + 164224, PA + 164224 + 8192, 64, h2, a64, S, false);
-    linear_rows<64>(PE, PE + 2048, 32, xe, e1, S, true);
-    linear_rows<32>(PE + 2080, PE + 2080 + 1024, 32, e1, e32, S, false);
-    for (int e = threadIdx.x; e < S * 96; e += blockDim.x) {
-        const int t = e / 96, d = e - t * 96;
-        ft[t * 96 + d] = d < 64 ? a64[t * 64 + d] : e32[t * 32 + d - 64];
+    if constexpr (KEPT) {
+        // ---- the forward's activations as dfn_encode_signal_keep left them (same arithmetic, same bits) ----
+        for (int e = threadIdx.x; e < S * 256; e += blockDim.x) h1[e] = kept[e];
+        for (int e = threadIdx.x; e < S * 128; e += blockDim.x) h2[e] = kept[SIG_MAX_WIN * 256 + e];
+        for (int e = threadIdx.x; e < S * 32; e += blockDim.x) e1[e] = kept[SIG_MAX_WIN * 384 + e];
+        for (int e = threadIdx.x; e < S * 96; e += blockDim.x) ft[e] = kept[SIG_MAX_WIN * 416 + e];
+        __syncthreads();
+    } else {
+        // ---- forward, every activation kept ----
+        linear_rows<512>(PA, PA + 131072, 256, xa, h1, S, true);
+        linear_rows<256>(PA + 131328, PA + 131328 + 32768, 128, h1, h2, S, true);
+        linear_rows<128>(PA + 164224, PA + 164224 + 8192, 64, h2, a64, S, false);
+        linear_rows<64>(PE, PE + 2048, 32, xe, e1, S, true);
+        linear_rows<32>(PE + 2080, PE + 2080 + 1024, 32, e1, e32, S, false);
+        for (int e = threadIdx.x; e < S * 96; e += blockDim.x) {
+            const int t = e / 96, d = e - t * 96;
+            ft[t * 96 + d] = d < 64 ? a64[t * 64 + d] : e32[t * 32 + d - 64];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // ---- backward ----
     if (smo > 0) {
         const float* Pl = stage_att(PT, ps, 96, S);
@@ -561,23 +580,25 @@ __global__ __launch_bounds__(SIG_THREADS) void encode_signal_torso_bwd_kernel(co
 
 hipError_t launch_encode_signal_bwd(const float* aud_params, const float* exp_params, const float* att_params,
                                     const float* auds, const float* exps, int N, int frame, int smo, const float* d_out,
-                                    float* g_aud, float* g_exp, float* g_att, bool set, hipStream_t st) {
+                                    float* g_aud, float* g_exp, float* g_att, bool set, const float* kept, hipStream_t st) {
     const size_t lds = sizeof(float) * (SIG_MAX_WIN * (512 + 256 + 128 + 64 + 32 + 96 + 64 + 32 + 96 + 256 + 256 + 33) + ATT_PARAMS_MAX);
     static bool done = false;
     if (!done) {
-        hipError_t e = hipFuncSetAttribute((const void*)encode_signal_bwd_kernel<false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)encode_signal_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)encode_signal_bwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)encode_signal_bwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)encode_signal_bwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)encode_signal_bwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         done = true;
     }
-    if (set)
-        hipLaunchKernelGGL(encode_signal_bwd_kernel<true>, dim3(1), dim3(SIG_THREADS), lds, st, aud_params, exp_params, att_params,
-                           auds, exps, N, frame, smo, d_out, g_aud, g_exp, g_att);
-    else
-        hipLaunchKernelGGL(encode_signal_bwd_kernel<false>, dim3(1), dim3(SIG_THREADS), lds, st, aud_params, exp_params, att_params,
-                           auds, exps, N, frame, smo, d_out, g_aud, g_exp, g_att);
+#define SIG_BWD_GO(SET_, KEPT_)                                                                                              \
+    hipLaunchKernelGGL((encode_signal_bwd_kernel<SET_, KEPT_>), dim3(1), dim3(SIG_THREADS), lds, st, aud_params, exp_params,   \
+                       att_params, auds, exps, N, frame, smo, d_out, g_aud, g_exp, g_att, kept)
+    if (set && kept) SIG_BWD_GO(true, true);
+    else if (set) SIG_BWD_GO(true, false);
+    else if (kept) SIG_BWD_GO(false, true);
+    else SIG_BWD_GO(false, false);
+#undef SIG_BWD_GO
     return hipGetLastError();
 }
 hipError_t launch_encode_signal_torso_bwd(const float* att_params, const float* poses, int pose_stride, int N, int frame,

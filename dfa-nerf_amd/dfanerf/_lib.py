@@ -47,6 +47,9 @@ def _load():
         "dfn_encode_signal_bwd": (i32, [fp, fp, fp, fp, fp, i32, i32, i32, fp, fp, fp, fp, vp]),
         "dfn_encode_signal_torso_bwd": (i32, [fp, fp, i32, i32, i32, i32, fp, fp, vp]),
         "dfn_encode_signal_bwd_set": (i32, [fp, fp, fp, fp, fp, i32, i32, i32, fp, fp, fp, fp, vp]),
+        "dfn_encode_signal_keep": (i32, [fp, fp, fp, fp, fp, i32, ip, i32, fp, fp, vp]),
+        "dfn_encode_signal_keep_floats": (lg, []),
+        "dfn_encode_signal_bwd_kept": (i32, [fp, fp, fp, fp, fp, i32, i32, i32, fp, fp, fp, fp, fp, vp]),
         "dfn_encode_signal_torso_bwd_set": (i32, [fp, fp, i32, i32, i32, i32, fp, fp, vp]),
         "dfn_fold_bias": (i32, [i32, i32, fp, fp, fp, fp, fp, vp]),
         "dfn_fold_bias_bwd": (i32, [i32, i32, fp, fp, fp, fp, fp, fp, fp, vp]),

@@ -36,6 +36,8 @@ _SIG_FIRST = os.environ.get("DFN_TRAIN_SIG_FIRST", "1") == "1"
 # launches in front of them).  Measured (round 4, interleaved, four rounds): writing is SLOWER - c4 0.994 -> 1.014 ms: the
 # single-workgroup kernel's 690 KB of gradient stores go faster into lines the fills just brought into L2 - so 0 stays
 _SIG_SET = os.environ.get("DFN_TRAIN_SIG_SET", "0") == "1"
+# the audio encoder's forward keeps its activations for its backward (1) or the backward recomputes them (0: A/B)
+_SIG_KEEP = os.environ.get("DFN_TRAIN_SIG_KEEP", "1") == "1"
 
 
 def _side_stream(device, high=False, role=None):
@@ -537,8 +539,20 @@ class _SignalFn(torch.autograd.Function):
         st_a = C.c_void_p(s_a.cuda_stream) if piped else st
         check(lib.dfn_encode_signal_torso(_ptr(p), _ptr(tr.poses), tr.pose_stride, length, _ptr(ids), 1, smo_t,
                                           _ptr(sigt), st_t), "dfn_encode_signal_torso")
-        check(lib.dfn_encode_signal(_ptr(a), _ptr(e), _ptr(t), _ptr(tr.auds), _ptr(tr.exps), length, _ptr(ids), 1, smo,
-                                    _ptr(sig), st_a), "dfn_encode_signal")
+        # the audio encoder also leaves the activations its backward needs (round 4: that backward is the step's one exposed
+        # side chain, and 40 % of it re-ran this forward): valid for the LAST encode only (ctx.keep_seq)
+        if _SIG_KEEP:
+            if getattr(tr, "_keep", None) is None:
+                tr._keep = torch.empty(check(lib.dfn_encode_signal_keep_floats(), "keep"), dtype=torch.float32, device=dev)
+                tr._keep_seq = 0
+            tr._keep_seq += 1
+            ctx.keep_seq = tr._keep_seq
+            check(lib.dfn_encode_signal_keep(_ptr(a), _ptr(e), _ptr(t), _ptr(tr.auds), _ptr(tr.exps), length, _ptr(ids), smo,
+                                             _ptr(sig), _ptr(tr._keep), st_a), "dfn_encode_signal_keep")
+        else:
+            ctx.keep_seq = -1
+            check(lib.dfn_encode_signal(_ptr(a), _ptr(e), _ptr(t), _ptr(tr.auds), _ptr(tr.exps), length, _ptr(ids), 1, smo,
+                                        _ptr(sig), st_a), "dfn_encode_signal")
         if s_p is not None:
             main.wait_stream(s_p)
         if piped:
@@ -591,8 +605,13 @@ class _SignalFn(torch.autograd.Function):
         bwd_a = lib.dfn_encode_signal_bwd_set if _SIG_SET else lib.dfn_encode_signal_bwd
         check(bwd_t(_ptr(p), _ptr(tr.poses), tr.pose_stride, length, frame, smo_t, _ptr(d_sigt), _ptr(g[3]), st_t),
               "dfn_encode_signal_torso_bwd")
-        check(bwd_a(_ptr(a), _ptr(e), _ptr(t), _ptr(tr.auds), _ptr(tr.exps), length, frame, smo, _ptr(d_sig), _ptr(g[0]),
-                    _ptr(g[1]), _ptr(g[2]), st_a), "dfn_encode_signal_bwd")
+        if not _SIG_SET and ctx.keep_seq >= 0 and ctx.keep_seq == getattr(tr, "_keep_seq", -2):
+            check(lib.dfn_encode_signal_bwd_kept(_ptr(a), _ptr(e), _ptr(t), _ptr(tr.auds), _ptr(tr.exps), length, frame, smo,
+                                                 _ptr(d_sig), _ptr(tr._keep), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), st_a),
+                  "dfn_encode_signal_bwd_kept")
+        else:
+            check(bwd_a(_ptr(a), _ptr(e), _ptr(t), _ptr(tr.auds), _ptr(tr.exps), length, frame, smo, _ptr(d_sig), _ptr(g[0]),
+                        _ptr(g[1]), _ptr(g[2]), st_a), "dfn_encode_signal_bwd")
         if s_a is not None:
             # Order the main stream behind these chains - ALWAYS: dfn_signal_grad's fold backward reads the DECODER's
             # parameters on these streams, and the decoder's Adam (main stream) must not overtake it.  (Leaving the join to

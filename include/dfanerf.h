@@ -107,6 +107,17 @@ int dfn_encode_signal_bwd(const float* aud_params, const float* exp_params, cons
                           float* g_exp, float* g_att, void* stream);
 int dfn_encode_signal_torso_bwd(const float* att_params, const float* poses, int pose_stride, int n_total, int frame,
                                 int smo_size, const float* d_out, float* g_att, void* stream);
+/* The training step's pair: dfn_encode_signal_keep = dfn_encode_signal for ONE frame that also leaves the activations the backward
+ * needs in `keep` (dfn_encode_signal_keep_floats() floats), dfn_encode_signal_bwd_kept = dfn_encode_signal_bwd reading them
+ * instead of running AudioNet's forward a second time (same arithmetic: same gradients bit for bit; frame and smo_size as in
+ * the keep call). */
+int dfn_encode_signal_keep(const float* aud_params, const float* exp_params, const float* att_params, const float* auds,
+                           const float* exps, int n_total, const int32_t* frame_id, int smo_size, float* out, float* keep,
+                           void* stream);
+long dfn_encode_signal_keep_floats(void);
+int dfn_encode_signal_bwd_kept(const float* aud_params, const float* exp_params, const float* att_params, const float* auds,
+                               const float* exps, int n_total, int frame, int smo_size, const float* d_out, const float* kept,
+                               float* g_aud, float* g_exp, float* g_att, void* stream);
 /* The same, WRITING the gradients instead of adding them (every element of g_aud / g_exp - and of g_att when smo_size > 0 -
  * has exactly one writer per call): the buffers need no zero fill in front of the call.  smo_size == 0: g_att untouched. */
 int dfn_encode_signal_bwd_set(const float* aud_params, const float* exp_params, const float* att_params, const float* auds,
