@@ -33,6 +33,13 @@ def test_single_gpu_line_has_the_contract_and_the_parity_binding():
     pc = out["parity_check"]
     assert "error" not in pc, pc
     assert pc["rays"] == 64 and pc["psnr_db"] >= 49.4 and pc["max_abs_rgb"] < 2e-2, pc
+    # the power ceiling measured in-process after the timed loops (dfn_debug_mfma_chain on the renderer's operand statistics):
+    # the bare MFMA chain sustains more than the renderer's instruction mix, which the timed kernel cannot beat by much
+    ce = out["roofline"]["power_ceiling"]
+    assert "error" not in ce, ce
+    assert 0.3 < ce["renderer_mix"]["frac_of_peak"] < ce["bare_chain"]["frac_of_peak"] < 1.0, ce
+    assert 0.5 < ce["frac_of_renderer_mix"] < 1.15 and 0.0 < ce["frac_of_ceiling"] < 1.0, ce
+    assert out["roofline"]["traffic"] is not None
 
 
 @pytest.mark.parametrize("workload", ["c2", "c5", "c4"])
