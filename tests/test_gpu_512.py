@@ -240,7 +240,7 @@ def test_training_step_512_vs_oracle_autograd(states, scene512, latents, tier, m
     np.testing.assert_allclose([loss.item(), lh.item(), lc.item()], ref_loss, rtol=3e-5 if tier == "f32" else 2e-2)
     loss.backward()
     torch.cuda.synchronize()
-    rel, rel_dir = (1e-3, 2e-3) if tier == "f32" else (6e-2, 1.5e-1)
+    rel, rel_dir = (1e-3, 5e-4) if tier == "f32" else (6e-2, 1.0e-1)          # (measured: 9.3e-5 / 1.7e-4 and 4.7e-2 / 6.9e-2)
     worst = worst_dir = 0.0
     for tag, m in mods.items():
         for k, p in m.named_parameters():

@@ -215,7 +215,7 @@ def test_training_step_full_size_vs_oracle_autograd(states, scene, latents, tier
             assert abs(gn - rn) <= rel * rn + 1e-9, (tag, k, gn, rn)
             d = float((g - ref).double().norm()) / rn
             worst_dir = max(worst_dir, d)
-            assert d <= (2e-3 if tier == "f32" else 1.5e-1), (tag, k, d)
+            assert d <= (5e-4 if tier == "f32" else 1.0e-1), (tag, k, d)       # (measured round 4: 6.4e-5 / 6.9e-2; until round 3 the gates were 2e-3 / 1.5e-1)
             gs, rs_ = g.reshape(-1), ref.reshape(-1)
             stride = max(1, gs.numel() // 8)
             rms = rn / np.sqrt(gs.numel())
