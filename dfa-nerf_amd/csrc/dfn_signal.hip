@@ -17,6 +17,7 @@
 namespace dfn {
 
 constexpr int SIG_MAX_WIN = 8;       // largest attention window (smo_size / smo_torse_size)
+constexpr int SIG_KEEP_ACT = 8 * (256 + 128 + 32 + 96);      // floats of kept activations; behind them: d h1 [8][256] | d h2 [8][128]
 constexpr int SIG_THREADS = 1024;     // 16 waves: the kernels are latency-bound chains of small layers
 
 __device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : 0.02f * x; }
@@ -261,13 +262,13 @@ __device__ __forceinline__ float dleaky(float post) { return post > 0.f ? 1.0f :
 // (dy already multiplied by act'), and optionally dx[t][k] = sum_o W[o][k] dy[t][o].
 // SET: the gradients are WRITTEN, not added (every element has exactly one writer per call): the caller's buffers need no
 // zero fill (round 4: three 6-us fills sat in front of the audio chain's 190-us backward, which a training step can end on).
-template <int K, bool SET = false>
+template <int K, bool SET = false, bool DW = true>
 __device__ void linear_rows_bwd(const float* __restrict__ W, float* GW, float* Gb, int M, const float* x, const float* dy,
                                 float* dx, int S) {
     constexpr int KU = (K + 63) / 64;
     constexpr int R = 1;                       // rows per iteration (more was slower, see linear_rows)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int o0 = wave * R; o0 < M; o0 += nw * R) {
+    for (int o0 = wave * R; DW && o0 < M; o0 += nw * R) {      // (DW = false: the weight gradients come from signal_dw12_kernel)
         float old[R][KU];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -534,10 +535,63 @@ __global__ __launch_bounds__(SIG_THREADS) void encode_signal_bwd_kernel(
     linear_rows_bwd<128, SET>(PA + 164224, GA + 164224, GA + 164224 + 8192, 64, h2, g0, g1, S);       // g1 = d h2
     for (int e = threadIdx.x; e < S * 128; e += blockDim.x) g1[e] *= dleaky(h2[e]);
     __syncthreads();
-    linear_rows_bwd<256, SET>(PA + 131328, GA + 131328, GA + 131328 + 32768, 128, h1, g1, g0, S);     // g0 = d h1
-    for (int e = threadIdx.x; e < S * 256; e += blockDim.x) g0[e] *= dleaky(h1[e]);
+    if constexpr (KEPT) {
+        // The two big weight gradients (W1: 256 x 512, W2: 128 x 256 - 24 of this kernel's ~60 dependent memory round trips, each
+        // 3 us next to the step's big kernels) are left to signal_dw12_kernel, 24 workgroups right behind this launch: here only
+        // d h1 = W2^T d h2, and both pre-activation gradients go to the scratch tail of the keep buffer.
+        float* dh = const_cast<float*>(kept) + SIG_KEEP_ACT;
+        linear_rows_bwd<256, SET, false>(PA + 131328, nullptr, nullptr, 128, h1, g1, g0, S);           // g0 = d h1
+        for (int e = threadIdx.x; e < S * 256; e += blockDim.x) dh[e] = g0[e] * dleaky(h1[e]);
+        for (int e = threadIdx.x; e < S * 128; e += blockDim.x) dh[SIG_MAX_WIN * 256 + e] = g1[e];
+    } else {
+        linear_rows_bwd<256, SET>(PA + 131328, GA + 131328, GA + 131328 + 32768, 128, h1, g1, g0, S);     // g0 = d h1
+        for (int e = threadIdx.x; e < S * 256; e += blockDim.x) g0[e] *= dleaky(h1[e]);
+        __syncthreads();
+        linear_rows_bwd<512, SET>(PA, GA, GA + 131072, 256, xa, g0, nullptr, S);
+    }
+}
+
+// GW1 / Gb1 (256 x 512) and GW2 / Gb2 (128 x 256) of AudioNet_W2L from what the two kernels above left: 384 output rows over
+// SIG_DW_BLOCKS x 4 waves, a row per wave and trip (a lane owns columns lane + 64 u), the sums over the S window rows in the
+// same order as linear_rows_bwd - the same gradients bit for bit.
+constexpr int SIG_DW_BLOCKS = 24;
+template <bool SET>
+__global__ __launch_bounds__(256) void signal_dw12_kernel(const float* __restrict__ auds, int N, int f, int smo,
+                                                          const float* __restrict__ kept, float* GA) {
+    __shared__ float xa[SIG_MAX_WIN * 512], h1[SIG_MAX_WIN * 256], d1[SIG_MAX_WIN * 256], d2[SIG_MAX_WIN * 128];
+    const int S = smo > 0 ? smo : 1, half = smo / 2;
+    for (int e = threadIdx.x; e < S * 512; e += blockDim.x) {
+        const int t = e >> 9, k = e & 511, src = smo > 0 ? f - half + t : f;
+        xa[t * 512 + k] = (smo == 0 || (src >= 0 && src < N)) ? auds[(long)src * 512 + k] : 0.f;
+    }
+    for (int e = threadIdx.x; e < S * 256; e += blockDim.x) { h1[e] = kept[e]; d1[e] = kept[SIG_KEEP_ACT + e]; }
+    for (int e = threadIdx.x; e < S * 128; e += blockDim.x) d2[e] = kept[SIG_KEEP_ACT + SIG_MAX_WIN * 256 + e];
     __syncthreads();
-    linear_rows_bwd<512, SET>(PA, GA, GA + 131072, 256, xa, g0, nullptr, S);
+    const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    for (int row = gw; row < 384; row += nw) {
+        const bool first = row < 256;
+        const int o = first ? row : row - 256, K = first ? 512 : 256, M = first ? 256 : 128;
+        const float* x = first ? xa : h1;
+        const float* dy = first ? d1 : d2;
+        float* g = GA + (first ? 0 : 131328) + (long)o * K;
+        float* gb = GA + (first ? 131072 : 131328 + 32768);
+        float acc[8], sb = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = (!SET && lane + 64 * u < K) ? g[lane + 64 * u] : 0.f;
+#pragma unroll
+        for (int t = 0; t < SIG_MAX_WIN; ++t)
+            if (t < S) {
+                const float d = dy[t * M + o];
+                sb += d;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (lane + 64 * u < K) acc[u] = fmaf(d, x[t * K + lane + 64 * u], acc[u]);
+            }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (lane + 64 * u < K) g[lane + 64 * u] = acc[u];
+        if (lane == 0) gb[o] = SET ? sb : gb[o] + sb;
+    }
 }
 
 template <bool SET>
@@ -599,6 +653,11 @@ hipError_t launch_encode_signal_bwd(const float* aud_params, const float* exp_pa
     else if (kept) SIG_BWD_GO(false, true);
     else SIG_BWD_GO(false, false);
 #undef SIG_BWD_GO
+    if (kept) {
+        if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
+        if (set) hipLaunchKernelGGL(signal_dw12_kernel<true>, dim3(SIG_DW_BLOCKS), dim3(256), 0, st, auds, N, frame, smo, kept, g_aud);
+        else hipLaunchKernelGGL(signal_dw12_kernel<false>, dim3(SIG_DW_BLOCKS), dim3(256), 0, st, auds, N, frame, smo, kept, g_aud);
+    }
     return hipGetLastError();
 }
 hipError_t launch_encode_signal_torso_bwd(const float* att_params, const float* poses, int pose_stride, int N, int frame,

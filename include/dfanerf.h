@@ -109,8 +109,9 @@ int dfn_encode_signal_torso_bwd(const float* att_params, const float* poses, int
                                 int smo_size, const float* d_out, float* g_att, void* stream);
 /* The training step's pair: dfn_encode_signal_keep = dfn_encode_signal for ONE frame that also leaves the activations the backward
  * needs in `keep` (dfn_encode_signal_keep_floats() floats), dfn_encode_signal_bwd_kept = dfn_encode_signal_bwd reading them
- * instead of running AudioNet's forward a second time (same arithmetic: same gradients bit for bit; frame and smo_size as in
- * the keep call). */
+ * instead of running AudioNet's forward a second time, and computing AudioNet's two big weight gradients in a second,
+ * many-workgroup launch (same arithmetic: same gradients bit for bit; frame and smo_size as in the keep call; the tail of `kept`
+ * is the backward's scratch: the buffer is written by the call although it is declared const). */
 int dfn_encode_signal_keep(const float* aud_params, const float* exp_params, const float* att_params, const float* auds,
                            const float* exps, int n_total, const int32_t* frame_id, int smo_size, float* out, float* keep,
                            void* stream);
