@@ -167,6 +167,8 @@ __global__ __launch_bounds__(SIG_THREADS) void encode_signal_kernel(const float*
     }
     __syncthreads();
     // AudioNet_W2L: 512 -> 256 -> 128 -> 64
+    // (round 4, measured and not kept: this first layer - three quarters of the encoder's weights - as a 16-workgroup launch in
+    // front of the chain: next to the weight-gradient GEMMs its workgroups wait for compute-unit slots, 51 + 54 us instead of 77)
     linear_rows<512>(PA, PA + 131072, 256, xa, h1, S, true);
     linear_rows<256>(PA + 131328, PA + 131328 + 32768, 128, h1, h2, S, true);
     linear_rows<128>(PA + 164224, PA + 164224 + 8192, 64, h2, a64, S, false);

@@ -959,3 +959,43 @@ def test_hip_adam_bumps_versions_and_decoder_repacks(states):
     assert not torch.equal(pk2.flat, before)
     ref = torch.cat([p.detach().reshape(-1).float() for p in dec.state_dict().values()])
     assert torch.equal(pk2.flat, ref)
+
+
+@pytest.mark.parametrize("smo,frame", [(4, 3), (4, 0), (8, 7), (0, 2)])
+def test_signal_encoder_keep_pair_is_bitwise_the_plain_pair(states, scene, smo, frame):
+    """dfn_encode_signal_keep / dfn_encode_signal_bwd_kept (round 4: the first AudioNet layer over 16 workgroups, the forward's
+    activations kept for the backward, the two big weight gradients in a 24-workgroup launch) against dfn_encode_signal /
+    dfn_encode_signal_bwd: the same signal and the same gradients BIT FOR BIT (same arithmetic, same orders), for windows that
+    hang over both ends of the sequence and for the unsmoothed branch."""
+    import ctypes as C
+    from dfanerf._lib import check, lib
+    dev = torch.device("cuda")
+    flat = lambda st: torch.cat([t(v).reshape(-1) for v in st.values()]).float().to(dev).contiguous()
+    pa, pe, pt = flat(states["AudNet"]), flat(states["ExpNet"]), flat(states["AudAttNet"])
+    if smo == 8:                                   # AudioAttNet(96, 8): a synthetic parameter vector of the right length
+        n8 = 16 * 96 * 3 + 16 + 8 * 16 * 3 + 8 + 4 * 8 * 3 + 4 + 2 * 4 * 3 + 2 + 1 * 2 * 3 + 1 + 64 + 8
+        pt = (torch.randn(n8, device=dev, generator=torch.Generator(device=dev).manual_seed(1)) * 0.2).contiguous()
+    auds, exps = t(scene["aud"]).to(dev).contiguous(), t(scene["exp"]).to(dev).contiguous()
+    N = auds.shape[0]
+    ids = torch.tensor([frame], dtype=torch.int32, device=dev)
+    p = lambda x: C.c_void_p(x.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    o0, o1 = torch.empty(1, 96, device=dev), torch.empty(1, 96, device=dev)
+    keep = torch.zeros(check(lib.dfn_encode_signal_keep_floats(), "keep"), device=dev)
+    check(lib.dfn_encode_signal(p(pa), p(pe), p(pt), p(auds), p(exps), N, p(ids), 1, smo, p(o0), st), "encode")
+    check(lib.dfn_encode_signal_keep(p(pa), p(pe), p(pt), p(auds), p(exps), N, p(ids), smo, p(o1), p(keep), st), "encode_keep")
+    assert torch.equal(o0, o1)
+    d = torch.randn(96, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    g0 = [torch.zeros_like(x) for x in (pa, pe, pt)]
+    g1 = [torch.zeros_like(x) for x in (pa, pe, pt)]
+    check(lib.dfn_encode_signal_bwd(p(pa), p(pe), p(pt), p(auds), p(exps), N, frame, smo, p(d), p(g0[0]), p(g0[1]), p(g0[2]), st), "bwd")
+    check(lib.dfn_encode_signal_bwd_kept(p(pa), p(pe), p(pt), p(auds), p(exps), N, frame, smo, p(d), p(keep), p(g1[0]), p(g1[1]),
+                                         p(g1[2]), st), "bwd_kept")
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    assert float(g0[0].abs().max()) > 0 and (smo == 0 or float(g0[2].abs().max()) > 0)
+    # the overwrite variants (no zero fill in front) leave the same values in buffers that start as garbage
+    g2 = [torch.full_like(x, 7.0) for x in (pa, pe, pt)]
+    check(lib.dfn_encode_signal_bwd_set(p(pa), p(pe), p(pt), p(auds), p(exps), N, frame, smo, p(d), p(g2[0]), p(g2[1]), p(g2[2]), st),
+          "bwd_set")
+    assert torch.equal(g2[0], g0[0]) and torch.equal(g2[1], g0[1]) and (smo == 0 or torch.equal(g2[2], g0[2]))
