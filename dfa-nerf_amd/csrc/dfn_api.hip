@@ -318,6 +318,7 @@ static int render_fwd_impl(int tier, const DfnFrame* frame, const void* packed_h
     A.act_T[0] = A.act_T[1] = nullptr;
     A.masks[0] = A.masks[1] = nullptr;
     A.NP = 0;
+    A.loss = DfnTrainLoss{};
     A.clock_probe = g_clock_probe;
     hipError_t err = launch_render(tier, A, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "render_kernel");
@@ -436,8 +437,11 @@ static int train_fwd_impl(int tier, const DfnFrame* frame, const void* packed_he
                           const float* bias_head, const float* bias_torso, const float* bg_f32, const uint8_t* bg_u8,
                           const int32_t* pix_index, float* rgb_head, float* rgb_com, float* samples, void* act_head,
                           uint32_t* masks_head, void* act_torso, uint32_t* masks_torso, float* z_all, uint8_t* ranks,
-                          bool hier, void* stream) {
+                          bool hier, void* stream, const DfnTrainLoss* loss = nullptr, bool with_loss = false) {
     const char* who = hier ? "dfn_train_fwd_hier" : "dfn_train_fwd";
+    if (with_loss && (!loss || !loss->img_head || !loss->img_com || !loss->d_rgb_head || !loss->d_rgb_com || !loss->losses ||
+                      !loss->workspace))
+        return fail(DFN_E_ARG, std::string(who) + "_loss: bad loss argument");
     if (!train_tier_ok(tier) || !frame || !packed_head || !packed_torso || !bias_head || !bias_torso || !rgb_head ||
         !rgb_com || !samples || !act_head || !masks_head || !act_torso || !masks_torso || (hier && (!z_all || !ranks)))
         return fail(DFN_E_ARG, std::string(who) + ": bad argument");
@@ -478,10 +482,31 @@ static int train_fwd_impl(int tier, const DfnFrame* frame, const void* packed_he
     A.masks[0] = masks_head;
     A.masks[1] = masks_torso;
     A.NP = NP;
+    A.loss = with_loss ? *loss : DfnTrainLoss{};
     A.clock_probe = nullptr;
     hipError_t err = launch_render(tier, A, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "render_kernel(train)");
     return DFN_OK;
+}
+
+// per-workgroup partial sums [2][workgroups] + the ticket; a workgroup renders at least 4 rays in every tier
+long dfn_train_loss_floats(int ray_count) { return ray_count <= 0 ? 4 : 2L * ((ray_count + 3) / 4) + 4; }
+int dfn_train_fwd_loss(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
+                       const float* bias_head, const float* bias_torso, const float* bg_f32, const uint8_t* bg_u8,
+                       const int32_t* pix_index, float* rgb_head, float* rgb_com, float* samples, void* act_head,
+                       uint32_t* masks_head, void* act_torso, uint32_t* masks_torso, const DfnTrainLoss* loss, void* stream) {
+    return train_fwd_impl(tier, frame, packed_head, packed_torso, bias_head, bias_torso, bg_f32, bg_u8, pix_index, rgb_head,
+                          rgb_com, samples, act_head, masks_head, act_torso, masks_torso, nullptr, nullptr, false, stream,
+                          loss, true);
+}
+int dfn_train_fwd_hier_loss(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
+                            const float* bias_head, const float* bias_torso, const float* bg_f32, const uint8_t* bg_u8,
+                            const int32_t* pix_index, float* rgb_head, float* rgb_com, float* samples, void* act_head,
+                            uint32_t* masks_head, void* act_torso, uint32_t* masks_torso, float* z_all, uint8_t* ranks,
+                            const DfnTrainLoss* loss, void* stream) {
+    return train_fwd_impl(tier, frame, packed_head, packed_torso, bias_head, bias_torso, bg_f32, bg_u8, pix_index, rgb_head,
+                          rgb_com, samples, act_head, masks_head, act_torso, masks_torso, z_all, ranks, true, stream, loss,
+                          true);
 }
 
 int dfn_train_fwd(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,

@@ -26,6 +26,8 @@ struct RenderArgs {
     void* act_T[2];
     unsigned* masks[2];
     long NP;
+    // training forward with the loss in its epilogue (dfn_train_fwd_loss; losses == null: off)
+    DfnTrainLoss loss;
     // debug (dfn_debug_clock_probe): the workgroup in the middle of the grid writes {shader cycles, 100 MHz ticks} of its
     // own lifetime -> the effective shader clock UNDER LOAD of this launch.  Null = off.
     unsigned long long* clock_probe;

@@ -583,6 +583,76 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
             }
         }
     }
+    if constexpr (TRAIN != 0) {
+        // dfn_train_fwd_loss: the step's loss and d loss / d rgb from the epilogue (include/dfanerf.h).  Ray: its target pixel,
+        // its row of d_rgb, its squared error; workgroup: its rays' in ray order; the last workgroup to get here (ticket in
+        // the caller's workspace): the workgroups' in workgroup order.
+        if (A.loss.losses) {                                         // (uniform over the launch)
+            const int total = 3 * F.ray_count;
+            if (lane == 0) {
+                float se_h = 0.f, se_c = 0.f;
+                if (valid) {
+                    const int pix = A.pix_index ? A.pix_index[r_raw] : F.ray_begin + r_raw;
+                    const float scale = div_(2.0f, (float)total);
+                    unsigned char th[3], tc[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        th[k] = A.loss.img_head[(size_t)pix * 3 + k];
+                        tc[k] = A.loss.img_com[(size_t)pix * 3 + k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float dh = sub_(st[RS_RGB_H + k], div_((float)th[k], 255.0f));
+                        const float dc = sub_(st[RS_RGB_C + k], div_((float)tc[k], 255.0f));
+                        se_h = add_(se_h, mul_(dh, dh));
+                        se_c = add_(se_c, mul_(dc, dc));
+                        A.loss.d_rgb_head[(size_t)r_raw * 3 + k] = mul_(scale, dh);
+                        A.loss.d_rgb_com[(size_t)r_raw * 3 + k] = mul_(scale, dc);
+                    }
+                }
+                st[RS_TH] = se_h;
+                st[RS_TC] = se_c;
+            }
+            __syncthreads();
+            const int nwg = gridDim.x;
+            float* part = A.loss.workspace;
+            unsigned* ticket = (unsigned*)(A.loss.workspace + 2 * nwg);
+            volatile lds_f32* st0 = (lds_f32*)(lds + L::SCRATCH) + L::STATE;      // wave 0's state block
+            if (tid == 0) {
+                float a = 0.f, b = 0.f;
+                for (int w = 0; w < C::WAVES; ++w) {
+                    volatile lds_f32* sw = (lds_f32*)(lds + L::SCRATCH + w * L::SCRATCH_PER_WAVE) + L::STATE;
+                    a = add_(a, sw[RS_TH]);
+                    b = add_(b, sw[RS_TC]);
+                }
+                part[blockIdx.x] = a;
+                part[nwg + blockIdx.x] = b;
+                __threadfence();
+                st0[RS_NH] = (atomicAdd(ticket, 1u) == (unsigned)nwg - 1u) ? 1.0f : 0.0f;
+            }
+            __syncthreads();
+            if (st0[RS_NH] != 0.0f && wave == 0) {
+                __threadfence();
+                float a = 0.f, b = 0.f;
+                for (int k = lane; k < nwg; k += 64) {            // lane l: workgroups l, l + 64, ... in sequence
+                    a = add_(a, ((volatile float*)part)[k]);
+                    b = add_(b, ((volatile float*)part)[nwg + k]);
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {               // then the lanes by a butterfly (same value in every lane)
+                    a = add_(a, __shfl_xor(a, m, 64));
+                    b = add_(b, __shfl_xor(b, m, 64));
+                }
+                if (lane == 0) {
+                    const float lh = div_(a, (float)total), lc = div_(b, (float)total);
+                    A.loss.losses[0] = lh;                          // img2mse(rgb_head, target_head)
+                    A.loss.losses[1] = lc;                          // img2mse(rgb_com, target_com)
+                    A.loss.losses[2] = add_(lc, lh);                // the step's loss (MAIN:902-907: loss_com + loss_head)
+                    *ticket = 0u;                                   // ready for the next launch on this workspace
+                }
+            }
+        }
+    }
     if (probe && lane == 0) {
         A.clock_probe[0] = __builtin_readcyclecounter() - probe_c0;
         A.clock_probe[1] = __builtin_amdgcn_s_memrealtime() - probe_r0;

@@ -23,6 +23,11 @@ class DfnFrame(C.Structure):
                 ("n_coarse", C.c_int), ("n_fine", C.c_int), ("fields", C.c_int), ("concate_bg", C.c_int)]
 
 
+class DfnTrainLoss(C.Structure):
+    _fields_ = [("img_head", C.c_void_p), ("img_com", C.c_void_p), ("d_rgb_head", C.c_void_p), ("d_rgb_com", C.c_void_p),
+                ("losses", C.c_void_p), ("workspace", C.c_void_p)]
+
+
 class DfnError(RuntimeError):
     pass
 
@@ -75,6 +80,11 @@ def _load():
         "dfn_train_prepare": (i32, [i32, fp, fp, fp, fp, fp, vp, vp, vp, vp, fp, fp, vp]),
         "dfn_train_fwd": (i32, [i32, C.POINTER(DfnFrame), vp, vp, fp, fp, fp, vp, ip, fp, fp, fp, vp, vp, vp, vp, vp]),
         "dfn_train_fwd_hier": (i32, [i32, C.POINTER(DfnFrame), vp, vp, fp, fp, fp, vp, ip, fp, fp, fp, vp, vp, vp, vp, fp, vp, vp]),
+        "dfn_train_loss_floats": (lg, [i32]),
+        "dfn_train_fwd_loss": (i32, [i32, C.POINTER(DfnFrame), vp, vp, fp, fp, fp, vp, ip, fp, fp, fp, vp, vp, vp, vp,
+                                     C.POINTER(DfnTrainLoss), vp]),
+        "dfn_train_fwd_hier_loss": (i32, [i32, C.POINTER(DfnFrame), vp, vp, fp, fp, fp, vp, ip, fp, fp, fp, vp, vp, vp, vp, fp,
+                                          vp, C.POINTER(DfnTrainLoss), vp]),
         "dfn_composite_bwd_hier": (i32, [C.POINTER(DfnFrame), ip, fp, vp, fp, fp, vp, fp, fp, fp, vp]),
         "dfn_composite_bwd_hier_z": (i32, [C.POINTER(DfnFrame), ip, fp, vp, fp, fp, vp, fp, fp, fp, fp, lg, vp]),
         "dfn_sample_pixels": (i32, [i32, i32, i32, i32, ip, C.c_uint64, C.c_uint64, ip, ip, vp]),

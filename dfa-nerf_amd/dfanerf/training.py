@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import engine
-from ._lib import FIELD_HEAD, FIELD_TORSO, check, lib
+from ._lib import FIELD_HEAD, FIELD_TORSO, DfnTrainLoss, check, lib
 from .engine import TIERS, _ptr, _stream
 
 
@@ -38,6 +38,8 @@ _SIG_FIRST = os.environ.get("DFN_TRAIN_SIG_FIRST", "1") == "1"
 _SIG_SET = os.environ.get("DFN_TRAIN_SIG_SET", "0") == "1"
 # the audio encoder's forward keeps its activations for its backward (1) or the backward recomputes them (0: A/B)
 _SIG_KEEP = os.environ.get("DFN_TRAIN_SIG_KEEP", "1") == "1"
+# the step's loss from the training forward's epilogue (1: dfn_train_fwd*_loss) or from its own launch (0: dfn_mse_loss_u8; A/B)
+_LOSS_IN_FWD = os.environ.get("DFN_TRAIN_LOSS_IN_FWD", "1") == "1"
 
 
 def _side_stream(device, high=False, role=None):
@@ -168,7 +170,8 @@ class FusedTrainFn(torch.autograd.Function):
         return _fused_backward(ctx, d_h, d_c)
 
 
-def _fused_forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app, defer):
+def _fused_forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app, defer, loss=None):
+    # loss: a _lib.DfnTrainLoss -> the forward's epilogue forms the step's loss and d loss / d rgb (dfn_train_fwd*_loss)
     # defer: the SignalTrainer whose _SignalFn produced both signals (their backward then picks d(signal) up on its own
     # streams and the main stream never waits for it), or None
     ctx.defer = defer if _OVERLAP else None
@@ -190,7 +193,18 @@ def _fused_forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape,
     rgb_c = torch.empty(n, 3, dtype=torch.float32, device=dev)
     bg_f32 = bg if bg.dtype == torch.float32 else None
     bg_u8 = bg if bg.dtype == torch.uint8 else None
-    if buf.n_fine:
+    if loss is not None and buf.n_fine:
+        check(lib.dfn_train_fwd_hier_loss(t, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias), bias_t,
+                                          _ptr(bg_f32), _ptr(bg_u8), _ptr(pix_index), _ptr(rgb_h), _ptr(rgb_c),
+                                          _ptr(buf.samples), _ptr(buf.act[0]), _ptr(buf.masks[0]), _ptr(buf.act[1]),
+                                          _ptr(buf.masks[1]), _ptr(buf.z_all), _ptr(buf.ranks), C.byref(loss), st),
+              "dfn_train_fwd_hier_loss")
+    elif loss is not None:
+        check(lib.dfn_train_fwd_loss(t, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias), bias_t,
+                                     _ptr(bg_f32), _ptr(bg_u8), _ptr(pix_index), _ptr(rgb_h), _ptr(rgb_c),
+                                     _ptr(buf.samples), _ptr(buf.act[0]), _ptr(buf.masks[0]), _ptr(buf.act[1]),
+                                     _ptr(buf.masks[1]), C.byref(loss), st), "dfn_train_fwd_loss")
+    elif buf.n_fine:
         check(lib.dfn_train_fwd_hier(t, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias), bias_t,
                                      _ptr(bg_f32), _ptr(bg_u8), _ptr(pix_index), _ptr(rgb_h), _ptr(rgb_c),
                                      _ptr(buf.samples), _ptr(buf.act[0]), _ptr(buf.masks[0]), _ptr(buf.act[1]),
@@ -727,14 +741,23 @@ class FusedTrainLossFn(torch.autograd.Function):
     def forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app, defer, img_head, img_com):
         if img_head.dtype != torch.uint8 or img_com.dtype != torch.uint8 or pix_index.dtype != torch.int32:
             raise TypeError("FusedTrainLossFn: uint8 frames and int32 pixel ids expected")
-        rgb_h, rgb_c = _fused_forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app, defer)
-        n = rgb_h.shape[0]
-        losses = torch.empty(3, dtype=torch.float32, device=rgb_h.device)
-        if getattr(buf, "_d_rgb", None) is None or buf._d_rgb[0].shape != rgb_h.shape:
-            buf._d_rgb = (torch.empty_like(rgb_h), torch.empty_like(rgb_c))
+        n, dev = frame.ray_count, buf.flat.device
+        losses = torch.empty(3, dtype=torch.float32, device=dev)
+        if getattr(buf, "_d_rgb", None) is None or buf._d_rgb[0].shape[0] != n:
+            buf._d_rgb = (torch.empty(n, 3, dtype=torch.float32, device=dev), torch.empty(n, 3, dtype=torch.float32, device=dev))
+            # the epilogue's partial sums + ticket: zero once, every launch leaves the ticket zero again
+            buf._loss_ws = torch.zeros(check(lib.dfn_train_loss_floats(n), "dfn_train_loss_floats"), dtype=torch.float32,
+                                       device=dev)
         d_h, d_c = buf._d_rgb
-        check(lib.dfn_mse_loss_u8(_ptr(rgb_h), _ptr(rgb_c), _ptr(img_head), _ptr(img_com), _ptr(pix_index), n, _ptr(losses),
-                                  _ptr(d_h), _ptr(d_c), _stream()), "dfn_mse_loss_u8")
+        if _LOSS_IN_FWD:
+            # the loss and d loss / d rgb come out of the forward's epilogue: no launch between the forward and the backward
+            arg = DfnTrainLoss(img_head.data_ptr(), img_com.data_ptr(), d_h.data_ptr(), d_c.data_ptr(), losses.data_ptr(),
+                               buf._loss_ws.data_ptr())
+            rgb_h, rgb_c = _fused_forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app, defer, arg)
+        else:
+            rgb_h, rgb_c = _fused_forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape, z_app, defer)
+            check(lib.dfn_mse_loss_u8(_ptr(rgb_h), _ptr(rgb_c), _ptr(img_head), _ptr(img_com), _ptr(pix_index), n,
+                                      _ptr(losses), _ptr(d_h), _ptr(d_c), _stream()), "dfn_mse_loss_u8")
         ctx.d = (d_h, d_c)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(rgb_h, rgb_c)

@@ -213,6 +213,32 @@ int dfn_sample_pixels(int H, int W, int n, int rect_num, const int32_t* rect, ui
  * Fixed reduction order (bit-reproducible). */
 int dfn_mse_loss_u8(const float* rgb_head, const float* rgb_com, const uint8_t* img_head, const uint8_t* img_com,
                     const int32_t* pix_index, int n, float* losses, float* d_rgb_head, float* d_rgb_com, void* stream);
+/* The same loss formed in the EPILOGUE of the training forward (one launch less between the forward and the dX chain: a
+ * single-workgroup loss kernel is 17-19 us of a 1-ms step): every ray's wave gathers its own target pixel, writes its row of
+ * d_rgb_head / d_rgb_com and its squared error; a workgroup adds its rays' in ray order, the workgroup that finishes LAST
+ * (a ticket in `workspace`) adds the workgroups' partial sums in workgroup order - fixed orders: bit-reproducible run to run;
+ * the sums are the same real numbers as dfn_mse_loss_u8's in another order (the two agree to rounding, not bit for bit).
+ *   workspace: dfn_train_loss_floats(ray_count) floats that must read ZERO before the first call; the call leaves the
+ *   ticket zero again (launches sharing a workspace must not overlap).  No state inside the library.
+ * frame->ray_count rays, pix_index as in the forward (null: ray_begin + r).                                            */
+typedef struct DfnTrainLoss {
+    const uint8_t* img_head;   /* uint8 [H*W,3] ground-truth frames resident on the device */
+    const uint8_t* img_com;
+    float* d_rgb_head;         /* out [ray_count,3] */
+    float* d_rgb_com;          /* out [ray_count,3] */
+    float* losses;             /* out [3], as dfn_mse_loss_u8 */
+    float* workspace;
+} DfnTrainLoss;
+long dfn_train_loss_floats(int ray_count);
+int dfn_train_fwd_loss(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
+                       const float* bias_head, const float* bias_torso, const float* bg_f32, const uint8_t* bg_u8,
+                       const int32_t* pix_index, float* rgb_head, float* rgb_com, float* samples, void* act_head,
+                       uint32_t* masks_head, void* act_torso, uint32_t* masks_torso, const DfnTrainLoss* loss, void* stream);
+int dfn_train_fwd_hier_loss(int tier, const DfnFrame* frame, const void* packed_head, const void* packed_torso,
+                            const float* bias_head, const float* bias_torso, const float* bg_f32, const uint8_t* bg_u8,
+                            const int32_t* pix_index, float* rgb_head, float* rgb_com, float* samples, void* act_head,
+                            uint32_t* masks_head, void* act_torso, uint32_t* masks_torso, float* z_all, uint8_t* ranks,
+                            const DfnTrainLoss* loss, void* stream);
 int dfn_composite_bwd(const DfnFrame* frame, const int32_t* pix_index, const float* bg_f32, const uint8_t* bg_u8,
                       const float* samples, const float* d_rgb_head, const float* d_rgb_com, float* dsamples,
                       void* stream);

@@ -853,6 +853,62 @@ def test_fused_mse_loss_matches_torch():
         training.mse_losses(a1, b1, img_h.float(), img_c, pix)
 
 
+@pytest.mark.parametrize("tier,n_fine,n", [("bf16", 0, 2048), ("f32", 0, 200), ("bf16", 128, 512), ("bf16", 0, 8)])
+def test_loss_in_the_forward_epilogue_equals_the_loss_kernel(states, scene, latents, tier, n_fine, n, monkeypatch):
+    """dfn_train_fwd_loss / dfn_train_fwd_hier_loss (the step's loss and d loss / d rgb from the forward's epilogue, the last
+    workgroup's ticket in a caller workspace) against the same forward + dfn_mse_loss_u8: images and d_rgb BITWISE (the same
+    operations per element), the losses to rounding (the same terms in another, fixed order); three calls through one
+    workspace (the ticket must come back to zero), every gradient of the step bitwise the loss-kernel route's."""
+    from dfanerf import engine, training
+    dev = torch.device("cuda")
+    H, W = scene["H"], scene["W"]
+    zs, za = [t(v).to(dev) for v in latents]
+    bg = (t(scene["bg"]).float() / 255.0).reshape(-1, 3).to(dev)
+    pix = (torch.arange(n, dtype=torch.int32, device=dev) * 397 + 11) % (H * W)
+    frame = engine.make_frame(H, W, scene["focal"], scene["cx"], scene["cy"], scene["poses"][1], scene["pose_body"], 0.3,
+                              0.9, 1e10, 0, n, 64, n_fine, 2, True)
+    g = torch.Generator(device=dev).manual_seed(9)
+    img_h = torch.randint(0, 256, (H * W, 3), dtype=torch.uint8, device=dev, generator=g)
+    img_c = torch.randint(0, 256, (H * W, 3), dtype=torch.uint8, device=dev, generator=g)
+
+    def run(in_fwd, reps):
+        monkeypatch.setattr(training, "_LOSS_IN_FWD", in_fwd)
+        mods = _modules(states, dev)
+        dec = mods["decoder"]
+        buf = training.TrainBuffers(tier, n, dev, n_fine=n_fine)
+        out = []
+        for _ in range(reps):
+            for p_ in dec.parameters():
+                p_.grad = None
+            sh = (t(synth.synth_tensor(0, "ff/sh", (1, 96), 0.3))).to(dev).requires_grad_(True)
+            st = (t(synth.synth_tensor(0, "ff/st", (42,), 0.3))).to(dev).requires_grad_(True)
+            loss, lh, lc, rh, rc = training.render_train_loss(dec, buf, frame, bg, pix, sh, st, zs[0, :2], za[0, :2],
+                                                              img_h, img_c)
+            d = [x.clone() for x in buf._d_rgb]
+            training.backward(loss, buf)
+            out.append((torch.stack([loss, lh, lc]).detach().clone(), rh.clone(), rc.clone(), d, sh.grad.clone(), st.grad.clone(),
+                        {k: p_.grad.clone() for k, p_ in dec.named_parameters() if p_.grad is not None}))
+        ticket = None
+        if in_fwd:       # the ticket word sits behind the [2][workgroups] partial sums
+            nwg = -(-n // (4 if tier == "f32" else 8))
+            ticket = buf._loss_ws.view(torch.int32)[2 * nwg].item()
+        return out, ticket
+
+    ref, _ = run(False, 1)
+    got, ticket = run(True, 3)
+    r = ref[0]
+    for o in got:
+        assert torch.equal(o[1], r[1]) and torch.equal(o[2], r[2])
+        assert torch.equal(o[3][0], r[3][0]) and torch.equal(o[3][1], r[3][1])
+        torch.testing.assert_close(o[0], r[0], rtol=2e-6, atol=0)
+        assert torch.equal(o[0], got[0][0])                             # run to run: bitwise
+        assert torch.equal(o[0][0], o[0][2] + o[0][1])
+        assert torch.equal(o[4], r[4]) and torch.equal(o[5], r[5]) and o[6].keys() == r[6].keys()
+        for k in o[6]:
+            assert torch.equal(o[6][k], r[6][k]), k
+    assert ticket == 0
+
+
 def _adam_pair(seed, shapes):
     g = torch.Generator().manual_seed(seed)
     ps = [torch.randn(*s, generator=g) for s in shapes]
