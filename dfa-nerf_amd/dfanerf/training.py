@@ -38,9 +38,6 @@ _SIG_FIRST = os.environ.get("DFN_TRAIN_SIG_FIRST", "1") == "1"
 _SIG_SET = os.environ.get("DFN_TRAIN_SIG_SET", "0") == "1"
 # the audio encoder's forward keeps its activations for its backward (1) or the backward recomputes them (0: A/B)
 _SIG_KEEP = os.environ.get("DFN_TRAIN_SIG_KEEP", "1") == "1"
-# the conditioning networks' gradient buffers are zeroed on their streams at the START of the decoder's backward (1) or in
-# front of their own backward kernels, behind d(signal) (0: A/B) - three fills + gaps off the audio chain
-_SIG_PREFILL = os.environ.get("DFN_TRAIN_SIG_PREFILL", "1") == "1"
 # the step's loss from the training forward's epilogue (1: dfn_train_fwd*_loss) or from its own launch (0: dfn_mse_loss_u8; A/B)
 _LOSS_IN_FWD = os.environ.get("DFN_TRAIN_LOSS_IN_FWD", "1") == "1"
 
@@ -316,8 +313,6 @@ def _fused_backward(ctx, d_h, d_c):
             ev = getattr(tr, "_dsig_ev", None)
             if ev is None:
                 ev = tr._dsig_ev = (torch.cuda.Event(), torch.cuda.Event())
-        if tr is not None and _SIG_PREFILL:
-            tr.prefill_grad_buffers()
         dx(0, st)
         # ONE event behind the head's dX chain for both side chains (every record is a packet in the main queue in front of the
         # torso's dX chain: two cost 14 us between the two dX kernels)
@@ -501,23 +496,6 @@ class SignalTrainer:
         self._pipelined = True
         self._fresh = True
 
-    def prefill_grad_buffers(self):
-        """Zero the networks' reusable gradient buffers on their streams NOW (FusedTrainFn.backward calls it before it makes
-        these streams wait for the dX chain): _SignalFn.backward then finds them filled and its three fills + their gaps
-        (~25 us) are no longer part of the chain d(signal) -> encoder backward -> Adam -> next forward.  Same conditions as
-        _SignalFn.backward's own reuse of a buffer; anything else is left to it."""
-        s_a, s_p = self.audio_stream(), self.pose_stream()
-        if s_a is None or _SIG_SET:
-            return
-        done = []
-        for n, s in zip(self.nets, (s_a, s_a, s_a, s_p)):
-            g = getattr(n, "_g_flat", None)
-            if g is not None and g.shape == n.flat.shape and g.device == n.flat.device and \
-                    not any(q.grad is not None for q in n.params):
-                check(lib.dfn_zero_async(_ptr(g), g.numel() * 4, C.c_void_p(s.cuda_stream)), "dfn_zero_async")
-                done.append(g.data_ptr())
-        self._prefilled = tuple(done)
-
     def join(self):
         """Order the current stream behind everything queued on the conditioning networks' streams (their backward, Adam,
         the next forward).  encode() does it for the training step; call it before anything ELSE reads these networks'
@@ -618,7 +596,6 @@ class _SignalFn(torch.autograd.Function):
             s_p.wait_event(tr._dsig_ev[1])          # (the torso's d(signal) may have been produced on the main stream: _SIG_FIRST)
         st_a = st if s_a is None else C.c_void_p(s_a.cuda_stream)
         st_t = st if s_p is None else C.c_void_p(s_p.cuda_stream)
-        pre, tr._prefilled = getattr(tr, "_prefilled", ()), ()       # (zeroed already: prefill_grad_buffers)
         def buffers(side, stream, nets):
             # _grad_buffer on an explicit stream (dfn_zero_async: no torch stream context per fill)
             out = []
@@ -631,7 +608,7 @@ class _SignalFn(torch.autograd.Function):
                         side.wait_stream(main)      # fresh memory of the main stream's pool: its last user ran there
                     if not any(q.grad is not None for q in n.params):
                         n._g_flat = g
-                if not _SIG_SET and g.data_ptr() not in pre:
+                if not _SIG_SET:
                     check(lib.dfn_zero_async(_ptr(g), g.numel() * 4, stream), "dfn_zero_async")
                 out.append(g)
             return out
