@@ -161,8 +161,15 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
                              // interleaved, three rounds): not adopted
 #define DFN_PIPE_TWO 0
 #endif
+#ifndef DFN_PIPE_TWO_HEAD    // 1: in the two-field kernel the HEAD's passes run the pipelined layers, the torso's (whose deformation
+                             // field and skip input hold the registers the second accumulator set needs) the plain ones: 256
+                             // VGPRs, nothing spilled, the same bits; C3 70.62 -> 70.24-70.36 ms (-0.4 %, interleaved, three rounds -
+                             // the kernel sits at its power ceiling, DESIGN.md 4.6: a better schedule is paid back in clock)
+#define DFN_PIPE_TWO_HEAD 1
+#endif
     typedef CtxT<TRAIN != 0, TRAIN == 0, TRAIN != 0, (DFN_PIPE != 0) && TRAIN == 0 && (!TWO || DFN_PIPE_TWO != 0), TRAIN != 0 && ACT_FP4> CtxK;      // (fused step: act_T in MX-fp4)
     CtxK ctx = {lds, wave, lane, lane >> 5, {}};
+    typedef CtxT<TRAIN != 0, TRAIN == 0, TRAIN != 0, (DFN_PIPE != 0) && TRAIN == 0 && (!TWO || DFN_PIPE_TWO != 0 || DFN_PIPE_TWO_HEAD != 0), TRAIN != 0 && ACT_FP4> CtxH;   // the head's passes
     constexpr bool two = TWO;
     const int NF = TRAIN == 1 ? 0 : F.n_fine;     // TRAIN == 1: the training forward is the reference's coarse renderer
     const bool hier = NF > 0;
@@ -327,7 +334,12 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
 #ifdef DFN_TIMING
             const unsigned long long tm0 = __builtin_readcyclecounter();
 #endif
-            a = mlp_head<TIER>(p, dref_h, bias_h, s, ctx);
+            if constexpr (std::is_same<CtxH, CtxK>::value) {
+                a = mlp_head<TIER>(p, dref_h, bias_h, s, ctx);
+            } else {
+                const CtxH ctx_h = {ctx.ring, ctx.wave, ctx.lane, ctx.half, ctx.rec};
+                a = mlp_head<TIER>(p, dref_h, bias_h, s, ctx_h);
+            }
 #ifdef DFN_TIMING
             T_mlp += __builtin_readcyclecounter() - tm0;
 #endif
