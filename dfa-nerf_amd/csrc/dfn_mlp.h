@@ -386,6 +386,10 @@ DFN_DEV void store_tile4(void* arr, int rows, long tile, int row0, const Vec<TIE
         o = __builtin_amdgcn_cvt_scalef32_pk_fp4_bf16(o, __builtin_bit_cast(bf16x2_q, w3), q.scale, 3);
         out[k] = o;
     }
+#ifdef DFN_REC8_NOSTORE       // timing experiment (wrong results): everything but the store instruction
+    asm volatile("" ::"v"(out));
+    return;
+#endif
     gchar* ubase = uniform_ptr((char*)arr + tile * act_tile_bytes(rows, true) + (long)row0 * 16);
     const unsigned voff = (unsigned)((c.lane & 31) * 16 + c.half * 8);
     __builtin_nontemporal_store(out, (__attribute__((address_space(1))) u32x2_*)(ubase + (t - t_first) * 512 + voff));
@@ -749,6 +753,9 @@ DFN_DEV void rec_mask_pair(const CT& c, int mask_dword, const f32x16 (&acc)[2]) 
 // quarter of the training forward's vector instructions were mask bits.
 template <int TIER, int NT, class CT>
 DFN_DEV void rec_mask_pair_packed(const CT& c, int mask_dword, const Vec<TIER, NT>& out, int t0) {
+#ifdef DFN_REC_NOMASK         // timing experiment (wrong results): no ReLU bits at all
+    return;
+#endif
     if constexpr (CT::rec_on && tier_is16(TIER)) {
         if (mask_dword >= 0) {
             typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
@@ -767,6 +774,10 @@ DFN_DEV void rec_mask_pair_packed(const CT& c, int mask_dword, const Vec<TIER, N
                 }
             }
             const unsigned bits = b2[0] | b2[1];
+#ifdef DFN_REC_NOMASKSTORE    // timing experiment (wrong results): the bits, not their store
+            asm volatile("" ::"v"(bits));
+            return;
+#endif
             gchar* mb = uniform_ptr(c.rec.masks + ((long)c.rec.pass * c.rec.mask_dwords + mask_dword) * 64);
             *(__attribute__((address_space(1))) unsigned*)(mb + (unsigned)c.lane * 4u) = bits;
         }
