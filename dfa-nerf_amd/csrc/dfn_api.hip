@@ -75,10 +75,11 @@ struct WgradEntry {
     int32_t* eof_dev = nullptr;      // dy_T row -> bias element
     int* prefix_dev = nullptr;
     // 16-bit tier: one workgroup per (GEMM, slice of the points), the slice count PER GEMM (balanced split, see wgrad_items)
-    WItem* items_dev = nullptr;
-    int n_items = 0;
-    unsigned char* blk_n_dev = nullptr;    // slices of the GEMM that owns each 256-element block of the dense C array
-    unsigned char* bias_n_dev = nullptr;   // slices of the GEMM that produces each bias element's row sum
+    // Two splits (WGRAD_SPLITS): [0] the reference's step (<= WGRAD_SMALL_NP points), [1] larger calls (the hierarchical step)
+    WItem* items_dev[2] = {nullptr, nullptr};
+    int n_items[2] = {0, 0};
+    unsigned char* blk_n_dev[2] = {nullptr, nullptr};    // slices of the GEMM that owns each 256-element block of the dense C array
+    unsigned char* bias_n_dev[2] = {nullptr, nullptr};   // slices of the GEMM that produces each bias element's row sum
     int32_t* sig_rows_dev = nullptr; // dfn_signal_grad: dy_T rows / bias elements behind d(signal)
     int32_t* sig_elems_dev = nullptr;
     int n_sig = 0;
@@ -86,6 +87,8 @@ struct WgradEntry {
 };
 WgradEntry g_wgrad[2];
 constexpr int WGRAD_KSPLIT = 32;
+constexpr long WGRAD_SMALL_NP = 196608;  // 16-bit tier: calls up to this many points use the split with more spare compute units
+
 constexpr int WS_KSPLIT_MAX = 32;       // slices the workspace is sized for (>= every tier's split)
 // head 16 / torso 18 (round 3, whole step, interleaved A/B over 600 steps x 4: torso 16 / 17 / 18 / 20 = 1.1056 / 1.1021 / 1.0975 /
 // 1.114 ms; head 19: worse).  Round 2: the kernel alone takes the same time for 16 ... 32 slices (0.81-0.82 ms for both fields, HBM-bound), the second stage
@@ -685,60 +688,75 @@ static int weight_grad_impl(int tier, int field, int act_format, const void* dy_
                 if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                     cus = prop.multiProcessorCount;
             }
-            // a few compute units are left to the single-workgroup kernels of the conditioning networks' chains (their backward,
-            // Adam, the next step's encoders): a launch of exactly one workgroup per compute unit, 144 KiB of LDS and 2 x 236
-            // registers per SIMD each, leaves them no slot until it ends (DFN_WGRAD_SPARE_CUS: developer override)
-            {
-                const char* e = getenv("DFN_WGRAD_SPARE_CUS");
-                const int spare = e ? atoi(e) : 8;
-                if (spare >= 0 && spare < cus / 2) cus -= spare;
-            }
-            std::vector<WItem> items;
-            std::vector<int> n_of;
-            wgrad_items(w.ops, field, cus, items, n_of);
-            // slices per 256-element block of C (every GEMM's C region is a multiple of 1024 elements: one GEMM per block) and per
-            // bias element (the GEMM that owns its dy_T row block)
-            std::vector<unsigned char> blk_n((w.map.size() + 255) / 256, 1), bias_n(w.bias_rows.size(), 1);
-            for (size_t i = 0; i < w.ops.size(); ++i) {
-                const WOpHost& o = w.ops[i];
-                if (o.c_off % 256) return fail(DFN_E_ARG, "internal: a GEMM's C region is not block-aligned");
-                for (long b = o.c_off / 256; b < (o.c_off + (long)o.M * o.N + 255) / 256; ++b) blk_n[b] = (unsigned char)n_of[i];
-                if (o.bias_owner)
-                    for (size_t e = 0; e < w.bias_rows.size(); ++e)
-                        if (w.bias_rows[e] >= o.a_row && w.bias_rows[e] < o.a_row + o.M) bias_n[e] = (unsigned char)n_of[i];
+            // some compute units are left to what runs NEXT to the GEMMs - the torso's dX chain next to the head's GEMMs, the
+            // single-workgroup kernels of the conditioning networks' chains (their backward, Adam, the next step's encoders) next to
+            // both: a launch of exactly one workgroup per compute unit, 144 KiB of LDS and 2 x 236 registers per SIMD each, leaves
+            // them no slot until it ends.  Measured, whole step, interleaved on three boxes: the reference's step (131,072 points)
+            // with 8 / 16 / 24 spare 0.99-1.02 ms, with 32 / 40 / 48 / 64: 0.95-0.97 (the GEMMs alone: 301 -> 307 us for both
+            // fields with 32, 318 with 64); the hierarchical step (393,216 points: its GEMMs are three times as long, what runs next to
+            // them is not) 2.756 with 8, 2.80 with 24, 2.788 with 40.  Hence two splits, by the size of the call: 32 / 8 spare.  (The
+            // split only changes the ORDER of the sums; the 200-step bf16-vs-f32 curve of tests/test_gpu_train.py, two chaotic
+            // trajectories, moves with it: worst step 1.95 % (32) ... 3.3 % (8) ... 5.2 % (40), final loss 0.014-1.0 %.)
+            // DFN_WGRAD_SPARE_CUS[_HEAD | _TORSO]: developer override (both splits)
+            const char* env = getenv(field == FIELD_TORSO ? "DFN_WGRAD_SPARE_CUS_TORSO" : "DFN_WGRAD_SPARE_CUS_HEAD");
+            if (!env) env = getenv("DFN_WGRAD_SPARE_CUS");
+            std::vector<WItem> items[2];
+            std::vector<unsigned char> blk_n[2], bias_n[2];
+            for (int c = 0; c < 2; ++c) {
+                const int spare = env ? atoi(env) : (c == 0 ? 32 : 8);
+                const int cus_c = (spare >= 0 && spare < cus / 2) ? cus - spare : cus;
+                std::vector<int> n_of;
+                wgrad_items(w.ops, field, cus_c, items[c], n_of);
+                // slices per 256-element block of C (every GEMM's C region is a multiple of 1024 elements: one GEMM per block) and
+                // per bias element (the GEMM that owns its dy_T row block)
+                blk_n[c].assign((w.map.size() + 255) / 256, 1);
+                bias_n[c].assign(w.bias_rows.size(), 1);
+                for (size_t i = 0; i < w.ops.size(); ++i) {
+                    const WOpHost& o = w.ops[i];
+                    if (o.c_off % 256) return fail(DFN_E_ARG, "internal: a GEMM's C region is not block-aligned");
+                    for (long bb = o.c_off / 256; bb < (o.c_off + (long)o.M * o.N + 255) / 256; ++bb) blk_n[c][bb] = (unsigned char)n_of[i];
+                    if (o.bias_owner)
+                        for (size_t e = 0; e < w.bias_rows.size(); ++e)
+                            if (w.bias_rows[e] >= o.a_row && w.bias_rows[e] < o.a_row + o.M) bias_n[c][e] = (unsigned char)n_of[i];
+                }
             }
             // upload into temporaries and publish every pointer only after ALL uploads succeeded: the guard above is keyed on
             // ops_dev, and a later call must never launch with a table that is still null
             WOp* d_ops = nullptr;
             int32_t *d_map = nullptr, *d_rows = nullptr;
             int* d_prefix = nullptr;
-            WItem* d_items = nullptr;
-            unsigned char *d_blk = nullptr, *d_bn = nullptr;
+            WItem* d_items[2] = {nullptr, nullptr};
+            unsigned char *d_blk[2] = {nullptr, nullptr}, *d_bn[2] = {nullptr, nullptr};
             hipError_t e = upload(&d_ops, ops.data(), ops.size());
             if (e == hipSuccess) e = upload(&d_map, w.map.data(), w.map.size());
             if (e == hipSuccess) e = upload(&d_prefix, w.prefix.data(), w.prefix.size());
             if (e == hipSuccess && !w.rows_dev) e = upload(&d_rows, w.bias_rows.data(), w.bias_rows.size());
-            if (e == hipSuccess) e = upload(&d_items, items.data(), items.size());
-            if (e == hipSuccess) e = upload(&d_blk, blk_n.data(), blk_n.size());
-            if (e == hipSuccess) e = upload(&d_bn, bias_n.data(), bias_n.size());
+            for (int c = 0; c < 2; ++c) {
+                if (e == hipSuccess) e = upload(&d_items[c], items[c].data(), items[c].size());
+                if (e == hipSuccess) e = upload(&d_blk[c], blk_n[c].data(), blk_n[c].size());
+                if (e == hipSuccess) e = upload(&d_bn[c], bias_n[c].data(), bias_n[c].size());
+            }
             if (e != hipSuccess) {
-                (void)hipFree(d_ops); (void)hipFree(d_map); (void)hipFree(d_prefix); (void)hipFree(d_rows); (void)hipFree(d_items);
-                (void)hipFree(d_blk); (void)hipFree(d_bn);
+                (void)hipFree(d_ops); (void)hipFree(d_map); (void)hipFree(d_prefix); (void)hipFree(d_rows);
+                for (int c = 0; c < 2; ++c) { (void)hipFree(d_items[c]); (void)hipFree(d_blk[c]); (void)hipFree(d_bn[c]); }
                 return hip_fail(e, "upload(wgrad plan)");
             }
             w.map_dev = d_map;
             w.prefix_dev = d_prefix;
             if (d_rows) w.rows_dev = d_rows;
-            w.items_dev = d_items;
-            w.n_items = (int)items.size();
-            w.blk_n_dev = d_blk;
-            w.bias_n_dev = d_bn;
+            for (int c = 0; c < 2; ++c) {
+                w.items_dev[c] = d_items[c];
+                w.n_items[c] = (int)items[c].size();
+                w.blk_n_dev[c] = d_blk[c];
+                w.bias_n_dev[c] = d_bn[c];
+            }
             w.ops_dev = d_ops;
         }
     }
     // Split-K without atomics: every (GEMM, slice of the points) writes its own slice of the partial arrays in the
     // workspace, the reduce kernels add the slices in index order -> bit-reproducible gradients.
     const long W = (long)w.map.size(), n_tiles = NP / 32;
+    const int sc = NP > WGRAD_SMALL_NP ? 1 : 0;                    // which of the two splits (above)
     const int nb = (int)w.bias_rows.size();
     const int ks = tier == DFN_TIER_BF16 ? wgrad_ksplit_bf16(field) : WGRAD_KSPLIT;
     if (tier == DFN_TIER_BF16 && (n_tiles & 1))
@@ -757,15 +775,15 @@ static int weight_grad_impl(int tier, int field, int act_format, const void* dy_
     // more, the streaming row-sum kernel is cheaper there (measured).
     const bool fuse = dbias && tier == DFN_TIER_BF16;
     if (tier == DFN_TIER_BF16)
-        err = launch_wgrad_bf16(field, act_format == DFN_ACT_E2M1, w.ops_dev, w.items_dev, w.n_items, dy_T, act_T, NP, c_parts, W,
+        err = launch_wgrad_bf16(field, act_format == DFN_ACT_E2M1, w.ops_dev, w.items_dev[sc], w.n_items[sc], dy_T, act_T, NP, c_parts, W,
                                 fuse ? w.eof_dev : nullptr, fuse ? b_parts : nullptr, nb, st);
     else
         err = launch_wgrad(tier, field, w.ops_dev, (int)w.ops.size(), w.prefix_dev, w.prefix.back(), dy_T, act_T, NP, ks,
                            c_parts, W, nullptr, nullptr, nb, st);
     if (err != hipSuccess) return hip_fail(err, "wgrad_kernel");
     if (fuse) {
-        err = launch_reduce_both(w.map_dev, c_parts, W, W, valid, grad_flat, w.rows_dev, b_parts, nb, dbias, w.blk_n_dev,
-                                 w.bias_n_dev, units, st);
+        err = launch_reduce_both(w.map_dev, c_parts, W, W, valid, grad_flat, w.rows_dev, b_parts, nb, dbias, w.blk_n_dev[sc],
+                                 w.bias_n_dev[sc], units, st);
         if (err != hipSuccess) return hip_fail(err, "reduce_both_kernel");
         return DFN_OK;
     }
@@ -774,7 +792,7 @@ static int weight_grad_impl(int tier, int field, int act_format, const void* dy_
         if (err != hipSuccess) return hip_fail(err, "bias_grad_kernel");
     }
     if (tier == DFN_TIER_BF16) {          // (weights only) the per-GEMM slice counts of the balanced split
-        err = launch_reduce_both(w.map_dev, c_parts, W, W, valid, grad_flat, nullptr, nullptr, 0, nullptr, w.blk_n_dev, nullptr,
+        err = launch_reduce_both(w.map_dev, c_parts, W, W, valid, grad_flat, nullptr, nullptr, 0, nullptr, w.blk_n_dev[sc], nullptr,
                                  units, st);
         if (err != hipSuccess) return hip_fail(err, "reduce_both_kernel");
         return DFN_OK;

@@ -232,7 +232,9 @@ def test_bf16_training_tracks_f32_over_200_steps(states, scene, latents):
     loss curve ends on the f32 one - mean of the last 20 losses within 2 %, every step of the second half within 5 %.  (The
     first ~40 steps are Adam's chaotic transient at lr 5e-4 - the loss overshoots and recovers - where two trajectories that
     differ by rounding are not comparable step by step; measured with the MX-fp8 recorder: 0.5 % at the end, <= 2.5 % per step
-    in the second half; with bf16 recording it was 0.13 % / 0.35 %; round 4, activations in MX-fp4: 0.014 % / 3.3 %.)"""
+    in the second half; with bf16 recording it was 0.13 % / 0.35 %; round 4, activations in MX-fp4: 0.014 % / 3.3 %.  The
+    per-step figure is trajectory noise, not accuracy: with nothing changed but the ORDER of the weight gradients' split-K sums
+    (DFN_WGRAD_SPARE_CUS = 8 ... 64) it reads 1.95-5.2 %, the final figure 0.014-1.0 %.)"""
     from dfanerf import frames, nets, run_nerf, training
     dev = torch.device("cuda")
     n, n_steps = 1024, 200
