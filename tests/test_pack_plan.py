@@ -83,6 +83,15 @@ def test_error_paths_without_gpu():
     assert L.dfn_train_prepare(2, one, one, one, one, one, one, one, one, one, one, one, N) == -1          # f16: inference only
     assert L.dfn_zero_async(N, 16, N) == -1 and L.dfn_zero_async(one, -1, N) == -1 and L.dfn_zero_async(one, 0, N) == 0
     assert L.dfn_train_rows(0, 5) == 128 * 512 + L.dfn_bias_floats(1, 0) and L.dfn_train_rows(1, 5) > 0
+    # round 4: the training forward with the loss in its epilogue - a loss block with any null member is refused
+    fr.n_fine, fr.fields, fr.ray_count = 0, 2, 8
+    args16 = (1, _lib.C.byref(fr), one, one, one, one, one, N, one, one, one, one, one, one, one, one)
+    assert L.dfn_train_fwd_loss(*args16, None, N) == -1 and b"loss" in L.dfn_last_error()
+    bad = _lib.DfnTrainLoss(one, one, one, one, one, None)                                                # no workspace
+    assert L.dfn_train_fwd_loss(*args16, _lib.C.byref(bad), N) == -1
+    assert L.dfn_train_fwd_hier_loss(*args16, one, one, None, N) == -1
+    assert L.dfn_train_loss_floats(2048) >= 2 * 256 + 1 and L.dfn_train_loss_floats(0) > 0
+    assert L.dfn_weight_bias_grad_fmt(1, 0, 7, one, one, 64, one, one, one, N) == -1 and b"act_format" in L.dfn_last_error()
 
 
 class Reader:
