@@ -887,7 +887,7 @@ int dfn_signal_grad(int tier, int field, const float* params, const void* dy_T, 
         }
     }
     float* parts = workspace;
-    float* dbias = workspace + (long)SIG_ROW_SLICES * w.n_sig;
+    float* dbias = workspace + (long)SIG_ROW_SLICES * 512;      // behind the partial sums' whole area (launch_signal_rows sizes the split)
     hipError_t err = launch_signal_rows(tier, field, w.sig_rows_dev, w.sig_elems_dev, w.n_sig, dy_T, NP, parts, dbias,
                                         (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "sig_rows_kernel");

@@ -910,8 +910,15 @@ hipError_t launch_signal_rows(int tier, int field, const int* row_of, const int*
                               float* parts, float* dbias, hipStream_t st) {
     const int rows = field == FIELD_TORSO ? GradMap::S_ROWS : GradMap::H_ROWS;
     const long n_tiles = NP / 32;
-    const int slices = (int)(n_tiles < SIG_ROW_SLICES ? n_tiles : SIG_ROW_SLICES);
+    int slices = (int)(n_tiles < SIG_ROW_SLICES ? n_tiles : SIG_ROW_SLICES);
     const dim3 grid(n_sig / 64, slices);
+    if (tier == TIER_BF16) {
+        // few signal rows (the torso's): more, shorter slices - the partial sums' area holds SIG_ROW_SLICES x 512 floats whatever
+        // n_sig is, and with 128 slices the torso's 4 row blocks were 512 waves walking 32 tiles each, two per compute unit:
+        // latency-, not byte-bound (17 us for 16 MB, on the step's main stream); down to eight tiles (one batch of loads) per wave
+        const long cap = (long)SIG_ROW_SLICES * 512 / n_sig, want = n_tiles / 8;
+        if (want > slices) slices = (int)(want < cap ? want : cap);
+    }
     if (tier == TIER_BF16)
         hipLaunchKernelGGL(sig_rows8_kernel, dim3(n_sig / 32, slices), dim3(64), 0, st, row_of, n_sig, (const unsigned char*)dy_T,
                            n_tiles, rows, parts);
