@@ -666,12 +666,14 @@ static int ensure_eof(WgradEntry& w, int tier, int field) {
     return DFN_OK;
 }
 
+// stages: 1 = the GEMMs (partial sums into the workspace), 2 = the reduction of the slices, 3 = both
 static int weight_grad_impl(int tier, int field, int act_format, const void* dy_T, const void* act_T, long NP, float* workspace,
-                            float* grad_flat, float* dbias, void* stream, const char* who) {
+                            float* grad_flat, float* dbias, void* stream, const char* who, int stages = 3) {
+    const bool gemm = stages & 1, red = stages & 2;
     if (act_format != DFN_ACT_E4M3 && act_format != DFN_ACT_E2M1)
         return fail(DFN_E_ARG, std::string(who) + ": act_format must be DFN_ACT_E4M3 or DFN_ACT_E2M1");
-    if (!train_tier_ok(tier) || (field != 0 && field != 1) || !dy_T || !act_T || !workspace || !grad_flat || NP <= 0 ||
-        NP % 32)
+    if (!train_tier_ok(tier) || (field != 0 && field != 1) || (gemm && (!dy_T || !act_T)) || !workspace || (red && !grad_flat) ||
+        NP <= 0 || NP % 32)
         return fail(DFN_E_ARG, std::string(who) + ": bad argument (NP must be a multiple of 32)");
     WgradEntry& w = wgrad_of(field);
     hipStream_t st = (hipStream_t)stream;
@@ -774,22 +776,24 @@ static int weight_grad_impl(int tier, int field, int act_format, const void* dy_
     // bf16 tier: the row sums ride along in the GEMMs (two cheap MFMAs per step).  f32 tier: an f32 MFMA costs 16x
     // more, the streaming row-sum kernel is cheaper there (measured).
     const bool fuse = dbias && tier == DFN_TIER_BF16;
-    if (tier == DFN_TIER_BF16)
+    if (!gemm) {
+    } else if (tier == DFN_TIER_BF16)
         err = launch_wgrad_bf16(field, act_format == DFN_ACT_E2M1, w.ops_dev, w.items_dev[sc], w.n_items[sc], dy_T, act_T, NP, c_parts, W,
                                 fuse ? w.eof_dev : nullptr, fuse ? b_parts : nullptr, nb, st);
     else
         err = launch_wgrad(tier, field, w.ops_dev, (int)w.ops.size(), w.prefix_dev, w.prefix.back(), dy_T, act_T, NP, ks,
                            c_parts, W, nullptr, nullptr, nb, st);
     if (err != hipSuccess) return hip_fail(err, "wgrad_kernel");
+    if (gemm && dbias && !fuse) {          // f32 tier: the row sums are a separate streaming kernel (final values: no second stage)
+        err = launch_bias_grad(tier, field, w.eof_dev, w.rows_dev, nb, dy_T, NP, b_parts, dbias, st);
+        if (err != hipSuccess) return hip_fail(err, "bias_grad_kernel");
+    }
+    if (!red) return DFN_OK;
     if (fuse) {
         err = launch_reduce_both(w.map_dev, c_parts, W, W, valid, grad_flat, w.rows_dev, b_parts, nb, dbias, w.blk_n_dev[sc],
                                  w.bias_n_dev[sc], units, st);
         if (err != hipSuccess) return hip_fail(err, "reduce_both_kernel");
         return DFN_OK;
-    }
-    if (dbias) {
-        err = launch_bias_grad(tier, field, w.eof_dev, w.rows_dev, nb, dy_T, NP, b_parts, dbias, st);
-        if (err != hipSuccess) return hip_fail(err, "bias_grad_kernel");
     }
     if (tier == DFN_TIER_BF16) {          // (weights only) the per-GEMM slice counts of the balanced split
         err = launch_reduce_both(w.map_dev, c_parts, W, W, valid, grad_flat, nullptr, nullptr, 0, nullptr, w.blk_n_dev[sc], nullptr,
@@ -820,6 +824,18 @@ int dfn_weight_bias_grad_fmt(int tier, int field, int act_format, const void* dy
                              float* grad_flat, float* dbias, void* stream) {
     if (!dbias) return fail(DFN_E_ARG, "dfn_weight_bias_grad_fmt: dbias is NULL");
     return weight_grad_impl(tier, field, act_format, dy_T, act_T, NP, workspace, grad_flat, dbias, stream, "dfn_weight_bias_grad_fmt");
+}
+
+int dfn_weight_bias_grad_partials(int tier, int field, int act_format, const void* dy_T, const void* act_T, long NP,
+                                  float* workspace, float* dbias, void* stream) {
+    if (!dbias) return fail(DFN_E_ARG, "dfn_weight_bias_grad_partials: dbias is NULL");
+    return weight_grad_impl(tier, field, act_format, dy_T, act_T, NP, workspace, nullptr, dbias, stream,
+                            "dfn_weight_bias_grad_partials", 1);
+}
+int dfn_weight_bias_grad_reduce(int tier, int field, long NP, float* workspace, float* grad_flat, float* dbias, void* stream) {
+    if (!dbias) return fail(DFN_E_ARG, "dfn_weight_bias_grad_reduce: dbias is NULL");
+    return weight_grad_impl(tier, field, DFN_ACT_E4M3, nullptr, nullptr, NP, workspace, grad_flat, dbias, stream,
+                            "dfn_weight_bias_grad_reduce", 2);
 }
 
 int dfn_bias_grad(int tier, int field, const void* dy_T, long NP, float* workspace, float* dbias, void* stream) {

@@ -38,6 +38,8 @@ _SIG_FIRST = os.environ.get("DFN_TRAIN_SIG_FIRST", "1") == "1"
 _SIG_SET = os.environ.get("DFN_TRAIN_SIG_SET", "0") == "1"
 # the audio encoder's forward keeps its activations for its backward (1) or the backward recomputes them (0: A/B)
 _SIG_KEEP = os.environ.get("DFN_TRAIN_SIG_KEEP", "1") == "1"
+# the main stream waits for the head's weight-gradient chain in front of the torso's REDUCTION (1) or in front of its GEMMs (0: A/B)
+_SPLIT_JOIN = os.environ.get("DFN_TRAIN_SPLIT_JOIN", "1") == "1"
 # the step's loss from the training forward's epilogue (1: dfn_train_fwd*_loss) or from its own launch (0: dfn_mse_loss_u8; A/B)
 _LOSS_IN_FWD = os.environ.get("DFN_TRAIN_LOSS_IN_FWD", "1") == "1"
 
@@ -118,6 +120,8 @@ class TrainBuffers:
         self.n_rays, self.NP = n_rays, n_rays * self.S
         assert self.NP % 512 == 0, "N_rand must be a multiple of 8"
         rows = lambda f, w: check(lib.dfn_train_rows(f, w), "dfn_train_rows")
+        # format of the fused step's recorded activations in this build (DFN_ACT_E2M1 = 1 unless built with -DDFN_ACT_FP4=0)
+        self.act_format = int(rows(0, 6) != rows(0, 8))
         if self.tier == 1:
             # 16-bit tier: the recorded arrays are MX-fp8 (e4m3 + one E8M0 scale per 32-row block and 32-point tile, the
             # operand format of the block-scaled MFMA the weight-gradient GEMMs run on): [tile][dfn_train_rows(f, 6 / 7)] bytes
@@ -285,10 +289,19 @@ def _fused_backward(ctx, d_h, d_c):
         check(lib.dfn_mlp_bwd(buf.tier, f, _ptr(buf.packed_T[f]), _ptr(buf.samples), _ptr(buf.dsamples),
                               _ptr(buf.masks[f]), buf.NP, _ptr(buf.dy[f]), stream), "dfn_mlp_bwd")
 
-    def dw(f, stream, g, with_sig):
+    def dw(f, stream, g, with_sig, before_reduce=None):
         gb = C.c_void_p(g_bias.data_ptr() + (4 * buf.nb[0] if f else 0))
-        check(lib.dfn_weight_bias_grad(buf.tier, f, _ptr(buf.dy[f]), _ptr(buf.act[f]), buf.NP, _ptr(buf.ws[f]),
-                                       _ptr(g), gb, stream), "dfn_weight_bias_grad")
+        if before_reduce is None:
+            check(lib.dfn_weight_bias_grad(buf.tier, f, _ptr(buf.dy[f]), _ptr(buf.act[f]), buf.NP, _ptr(buf.ws[f]),
+                                           _ptr(g), gb, stream), "dfn_weight_bias_grad")
+        else:
+            # the two stages apart: the GEMMs only write their own workspace; what must not overtake the other field's
+            # reduction (the fields share most parameters: one += after the other, in a fixed order) is the REDUCTION
+            check(lib.dfn_weight_bias_grad_partials(buf.tier, f, buf.act_format, _ptr(buf.dy[f]), _ptr(buf.act[f]), buf.NP,
+                                                    _ptr(buf.ws[f]), gb, stream), "dfn_weight_bias_grad_partials")
+            before_reduce()
+            check(lib.dfn_weight_bias_grad_reduce(buf.tier, f, buf.NP, _ptr(buf.ws[f]), _ptr(g), gb, stream),
+                  "dfn_weight_bias_grad_reduce")
         ds = C.c_void_p(d_sig.data_ptr() + (4 * 96 if f else 0)) if with_sig else None
         check(lib.dfn_fold_bias_bwd(buf.tier, FIELD_TORSO if f else FIELD_HEAD, _ptr(flat), _ptr(stt if f else sh),
                                     _ptr(zs[f]), _ptr(za[f]), gb, _ptr(g), ds, stream), "dfn_fold_bias_bwd")
@@ -348,9 +361,15 @@ def _fused_backward(ctx, d_h, d_c):
             dsig(1, C.c_void_p(s_p.cuda_stream))
             if ev is not None:
                 ev[1].record(s_p)
-        if over:
-            main.wait_stream(side)
-        dw(1, st, g_flat, False)
+        if over and _SPLIT_JOIN:
+            # the main stream joins the head's chain (GEMMs, reduction, fold backward on the side stream) in front of the torso's
+            # REDUCTION, not in front of its GEMMs: the cross-queue wait sat between d(signal) and a 130-us kernel that does
+            # not depend on it - 17 us of the critical path (profiles/r04g_c4_timeline.txt)
+            dw(1, st, g_flat, False, before_reduce=lambda: main.wait_stream(side))
+        else:
+            if over:
+                main.wait_stream(side)
+            dw(1, st, g_flat, False)
         if tr is None:          # torch autograd consumes d_sig on the main stream
             main.wait_stream(s_a)
             main.wait_stream(s_p)

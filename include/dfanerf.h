@@ -270,6 +270,17 @@ int dfn_weight_bias_grad(int tier, int field, const void* dy_T, const void* act_
 #define DFN_ACT_E2M1 1
 int dfn_weight_bias_grad_fmt(int tier, int field, int act_format, const void* dy_T, const void* act_T, long NP, float* workspace,
                              float* grad_flat, float* dbias, void* stream);
+/* dfn_weight_bias_grad_fmt in its two stages, for a caller that has something to wait for in between: _partials runs the GEMMs
+ * (every (GEMM, slice of the points) writes its own slice of `workspace`; nothing outside it is touched), _reduce adds the slices
+ * in index order into grad_flat (+=) and writes dbias.  The two fields of a decoder share most parameters, so their _reduce
+ * stages must run one after the other (a fixed order: bit-reproducible sums) - their _partials stages need not: the training
+ * step launches the torso's GEMMs without waiting for the head's reduction on the other stream (a cross-queue wait in front of a
+ * 130-us kernel was 17 us of the step's critical path) and waits in front of the torso's reduction instead.  Same NP,
+ * workspace and tier / field in both calls; f32 tier: dbias is written by _partials already (its row sums are a separate
+ * streaming kernel) and _reduce ignores it. */
+int dfn_weight_bias_grad_partials(int tier, int field, int act_format, const void* dy_T, const void* act_T, long NP,
+                                  float* workspace, float* dbias, void* stream);
+int dfn_weight_bias_grad_reduce(int tier, int field, long NP, float* workspace, float* grad_flat, float* dbias, void* stream);
 /* Backward of dfn_fold_bias (the fold is linear; upstream it is the autograd of DEC:293-295, 311, 318, 332):
  * dbias [dfn_bias_floats] -> grad_flat (+=, layout of `params`: fc_z / fc_z_skips / fc_z_view, the signal columns
  * of fc_in / fc_p_skips / the deformation nets, every bias) and d_signal (+=, [96] head / [42] torso; may be NULL).

@@ -92,6 +92,11 @@ def test_error_paths_without_gpu():
     assert L.dfn_train_fwd_hier_loss(*args16, one, one, None, N) == -1
     assert L.dfn_train_loss_floats(2048) >= 2 * 256 + 1 and L.dfn_train_loss_floats(0) > 0
     assert L.dfn_weight_bias_grad_fmt(1, 0, 7, one, one, 64, one, one, one, N) == -1 and b"act_format" in L.dfn_last_error()
+    # the weight gradients in two stages (GEMMs into the workspace | the reduction of the slices)
+    assert L.dfn_weight_bias_grad_partials(1, 0, 1, N, one, 64, one, one, N) == -1                        # no dy_T
+    assert L.dfn_weight_bias_grad_partials(1, 0, 1, one, one, 64, one, N, N) == -1 and b"dbias" in L.dfn_last_error()
+    assert L.dfn_weight_bias_grad_reduce(1, 0, 64, one, N, one, N) == -1                                  # no grad_flat
+    assert L.dfn_weight_bias_grad_reduce(2, 0, 64, one, one, one, N) == -1                                # f16: inference only
 
 
 class Reader:
