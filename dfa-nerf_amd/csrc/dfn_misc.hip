@@ -681,6 +681,7 @@ hipError_t launch_mfma_chain(bool f16, int lds2, int valu2, const void* frags, c
     if (lds2 == 0 && valu2 == 4) { if (f16) PC_GO(true, 0, 4) else PC_GO(false, 0, 4) }
     if (lds2 == 2 && valu2 == 0) { if (f16) PC_GO(true, 2, 0) else PC_GO(false, 2, 0) }
     if (lds2 == 1 && valu2 == 2) { if (f16) PC_GO(true, 1, 2) else PC_GO(false, 1, 2) }
+    if (lds2 == 2 && valu2 == 2) { if (f16) PC_GO(true, 2, 2) else PC_GO(false, 2, 2) }
 #undef PC_GO
     return hipErrorInvalidValue;
 }

@@ -24,7 +24,8 @@ out = torch.empty(blocks * 512, dtype=torch.float32, device=dev)
 clk = torch.zeros(2, dtype=torch.int64, device=dev)
 st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 names = {(0, 0): "bare chain", (2, 4): "renderer mix: 1 fragment read + 2 epilogue instructions per MFMA", (1, 4): "half the fragment reads",
-         (0, 4): "no fragment reads", (2, 0): "no epilogue instructions", (1, 2): "half of both"}
+         (0, 4): "no fragment reads", (2, 0): "no epilogue instructions", (1, 2): "half of both",
+         (2, 2): "half the epilogue instructions (one per two values: conversion and ReLU in one)"}
 for rnd in range(2):
     for (l, v), name in names.items():
         best = 0.0
