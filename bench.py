@@ -88,6 +88,9 @@ def parse():
                     help="length of the sustained run after the K timed steps (0 = off; skipped when the K steps "
                          "themselves already lasted that long)")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other workloads (N == 1)")
+    ap.add_argument("--size", type=int, default=450, choices=[450, 512],
+                    help="frame size of the render workloads (512 = what scripts/process_data.sh emits; the counter passes of "
+                         "`c2_512` in profiles/traffic.json use it)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the 64-ray oracle check after the timed loops (N == 1)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)      # internal: one process of cpu_baseline.multi_process
     return ap.parse_args()
@@ -720,8 +723,8 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
     traffic, traffic_src = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            tr = json.load(f).get(f"{'c2' if workload == 'c5' else workload}_{tier}")
-        if tr and world == 1 and size == 450:
+            tr = json.load(f).get(f"{'c2' if workload == 'c5' else workload}{'_512' if size == 512 else ''}_{tier}")
+        if tr and world == 1:
             traffic, traffic_src = tr["hbm_bytes_per_launch"], "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
     except OSError:
         pass
@@ -854,7 +857,7 @@ def main():
         out = bench_training(args, headline, args.steps, args.warmup, world, rank, dev, args.sustain_seconds)
     else:
         out = bench_render(args, headline, args.tier, args.steps, args.warmup, world, rank, dev,
-                           args.sustain_seconds, check=not args.no_parity_check)
+                           args.sustain_seconds, check=not args.no_parity_check, size=args.size)
     extra = {}
     multi = world > 1 or dist.is_initialized()
     if (world == 1 and not args.no_extra) or run_all:

@@ -279,8 +279,12 @@ def test_bf16_training_tracks_f32_over_200_steps(states, scene, latents):
     assert a[-20:].mean() < 0.7 * a[:5].mean() and b[-20:].mean() < 0.7 * b[:5].mean(), (a[:5], a[-5:], b[-5:])      # both train
     final = abs(b[-20:].mean() - a[-20:].mean()) / a[-20:].mean()
     worst = float(np.max((np.abs(b - a) / a)[n_steps // 2:]))
-    print(f"bf16 vs f32 over {n_steps} steps: final-loss difference {final:.3%}, worst step of the second half {worst:.3%}; "
-          f"loss {a[0]:.4f} -> {a[-1]:.4f}")
+    # the trajectory noise averaged out: both curves smoothed over 20 steps (5 passes over the 4 frames), second half
+    ker = np.ones(20) / 20
+    sa, sb = np.convolve(a, ker, "valid"), np.convolve(b, ker, "valid")
+    smooth = float(np.max((np.abs(sb - sa) / sa)[len(sa) // 2:]))
+    print(f"bf16 vs f32 over {n_steps} steps: final-loss difference {final:.3%}, worst step of the second half {worst:.3%}, "
+          f"worst 20-step mean of the second half {smooth:.3%}; loss {a[0]:.4f} -> {a[-1]:.4f}")
     assert final <= 0.02 and worst <= 0.05, (final, worst)
 
 
