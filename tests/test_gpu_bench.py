@@ -103,6 +103,13 @@ def test_inference_in_the_multi_rank_schedule_over_rccl(workload):
     assert out["gather"]["render_streams"] == 2
     assert out["gather_check"].get("identical") is True, out["gather_check"]
     assert out["per_rank"]["ms_per_step"][0] > 0 and 0.0 < out["roofline"]["whole_job"]["frac"] < 1.0
+    # two launches co-run on the two render streams: the per-launch figure is the union of the launch intervals over the
+    # launches (what the kernel occupied the GPU for), so the per-launch fraction stays next to the wall-clock one; the
+    # plain event pairs, which count the shared time twice, are reported beside it
+    rf = out["roofline"]
+    assert rf["render_streams"] == 2 and rf["kernel_ms"] <= rf["kernel_ms_event_pairs"] * 1.001
+    assert rf["kernel_ms"] <= out["ms_per_step"] / out["config"]["frames_per_step"] * 1.02, rf
+    assert rf["whole_job"]["frac"] <= rf["frac"] * 1.02 and rf["frac"] <= rf["whole_job"]["frac"] * 1.15, rf
     pc = out["parity_check"]                                   # and the timed configuration still matches the oracle
     assert "error" not in pc and pc["psnr_db"] >= 49.4, pc
 

@@ -234,7 +234,9 @@ def test_bf16_training_tracks_f32_over_200_steps(states, scene, latents):
     differ by rounding are not comparable step by step; measured with the MX-fp8 recorder: 0.5 % at the end, <= 2.5 % per step
     in the second half; with bf16 recording it was 0.13 % / 0.35 %; round 4, activations in MX-fp4: 0.014 % / 3.3 %.  The
     per-step figure is trajectory noise, not accuracy: with nothing changed but the ORDER of the weight gradients' split-K sums
-    (DFN_WGRAD_SPARE_CUS = 8 ... 64) it reads 1.95-5.2 %, the final figure 0.014-1.0 %.)"""
+    (DFN_WGRAD_SPARE_CUS = 8 ... 64) it reads 1.95-5.2 %, the final figure 0.014-1.0 %.  With the noise averaged out - the worst
+    20-step mean of the second half - the two curves are within 2 %; at the round's last commit: 0.50 % final, 1.5 % worst
+    step, 0.50 % worst 20-step mean.)"""
     from dfanerf import frames, nets, run_nerf, training
     dev = torch.device("cuda")
     n, n_steps = 1024, 200
@@ -285,7 +287,7 @@ def test_bf16_training_tracks_f32_over_200_steps(states, scene, latents):
     smooth = float(np.max((np.abs(sb - sa) / sa)[len(sa) // 2:]))
     print(f"bf16 vs f32 over {n_steps} steps: final-loss difference {final:.3%}, worst step of the second half {worst:.3%}, "
           f"worst 20-step mean of the second half {smooth:.3%}; loss {a[0]:.4f} -> {a[-1]:.4f}")
-    assert final <= 0.02 and worst <= 0.05, (final, worst)
+    assert final <= 0.02 and worst <= 0.05 and smooth <= 0.02, (final, worst, smooth)
 
 
 def test_fused_fold_backward_matches_torch_fold(states, scene, latents):
