@@ -662,14 +662,7 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
         if not multi:
             return state["pair_ms"]
         z = ev[0][0]
-        iv = sorted((z.elapsed_time(a), z.elapsed_time(b)) for a, b in ev)
-        busy, (lo, hi) = 0.0, iv[0]
-        for a, b in iv[1:]:
-            if a > hi:
-                busy, lo, hi = busy + (hi - lo), a, b
-            else:
-                hi = max(hi, b)
-        return (busy + (hi - lo)) / len(iv)
+        return union_length([(z.elapsed_time(a), z.elapsed_time(b)) for a, b in ev]) / len(ev)
 
     state = {}
 
@@ -799,6 +792,20 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
             out["parity_check"] = {"error": f"{type(e).__name__}: {e}"}
     out["_scene"] = (sc, st, zs, za, n_fine, fields)
     return out
+
+
+def union_length(intervals):
+    """Total length covered by a list of (start, end) intervals (any order, overlaps counted once)."""
+    iv = sorted(intervals)
+    if not iv:
+        return 0.0
+    busy, (lo, hi) = 0.0, iv[0]
+    for a, b in iv[1:]:
+        if a > hi:
+            busy, lo, hi = busy + (hi - lo), a, b
+        else:
+            hi = max(hi, b)
+    return busy + (hi - lo)
 
 
 def free_port():

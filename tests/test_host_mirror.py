@@ -497,3 +497,21 @@ def test_device_frame_cache_preload_lru_and_zero_reads_when_warm(tmp_path):
     assert small.host_reads == 10 and np.array_equal(small.get(1)[0].numpy().reshape(H, W, 3), imgs[1][0])
     with pytest.raises(ValueError):
         frames.DeviceFrameCache(ph, pc, H + 1, W, torch.device("cpu")).get(0)
+
+
+def test_bench_union_of_launch_intervals():
+    """bench.py's per-launch kernel time under the two-stream N > 1 schedule: co-running launches are counted for the time
+    the kernel occupied the GPU (union of the intervals), not for the sum of their own durations."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    u = bench.union_length
+    assert u([]) == 0.0
+    assert u([(0.0, 1.0), (2.0, 3.5)]) == 2.5                               # one stream: the sum
+    assert u([(2.0, 3.5), (0.0, 1.0)]) == 2.5                               # any order
+    assert u([(0.0, 2.0), (1.0, 3.0), (2.5, 4.0)]) == 4.0                   # two streams, every launch shares half its time
+    assert u([(0.0, 10.0), (1.0, 2.0), (3.0, 4.0)]) == 10.0                 # nested
+    # two alternating streams, 8 launches of 66 ms that start every 33 ms: 33 ms per launch plus the last one's tail
+    iv = [(33.0 * i, 33.0 * i + 66.0) for i in range(8)]
+    assert abs(u(iv) / len(iv) - (33.0 * 7 + 66.0) / 8) < 1e-9
