@@ -522,6 +522,20 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
         sc["focal"] = 1200.0 * size / 450
         desc = desc.replace("450x450", f"{size}x{size}")
     st = synth.synth_all_states(0)
+    if os.environ.get("DFN_BENCH_ACT_SCALE"):
+        # developer switch (the DFN_EXP_CLAMPCVT build): the HEAD field's hidden activations scaled by s - a ReLU
+        # network is positively homogeneous, so scaling what enters each layer besides the previous activations (input layer,
+        # latent / skip / view projections: weights and biases; hidden layers: biases) scales every activation by s and
+        # nothing else.  With s = 1/16 the synthetic network's activations (max 13) stay below 1.
+        sc_a = float(os.environ["DFN_BENCH_ACT_SCALE"])
+        dec = st["decoder"] = dict(st["decoder"])
+        both = ("fc_in", "fc_z", "fc_z_skips.0", "fc_p_skips.0", "fc_z_view", "fc_view")
+        for k in list(dec):
+            base, _, leaf = k.rpartition(".")
+            if base in both or (leaf == "bias" and (base.startswith("blocks.") or base == "feat_view")):
+                dec[k] = (dec[k] * np.float32(sc_a)).astype(np.float32)
+            elif k in ("sigma_out.weight", "feat_out.weight"):      # the output layers undo it: the same images
+                dec[k] = (dec[k] / np.float32(sc_a)).astype(np.float32)
     zs, za = synth.synth_latents(0)
     H, W = sc["H"], sc["W"]
     R = H * W
