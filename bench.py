@@ -17,7 +17,9 @@ the exact f32 tier).  --tier bf16 is the 16-bit training tier (faster by ~5 %, 4
 
 Prints ONE JSON line on rank 0 (fields: see the driver contract), including
   roofline     - MFMA roofline of the dominant kernel (render_kernel), from algorithmic FLOPs and HIP-event
-                 timings of the launches inside the timed region; `clock_ghz` = the shader clock under load read inside
+                 timings of the launches inside the timed region (`kernel_ms`; under the N > 1 schedule, where two launches
+                 co-run on the two render streams, the union of the launch intervals per launch, with the plain mean of
+                 the event pairs beside it as `kernel_ms_event_pairs`); `clock_ghz` = the shader clock under load read inside
                  the kernel (s_memtime / s_memrealtime): the launch is power-bound, the 2.5 PF peak assumes 2.4 GHz;
   sustained    - the same step repeated for >= --sustain-seconds (default 10 s) after the K timed steps: the K steps
                  the driver asks for last well under a second, the chip's DVFS settles later;
