@@ -24,11 +24,13 @@ Prints ONE JSON line on rank 0 (fields: see the driver contract), including
   sustained    - the same step repeated for >= --sustain-seconds (default 10 s) after the K timed steps: the K steps
                  the driver asks for last well under a second, the chip's DVFS settles later;
   cpu_baseline - the oracle (oracle/dfa_oracle.py, a port of the reference's CPU path) timed on a bounded
-                 sample of the same workload on this host's cores, at the best of a sweep over thread counts
-                 (rank 0, N == 1 only);
+                 sample of the same workload on this host's cores (rank 0, N == 1 only): `value` = the best of
+                 {one process at the best thread count of a sweep, P processes x T threads filling every physical
+                 core for T in 16, 32}; `cores` = the cores that configuration used;
   other_workloads - (N == 1) short runs of the other BASELINE configs in the same process: c3 (two-field render), c1
                  (coarse), c2_f32 (the exact tier: the one that meets "within 1e-4 PSNR"), c4 / c4h (training step, coarse and
-                 hierarchical), so that they are driver-timed numbers too;
+                 hierarchical, 16-bit training tier - `dtype` spells out its operand formats) and c4_f32 (the training step
+                 in the exact tier), so that they are driver-timed numbers too;
   parity_check - (N == 1) after the timed loops, 64 rays of the LAST timed frame rendered again in the timed configuration
                  and compared with the CPU oracle (outside the timed region): binds the timed launch to the parity suite.
 
@@ -131,8 +133,8 @@ def cpu_baseline(args, sc, st, zs, za, n_fine, fields):
         for nt in sorted({n for n in (8, 16, 32, 64, 128, cores) if n <= cores}):
             torch.set_num_threads(nt)
             run(0, 128, 2048)
-            sweep[nt] = 1024 / run(101250, 1024, 2048)           # rays/s on a 1024-ray piece from the middle of the frame
-        best = max(sweep, key=sweep.get)
+            sweep[nt] = 2048 / run(101250, 2048, 2048)           # rays/s on ONE WHOLE 2048-ray chunk from the middle of the frame
+        best = max(sweep, key=sweep.get)                         # (round 4 swept 1024-ray pieces: its optimum moved between 8 and 32)
         torch.set_num_threads(best)
         chunk, done, t_used = 2048, 0, 0.0
         while t_used < args.cpu_seconds and done < H * W:
@@ -140,35 +142,57 @@ def cpu_baseline(args, sc, st, zs, za, n_fine, fields):
             t_used += run(done, n, chunk)
             done += n
     out = {"value": done / t_used, "unit": "rays/s", "cores": int(best), "kind": "port",
-           "host_physical_cores": int(cores),
+           "host_physical_cores": int(cores), "single_process_value": done / t_used, "single_process_threads": int(best),
            "thread_sweep_rays_per_s": {str(k): round(v, 1) for k, v in sweep.items()},
            "sample": f"{done} rays ({done // chunk} chunks of 2048) of frame 0, same workload, fp32, "
                      f"torch {torch.__version__} CPU, {best} threads (best of the sweep), {t_used:.1f} s.  The sweep's optimum is "
                      "the limit of torch's INTRA-OP parallelism on 2048-ray chunks (more threads are slower), not the host's "
                      "capacity: `multi_process` runs that many-thread process several times side by side"}
-    # the host's capacity: P = cores // best processes of `best` threads each, side by side on disjoint chunks of the frame
-    n_proc = max(1, min(8, int(cores) // int(best)))
-    if n_proc > 1 and not os.environ.get("DFN_BENCH_NO_CPU_MP"):
-        try:
-            import subprocess
-            chunks_each = max(1, int(args.cpu_seconds / 2 / max(chunk / out["value"], 1e-3)))
-            procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker",
-                                       f"{(i * chunks_each * chunk) % (H * W - chunks_each * chunk)},{chunks_each},{best},{n_fine},{fields}"],
-                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
-                                      env=dict(os.environ, OMP_NUM_THREADS=str(best), MKL_NUM_THREADS=str(best)))
-                     for i in range(n_proc)]
-            res = []
-            for pr in procs:
-                o, _ = pr.communicate(timeout=600)
-                res.append(json.loads([ln for ln in o.splitlines() if ln.startswith("{")][-1]))
-            rays = sum(r["rays"] for r in res)
-            secs = max(r["seconds"] for r in res)
-            out["multi_process"] = {"value": rays / secs, "unit": "rays/s", "processes": n_proc, "threads_per_process": int(best),
-                                    "cores": n_proc * int(best),
-                                    "sample": f"{n_proc} processes x {chunks_each} chunks of 2048 rays each, concurrently "
-                                              f"({secs:.1f} s): the fair 'host cores of the same box' figure"}
-        except Exception as e:                      # a reported extra: never lose the line to it
-            out["multi_process"] = {"error": f"{type(e).__name__}: {e}"}
+    # The host's capacity - the north star's "reference CPU render timed on the host cores of the same box (core count stated)":
+    # P processes of T threads each with P * T = every physical core, side by side on disjoint chunks of the frame, for T in
+    # {16, 32} (one process cannot use a 128-core host: the sweep's optimum is 8-32 threads).  The BEST of these (and of the
+    # single process) is `value`, with cores = P * T: the steadier and the fairer figure (round 4's line reported the single
+    # process at the sweep's noisy optimum: 582-712 rays/s by run).
+    mp_runs = []
+    if not os.environ.get("DFN_BENCH_NO_CPU_MP"):
+        import subprocess
+        for T in (16, 32):
+            n_proc = int(cores) // T
+            if n_proc < 2:
+                continue
+            try:
+                per_proc = max(out["single_process_value"] / n_proc * 1.3, 20.0)       # expected rays/s of one of P processes
+                chunks_each = max(1, int(round(args.cpu_seconds / 2 / (chunk / per_proc))))
+                span = H * W - chunks_each * chunk
+                procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker",
+                                           f"{(i * chunks_each * chunk) % span},{chunks_each},{T},{n_fine},{fields}"],
+                                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                                          env=dict(os.environ, OMP_NUM_THREADS=str(T), MKL_NUM_THREADS=str(T)))
+                         for i in range(n_proc)]
+                res = []
+                for pr in procs:
+                    o, _ = pr.communicate(timeout=600)
+                    res.append(json.loads([ln for ln in o.splitlines() if ln.startswith("{")][-1]))
+                rays = sum(r["rays"] for r in res)
+                secs = max(r["seconds"] for r in res)
+                mp_runs.append({"value": rays / secs, "unit": "rays/s", "processes": n_proc, "threads_per_process": T,
+                                "cores": n_proc * T, "seconds": secs, "chunks_per_process": chunks_each})
+            except Exception as e:                      # a reported extra: never lose the line to it
+                mp_runs.append({"error": f"{type(e).__name__}: {e}", "threads_per_process": T})
+    good = [m for m in mp_runs if "value" in m]
+    if good:
+        top = max(good, key=lambda m: m["value"])
+        out["multi_process"] = top
+        out["multi_process_runs"] = mp_runs
+        if top["value"] > out["value"]:
+            out["value"], out["cores"] = top["value"], int(top["cores"])
+            out["sample"] = (f"{top['processes']} processes x {top['threads_per_process']} threads = {top['cores']} of the host's "
+                             f"{int(cores)} physical cores, each process {top['chunks_per_process']} chunks of 2048 rays of frame 0 "
+                             f"concurrently ({top['seconds']:.1f} s), same workload, fp32, torch {torch.__version__} CPU: the oracle on "
+                             f"every host core.  One process alone: {out['single_process_value']:.0f} rays/s at {best} threads, the "
+                             "best of the thread sweep (torch's intra-op parallelism on 2048-ray chunks stops scaling at 8-32 threads)")
+    elif mp_runs:
+        out["multi_process"] = mp_runs[-1]
     return out
 
 
@@ -202,14 +226,14 @@ def cpu_worker(spec):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.0):
+def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.0, tier=None):
     """configs[3]: one optimisation step per `step`: signals -> fold -> fused HIP forward (recorder on) -> MSE
     losses -> HIP backward (compositing, dX chain, weight-gradient GEMMs) -> flat-bucket all_reduce -> gated Adams.
     Ground-truth frames and background are resident uint8 device tensors; pixels are drawn and targets gathered on
     the device (frames.PixelSampler, dfn_mse_loss_u8): no host image read, no host-to-device copy per step."""
     from dfanerf import nets, parallel, run_nerf, synth, training
     from dfanerf.decoder import Decoder
-    tier = "bf16" if args.tier == "f16" else args.tier           # the 16-bit training tier (f16 is inference only)
+    tier = tier or ("bf16" if args.tier == "f16" else args.tier)           # the 16-bit training tier (f16 is inference only)
     n_fine, _, desc = WORKLOADS[workload]
     strong = workload == "c4s"
     N_RAND = 2048 // world if strong else 2048
@@ -389,8 +413,13 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
             "value": N_RAND * world * steps / dt, "unit": "rays/s", "n_gpus": world, "steps": steps,
             "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": tier, "data": "synthetic",
+            # what the step computes in: the 16-bit training tier is bf16 MFMAs in the forward and the dX chain, and the weight
+            # gradients on block-scaled MX operands (dY e4m3 x recorded activations e2m1 or e4m3) - the label says so
+            "vs_baseline": None, "dtype": (tier if tier != "bf16" else
+                                           "bf16 fwd+dX, mx-fp8(e4m3) x mx-" + ("fp4(e2m1)" if buf.act_format == 1 else "fp8(e4m3)") + " wgrad"),
+            "data": "synthetic",
             "config": {"workload": desc, "H": H, "W": W, "N_rand_per_gpu": N_RAND, "n_coarse": 64, "n_fine": n_fine,
+                       "recorded_activation_format": (("e2m1 (MX-fp4)" if buf.act_format == 1 else "e4m3 (MX-fp8)") if tier == "bf16" else "f32"),
                        "fields": 2, "parallelism": f"dp{world}, three in-place all_reduces per step, each on the stream its gradients are produced on: audio-side networks (180,785 floats), PoseAttNet (2,629), decoder (955,242)"},
             "roofline": {"bound": "mfma", "kernel": "whole step (render_kernel<train>, mlp_bwd, wgrad_mx)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "flop_per_ray": flop_ray,
@@ -797,8 +826,15 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
         out["sustained"] = sus
     if check and world == 1 and tier in ("f16", "bf16") and not os.environ.get("DFN_BENCH_NO_CEILING"):
         try:                                        # after the timed loops; never lose the headline line to it
-            out["roofline"]["power_ceiling"] = power_ceiling(pk, tier, dev, out["sustained"]["roofline_frac"] * peak
-                                                             if sus else achieved)
+            pc = out["roofline"]["power_ceiling"] = power_ceiling(pk, tier, dev, out["sustained"]["roofline_frac"] * peak
+                                                                  if sus else achieved)
+            # the same as SCALAR keys of `roofline` (a line parser that keeps only scalars keeps these): what the matrix pipe
+            # sustains under the power limit on THIS box as a fraction of the 2.5 PF peak - the bare MFMA chain and the
+            # renderer's instruction mix - and the timed kernel against the latter
+            out["roofline"]["ceiling_bare_frac"] = pc["bare_chain"]["frac_of_peak"]
+            out["roofline"]["ceiling_mix_frac"] = pc["renderer_mix"]["frac_of_peak"]
+            out["roofline"]["frac_of_mix"] = pc["frac_of_renderer_mix"]
+            out["roofline"]["ceiling_mix_clock_ghz"] = pc["renderer_mix"]["clock_ghz"]
         except Exception as e:
             out["roofline"]["power_ceiling"] = {"error": f"{type(e).__name__}: {e}"}
     if check and world == 1:
@@ -914,7 +950,9 @@ def main():
         # at N > 1, or DFN_BENCH_RCCL_WORLD1) every rank runs the same list in the same order; a workload that raises on a
         # rank is recorded in the line (`error`) and, after the ranks have agreed on it, the list goes on.
         todo = [("c3", "c3", args.tier, 40, 5), ("c1", "c1", args.tier, 60, 5), ("c2_f32", "c2", "f32", 5, 1),
-                ("c5", "c5", args.tier, 4, 1), ("c4", "c4", args.tier, 150, 20), ("c4h", "c4h", args.tier, 60, 10)]
+                ("c5", "c5", args.tier, 4, 1), ("c4", "c4", args.tier, 150, 20), ("c4h", "c4h", args.tier, 60, 10),
+                # the training step in the EXACT tier (f32 MFMAs, f32 recording): the reference's own arithmetic, driver-timed
+                ("c4_f32", "c4", "f32", 20, 3)]
         if world == 1 and not multi:
             # 512 x 512: the frame size the reference's own preprocessing emits (scripts/process_data.sh:4)
             todo.insert(3, ("c2_512", "c2", args.tier, 10, 2))
@@ -927,7 +965,7 @@ def main():
             r, err = None, None
             try:
                 if wl in TRAIN_WORKLOADS:
-                    r = bench_training(args, wl, k, w, world, rank, dev)
+                    r = bench_training(args, wl, k, w, world, rank, dev, tier="f32" if name == "c4_f32" else None)
                 else:
                     r = bench_render(args, wl, tier, k, w, world, rank, dev, size=512 if name == "c2_512" else 450,
                                      check=(name == "c2_f32" and not args.no_parity_check))

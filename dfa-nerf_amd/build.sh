@@ -11,13 +11,23 @@ SRC="$HERE/csrc"
 OUT="$HERE/dfanerf/libdfanerf.so"
 OBJ="$HERE/build"
 if [ "$1" = "--clean" ]; then rm -rf "$OBJ" "$OUT"; fi
+# DFN_EXTRA_FLAGS is a developer hook (timing / ablation switches: csrc/dfn_devguard.h): one stray -D would build a product
+# library that renders garbage at full speed.  Extra flags need DFN_DEV_BUILD=1, which marks the library (dfn_version()
+# ends in " DEV") so that dfanerf._lib refuses it on the in-tree path.
+if [ -n "$DFN_EXTRA_FLAGS" ]; then
+  if [ "$DFN_DEV_BUILD" != "1" ]; then
+    echo "build.sh: DFN_EXTRA_FLAGS='$DFN_EXTRA_FLAGS' without DFN_DEV_BUILD=1: refusing to build the product library with developer switches (tools/build_variant.sh builds variant libraries next to it)" >&2
+    exit 2
+  fi
+  DFN_EXTRA_FLAGS="$DFN_EXTRA_FLAGS -DDFN_DEV_BUILD=1"
+fi
 mkdir -p "$OBJ"
 # -pragma-unroll-threshold: the MLP bodies MUST unroll completely (every fragment index, ring slot and recorder dword is a
 # compile-time constant by construction; a loop left rolled puts the fragment ring and the operand vectors into scratch
 # memory) and with the MX-fp8 recorder some bodies exceed LLVM's default budget of 16384 instructions
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -mllvm -pragma-unroll-threshold=200000 -I$SRC -I$HERE/../include $DFN_EXTRA_FLAGS"
 HDR_HASH="$( (cat "$SRC"/*.h "$HERE"/../include/*.h; echo "$FLAGS" | sed "s#$HERE#.#g"; hipcc --version 2>/dev/null | head -2) | sha256sum | cut -d' ' -f1)"
-UNITS="dfn_render dfn_render_f32 dfn_render_bf16 dfn_render_f16 dfn_misc dfn_api dfn_train dfn_bwd_bf16 dfn_wgrad_bf16 dfn_signal"
+UNITS="dfn_render dfn_render_f32 dfn_render_bf16 dfn_render_bf16e dfn_render_f16 dfn_misc dfn_api dfn_train dfn_bwd_bf16 dfn_wgrad_bf16 dfn_signal"
 # the library's own stamp (next to the .so: it travels with it to the GPU box, the object directory does not): everything it
 # is made from, hashed - an up-to-date library is not rebuilt
 LIB_HASH="$( (echo "$HDR_HASH"; cat "$SRC"/*.hip "$SRC"/*.cpp) | sha256sum | cut -d' ' -f1)"
@@ -37,7 +47,7 @@ done
 g++ -O2 -std=c++17 -fPIC -I"$SRC" -I"$HERE/../include" -c "$SRC/dfn_plan.cpp" -o "$OBJ/dfn_plan.o"
 for p in "${pids[@]}"; do wait $p; done
 # the asm fragment fetch (DFN_ASM_FETCH) is only safe if nothing touches an in-flight destination register
-for t in bf16 f16; do
+for t in bf16 bf16e f16; do
   ISA="$OBJ/dfn_render_$t-hip-amdgcn-amd-amdhsa-gfx950.s"
   if [ -f "$ISA" ]; then
     python3 "$HERE/../tools/check_inflight.py" "$ISA" || { echo "build.sh: in-flight register hazard in the $t render kernels" >&2; exit 1; }

@@ -182,7 +182,11 @@ WgradEntry& wgrad_of(int field) {
 extern "C" {
 
 const char* dfn_last_error(void) { return g_err.c_str(); }
+#ifdef DFN_DEV_BUILD      // (dfn_devguard.h: a library built with developer switches says so, and dfanerf._lib refuses it in-tree)
+const char* dfn_version(void) { return "dfanerf 0.1 gfx950 DEV"; }
+#else
 const char* dfn_version(void) { return "dfanerf 0.1 gfx950"; }
+#endif
 
 long dfn_packed_bytes(int tier, int field) {
     if (!tier_ok(tier) || !field_ok(field)) return fail(DFN_E_ARG, "dfn_packed_bytes: bad tier/field");
@@ -321,6 +325,7 @@ static int render_fwd_impl(int tier, const DfnFrame* frame, const void* packed_h
     A.act_T[0] = A.act_T[1] = nullptr;
     A.masks[0] = A.masks[1] = nullptr;
     A.NP = 0;
+    A.act_e4m3 = 0;
     A.loss = DfnTrainLoss{};
     A.clock_probe = g_clock_probe;
     hipError_t err = launch_render(tier, A, (hipStream_t)stream);
@@ -358,9 +363,10 @@ long dfn_train_rows(int field, int what) {
     case 4: return (long)BIAS_GRAD_SLICES * dfn_bias_floats(DFN_TIER_BF16, field);   // dfn_bias_grad workspace floats
     case 5: return (long)SIG_ROW_SLICES * 512 + dfn_bias_floats(DFN_TIER_BF16, field);   // dfn_signal_grad workspace floats
     // 16-bit tier: bytes per 32-point tile of the MX-fp8 arrays act_T / dy_T (rows x 32 e4m3 bytes + the scale block)
-    case 6: return act_tile_bytes(t ? 64 + 640 + 128 + 9 * 256 + 32 : 64 + 9 * 256 + 32, ACT_FP4);      // act_T of the FUSED step (MX-fp4: 16 bytes per row)
+    case 6: return act_tile_bytes(t ? 64 + 640 + 128 + 9 * 256 + 32 : 64 + 9 * 256 + 32, true);      // act_T of the FUSED step in its default format (MX-fp4: 16 bytes per row)
     case 7: return rec8_tile_bytes(t ? 896 + 10 * 256 + 64 : 10 * 256 + 64);
-    // act_T of dfn_decoder_train_fwd (Decoder.forward on explicit points under autograd): e4m3, rows x 32 bytes + the scale block
+    // act_T in e4m3 (rows x 32 bytes + the scale block): dfn_decoder_train_fwd (Decoder.forward on explicit points under autograd)
+    // and the fused step with DFN_TRAIN_ACT_E4M3
     case 8: return act_tile_bytes(t ? 64 + 640 + 128 + 9 * 256 + 32 : 64 + 9 * 256 + 32, false);
     default: return fail(DFN_E_ARG, "dfn_train_rows: bad selector");
     }
@@ -442,6 +448,10 @@ static int train_fwd_impl(int tier, const DfnFrame* frame, const void* packed_he
                           uint32_t* masks_head, void* act_torso, uint32_t* masks_torso, float* z_all, uint8_t* ranks,
                           bool hier, void* stream, const DfnTrainLoss* loss = nullptr, bool with_loss = false) {
     const char* who = hier ? "dfn_train_fwd_hier" : "dfn_train_fwd";
+    // the format flag rides in the tier argument (include/dfanerf.h: DFN_TRAIN_ACT_E4M3); 16-bit tier only
+    const int act_e4m3 = (tier & DFN_TRAIN_ACT_E4M3) != 0;
+    if (tier >= 0) tier &= ~DFN_TRAIN_ACT_E4M3;
+    if (act_e4m3 && tier != DFN_TIER_BF16) return fail(DFN_E_ARG, std::string(who) + ": DFN_TRAIN_ACT_E4M3 applies to DFN_TIER_BF16 only");
     if (with_loss && (!loss || !loss->img_head || !loss->img_com || !loss->d_rgb_head || !loss->d_rgb_com || !loss->losses ||
                       !loss->workspace))
         return fail(DFN_E_ARG, std::string(who) + "_loss: bad loss argument");
@@ -485,6 +495,7 @@ static int train_fwd_impl(int tier, const DfnFrame* frame, const void* packed_he
     A.masks[0] = masks_head;
     A.masks[1] = masks_torso;
     A.NP = NP;
+    A.act_e4m3 = act_e4m3;
     A.loss = with_loss ? *loss : DfnTrainLoss{};
     A.clock_probe = nullptr;
     hipError_t err = launch_render(tier, A, (hipStream_t)stream);
@@ -809,14 +820,14 @@ static int weight_grad_impl(int tier, int field, int act_format, const void* dy_
 // (the two entry points without a format argument consume what the FUSED step records: dfn_train_fwd / dfn_train_fwd_hier)
 int dfn_weight_grad(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
                     float* grad_flat, void* stream) {
-    return weight_grad_impl(tier, field, ACT_FP4 ? DFN_ACT_E2M1 : DFN_ACT_E4M3, dy_T, act_T, NP, workspace, grad_flat, nullptr, stream,
+    return weight_grad_impl(tier, field, DFN_ACT_E2M1, dy_T, act_T, NP, workspace, grad_flat, nullptr, stream,
                             "dfn_weight_grad");
 }
 
 int dfn_weight_bias_grad(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
                          float* grad_flat, float* dbias, void* stream) {
     if (!dbias) return fail(DFN_E_ARG, "dfn_weight_bias_grad: dbias is NULL");
-    return weight_grad_impl(tier, field, ACT_FP4 ? DFN_ACT_E2M1 : DFN_ACT_E4M3, dy_T, act_T, NP, workspace, grad_flat, dbias, stream,
+    return weight_grad_impl(tier, field, DFN_ACT_E2M1, dy_T, act_T, NP, workspace, grad_flat, dbias, stream,
                             "dfn_weight_bias_grad");
 }
 

@@ -12,6 +12,7 @@
 // a wave carries its 32 points through the whole MLP in registers.
 #pragma once
 #include <stdint.h>
+#include "dfn_devguard.h"
 
 #if defined(__HIPCC__)
 #define DFN_HD __host__ __device__ inline

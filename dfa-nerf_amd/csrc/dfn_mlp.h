@@ -292,16 +292,14 @@ DFN_HD constexpr long rec8_tile_bytes(int rows) { return (long)rows * 32 + REC8_
 // averages out like the e4m3 one did.  Layout per 32-point tile: one 512-BYTE block per 32-row block - [point n][half h][8
 // bytes = 16 nibbles, nibble r = accumulator register r = feature tile_feat(h, r)], a lane's two dwords - then the scale
 // bytes.  The consumer transposes with ds_read_b64_tr_b4 (tools/fp4_probe.hip pins the conversion, the operand's K order
-// and the transpose on the hardware).  -DDFN_ACT_FP4=0 restores the e4m3 activations (A/B builds on real data).
-#ifndef DFN_ACT_FP4
-#define DFN_ACT_FP4 1
-#endif
+// and the transpose on the hardware).  Run-time opt-out (round 5): DFN_TRAIN_ACT_E4M3 in the tier argument of dfn_train_fwd* selects
+// the kernels whose recorder writes e4m3 activations (render_kernel<.., ACT4 = false>, dfn_render_bf16e.hip): A/B runs of the two
+// formats on real data in one process (dfanerf.training.TrainBuffers(act_format=...), --hip_train_act, DFN_TRAIN_ACT).
 // WHICH recorder writes MX-fp4: the fused training step's (render_kernel<.., TRAIN>: 131,072+ points per weight gradient).  The
 // decoder-on-points recorder (decoder_kernel<.., REC>: Decoder.forward under autograd, any number of points - a reference-shaped loop,
 // tests with a few thousand points) keeps e4m3: with 4,096 points the e2m1 rounding no longer averages out (whole-tensor
 // error 9.5 % where the gate is 8 %).  The format is a property of the recording context (CtxT<..>::act_fp4) and an argument of the
 // weight-gradient entry points (dfn_weight_bias_grad_fmt).
-constexpr bool ACT_FP4 = DFN_ACT_FP4 != 0;               // format of the FUSED STEP's recorder
 DFN_HD constexpr int act_row_bytes(bool fp4) { return fp4 ? 16 : 32; }          // bytes of one feature row of a 32-point tile
 DFN_HD constexpr long act_tile_bytes(int rows, bool fp4) { return (long)rows * act_row_bytes(fp4) + REC8_SCALE_BYTES; }
 struct Q8 {

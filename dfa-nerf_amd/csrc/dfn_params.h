@@ -26,6 +26,7 @@ struct RenderArgs {
     void* act_T[2];
     unsigned* masks[2];
     long NP;
+    int act_e4m3;               // 16-bit training forward: act_T as MX-fp8 e4m3 instead of MX-fp4 (DFN_TRAIN_ACT_E4M3)
     // training forward with the loss in its epilogue (dfn_train_fwd_loss; losses == null: off)
     DfnTrainLoss loss;
     // debug (dfn_debug_clock_probe): the workgroup in the middle of the grid writes {shader cycles, 100 MHz ticks} of its

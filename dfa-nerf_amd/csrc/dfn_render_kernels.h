@@ -138,7 +138,9 @@ template <int TIER, bool TWO = false> struct KernelLds {
 // sample_pdf, as in the NeRF lineage - and the loss sees the merged 64 + n_fine samples: every point is evaluated ONCE with
 // the recorder on, the coarse points in the coarse pass, the fine points in the fine passes, recorded in evaluation
 // order; the backward gets the merged depths and each point's merged rank to composite them in depth order)
-template <int TIER, bool TWO, int TRAIN>
+// ACT4 (training forwards only): the recorder writes act_T as MX-fp4 (the default of the fused step) or as MX-fp8 e4m3 (the
+// run-time opt-out: DFN_TRAIN_ACT_E4M3 or'ed into the tier of the dfn_train_fwd* calls; instantiated in dfn_render_bf16e.hip)
+template <int TIER, bool TWO, int TRAIN, bool ACT4 = true>
 __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 256) void render_kernel(
     const RenderArgs A) {
     using C = TierCfg<TIER>;
@@ -167,9 +169,9 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
                              // the kernel sits at its power ceiling, DESIGN.md 4.6: a better schedule is paid back in clock)
 #define DFN_PIPE_TWO_HEAD 1
 #endif
-    typedef CtxT<TRAIN != 0, TRAIN == 0, TRAIN != 0, (DFN_PIPE != 0) && TRAIN == 0 && (!TWO || DFN_PIPE_TWO != 0), TRAIN != 0 && ACT_FP4> CtxK;      // (fused step: act_T in MX-fp4)
+    typedef CtxT<TRAIN != 0, TRAIN == 0, TRAIN != 0, (DFN_PIPE != 0) && TRAIN == 0 && (!TWO || DFN_PIPE_TWO != 0), TRAIN != 0 && ACT4> CtxK;      // (fused step: act_T in MX-fp4 unless ACT4 is off)
     CtxK ctx = {lds, wave, lane, lane >> 5, {}};
-    typedef CtxT<TRAIN != 0, TRAIN == 0, TRAIN != 0, (DFN_PIPE != 0) && TRAIN == 0 && (!TWO || DFN_PIPE_TWO != 0 || DFN_PIPE_TWO_HEAD != 0), TRAIN != 0 && ACT_FP4> CtxH;   // the head's passes
+    typedef CtxT<TRAIN != 0, TRAIN == 0, TRAIN != 0, (DFN_PIPE != 0) && TRAIN == 0 && (!TWO || DFN_PIPE_TWO != 0 || DFN_PIPE_TWO_HEAD != 0), TRAIN != 0 && ACT4> CtxH;   // the head's passes
     constexpr bool two = TWO;
     const int NF = TRAIN == 1 ? 0 : F.n_fine;     // TRAIN == 1: the training forward is the reference's coarse renderer
     const bool hier = NF > 0;
@@ -750,17 +752,17 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
 template <typename K> static hipError_t set_lds(K kernel, int lds) {
     return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
-template <int TIER, bool TWO, int TRAIN = 0> static hipError_t launch_render_t(const RenderArgs& A, hipStream_t st) {
+template <int TIER, bool TWO, int TRAIN = 0, bool ACT4 = true> static hipError_t launch_render_t(const RenderArgs& A, hipStream_t st) {
     using C = TierCfg<TIER>;
     const int lds = KernelLds<TIER, TWO>::TOTAL;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = set_lds(render_kernel<TIER, TWO, TRAIN>, lds);
+        hipError_t e = set_lds(render_kernel<TIER, TWO, TRAIN, ACT4>, lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     const int blocks = (A.frame.ray_count + C::WAVES - 1) / C::WAVES;
-    hipLaunchKernelGGL((render_kernel<TIER, TWO, TRAIN>), dim3(blocks), dim3(C::THREADS), lds, st, A);
+    hipLaunchKernelGGL((render_kernel<TIER, TWO, TRAIN, ACT4>), dim3(blocks), dim3(C::THREADS), lds, st, A);
     return hipGetLastError();
 }
 template <int TIER, bool TORSO, bool REC = false> static hipError_t launch_decoder_t(const DecoderArgs& A, hipStream_t st) {
@@ -778,13 +780,16 @@ template <int TIER, bool TORSO, bool REC = false> static hipError_t launch_decod
     return hipGetLastError();
 }
 
+hipError_t launch_train_bf16_e4m3(const RenderArgs& A, hipStream_t st);      // dfn_render_bf16e.hip
 // all launches of one tier; TRAINABLE: the tier has a training forward (recorder on)
 template <int TIER, bool TRAINABLE> static hipError_t launch_render_tier(const RenderArgs& A, hipStream_t st) {
     const bool two = A.frame.fields == 2;
     if (A.samples_out) {     // training step: two fields, recorder on; coarse only (MAIN:855-899) or hierarchical (row H)
-        if constexpr (TRAINABLE)
+        if constexpr (TRAINABLE) {
+            // 16-bit tier with the e4m3 opt-out for act_T: those two kernels are a translation unit of their own
+            if (TIER == TIER_BF16 && A.act_e4m3) return launch_train_bf16_e4m3(A, st);
             return A.frame.n_fine > 0 ? launch_render_t<TIER, true, 2>(A, st) : launch_render_t<TIER, true, 1>(A, st);
-        else return hipErrorInvalidValue;
+        } else return hipErrorInvalidValue;
     }
     return two ? launch_render_t<TIER, true>(A, st) : launch_render_t<TIER, false>(A, st);
 }

@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DFN_LIB") or os.path.join(_HERE, "libdfanerf.so")
 
 TIER_F32, TIER_BF16, TIER_F16 = 0, 1, 2
+TRAIN_ACT_E4M3 = 0x100      # or'ed into the tier of dfn_train_fwd*: e4m3 instead of e2m1 activations (include/dfanerf.h)
+ACT_E4M3, ACT_E2M1 = 0, 1
 FIELD_HEAD, FIELD_TORSO, FIELD_LISTENER = 0, 1, 2
 N_DECODER_PARAMS = 955242
 
@@ -105,6 +107,12 @@ def _load():
         fn = getattr(lib, name)          # AttributeError here = header and library out of sync
         fn.restype = res
         fn.argtypes = args
+    # A library built with developer / timing switches (csrc/dfn_devguard.h: ablations that compute WRONG results at full
+    # speed, instrumented kernels) says so in its version string.  It is only ever loaded on purpose: through DFN_LIB (the
+    # variant libraries of tools/build_variant.sh) - never as the in-tree product library.
+    if b"DEV" in lib.dfn_version() and not os.environ.get("DFN_LIB"):
+        raise ImportError(f"{LIB_PATH} was built with developer switches ({lib.dfn_version().decode()}): rebuild it with "
+                          "dfa-nerf_amd/build.sh --clean (no DFN_EXTRA_FLAGS), or select a variant library explicitly with DFN_LIB")
     return lib, sorted(sig)
 
 

@@ -184,6 +184,10 @@ class FramePrefetcher:
         nb = packed.bias_floats(FIELD_HEAD) + (packed.bias_floats(FIELD_TORSO) if self.fields == 2 else 0)
         self.slots = [{"bias": torch.empty(nb, dtype=torch.float32, device=packed.device), "ready": None, "free": None,
                        "frame": None} for _ in range(2)]
+        # ... and they are WRITTEN on the side stream: tell the allocator, so that a blob freed while a queued _produce has
+        # not run yet is not handed out again before the side stream got there
+        for sl in self.slots:
+            sl["bias"].record_stream(self.side)
         self.k = 0
         self._home = torch.cuda.current_stream(packed.device)
         self._stale = True                                 # the side stream has not seen the parameters yet

@@ -98,14 +98,19 @@ _FLAGS = [
 # (the 16-bit TRAINING tier; also selected for the training step when --hip_tier f16)
 # --image_ext: file type of the rendered frames (upstream writes .jpg, MAIN:722-732; png = the kernel's uint8 output
 # losslessly, which is what the parity tests read back)
-_EXTRA_FLAGS = [("hip_tier", str, 'f32'), ("hierarchical", None, None), ("image_ext", str, 'jpg')]
+# --hip_train_act: format of the activations the 16-bit training step records for its weight gradients (fp4 | e4m3)
+_EXTRA_FLAGS = [("hip_tier", str, 'f32'), ("hierarchical", None, None), ("image_ext", str, 'jpg'), ("hip_train_act", str, 'fp4')]
 _EXTRA_HELP = {
     "hip_tier": "precision tier of the HIP path: f32 (exact MFMA products, the parity tier; default) | f16 (throughput tier "
                 "for rendering: f16 MFMA operands, f32 accumulation) | bf16.  TRAINING with f16 or bf16 runs the 16-bit "
                 "training tier: bf16 MFMA operands in the forward and the dX chain, and the arrays recorded for the backward "
-                "(layer inputs, pre-activation gradients) in MX-fp8 (e4m3 values + one power-of-two scale per 64 features x "
-                "32 points; the weight-gradient GEMMs run on them: values below amax * 2^-17 of a block flush to zero).  "
+                "in MX block formats (one power-of-two scale per 64 features x 32 points): the pre-activation gradients as "
+                "MX-fp8 (e4m3; values below amax * 2^-17 of a block flush to zero), the layer inputs as MX-fp4 (e2m1: ONE "
+                "mantissa bit; --hip_train_act e4m3 records them in 8 bits instead) - the weight-gradient GEMMs run on them.  "
                 "Use f32 for a reference-exact training run",
+    "hip_train_act": "16-bit training tier: format of the recorded layer inputs that feed the weight gradients: fp4 (MX-fp4 "
+                     "e2m1, default: half the bytes; a weight gradient sums >= 131,072 points and the rounding averages out - "
+                     "tests/test_gpu_convergence.py trains to convergence in both) | e4m3 (MX-fp8, +5 % step time)",
     "hierarchical": "64 + N_importance samples per ray (coarse pass -> sample_pdf -> the same decoder on the merged depths)",
     "image_ext": "file type of the rendered frames (jpg as upstream; png keeps the kernel's uint8 output losslessly)",
 }
@@ -247,11 +252,16 @@ class _FrameWriter:
         self._keep_list = None
         self._flushed = 0
         self.busy_s, self.blocked_s, self.t0 = 0.0, 0.0, None
+        import threading
+        self._lock = threading.Lock()                        # _kept / busy_s are touched by the worker threads
 
     def _flush_kept(self):
         # hand the kept frames to the caller's list in submission order, as far as they are complete
+        # (frames submitted without a keep list leave a None marker: it advances the sequence and is not appended)
         while self._keep_list is not None and self._flushed in self._kept:
-            self._keep_list.append(self._kept.pop(self._flushed))
+            a = self._kept.pop(self._flushed)
+            if a is not None:
+                self._keep_list.append(a)
             self._flushed += 1
 
     def submit(self, images, paths, keep=None):
@@ -267,7 +277,10 @@ class _FrameWriter:
             self.blocked_s += self._time() - t
         if keep is not None:
             self._keep_list = keep
-        self._flush_kept()
+        elif self._keep_list is None:
+            self._flushed = self.k                           # nothing is kept for this frame: the sequence starts behind it
+        with self._lock:
+            self._flush_kept()
         bufs = self.ring[slot]
         for b, img in zip(bufs, images):
             b.copy_(img, non_blocking=True)
@@ -284,11 +297,15 @@ class _FrameWriter:
             for a, pth in zip(arrs, paths):
                 if pth:
                     _imwrite(pth, a)
-            if keep is not None:
-                self._kept[seq] = arrs[0]
-            else:
-                self._kept[seq] = None
-            self.busy_s += self._time() - t                  # (a float add under the GIL: good enough for a statistic)
+            dt = self._time() - t
+            with self._lock:
+                # a marker per frame only while a keep list is active (it keeps the sequence gap-free for _flush_kept);
+                # with keep=None throughout nothing is stored at all
+                if keep is not None:
+                    self._kept[seq] = arrs[0]
+                elif self._keep_list is not None:
+                    self._kept[seq] = None
+                self.busy_s += dt
         self.pending[slot] = self.pool.submit(work)
 
     def drain(self):
@@ -296,10 +313,11 @@ class _FrameWriter:
             if f is not None:
                 f.result()
         self.pending = [None] * len(self.pending)
-        if self._keep_list is None:
-            self._kept.clear()
-            self._flushed = self.k
-        self._flush_kept()
+        with self._lock:
+            if self._keep_list is None:
+                self._kept.clear()
+                self._flushed = self.k
+            self._flush_kept()
 
     def stats(self):
         wall = (self._time() - self.t0) if self.t0 is not None else 0.0
@@ -686,6 +704,8 @@ def check_supported(args):
         bad.append(f"--n_object {args.n_object} (the scripts train one person: 1)")
     if args.hip_tier not in ("f32", "f16", "bf16"):
         bad.append(f"--hip_tier {args.hip_tier} (f32 | f16 | bf16)")
+    if getattr(args, "hip_train_act", "fp4") not in ("fp4", "e4m3"):
+        bad.append(f"--hip_train_act {args.hip_train_act} (fp4 | e4m3)")
     if bad:
         raise SystemExit("run_nerf_com_trainExpLater.py (MI355X build): unsupported configuration:\n  " + "\n  ".join(bad))
 
@@ -824,7 +844,8 @@ def train():
     # the 16-bit training tier is bf16 (f16, the inference throughput tier, has too little exponent range for gradients)
     tier = getattr(args, "hip_tier", "f32")
     train_buf = training.TrainBuffers("bf16" if tier == "f16" else tier, args.N_rand, dev,
-                                      n_fine=args.N_importance if getattr(args, "hierarchical", False) else 0)
+                                      n_fine=args.N_importance if getattr(args, "hierarchical", False) else 0,
+                                      act_format=getattr(args, "hip_train_act", None))
     if "PoseAttNet" in nets and _hip_signals_ok(args):
         train_buf.signal_trainer = training.SignalTrainer(nets["AudNet"], nets["ExpNet"], nets["AudAttNet"],
                                                           nets["PoseAttNet"], ds['auds'], ds['exp'], ds['poses'])

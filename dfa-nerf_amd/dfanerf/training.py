@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import engine
-from ._lib import FIELD_HEAD, FIELD_TORSO, DfnTrainLoss, check, lib
+from ._lib import ACT_E2M1, ACT_E4M3, FIELD_HEAD, FIELD_TORSO, TRAIN_ACT_E4M3, DfnTrainLoss, check, lib
 from .engine import TIERS, _ptr, _stream
 
 
@@ -107,7 +107,10 @@ class TrainBuffers:
     """Device buffers of one training step, sized for `n_rays` rays of 64 + n_fine samples (reused across steps).
     n_fine = 0: the reference's coarse step (MAIN:855-899); 64 / 128: the hierarchical variant (dfn_train_fwd_hier)."""
 
-    def __init__(self, tier, n_rays, device, n_fine=0):
+    def __init__(self, tier, n_rays, device, n_fine=0, act_format=None):
+        """act_format (16-bit tier): 'fp4' = the fused step records its GEMM inputs as MX-fp4 (e2m1, the default), 'e4m3' = as
+        MX-fp8 (twice the bytes, 3 mantissa bits instead of 1): the run-time opt-out, one switch for an A/B of the two on real
+        data (--hip_train_act, or DFN_TRAIN_ACT in the environment when the argument is None)."""
         self.flat = None            # [955242] f32 copy of the decoder parameters (state_dict order), see bind()
         self.flat_views = None
         self.tier = TIERS[tier]
@@ -120,14 +123,20 @@ class TrainBuffers:
         self.n_rays, self.NP = n_rays, n_rays * self.S
         assert self.NP % 512 == 0, "N_rand must be a multiple of 8"
         rows = lambda f, w: check(lib.dfn_train_rows(f, w), "dfn_train_rows")
-        # format of the fused step's recorded activations in this build (DFN_ACT_E2M1 = 1 unless built with -DDFN_ACT_FP4=0)
-        self.act_format = int(rows(0, 6) != rows(0, 8))
+        # format of the fused step's recorded activations (include/dfanerf.h: DFN_ACT_E2M1 / DFN_ACT_E4M3; DFN_TRAIN_ACT_E4M3 in the
+        # tier argument of the forward selects the e4m3 recorder)
+        fmt = act_format if act_format is not None else os.environ.get("DFN_TRAIN_ACT", "fp4")
+        if fmt not in ("fp4", "e4m3"):
+            raise ValueError(f"TrainBuffers: act_format must be 'fp4' or 'e4m3', got {fmt!r}")
+        self.act_format = ACT_E2M1 if fmt == "fp4" else ACT_E4M3
+        self.fwd_tier = self.tier | (TRAIN_ACT_E4M3 if (self.tier == 1 and self.act_format == ACT_E4M3) else 0)
+        act_sel = 6 if self.act_format == ACT_E2M1 else 8
         if self.tier == 1:
             # 16-bit tier: the recorded arrays are MX-fp8 (e4m3 + one E8M0 scale per 32-row block and 32-point tile, the
             # operand format of the block-scaled MFMA the weight-gradient GEMMs run on): [tile][dfn_train_rows(f, 6 / 7)] bytes
             # (act_T: MX-fp4 since round 4, 16 bytes per row and tile; + one tile: the weight-gradient GEMMs' 1-KiB DMA pieces
             # may take up to 512 bytes behind an odd last 512-byte block along)
-            self.act = [torch.zeros(self.NP // 32 + 1, rows(f, 6), dtype=torch.uint8, device=device) for f in (0, 1)]
+            self.act = [torch.zeros(self.NP // 32 + 1, rows(f, act_sel), dtype=torch.uint8, device=device) for f in (0, 1)]
             self.dy = [torch.empty(self.NP // 32, rows(f, 7), dtype=torch.uint8, device=device) for f in (0, 1)]
         else:
             self.act = [torch.empty(rows(f, 0), self.NP, dtype=torch.float32, device=device) for f in (0, 1)]
@@ -198,23 +207,23 @@ def _fused_forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape,
     bg_f32 = bg if bg.dtype == torch.float32 else None
     bg_u8 = bg if bg.dtype == torch.uint8 else None
     if loss is not None and buf.n_fine:
-        check(lib.dfn_train_fwd_hier_loss(t, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias), bias_t,
+        check(lib.dfn_train_fwd_hier_loss(buf.fwd_tier, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias), bias_t,
                                           _ptr(bg_f32), _ptr(bg_u8), _ptr(pix_index), _ptr(rgb_h), _ptr(rgb_c),
                                           _ptr(buf.samples), _ptr(buf.act[0]), _ptr(buf.masks[0]), _ptr(buf.act[1]),
                                           _ptr(buf.masks[1]), _ptr(buf.z_all), _ptr(buf.ranks), C.byref(loss), st),
               "dfn_train_fwd_hier_loss")
     elif loss is not None:
-        check(lib.dfn_train_fwd_loss(t, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias), bias_t,
+        check(lib.dfn_train_fwd_loss(buf.fwd_tier, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias), bias_t,
                                      _ptr(bg_f32), _ptr(bg_u8), _ptr(pix_index), _ptr(rgb_h), _ptr(rgb_c),
                                      _ptr(buf.samples), _ptr(buf.act[0]), _ptr(buf.masks[0]), _ptr(buf.act[1]),
                                      _ptr(buf.masks[1]), C.byref(loss), st), "dfn_train_fwd_loss")
     elif buf.n_fine:
-        check(lib.dfn_train_fwd_hier(t, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias), bias_t,
+        check(lib.dfn_train_fwd_hier(buf.fwd_tier, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias), bias_t,
                                      _ptr(bg_f32), _ptr(bg_u8), _ptr(pix_index), _ptr(rgb_h), _ptr(rgb_c),
                                      _ptr(buf.samples), _ptr(buf.act[0]), _ptr(buf.masks[0]), _ptr(buf.act[1]),
                                      _ptr(buf.masks[1]), _ptr(buf.z_all), _ptr(buf.ranks), st), "dfn_train_fwd_hier")
     else:
-        check(lib.dfn_train_fwd(t, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias), bias_t,
+        check(lib.dfn_train_fwd(buf.fwd_tier, C.byref(frame), _ptr(buf.packed[0]), _ptr(buf.packed[1]), _ptr(bias), bias_t,
                                 _ptr(bg_f32), _ptr(bg_u8), _ptr(pix_index), _ptr(rgb_h), _ptr(rgb_c),
                                 _ptr(buf.samples), _ptr(buf.act[0]), _ptr(buf.masks[0]), _ptr(buf.act[1]),
                                 _ptr(buf.masks[1]), st), "dfn_train_fwd")
@@ -244,7 +253,9 @@ def _fused_backward(ctx, d_h, d_c):
     # (_grad_buffer) - then the compositing backward's launch zeroes it on the way (dfn_composite_bwd*_z: its own fill was a
     # 9-us launch + a gap in front of the dX chain); a fresh buffer (gradient accumulation) comes zeroed from the allocator
     g_flat = getattr(buf.net, "_g_flat", None)
-    reuse = g_flat is not None and g_flat.shape == flat.shape and g_flat.device == dev and \
+    # (dfn_composite_bwd*_z wants a 16-byte aligned fill: a gradient buffer adopted by parallel.FlatGradBucket is a slice of the
+    # bucket at an arbitrary element offset - when the decoder does not come first it is only 4-byte aligned: plain fill then)
+    reuse = g_flat is not None and g_flat.shape == flat.shape and g_flat.device == dev and g_flat.data_ptr() % 16 == 0 and \
         not any(p.grad is not None for p in buf.params)
     if not reuse:
         g_flat = _grad_buffer(buf.net, "_g_flat", flat, buf.params)
@@ -292,8 +303,8 @@ def _fused_backward(ctx, d_h, d_c):
     def dw(f, stream, g, with_sig, before_reduce=None):
         gb = C.c_void_p(g_bias.data_ptr() + (4 * buf.nb[0] if f else 0))
         if before_reduce is None:
-            check(lib.dfn_weight_bias_grad(buf.tier, f, _ptr(buf.dy[f]), _ptr(buf.act[f]), buf.NP, _ptr(buf.ws[f]),
-                                           _ptr(g), gb, stream), "dfn_weight_bias_grad")
+            check(lib.dfn_weight_bias_grad_fmt(buf.tier, f, buf.act_format, _ptr(buf.dy[f]), _ptr(buf.act[f]), buf.NP,
+                                               _ptr(buf.ws[f]), _ptr(g), gb, stream), "dfn_weight_bias_grad_fmt")
         else:
             # the two stages apart: the GEMMs only write their own workspace; what must not overtake the other field's
             # reduction (the fields share most parameters: one += after the other, in a fixed order) is the REDUCTION

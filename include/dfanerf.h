@@ -155,16 +155,27 @@ int dfn_render_fwd_u8(int tier, const DfnFrame* frame, const void* packed_head, 
  * Buffers, NP = 64 * ray_count (a multiple of 64 in the 16-bit tier):
  *   samples, dsamples  f32 [NP][8]  (sigma_h, rgb_h[3], sigma_t, rgb_t[3]) and their gradients
  *   act_<field>        inputs of every GEMM.   f32 tier: f32 [NP/32][dfn_train_rows(field,0)][32] (feature-major per 32-point
- *                      tile).  16-bit tier (DFN_TIER_BF16): MX-fp8, u8 [NP/32][dfn_train_rows(field,6)]: per tile one 1-KiB
- *                      block per 32 feature rows, e4m3, point-major ([point][half][register]: feature = the MFMA C/D map), then
- *                      a 128-byte block of E8M0 scales, one per 32-row block - the operand format of
- *                      v_mfma_scale_f32_32x32x64_f8f6f4, which the weight-gradient GEMMs run on
+ *                      tile).  16-bit tier (DFN_TIER_BF16), default: MX-fp4, u8 [NP/32 + 1][dfn_train_rows(field,6)]: per tile
+ *                      one 512-BYTE block per 32 feature rows - e2m1 nibbles, point-major ([point][half][8 bytes = 16 nibbles,
+ *                      nibble r = accumulator register r]: feature = the MFMA C/D map), 16 bytes per row and tile - then a
+ *                      128-byte block of E8M0 scales, one per 32-row block: the narrowest B-operand format of
+ *                      v_mfma_scale_f32_32x32x64_f8f6f4, which the weight-gradient GEMMs run on.  ONE TILE MORE than NP/32 must
+ *                      be allocated (readable, contents ignored): the GEMMs' 1-KiB DMA pieces carry two 512-byte blocks and
+ *                      may read up to 512 bytes behind the last block of the last tile.
+ *                      With DFN_TRAIN_ACT_E4M3 or'ed into `tier` (below): MX-fp8 e4m3, u8 [NP/32 + 1][dfn_train_rows(field,8)],
+ *                      1-KiB blocks of 32 bytes per row and tile in the same point-major order
  *   masks_<field>      u32 [NP/32][dfn_train_rows(field,2)][64]   ReLU bits
- *   dy_T               pre-activation gradients, like act_<field>: rows dfn_train_rows(field,1) / bytes per tile
- *                      dfn_train_rows(field,7)
+ *   dy_T               pre-activation gradients: MX-fp8 e4m3 always, u8 [NP/32][dfn_train_rows(field,7)] (rows
+ *                      dfn_train_rows(field,1); f32 tier: f32 [NP/32][rows][32])
  *   workspace          f32 [dfn_train_rows(field,3)]  split-K partial slices; the reduction adds them in a fixed
  *                      order (no float atomics): the gradients are bit-reproducible run to run                      */
 long dfn_train_rows(int field, int what);
+/* Format of the activations the fused 16-bit training forward records, chosen PER CALL: or this flag into the `tier` argument of
+ * dfn_train_fwd / _hier / _loss / _hier_loss (DFN_TIER_BF16 | DFN_TRAIN_ACT_E4M3) and the recorder writes e4m3 (8 bits) instead
+ * of e2m1 (4 bits); pass DFN_ACT_E4M3 to dfn_weight_bias_grad_fmt / _partials for that step's weight gradients.  The run-time
+ * opt-out of the narrow format: A/B runs of the two on real data in one process (a 1-mantissa-bit activation feeds every weight
+ * gradient; evidence for it: tests/test_gpu_convergence.py, profiles/r05_convergence.txt).  Every other entry point rejects the flag. */
+#define DFN_TRAIN_ACT_E4M3 0x100
 long dfn_packed_bwd_bytes(int tier, int field);
 int dfn_pack_weights_bwd(int tier, int field, const float* params, void* packed_T, void* stream);
 
@@ -252,6 +263,8 @@ int dfn_composite_bwd_hier_z(const DfnFrame* frame, const int32_t* pix_index, co
                              const float* d_rgb_com, float* dsamples, float* zero_buf, long zero_floats, void* stream);
 int dfn_mlp_bwd(int tier, int field, const void* packed_T, const float* samples, const float* dsamples,
                 const uint32_t* masks, long NP, void* dy_T, void* stream);
+/* (16-bit tier: dfn_weight_grad / dfn_weight_bias_grad read act_T in the fused step's DEFAULT format, MX-fp4 - 16 bytes per row and
+ * tile, dfn_train_rows(field, 6) bytes per tile, NP/32 + 1 tiles allocated, see above; for e4m3 arrays use the _fmt entry point) */
 int dfn_weight_grad(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
                     float* grad_flat, void* stream);
 /* workspace: f32 [dfn_train_rows(field,4)] (partial row sums per slice of the points) */

@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_multirank.py: launched twice by torch.distributed.run, BOTH ranks on GPU 0 over the gloo backend
+"""Worker of tests/test_gpu_multirank.py: launched 2 or 8 times by torch.distributed.run, ALL ranks on GPU 0 over the gloo backend
 (RCCL refuses two ranks on one device), so that the product's multi-rank code paths run on hardware on a one-GPU box:
 FrameRenderer.render_image (ray shards + ONE gather per frame) and the data-parallel training step (FlatGradBucket all-reduce,
 replica broadcast, the optimizers' stream rules with more than one rank).  Prints one line 'MULTIRANK_OK ...' from rank 0."""
@@ -128,7 +128,7 @@ def main():
     flat = torch.cat([p.detach().reshape(-1) for m in mods.values() for p in m.parameters()])
     both = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(both, flat)
-    same = bool(torch.equal(both[0], both[1]))
+    same = all(bool(torch.equal(both[0], b)) for b in both[1:])          # every replica against rank 0's (world = 2 or 8)
     moved = bool((flat != torch.cat([t(v).reshape(-1).to(dev) for k in mods for v in
                                      [st[k][n] for n, _ in mods[k].named_parameters()]])).any())
     if rank == 0:

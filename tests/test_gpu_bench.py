@@ -134,3 +134,26 @@ def test_workload_all_two_ranks_and_fail_fast_without_devices():
         r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + FAST, capture_output=True, text=True, timeout=300, cwd=ROOT,
                            env={k: v for k, v in os.environ.items() if k != "DFN_BENCH_ONE_GPU"})
         assert r.returncode == 2 and "HIP device" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_workload_all_eight_ranks_on_one_gpu():
+    """`bench.py --gpus 8 --workload all` with all eight ranks on GPU 0 over gloo - the command the driver's
+    8-GPU lease runs, executed before that lease is the first time eight ranks, the 25,309-ray short shard and 8 x 3 collectives
+    per training step ever run.  Bitwise gather checks for c2 / c3 / c5, per-rank fields for 8 ranks, c4 weak and c4s strong."""
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    out = _line([sys.executable, BENCH, "--gpus", "8", "--workload", "all", "--steps", "2", "--warmup", "1",
+                 "--sustain-seconds", "0", "--no-cpu-baseline"], env={"DFN_BENCH_ONE_GPU": "1", "OMP_NUM_THREADS": "4"},
+                timeout=2400)
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["backend"] == "gloo"
+    assert out["gather_check"].get("identical") is True, out["gather_check"]
+    assert out["roofline"]["rays_per_launch"] == 25313 and len(out["per_rank"]["ms_per_step"]) == 8
+    assert "25313 rays per rank" in out["config"]["parallelism"]
+    ow = out["other_workloads"]
+    assert set(ow) == {"c3", "c5", "c4", "c4s"}, sorted(ow)
+    for k, v in ow.items():
+        assert "error" not in v, (k, v)
+        assert v["n_gpus"] == 8 and v["ms_per_step"] > 0 and len(v["per_rank"]["ms_per_step"]) == 8 and \
+            all(x > 0 for x in v["per_rank"]["ms_per_step"]), (k, v["per_rank"])
+    assert ow["c3"]["gather_check"]["identical"] and ow["c5"]["gather_check"]["identical"]
+    assert ow["c4"]["scaling"] == "weak" and ow["c4s"]["scaling"] == "strong"

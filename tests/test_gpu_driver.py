@@ -77,14 +77,15 @@ def _run(root, extra):
     return r.stdout
 
 
-def _run2(root, extra):
-    """the same CLI as two ranks (torch.distributed.run), both on GPU 0 over gloo (DFN_ONE_GPU)"""
+def _run2(root, extra, world=2):
+    """the same CLI as `world` ranks (torch.distributed.run), all on GPU 0 over gloo (DFN_ONE_GPU)"""
     from conftest import free_port
     for attempt in range(2):          # one retry: a free port can be taken between the probe and the rendezvous
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
                "127.0.0.1", "--master-port", str(free_port()),
                os.path.join(ROOT, "NeRFs", "DFANeRF", "run_nerf_com_trainExpLater.py")] + (COMMON + " " + extra).split()
-        r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900, env=dict(os.environ, DFN_ONE_GPU="1"))
+        r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=1500,
+                           env=dict(os.environ, DFN_ONE_GPU="1", OMP_NUM_THREADS="4"))
         if r.returncode == 0:
             break
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -190,8 +191,9 @@ def test_training_cli_writes_reference_checkpoint(dataset):
     assert (hb / "280005.tar").exists()
 
 
-def test_cli_with_two_ranks_on_one_gpu(dataset):
-    """torchrun --nproc-per-node 2 of the drop-in CLI (both ranks on GPU 0 over gloo): --render_person writes byte-identical
+@pytest.mark.parametrize("world", [2, 8])
+def test_cli_with_several_ranks_on_one_gpu(dataset, world):
+    """torchrun --nproc-per-node 2 / 8 of the drop-in CLI (all ranks on GPU 0 over gloo): --render_person writes byte-identical
     PNG frames to the single-process run (ray shards + one gather per frame), and a short data-parallel training run
     (replica broadcast, per-rank frames and pixels, gradient bucket, gated optimizers) writes its checkpoint."""
     from PIL import Image
@@ -203,12 +205,12 @@ def test_cli_with_two_ranks_on_one_gpu(dataset):
     for sub in one:
         for f in os.listdir(out / sub):
             os.remove(out / sub / f)
-    _run2(root, "--render_person --test_file transforms_val_ba.json --N_rand=2048 --N_iters=600000 --image_ext png")
+    _run2(root, "--render_person --test_file transforms_val_ba.json --N_rand=2048 --N_iters=600000 --image_ext png", world)
     for sub in one:
         assert sorted(os.listdir(out / sub)) == [f"test_{k:06d}.png" for k in range(F_VAL)]
         for k in range(F_VAL):
             assert np.array_equal(np.asarray(Image.open(out / sub / f"test_{k:06d}.png")), one[sub][k]), (sub, k)
-    log = _run2(root, "--N_rand=256 --N_iters=280006 --i_weights=3 --hip_tier bf16")
+    log = _run2(root, "--N_rand=256 --N_iters=280006 --i_weights=3 --hip_tier bf16", world)
     ck = root / "dataset" / "train_together" / "obama_TrainExpLater_smoMix"
     assert (ck / "280005.tar").exists(), log[-1500:]          # i_weights=3: saved at loop indices 280002, 280005
     lines = [ln for ln in open(ck / "loss.txt").read().split("\n") if ln.startswith("[TRAIN] Iter: 280006")]

@@ -45,7 +45,7 @@ def test_cli_flags_match_reference():
             if f["type"]:
                 assert a.type.__name__ == f["type"], f
     extra = set(acts) - {f["name"] for f in want} - {"help"}
-    assert extra == {"hip_tier", "hierarchical", "image_ext"}
+    assert extra == {"hip_tier", "hierarchical", "image_ext", "hip_train_act"}
 
 
 def test_config_file_and_script_flags(tmp_path):
@@ -72,7 +72,7 @@ def test_unsupported_configurations_are_refused_at_parse_time():
         "--expname t --n_feat 256 --z_dim 256 --dim_signal 96 --n_object 1 --use_deformation_field".split())
     run_nerf.check_supported(ok)
     for extra in ("--n_feat 128", "--N_samples 32", "--dim_signal 128", "--hierarchical --N_importance 96", "--n_object 2",
-                  "--hip_tier fp8", "--use_expression"):
+                  "--hip_tier fp8", "--use_expression", "--hip_train_act e2m3"):
         a = run_nerf.config_parser().parse_args(
             ("--expname t --z_dim 256 --dim_signal 96 --n_object 1 --use_deformation_field --n_feat 256 " + extra).split())
         with pytest.raises(SystemExit, match="unsupported configuration"):
@@ -436,6 +436,24 @@ def test_frame_writer_pipeline(tmp_path):
         im = np.asarray(Image.open(tmp_path / f"com_{i}.jpg"))
         assert im.shape == (H, W, 3) and abs(int(im.mean()) - 10 * i) <= 2
         assert (tmp_path / f"head_{i}.jpg").exists() == (i % 2 == 0)
+
+
+def test_frame_writer_mixed_keep_and_no_keep():
+    """frames submitted with keep=None must neither append None entries to a keep list used by other submissions nor
+    pile up markers when nothing is kept at all."""
+    H, W = 8, 8
+    img = lambda v: [torch.full((H, W, 3), v, dtype=torch.uint8)]
+    w = run_nerf._FrameWriter(H, W, 1, depth=2)
+    for i in range(6):                       # nothing kept at all: no bookkeeping grows
+        w.submit(img(i), [None])
+    w.drain()
+    assert w._kept == {}
+    kept = []
+    for i in range(6):                       # then a loop that keeps every other frame
+        w.submit(img(100 + i), [None], keep=kept if i % 2 == 0 else None)
+    w.drain()
+    assert [int(k[0, 0, 0]) for k in kept] == [100, 102, 104] and all(k is not None for k in kept)
+    assert w._kept == {} and w.stats()["frames"] == 12 and w.stats()["encoder_busy_s"] >= 0.0
 
 
 def test_pixel_sampler_matches_select_coords_semantics():

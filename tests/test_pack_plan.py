@@ -37,6 +37,27 @@ def test_header_symbols_exported():
     assert b"gfx950" in _lib.lib.dfn_version()
 
 
+def test_developer_switches_cannot_reach_the_product_library(tmp_path):
+    """the kernels' timing / ablation switches render wrong results at full speed.  (1) the in-tree library
+    is not a developer build; (2) defining any of them without DFN_DEV_BUILD is a compile error (csrc/dfn_devguard.h);
+    (3) build.sh refuses DFN_EXTRA_FLAGS without DFN_DEV_BUILD=1 before it compiles anything."""
+    import subprocess
+    assert b"DEV" not in _lib.lib.dfn_version()
+    src = tmp_path / "probe.cpp"
+    src.write_text('#include "dfn_layout.h"\nint main() { return dfn::SLAB_FRAGS > 0 ? 0 : 1; }\n')
+    inc = ["-I", os.path.join(ROOT, "dfa-nerf_amd", "csrc"), "-I", os.path.join(ROOT, "include")]
+    base = ["g++", "-std=c++17", "-fsyntax-only", str(src)] + inc
+    assert subprocess.run(base, capture_output=True).returncode == 0
+    for sw in ("DFN_EXP_NOEPI", "DFN_REC8_NOAMAX", "DFN_NOMASK", "DFN_TIMING", "DFN_WL_NOMFMA"):
+        r = subprocess.run(base + ["-D" + sw], capture_output=True, text=True)
+        assert r.returncode != 0 and "DFN_DEV_BUILD" in r.stderr, (sw, r.stderr[-300:])
+        assert subprocess.run(base + ["-D" + sw, "-DDFN_DEV_BUILD=1"], capture_output=True).returncode == 0, sw
+    r = subprocess.run(["bash", os.path.join(ROOT, "dfa-nerf_amd", "build.sh")], capture_output=True, text=True,
+                       env=dict(os.environ, DFN_EXTRA_FLAGS="-DDFN_EXP_NOEPI"), timeout=60)
+    assert r.returncode == 2 and "DFN_DEV_BUILD" in r.stderr, r.stderr[-300:]
+    assert b"DEV" not in _lib.lib.dfn_version() and os.path.exists(_lib.LIB_PATH)        # ... and it touched nothing
+
+
 def test_error_paths_without_gpu():
     assert _lib.lib.dfn_packed_bytes(7, 0) < 0 and b"bad tier" in _lib.lib.dfn_last_error()
     assert _lib.lib.dfn_bias_floats(0, 9) < 0
@@ -92,6 +113,10 @@ def test_error_paths_without_gpu():
     assert L.dfn_train_fwd_hier_loss(*args16, one, one, None, N) == -1
     assert L.dfn_train_loss_floats(2048) >= 2 * 256 + 1 and L.dfn_train_loss_floats(0) > 0
     assert L.dfn_weight_bias_grad_fmt(1, 0, 7, one, one, 64, one, one, one, N) == -1 and b"act_format" in L.dfn_last_error()
+    # DFN_TRAIN_ACT_E4M3 rides in the tier argument of the training forwards only: 16-bit tier only, rejected everywhere else
+    assert L.dfn_packed_bytes(1 | _lib.TRAIN_ACT_E4M3, 0) < 0
+    assert L.dfn_train_fwd(0 | _lib.TRAIN_ACT_E4M3, *args16[1:], N) == -1 and b"DFN_TRAIN_ACT_E4M3" in L.dfn_last_error()   # f32 tier
+    assert L.dfn_train_rows(0, 8) == 2 * (L.dfn_train_rows(0, 6) - 128) + 128           # e4m3 rows are twice the e2m1 rows
     # the weight gradients in two stages (GEMMs into the workspace | the reduction of the slices)
     assert L.dfn_weight_bias_grad_partials(1, 0, 1, N, one, 64, one, one, N) == -1                        # no dy_T
     assert L.dfn_weight_bias_grad_partials(1, 0, 1, one, one, 64, one, N, N) == -1 and b"dbias" in L.dfn_last_error()

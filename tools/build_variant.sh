@@ -12,7 +12,7 @@ BASE="$ROOT/dfa-nerf_amd/build"
 OBJ="$ROOT/exp_libs/obj_$NAME"
 mkdir -p "$OBJ"
 UNITS="${VARIANT_UNITS:-dfn_render_f16 dfn_render_bf16}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -mllvm -pragma-unroll-threshold=200000 -I$SRC -I$ROOT/include $*"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -mllvm -pragma-unroll-threshold=200000 -I$SRC -I$ROOT/include -DDFN_DEV_BUILD=1 $*"
 pids=()
 for f in $UNITS; do
   ( hipcc $FLAGS --save-temps=obj -c "$SRC/$f.hip" -o "$OBJ/$f.o" 2>"$OBJ/$f.log" ) &
@@ -24,6 +24,9 @@ for f in $UNITS; do
   python3 "$ROOT/tools/check_inflight.py" "$ISA" | grep -v " 0 hazard" || true
   python3 "$ROOT/tools/check_scratch.py" "$ISA" | grep FAIL || true
 done
+# dfn_api carries dfn_version(): the variant library must say " DEV" (dfanerf._lib then only loads it through DFN_LIB)
+hipcc $FLAGS -c "$SRC/dfn_api.hip" -o "$OBJ/dfn_api.o"
+UNITS="$UNITS dfn_api"
 OTHERS=""
 for o in "$BASE"/*.o; do
   b=$(basename "$o" .o); skip=0; case "$b" in *-hip-amdgcn-*) continue;; esac

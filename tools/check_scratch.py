@@ -26,19 +26,27 @@ def kernels(text):
 
 
 def main(paths):
-    bad = 0
+    bad = seen = 0
     for p in paths:
         for name, (priv, spill, body) in kernels(open(p).read()).items():
-            # the last template argument is TRAIN / REC (recorder on): those are training kernels, not checked here
-            infer = ("render_kernel" in name and name.endswith("ELb0EEEvNS_10RenderArgsE")) or \
+            # render_kernel<TIER, TWO, TRAIN (int), ACT4>: TRAIN != 0 are training kernels; decoder_kernel<TIER, TORSO, REC>: REC
+            # likewise - not checked here.  (Until round 5 the render_kernel test looked for a BOOL last argument and, since
+            # TRAIN had become an int, silently matched nothing: only the decoder kernels were checked.)
+            m = re.search(r"render_kernelILi\d+ELb[01]ELi(\d+)E(?:Lb[01]E)?E", name)
+            infer = (m is not None and m.group(1) == "0") or \
                     ("decoder_kernel" in name and name.endswith("ELb0EEEvNS_11DecoderArgsE"))
             if not infer:
                 continue
+            seen += 1
             n_scr = len(re.findall(r"^\s+scratch_", body, re.M))
             ok = priv == 0 and spill == 0 and n_scr == 0
             print(f"{name}: private segment {priv} B, {spill} spilled VGPRs, {n_scr} scratch instructions"
                   + ("" if ok else "   <-- FAIL"))
             bad += not ok
+    if any("dfn_render_f16" in p or p.endswith("dfn_render_bf16-hip-amdgcn-amd-amdhsa-gfx950.s") for p in paths) and seen < 4:
+        print(f"check_scratch: only {seen} inference kernels recognised (expected 2 render + 2 decoder per 16-bit unit): the "
+              "name patterns are out of date   <-- FAIL")
+        return 1
     return 1 if bad else 0
 
 
