@@ -166,13 +166,15 @@ def _oracle_full_step(states, scene, latents, sel, tgt_h, tgt_c, step):
     return _FULL[key]
 
 
-@pytest.mark.parametrize("tier", ["f32", "bf16"])
-def test_training_step_full_size_vs_oracle_autograd(states, scene, latents, tier):
+@pytest.mark.parametrize("tier,act_format", [("f32", None), ("bf16", None), ("bf16", "e4m3")])
+def test_training_step_full_size_vs_oracle_autograd(states, scene, latents, tier, act_format):
     """The reference's step at its FULL size - N_rand = 2048 distinct pixels, both fields, all five networks, smoothed
     signal branch (step 300000) - through the HIP forward + backward against torch CPU autograd through the oracle
     (MAIN:855-931): loss, per-tensor gradient norms, sampled entries and whole-tensor direction, with golden G8's
     assertions (G8 itself runs 256 rays: the kernels' split-K slices, the recorder's tile walk and the second-stage
-    reductions only see their production sizes here)."""
+    reductions only see their production sizes here).  act_format "e4m3": the run-time opt-out of the MX-fp4 activations
+    (DFN_TRAIN_ACT_E4M3: the e4m3 recorder kernels of dfn_render_bf16e.hip + the e4m3 path of the weight-gradient GEMMs), same
+    gates - its whole-tensor errors come out below the fp4 default's."""
     from dfanerf import nets, run_nerf, training
     dev = torch.device("cuda")
     step, n = 300000, 2048
@@ -191,7 +193,8 @@ def test_training_step_full_size_vs_oracle_autograd(states, scene, latents, tier
            "near": 0.3, "far": 0.9}]
     zs, za = [t(v).to(dev) for v in latents]
     embed_fn, _ = nets.get_embedder(3, 0)
-    buf = training.TrainBuffers(tier, n, dev)
+    buf = training.TrainBuffers(tier, n, dev, act_format=act_format)
+    assert buf.act_format == (0 if act_format == "e4m3" else 1) and (buf.fwd_tier != buf.tier) == (act_format == "e4m3")
     buf.signal_trainer = training.SignalTrainer(mods["AudNet"], mods["ExpNet"], mods["AudAttNet"], mods["PoseAttNet"],
                                                 ds[0]["auds"], ds[0]["exp"], ds[0]["poses"])
     ys, xs = t(sel[:, 0]).to(dev), t(sel[:, 1]).to(dev)
@@ -223,7 +226,7 @@ def test_training_step_full_size_vs_oracle_autograd(states, scene, latents, tier
                 np.testing.assert_allclose(gs[::stride][:8].numpy(), rs_[::stride][:8].numpy(), rtol=2e-2, atol=1e-3 * rms + 1e-9)
             else:
                 np.testing.assert_allclose(gs[::stride][:8].numpy(), rs_[::stride][:8].numpy(), rtol=1e-1, atol=2e-1 * rms + 1e-9)
-    print(f"full-size {tier}: worst relative gradient-norm error {worst:.2e}, worst whole-tensor error {worst_dir:.2e}")
+    print(f"full-size {tier}{'/' + act_format if act_format else ''}: worst relative gradient-norm error {worst:.2e}, worst whole-tensor error {worst_dir:.2e}")
 
 
 def test_bf16_training_tracks_f32_over_200_steps(states, scene, latents):
