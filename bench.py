@@ -558,15 +558,7 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
         # network is positively homogeneous, so scaling what enters each layer besides the previous activations (input layer,
         # latent / skip / view projections: weights and biases; hidden layers: biases) scales every activation by s and
         # nothing else.  With s = 1/16 the synthetic network's activations (max 13) stay below 1.
-        sc_a = float(os.environ["DFN_BENCH_ACT_SCALE"])
-        dec = st["decoder"] = dict(st["decoder"])
-        both = ("fc_in", "fc_z", "fc_z_skips.0", "fc_p_skips.0", "fc_z_view", "fc_view")
-        for k in list(dec):
-            base, _, leaf = k.rpartition(".")
-            if base in both or (leaf == "bias" and (base.startswith("blocks.") or base == "feat_view")):
-                dec[k] = (dec[k] * np.float32(sc_a)).astype(np.float32)
-            elif k in ("sigma_out.weight", "feat_out.weight"):      # the output layers undo it: the same images
-                dec[k] = (dec[k] / np.float32(sc_a)).astype(np.float32)
+        st["decoder"] = synth.scale_head_activations(st["decoder"], float(os.environ["DFN_BENCH_ACT_SCALE"]))
     zs, za = synth.synth_latents(0)
     H, W = sc["H"], sc["W"]
     R = H * W
@@ -837,6 +829,24 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
             out["roofline"]["ceiling_mix_clock_ghz"] = pc["renderer_mix"]["clock_ghz"]
         except Exception as e:
             out["roofline"]["power_ceiling"] = {"error": f"{type(e).__name__}: {e}"}
+    if check and world == 1 and tier == "f16":
+        # the f16 tier's range guard (dfanerf/f16guard.py), as the render CLI runs it before a sequence: max |activation| per
+        # layer over 256 rays of each of the F frames in the exact tier, max |parameter|; outside the timed region
+        try:
+            from dfanerf import f16guard
+            frs, sh, stt = [], [], []
+            for f in range(F):
+                s2, t2 = enc.encode([f], A.smo_size, A.smo_torse_size)
+                sh.append(s2[0])
+                stt.append(t2[0])
+                frs.append(engine.make_frame(H, W, sc["focal"], sc["cx"], sc["cy"], sc["poses"][f], sc["pose_body"], sc["near"], sc["far"]))
+            b = f16guard.activation_bounds(flat, frs, sh, stt, zs_d, za_d, bg)
+            top = f16guard.check(b, pk.f16_weight_max)
+            out["f16_range"] = {"max_activation": top, "max_parameter": pk.f16_weight_max, "f16_max": f16guard.F16_MAX,
+                                "margin": f16guard.MARGIN, "frames": F, "rays_per_frame": 256,
+                                "worst_layer": max(((v, f"{fld}: {ly}") for fld, d in b.items() for ly, v in d.items()))[1]}
+        except Exception as e:
+            out["f16_range"] = {"error": f"{type(e).__name__}: {e}"}
     if check and world == 1:
         try:
             out["parity_check"] = parity_check(sc, st, zs, za, pk, n_fine, fields, ((warmup + steps) * B - 1) % F, dev, tier)

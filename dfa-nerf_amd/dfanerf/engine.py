@@ -55,12 +55,20 @@ class PackedDecoder:
         self.flat = flat_params
         self.device = flat_params.device
         self.packed = {}
+        self.f16_bounds = None          # f16 tier: calibrated max |activation| per layer (f16guard.activation_bounds), once known
+        self.f16_weight_max = None
         for f in fields:
             nbytes = check(lib.dfn_packed_bytes(self.tier, f), "dfn_packed_bytes")
             self.packed[f] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self.repack()
 
     def repack(self):
+        if self.tier == TIERS["f16"]:
+            # half precision's range (f16guard.py): a weight beyond it would be packed as inf.  One device reduction and one
+            # host read per (re)pack - the f16 tier is inference only: it packs once per checkpoint, not once per step
+            from . import f16guard
+            self.f16_weight_max = f16guard.weight_bound(self.flat)
+            f16guard.check(None, self.f16_weight_max, what="a decoder parameter")
         for f, buf in self.packed.items():
             check(lib.dfn_pack_weights(self.tier, f, _ptr(self.flat), _ptr(buf), _stream()), "dfn_pack_weights")
 

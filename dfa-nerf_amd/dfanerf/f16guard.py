@@ -1,0 +1,111 @@
+"""Range guard of the f16 inference tier.
+
+The throughput tier carries the decoder's activations and weights as IEEE half precision (v_mfma_f32_32x32x16_f16:
+10 mantissa bits, 5 exponent bits).  The conversion at the end of every layer (v_cvt_pk_f16_f32) does not saturate: an
+activation above 65504 becomes inf, the next layer turns it into NaN, and the frame comes out black or NaN - silently.
+The synthetic networks of the tests peak at |h| = 13; a trained checkpoint is whatever training made it.  So before the
+f16 tier renders a sequence it is CALIBRATED:
+
+  weights      max |w| over the decoder's parameters (what dfn_pack_weights rounds to f16), at pack time;
+  activations  one launch of the EXACT tier's training forward (dfn_train_fwd, f32: its recorder writes every GEMM input -
+               i.e. exactly the values the 16-bit tiers convert - feature-major) over a few hundred rays of up to eight
+               frames of the sequence, with the sequence's own poses and conditioning signals: max |h_l| per layer.
+
+check() refuses (F16RangeError, naming the layer) when a bound times MARGIN exceeds f16's largest value; the bounds stay
+with the packed decoder (PackedDecoder.f16_bounds) so that a caller can read them.  bf16 and f32 have f32's exponent range
+and need no guard.  Reference semantics of the path: decoder.py:277-349 (fp32 throughout upstream)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import engine
+from ._lib import FIELD_HEAD, FIELD_TORSO, check as _chk, lib
+from .engine import _ptr, _stream
+
+F16_MAX = 65504.0
+MARGIN = 4.0          # an unseen frame may exceed the calibrated maximum; 4x still leaves f16 13 binades above a |h| of 13
+
+
+class F16RangeError(RuntimeError):
+    pass
+
+
+# groups of act_T rows (csrc/dfn_mlp.h: RecMap): every GEMM input of a field, in recorder order
+def _groups(field):
+    g, r = [], 0
+
+    def add(name, n):
+        nonlocal r
+        g.append((name, r, r + n))
+        r += n
+    add("positional encoding", 64)
+    if field == FIELD_TORSO:
+        for k in range(5):
+            add(f"deform_net.blocks_embed.{k} output", 64)
+            add(f"deform_net.blocks_signal.{k} output", 64)
+        add("deformed point / pose signal (fc_in_torso input)", 128)
+    add("fc_in output", 256)
+    for k in range(7):
+        add(f"blocks.{k} output" + (" + skip" if k == 3 else ""), 256)
+    add("feat_view output", 256)
+    add("view encoding", 32)
+    return g
+
+
+def weight_bound(flat_params):
+    """max |parameter| of the decoder (one device reduction + one host read)"""
+    return float(flat_params.detach().abs().max())
+
+
+def activation_bounds(flat_params, frames, sig_heads, sig_torsos, z_shape, z_app, bg, n_rays=256, seed=0):
+    """max |GEMM input| per layer and field over n_rays random pixels of every frame in `frames` (engine.make_frame objects with
+    fields = 2, n_fine = 0; ray_count is overwritten), with that frame's conditioning signals sig_heads[k] [96] /
+    sig_torsos[k] [42].  -> {"head": {layer: max}, "torso": {...}}.  Runs in the EXACT tier (f32 MFMAs, f32 recording)."""
+    dev = flat_params.device
+    pk = engine.PackedDecoder(flat_params, "f32", fields=(FIELD_HEAD, FIELD_TORSO))
+    rows = [_chk(lib.dfn_train_rows(f, 0), "dfn_train_rows") for f in (0, 1)]
+    mrows = [_chk(lib.dfn_train_rows(f, 2), "dfn_train_rows") for f in (0, 1)]
+    NP = n_rays * 64
+    act = [torch.empty(NP // 32, rows[f], 32, dtype=torch.float32, device=dev) for f in (0, 1)]
+    masks = [torch.empty(NP // 32, mrows[f], 64, dtype=torch.int32, device=dev) for f in (0, 1)]
+    samples = torch.empty(NP, 8, dtype=torch.float32, device=dev)
+    rgb = torch.empty(2, n_rays, 3, dtype=torch.float32, device=dev)
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    top = [torch.zeros(rows[f], dtype=torch.float32, device=dev) for f in (0, 1)]
+    nh = pk.bias_floats(FIELD_HEAD)
+    bg_f32 = bg if bg.dtype == torch.float32 else None
+    bg_u8 = bg if bg.dtype == torch.uint8 else None
+    for k, fr in enumerate(frames):
+        pix = torch.randperm(fr.H * fr.W, generator=gen)[:n_rays].to(torch.int32).to(dev)
+        bias = pk.fold(sig_heads[k], sig_torsos[k], z_shape, z_app)
+        fr.ray_begin, fr.ray_count, fr.n_fine, fr.fields = 0, n_rays, 0, 2
+        _chk(lib.dfn_train_fwd(0, C.byref(fr), _ptr(pk.packed[FIELD_HEAD]), _ptr(pk.packed[FIELD_TORSO]), _ptr(bias),
+                               C.c_void_p(bias.data_ptr() + 4 * nh), _ptr(bg_f32), _ptr(bg_u8), _ptr(pix), _ptr(rgb[0]),
+                               _ptr(rgb[1]), _ptr(samples), _ptr(act[0]), _ptr(masks[0]), _ptr(act[1]), _ptr(masks[1]),
+                               _stream()), "dfn_train_fwd(calibration)")
+        for f in (0, 1):
+            top[f] = torch.maximum(top[f], act[f].abs().amax(dim=(0, 2)))
+    out = {}
+    for f, name in ((FIELD_HEAD, "head"), (FIELD_TORSO, "torso")):
+        t = top[f].cpu().numpy()
+        out[name] = {g: float(np.nanmax(t[a:b])) if np.isfinite(t[a:b]).all() else float("inf") for g, a, b in _groups(f)}
+    return out
+
+
+def check(bounds, weight_max=None, margin=MARGIN, what="the decoder"):
+    """raise F16RangeError if a calibrated bound x margin does not fit f16; -> the largest activation bound otherwise"""
+    bad, top = [], 0.0
+    if weight_max is not None and not (weight_max * margin < F16_MAX):
+        bad.append(f"max |parameter| = {weight_max:.4g}")
+    for field, layers in (bounds or {}).items():
+        for layer, v in layers.items():
+            top = max(top, v)
+            if not (v * margin < F16_MAX):
+                bad.append(f"{field} field, {layer}: max |activation| = {v:.4g}")
+    if bad:
+        raise F16RangeError(
+            f"--hip_tier f16: {what} does not fit half precision's range (largest value {F16_MAX:.0f}, calibration margin "
+            f"x{margin:g}): " + "; ".join(bad) + ".  The f16 tier's conversions do not saturate - it would render inf / NaN.  "
+            "Use --hip_tier bf16 (same speed, f32's exponent range, 7 mantissa bits) or --hip_tier f32 (exact)")
+    return top

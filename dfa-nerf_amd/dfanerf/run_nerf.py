@@ -346,6 +346,31 @@ class FrameRenderer:
         self.za = z_app[0, 2 * itr_obj:2 * itr_obj + 2].to(dev).float().contiguous()
         self.n_fine = args.N_importance if getattr(args, "hierarchical", False) else 0
 
+    def check_f16_range(self, poses, pose_body, signals, max_frames=8, n_rays=256):
+        """f16 tier only (no-op otherwise): calibrate the decoder's activation range on up to `max_frames` of the frames about
+        to be rendered - poses[k] (3x4 host), signals(k) -> (sig_head [96], sig_torso [42]) - in the exact tier, and refuse
+        (f16guard.F16RangeError) if half precision cannot hold it with margin: the f16 conversions do not saturate, an
+        out-of-range checkpoint would render NaN silently.  The bounds stay on the packed decoder (`f16_bounds`)."""
+        if self.tier != "f16" or len(poses) == 0:
+            return None
+        from . import f16guard
+        pk = self.decoder.packed("f16")                     # (its weight bound was checked when it was packed)
+        pick = sorted(set(np.linspace(0, len(poses) - 1, min(max_frames, len(poses))).astype(int).tolist()))
+        frs, sh, stt = [], [], []
+        for k in pick:
+            a, b = signals(k)
+            sh.append(a.reshape(-1))
+            stt.append(b.reshape(-1))
+            frs.append(self.engine.make_frame(self.H, self.W, self.focal, self.cx, self.cy, _host(poses[k]), _host(pose_body),
+                                              self.near, self.far, self.args.last_dist, 0, n_rays, self.args.N_samples, 0, 2,
+                                              self.args.concate_bg))
+        with torch.no_grad():
+            pk.f16_bounds = f16guard.activation_bounds(pk.flat, frs, sh, stt, self.zs, self.za, self.bg, n_rays=n_rays)
+        top = f16guard.check(pk.f16_bounds, pk.f16_weight_max)
+        print(f"[dfanerf] f16 tier: calibrated on {len(pick)} frames x {n_rays} rays in the exact tier: max |activation| "
+              f"{top:.4g}, max |parameter| {pk.f16_weight_max:.4g} (half precision holds {f16guard.F16_MAX:.0f}; margin x{f16guard.MARGIN:g})")
+        return pk.f16_bounds
+
     def render(self, pose, pose_body, signal, signal_torso, ray_begin=0, ray_count=None, pix_index=None, fields=2,
                out_u8=False, out=None, bias=None):
         """-> rgb_head [n,3], rgb_com [n,3] (None if fields == 1); out_u8: uint8 images, to8b fused into the kernel;
@@ -794,6 +819,22 @@ def train():
             pf = engine.FramePrefetcher(enc, renderer.decoder.packed(renderer.tier), renderer.zs, renderer.za,
                                         args.smo_size if smoothed else 0, args.smo_torse_size if smoothed else 0, fields=2,
                                         length=len_sig)
+        if renderer.tier == "f16" and frame_ids:
+            # range guard of the f16 tier (f16guard.py): a few hundred rays of up to eight of these frames through the exact
+            # tier, with their own poses and signals; refuses a checkpoint whose activations half precision cannot hold
+            def sig_of(k):
+                img_i = frame_ids[k]
+                if enc is not None:
+                    s2, t2 = enc.encode([img_i], args.smo_size if smoothed else 0, args.smo_torse_size if smoothed else 0,
+                                        length=len_sig)
+                    return s2[0], t2[0]
+                with torch.no_grad():
+                    sg = encode_signal(datasets, itr_obj, img_i, args.dim_aud, nets["AudNet"], nets["ExpNet"], nets["AudAttNet"],
+                                       global_step, args, len_sig, embed_fn=embed_fn)
+                    st_ = encode_signal_torso(datasets, itr_obj, img_i, nets.get("PoseAttNet"), global_step, args, len_sig,
+                                              embed_fn=embed_fn)
+                return sg[0], st_
+            renderer.check_f16_range([poses_host[i] for i in frame_ids], body_host, sig_of)
         for k, img_i in enumerate(frame_ids):
             with torch.no_grad():
                 if pf is not None:

@@ -187,3 +187,20 @@ def bench_scene(seed=0, n_frames=8, H=450, W=450):
     aud, exp = synth_features(seed, n_frames)
     return dict(H=H, W=W, focal=1200.0, cx=W / 2.0, cy=H / 2.0, near=0.3, far=0.9,
                 poses=poses, pose_body=pose_body, bg=bg, aud=aud, exp=exp)
+
+
+def scale_head_activations(decoder_state, s):
+    """The same decoder with the HEAD field's hidden activations scaled by s: a ReLU network is positively homogeneous, so
+    scaling what enters each layer besides the previous activations (input layer, latent / skip / view projections: weights
+    and biases; hidden layers: biases) scales every activation by s, and the two output layers undo it (weights / s): the
+    head image is unchanged in exact arithmetic.  (The torso shares the trunk: its image changes.)  Used by the f16 range
+    guard's tests (s = 1e4: activations beyond half precision) and bench.py's DFN_BENCH_ACT_SCALE."""
+    dec = dict(decoder_state)
+    both = ("fc_in", "fc_z", "fc_z_skips.0", "fc_p_skips.0", "fc_z_view", "fc_view")
+    for k in list(dec):
+        base, _, leaf = k.rpartition(".")
+        if base in both or (leaf == "bias" and (base.startswith("blocks.") or base == "feat_view")):
+            dec[k] = (dec[k] * np.float32(s)).astype(np.float32)
+        elif k in ("sigma_out.weight", "feat_out.weight"):
+            dec[k] = (dec[k] / np.float32(s)).astype(np.float32)
+    return dec

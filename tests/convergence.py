@@ -10,10 +10,16 @@ trained in the 16-bit tier come out as good as one trained in the exact tier?
             expression features (synth.bench_scene), rendered by the f32 tier (64 coarse samples, both fields: exactly
             what the training step differentiates, MAIN:855-899) -> uint8 ground-truth frames (head, composite), as a
             dataset on disk would hold them;
-  students  fresh networks (torch's default initialisation under a fixed seed - NOT the teacher's), trained with the
-            PRODUCTION step (run_nerf.train_step_loss_hip -> training.backward -> run_nerf.optimizer_steps: device pixel
-            sampler, uint8 targets gathered in the forward's epilogue, HipAdam, all five optimizers live) on the first
-            F_train frames, same start, same frame and pixel sequence in every tier;
+  students  the teacher's networks with EVERY tensor of all five moved by `perturb` x rms(tensor) x N(0, 1) (a fixed seed): the
+            rendered frames start ~15-20 dB from the ground truth and training has to find the way back - all five networks
+            receive gradients, and the end of the run is where a quantised gradient matters most: close to an optimum, where
+            the true gradient is small against the rounding of its operands.  (A student initialised from scratch - torch's
+            default initialisation - is the other possible start; on THIS synthetic scene its head field's density dies in
+            the first steps - relu(sigma) = 0 on every ray, in every tier, the exact one included: the head image stays the
+            background, 10.94 dB, for 12,000 steps - so it measures nothing about the tiers: profiles/r05a_convergence_fresh_init.txt.)
+            Trained with the PRODUCTION step (run_nerf.train_step_loss_hip -> training.backward -> run_nerf.optimizer_steps:
+            device pixel sampler, uint8 targets gathered in the forward's epilogue, HipAdam, all five optimizers live) on the
+            first F_train frames, same start, same frame and pixel sequence in every tier;
   score     PSNR of the student's f32-tier renders against the ground truth, on the training frames and on the HELD-OUT
             frames (poses and audio the student never saw), head and composite images.
 Training trajectories are chaotic: two runs that differ in rounding only end at slightly different models.  The harness
@@ -41,16 +47,24 @@ def _t(x):
     return torch.from_numpy(np.asarray(x))
 
 
-def make_modules(dev, states=None, seed=None):
-    """the five networks: from a state dict set (the teacher) or freshly initialised under `seed` (a student)"""
+def make_modules(dev, states=None, seed=None, perturb=None):
+    """the five networks: from a state dict set (the teacher), freshly initialised under `seed` (torch's default
+    initialisation), or - perturb = a - the state dicts with every tensor moved by a x rms(tensor) x N(0, 1) under `seed`"""
     if seed is not None:
         torch.manual_seed(seed)
     mods = {"decoder": Decoder(z_dim=256, hidden_size=256, dim_signal=96, use_deformation_field=True),
             "AudNet": nets.AudioNet_W2L(), "ExpNet": nets.ExpressionEnc(), "AudAttNet": nets.AudioAttNet(96, 4),
             "PoseAttNet": nets.AudioAttNet(42, 8)}
+    gen = torch.Generator().manual_seed(0 if seed is None else seed)
     for k, m in mods.items():
         if states is not None:
-            m.load_state_dict({kk: _t(v) for kk, v in states[k].items()})
+            sd = {kk: _t(v).clone() for kk, v in states[k].items()}
+            if perturb:
+                for kk, v in sd.items():
+                    if v.dtype.is_floating_point:
+                        rms = float(v.double().pow(2).mean().sqrt())
+                        sd[kk] = v + perturb * rms * torch.randn(v.shape, generator=gen)
+            m.load_state_dict(sd)
         m.to(dev)
     return mods
 
@@ -116,11 +130,21 @@ def score(scene, mods, gt8, split, tier="f32"):
     return {k: float(10.0 * np.log10(len(imgs) / v)) for k, v in se.items()}
 
 
+PERTURB = 0.2
+
+
+def student_start(dev, init_seed=1234, perturb=PERTURB):
+    """the students' common start: the perturbed teacher (perturb > 0) or torch's default initialisation (perturb = None)"""
+    if perturb:
+        return make_modules(dev, states=synth.synth_all_states(0), seed=init_seed, perturb=perturb)
+    return make_modules(dev, seed=init_seed)
+
+
 def train_student(scene, gt8, tier, steps, act_format=None, init_seed=1234, pixel_seed=100, n_rand=2048, curve_every=0,
-                  log=None):
-    """`steps` production steps of a fresh student on the F_TRAIN training frames.  -> (modules, info)"""
+                  log=None, perturb=PERTURB):
+    """`steps` production steps of a student on the F_TRAIN training frames.  -> (modules, info)"""
     dev, sc = scene.dev, scene.sc
-    mods = make_modules(dev, seed=init_seed)
+    mods = student_start(dev, init_seed, perturb)
     a = run_nerf.config_parser().parse_args(
         (f"--expname conv --concate_bg --N_rand={n_rand} --sample_rate=0 --smo_size=4 --smo_torse_size 8 --use_et_embed "
          "--dim_signal=96 --dim_aud=96 --n_object=1 --use_deformation_field --nosmo_iters 0 --noexp_iters 0 "
@@ -177,17 +201,18 @@ def teacher_ground_truth(scene):
     return [(to8b(rh), to8b(rc)) for rh, rc in imgs]
 
 
-def run(steps, variants, size=450, curve_every=0, log=None, with_inference_check=True):
+def run(steps, variants, size=450, curve_every=0, log=None, with_inference_check=True, perturb=PERTURB):
     """variants: list of (name, tier, act_format, pixel_seed).  -> dict of per-variant scores and the pairwise differences"""
     dev = torch.device("cuda")
     scene = Scene(dev, size)
     gt8 = teacher_ground_truth(scene)
-    res = {"steps": steps, "size": size, "frames_train": F_TRAIN, "frames_held_out": F_HELD, "variants": {}}
-    # what an untrained student scores (the scale of what training buys)
-    res["untrained"] = score(scene, make_modules(dev, seed=1234), gt8, "held")
+    res = {"steps": steps, "size": size, "frames_train": F_TRAIN, "frames_held_out": F_HELD, "perturb": perturb, "variants": {}}
+    # what the students' start scores (the scale of what training buys)
+    res["untrained"] = score(scene, student_start(dev, 1234, perturb), gt8, "held")
     keep = {}
     for name, tier, fmt, pseed in variants:
-        mods, info = train_student(scene, gt8, tier, steps, act_format=fmt, pixel_seed=pseed, curve_every=curve_every, log=log)
+        mods, info = train_student(scene, gt8, tier, steps, act_format=fmt, pixel_seed=pseed, curve_every=curve_every, log=log,
+                                   perturb=perturb)
         info["psnr_held_out"] = score(scene, mods, gt8, "held")
         info["psnr_train_frames"] = score(scene, mods, gt8, "train")
         res["variants"][name] = info

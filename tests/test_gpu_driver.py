@@ -215,3 +215,33 @@ def test_cli_with_several_ranks_on_one_gpu(dataset, world):
     assert (ck / "280005.tar").exists(), log[-1500:]          # i_weights=3: saved at loop indices 280002, 280005
     lines = [ln for ln in open(ck / "loss.txt").read().split("\n") if ln.startswith("[TRAIN] Iter: 280006")]
     assert lines and np.isfinite(float(lines[-1].split("Com Loss: ")[1].split()[0]))
+
+
+def test_f16_tier_refuses_an_out_of_range_checkpoint_loudly(dataset, states, latents):
+    """--hip_tier f16 on a checkpoint whose activations exceed half precision: the CLI stops with the guard's message before it
+    writes a frame (it used to render NaN frames silently); the same command on the in-range checkpoint reports its calibration."""
+    from dfanerf import nets, run_nerf
+    from dfanerf.decoder import Decoder
+    root, _ = dataset
+    base = "--render_person --test_file transforms_val_ba.json --N_rand=2048 --N_iters=600000 --image_ext png --hip_tier f16"
+    out = _run(root, base)
+    assert "f16 tier: calibrated on" in out and "max |activation|" in out
+    st = dict(states)
+    st["decoder"] = synth.scale_head_activations(states["decoder"], 1.0e4)
+    mods = {"decoder": Decoder(z_dim=256, hidden_size=256, dim_signal=96, use_deformation_field=True),
+            "AudNet": nets.AudioNet_W2L(), "ExpNet": nets.ExpressionEnc(), "AudAttNet": nets.AudioAttNet(96, 4),
+            "PoseAttNet": nets.AudioAttNet(42, 8)}
+    for k, m in mods.items():
+        m.load_state_dict({kk: t(v) for kk, v in st[k].items()})
+    opts = {k: torch.optim.Adam(m.parameters(), lr=5e-4) for k, m in mods.items()}
+    ck = root / "dataset" / "train_together" / "big_acts"
+    ck.mkdir(parents=True, exist_ok=True)
+    run_nerf.save_checkpoint(str(ck / "280000.tar"), 280000, t(latents[0]), t(latents[1]), mods, opts)
+    cmd = [sys.executable, os.path.join(ROOT, "NeRFs", "DFANeRF", "run_nerf_com_trainExpLater.py")] + \
+        (COMMON + " " + base + " --expname big_acts --resume dataset/train_together/big_acts/280000.tar").split()
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "F16RangeError" in r.stderr and "--hip_tier bf16" in r.stderr, r.stderr[-1500:]
+    res = root / "dataset" / "train_together" / "big_acts" / "obama" / "person" / "render_com"
+    assert not res.exists() or not os.listdir(res)
+    _run(root, base.replace("--hip_tier f16", "--hip_tier bf16") + " --expname big_acts --resume dataset/train_together/big_acts/280000.tar")
+    assert len(os.listdir(res)) == F_VAL
