@@ -264,51 +264,6 @@ template <int TIER, bool TORSO, class CT>
 DFN_DEV void bwd_trunk(const BwdIn& in, Vec<TIER, 8>& dy0, Vec<TIER, 4>& gpd_skip, const BwdIO& io, int g_trunk,
                        int m_trunk, int& f, Fetch<TIER>& fe, Stream& s, const CT& c) {
     using B = BProg<TIER>;
-#ifndef DFN_BWD_PINGPONG      // 1 (round 5, 16-bit tiers): the trunk's gradient vectors alternate between two registers sets BY NAME (`dy0` and
-                              // one local) instead of `cur = nxt` after every layer: the unrolled kernels carried 683 v_mov for them
-#define DFN_BWD_PINGPONG 1
-#endif
-    if constexpr (tier_is16(TIER) && (DFN_BWD_PINGPONG != 0)) {
-        Vec<TIER, 8>& a = dy0;
-        Vec<TIER, 8> b;
-        {   // feat_out^T: d(pre-rgb) [3 of a 32-row tile] -> g_h, masked with h > 0
-            Vec<TIER, 1> dout;
-#pragma unroll
-            for (int L = 0; L < 16; ++L) dout.set(L, (c.half == 0 && L < 3) ? in.dpre[L < 3 ? L : 0] : 0.f);
-            put<TIER, 1>(io, g_trunk + GradMap::T_DYO, dout, c);
-            bwd_layer<TIER, 8, B::KU_T, 1>(a, dout, m_trunk + RecMap::TM_H, io, f, fe, s, c);
-        }
-        {   // [feat_view ; sigma_out]^T -> g_a7, masked with a7 > 0: dy7
-            Vec<TIER, 1> dsig;
-#pragma unroll
-            for (int L = 0; L < 16; ++L) dsig.set(L, (c.half == 0 && L == 0) ? in.dsigma : 0.f);
-            put<TIER, 1>(io, g_trunk + GradMap::T_DSIG, dsig, c);
-            bwd_layer2<TIER, 8, B::KU_ACT, 8, B::KU_T, 1>(b, a, dsig, m_trunk + RecMap::TM_A5 + 8, io, f, fe, s, c,
-                                                          g_trunk + GradMap::T_DYV);
-        }
-        // blocks[6]^T, blocks[5]^T -> dy6, dy5; blocks[4]^T -> g4 = dL/d a4 (post-skip, no activation)
-        bwd_layer<TIER, 8, B::KU_ACT, 8>(a, b, m_trunk + RecMap::TM_A5 + 4, io, f, fe, s, c, g_trunk + GradMap::T_DY5 + 512);
-        bwd_layer<TIER, 8, B::KU_ACT, 8>(b, a, m_trunk + RecMap::TM_A5, io, f, fe, s, c, g_trunk + GradMap::T_DY5 + 256);
-        bwd_layer<TIER, 8, B::KU_ACT, 8>(a, b, -1, io, f, fe, s, c, g_trunk + GradMap::T_DY5);
-#if DFN_TORSO_G4_SPREAD
-        if constexpr (TORSO) bwd_layer<TIER, 4, B::KU_ACT, 8>(gpd_skip, a, -1, io, f, fe, s, c, g_trunk + GradMap::T_G4);   // fc_p_skips_torso^T
-        else put<TIER, 8>(io, g_trunk + GradMap::T_G4, a, c);           // (masked in place next: no consumer layer to ride on)
-#else
-        put<TIER, 8>(io, g_trunk + GradMap::T_G4, a, c);                // (masked in place below)
-        if constexpr (TORSO) bwd_layer<TIER, 4, B::KU_ACT, 8>(gpd_skip, a, -1, io, f, fe, s, c);   // fc_p_skips_torso^T
-#endif
-        if constexpr (TORSO) pin_vec(gpd_skip);
-#pragma unroll
-        for (int w = 0; w < 4; ++w)          // dy4 = g4 * [y4 > 0]
-            apply_mask_packed<TIER, 8>(a, 2 * w, mask_word(io, m_trunk + RecMap::TM_A4R + w, c.lane));
-        // blocks[3..0]^T -> dy3 .. dy0; layer l writes its input: dy4 (l = 3), then dy3 .. dy1
-        bwd_layer<TIER, 8, B::KU_ACT, 8>(b, a, m_trunk + RecMap::TM_A0 + 12, io, f, fe, s, c, g_trunk + GradMap::T_DY4);
-        bwd_layer<TIER, 8, B::KU_ACT, 8>(a, b, m_trunk + RecMap::TM_A0 + 8, io, f, fe, s, c, g_trunk + GradMap::T_DY0 + 768);
-        bwd_layer<TIER, 8, B::KU_ACT, 8>(b, a, m_trunk + RecMap::TM_A0 + 4, io, f, fe, s, c, g_trunk + GradMap::T_DY0 + 512);
-        bwd_layer<TIER, 8, B::KU_ACT, 8>(a, b, m_trunk + RecMap::TM_A0, io, f, fe, s, c, g_trunk + GradMap::T_DY0 + 256);
-        if constexpr (!TORSO || !DFN_TORSO_DY0_SPREAD) put<TIER, 8>(io, g_trunk + GradMap::T_DY0, a, c);      // torso: the caller's next layer writes dy0
-        return;
-    }
     Vec<TIER, 8> cur, nxt;
     // Every 8-tile gradient vector is written to dy_T by the layer that CONSUMES it (put_row of bwd_layer: its stores go out
     // between that layer's MFMAs, PutSide), not in a burst behind the layer that produced it.

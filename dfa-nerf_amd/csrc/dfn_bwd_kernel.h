@@ -29,14 +29,7 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
 #endif
     // LDS-DMA as asm: the ReLU mask loads must not drain the dY stores.  DFN_BWD_ASMF: the fragment reads as asm with counted
     // waits too (16-bit tiers), like the inference kernels
-#ifndef DFN_DEPHASE_BWD       // 1: waves 4-7 half a slab behind waves 0-3 (dfn_mlp.h, "de-phased hand-over"; 16-bit tier)
-#define DFN_DEPHASE_BWD 1
-#endif
-    static_assert(!tier_is16(TIER) || ((BProg<TIER>::H_FRAGS % SLAB_FRAGS == 0 || BProg<TIER>::H_FRAGS % SLAB_FRAGS >= 15) &&
-                                       (BProg<TIER>::S_FRAGS % SLAB_FRAGS == 0 || BProg<TIER>::S_FRAGS % SLAB_FRAGS >= 15)),
-                  "de-phased hand-over: see dfn_mlp.h");
-    constexpr bool DEPH = tier_is16(TIER) && (DFN_DEPHASE_BWD != 0);
-    typedef CtxT<false, (DFN_BWD_ASMF != 0), true, false, false, DEPH> CtxB;
+    typedef CtxT<false, (DFN_BWD_ASMF != 0), true> CtxB;
     const CtxB ctx = {lds, wave, lane, lane >> 5, {}};
     Stream s;
     s.base0 = s.base1 = A.wblob_T;
@@ -54,7 +47,6 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     io.rows = TORSO ? GradMap::S_ROWS : GradMap::H_ROWS;
     io.mask_dwords = TORSO ? RecMap::S_MDWORDS : RecMap::H_MDWORDS;
     __syncthreads();
-    if constexpr (DEPH) dephase_begin<TIER>(wave);
     // One pass per workgroup by default (gridDim = tiles / 8).  DFN_BWD_PERSIST: the launcher sizes the grid to one workgroup
     // per compute unit and a workgroup walks tiles blockIdx, + gridDim, ... with the weight stream running on across its
     // passes - no launch / ring-fill / drain bubble between the two rounds a compute unit runs; measured neutral.
@@ -78,7 +70,6 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
         if constexpr (TORSO) bwd_torso<TIER>(in, io, s, ctx);
         else bwd_head<TIER>(in, io, s, ctx);
     }
-    if constexpr (DEPH) dephase_end(wave);
 #ifdef DFN_TIMING
     if (lane == 0) {
         const long w = ((long)blockIdx.x * C::WAVES + wave) & 8191;

@@ -123,22 +123,6 @@ DFN_DEV void stream_issue_piece(const Stream& s, lds_char* ring, int wave, int l
             (DFN_LDS void*)(ring + s.pf_slot * SLAB_BYTES + f * FRAG_BYTES), 16, 0, 0);
     }
 }
-// The same piece under a wave-uniform predicate (de-phased hand-over, below): `on` = all ones / zero.  The instruction is issued
-// with EXEC = 0 when off - no branch: a branch per piece cuts the MLP body into small basic blocks the register allocator
-// spills around (the first version of the de-phased kernels: 31-43 spilled registers).
-template <int TIER>
-DFN_DEV void stream_issue_piece_if(const Stream& s, lds_char* ring, int wave, int lane, int k, bool on_) {
-    using C = TierCfg<TIER>;
-    const int f = k * C::WAVES + wave;
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)ring + s.pf_slot * SLAB_BYTES + (unsigned)f * FRAG_BYTES);
-    const gchar_c* sb = (const gchar_c*)(s.pf_ptr + f * FRAG_BYTES);
-    const unsigned voff = (unsigned)lane * 16u;
-    const unsigned on = __builtin_amdgcn_readfirstlane(on_ ? ~0u : 0u);      // (pinned to an SGPR: the predicate is wave-uniform)
-    unsigned long save;
-    asm volatile("s_mov_b64 %0, exec\n\ts_and_b32 exec_lo, exec_lo, %4\n\ts_and_b32 exec_hi, exec_hi, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"
-                 : "=&s"(save) : "v"(voff), "s"(sb), "s"(dst), "s"(on) : "memory", "m0", "scc");
-}
 // advance the prefetch cursor to the next slab; at the end of a pass it jumps to the stream of the next pass
 // (next_ptr / next_left, set when the CONSUMER starts a pass: the cursor is only two slabs ahead of it).
 // Two cheap selects on purpose: anything heavier is turned into a branch per slab, which cuts the MLP into
@@ -150,16 +134,6 @@ DFN_DEV void stream_cursor_next(Stream& s) {
     const bool wrap = left == 0;
     s.pf_ptr = wrap ? s.next_ptr : s.pf_ptr + SLAB_BYTES;
     s.pf_left = wrap ? s.next_left : left;
-}
-DFN_DEV void stream_cursor_next_if(Stream& s, bool on) {      // selects, no branch
-    const unsigned slot = (s.pf_slot + 1 == RING_SLOTS) ? 0u : s.pf_slot + 1;
-    const int left = s.pf_left - 1;
-    const bool wrap = left == 0;
-    const char* ptr = wrap ? s.next_ptr : s.pf_ptr + SLAB_BYTES;
-    const int nl = wrap ? s.next_left : left;
-    s.pf_slot = on ? slot : s.pf_slot;
-    s.pf_ptr = on ? ptr : s.pf_ptr;
-    s.pf_left = on ? nl : s.pf_left;
 }
 // the consumer starts pass s.pass: publish where the cursor goes after the end of this pass
 DFN_DEV void stream_pass_begin(Stream& s) {
@@ -235,67 +209,6 @@ DFN_DEV void slab_advance(Stream& s, lds_char* ring, int wave, int lane) {
     s.pf_owed += C::LOADS_PER_SLAB;
 }
 
-// ---- de-phased hand-over (round 5; training kernels) ---------------------------------------------------------------------
-// One s_barrier per slab keeps the eight waves of a workgroup in LOCKSTEP: a tile pair of a 256-wide layer is exactly one slab
-// (32 fragments), so every wave reaches its convert / mask / quantise epilogue at the same moment - and the two waves that share
-// a SIMD (w and w + 4) leave its matrix pipe idle together, then compete for it together.  The training kernels' epilogues are
-// long (recorder, ReLU bits, MX quantisation: 5-6 vector instructions per MFMA): the pipe was 35-49 % busy.
-// Here the waves 4-7 ("lag") run the SAME program half a slab behind the waves 0-3 ("lead"): everybody meets at a barrier
-// every 16 fragments, and because the lag group enters through one extra barrier (dephase_begin) its k-th barrier pairs with
-// the lead group's (k + 1)-th - at every barrier one group stands at a slab boundary and the other in the middle of a slab,
-// so one wave of a SIMD issues MFMAs while the other runs its epilogue.  What the ring needs (3 slots: slabs g-1, g, g+1):
-//   * a slab is read only after EVERY wave's DMA pieces of it have landed: at the barrier where the lead group starts slab g
-//     (lag: middle of g-1) everybody waits for its own pieces of g (the 4 pieces of g+1 are the only younger loads);
-//   * the slot of slab g-1 is rewritten (pieces of g+2) only after both groups have read it: the lead group issues its pieces
-//     in the SECOND half of its slab g, the lag group in the FIRST half of its slab g - both behind the barrier at which the
-//     lag group starts slab g (lgkmcnt(0): its reads of g-1 have returned);
-//   * pieces a pass's partial last slab did not get to are issued behind the next pass's first barrier (not in front of it);
-//     the LAG group must not owe any (its wait in the middle of a slab counts on four younger pieces): every program's last
-//     slab has >= 15 fragments (static_assert next to the kernels).
-// The lead group leaves through one extra barrier (dephase_end): the counts match again and later __syncthreads() pair up.
-// Both groups run IDENTICAL code (no group-dependent branch inside the MLP body): the waits below are right for either group -
-// lead at a slab start / lag in the middle of a slab: the slab the lead group is about to read has landed once at most the
-// four youngest loads (the pieces of the slab behind it) are outstanding; at the other two points the same wait only asks for
-// pieces that landed long ago.  (Pieces issued with EXEC = 0 may or may not count in vmcnt: the four youngest REAL pieces are
-// the youngest loads at the two points that matter either way.)
-template <int TIER, bool ASM>
-DFN_DEV void slab_advance_dephased(Stream& s, lds_char* ring, int wave, int lane, bool slab_start, bool pass_start) {
-    using C = TierCfg<TIER>;
-    static_assert(C::WAVES == 8 && C::LOADS_PER_SLAB == 4, "two waves per SIMD, four pieces per wave and slab");
-    if (slab_start) {
-        // first slab of a pass: the lead group has NOT issued the pieces of the slab behind it yet when the previous pass ended on
-        // a partial slab (its issue window is the second half of a slab; they go out below, behind the barrier) - the pieces
-        // of THIS slab are then the youngest loads: wait for all of them
-        if (pass_start) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::LOADS_PER_SLAB) : "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (pass_start) stream_flush<TIER, ASM>(s, ring, wave, lane);     // (what the previous pass's last slab still owed: safe only here)
-        s.rd_slot = (s.rd_slot + 1 == RING_SLOTS) ? 0u : s.rd_slot + 1;
-        s.rd_off = s.rd_slot * SLAB_BYTES;
-        s.rd_vaddr = (unsigned)(unsigned long)ring + (unsigned)lane * 16u + s.rd_off;
-        s.pf_owed += C::LOADS_PER_SLAB;
-    } else {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::LOADS_PER_SLAB) : "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
-}
-// in front of the first pass (behind the __syncthreads() that follows stream_begin) / behind the last pass
-template <int TIER> DFN_DEV void dephase_begin(int wave) {
-    if (wave >= 4) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TierCfg<TIER>::LOADS_PER_SLAB) : "memory");      // slab 0 landed (slab 1 is younger)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
-}
-DFN_DEV void dephase_end(int wave) {
-    if (wave < 4) {
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
-}
-
 // ---- GEMM pieces ------------------------------------------------------------------------------------------
 // Training-mode recorder: the forward pass leaves what the backward kernels need (all null otherwise).
 //   act_T : feature-major activations per 32-point tile, [tile][rows][32] (bf16 / f32 by tier): the inputs of
@@ -316,10 +229,8 @@ struct Rec {
 // still in flight - at each use of an ordinary load (a ReLU mask word, a spill reload); without it the waits are counted.
 // PIPE = software-pipelined layers (layer_pipe below): the convert / ReLU epilogue of a tile pair and the bias reads of the
 // next one are issued between the MFMAs of the pair in between, on a second set of accumulators (+32 registers).
-// DEPH = the two waves of a SIMD run the weight stream HALF A SLAB APART (slab_advance_dephased below; 16-bit tiers, 8 waves)
-template <bool REC, bool ASMF = false, bool ASMD = false, bool PIPE = false, bool ACT4 = false, bool DEPH = false> struct CtxT {
+template <bool REC, bool ASMF = false, bool ASMD = false, bool PIPE = false, bool ACT4 = false> struct CtxT {
     static constexpr bool rec_on = REC;
-    static constexpr bool dephase = DEPH;
     static constexpr bool act_fp4 = ACT4;            // the recorder writes act_T as MX-fp4 (dfn_mlp.h "Round 4")
 #ifndef DFN_TRAIN_ASMF      // 1: the asm fragment fetch in the recording (training forward) kernels too: 413 -> 402 us; tools/check_inflight.py
                             // (run by build.sh on their ISA as well) proves no spill or copy touches an in-flight destination
@@ -402,39 +313,6 @@ typedef __bf16 bf16x2_q __attribute__((ext_vector_type(2)));
 // FP4: the scale of an e2m1 block: amax / scale in (3, 6] (6 = the format's largest value: nothing saturates)
 template <int NT, bool NONNEG = false, bool FP4 = false> DFN_DEV Q8 q8_of_tiles(const Vec<TIER_BF16, NT>& v, int t0, int n) {
     typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-#ifndef DFN_AMAX3
-#define DFN_AMAX3 1
-#endif
-#if DFN_AMAX3
-    // Round 5: gfx950's three-input packed maximum.  A bf16 bit pattern read as an f16 orders the same way (sign + magnitude in
-    // both; the patterns of |x| >= 2^121 would read as f16 infinities / NaNs: no activation or gradient gets there), and VOP3P
-    // carries NEGATE modifiers: |x| of both halves of a word is max(x, -x), so ONE v_pk_maximum3_f16 m, w, -w accumulates a signed
-    // word (the packed integer form needed an AND and a max per word) and one accumulates TWO words of ReLU outputs.  Same
-    // maximum, bit for bit (f16 denormals = |x| < 2^-119, where the scale is clamped anyway).  asm: no builtin; the operands are
-    // packed operand words (VALU results), never MFMA accumulators (inline-asm VALU gets no MFMA wait states).
-    unsigned m4[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-        if (t >= t0 && t < t0 + n)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const u32x4_ q = __builtin_bit_cast(u32x4_, v.u[2 * t + h]);
-                const unsigned w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];      // (scalars: __builtin_bit_cast of a vector ELEMENT miscompiles)
-                if constexpr (NONNEG) {          // two chains per half: 2 instructions per 4 words
-                    asm("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(m4[2 * h]) : "v"(w0), "v"(w1));
-                    asm("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(m4[2 * h + 1]) : "v"(w2), "v"(w3));
-                } else {                         // four chains: 1 instruction per word
-                    asm("v_pk_maximum3_f16 %0, %0, %1, %1 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "+v"(m4[0]) : "v"(w0));
-                    asm("v_pk_maximum3_f16 %0, %0, %1, %1 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "+v"(m4[1]) : "v"(w1));
-                    asm("v_pk_maximum3_f16 %0, %0, %1, %1 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "+v"(m4[2]) : "v"(w2));
-                    asm("v_pk_maximum3_f16 %0, %0, %1, %1 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "+v"(m4[3]) : "v"(w3));
-                }
-            }
-    unsigned mm = m4[3];
-    asm("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(mm) : "v"(m4[0]), "v"(m4[1]));
-    asm("v_pk_max_f16 %0, %0, %1" : "+v"(mm) : "v"(m4[2]));
-    unsigned x = max(mm & 0xffffu, mm >> 16);
-#else
     // a TREE of packed maxima (four independent chains, then their maximum): as one chain the 15 dependent v_pk_max_u16 of a
     // tile pair sit in front of everything the wave issues next (in-order issue), MFMAs included
     u16x2 m4[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
@@ -452,7 +330,6 @@ template <int NT, bool NONNEG = false, bool FP4 = false> DFN_DEV Q8 q8_of_tiles(
             }
     const u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(m4[0], m4[1]), __builtin_elementwise_max(m4[2], m4[3]));
     unsigned x = max((unsigned)m[0], (unsigned)m[1]);
-#endif
     // row maxima by DPP (quad swaps, half-row mirror, row mirror), then the four rows by readlane: an SGPR.  As asm: the
     // update_dpp builtin compiles to v_mov + v_mov_dpp + v_max per step (12 VALU), v_max_u32_dpp with the DPP on its own first
     // operand is one; dst = src0 = src1, so a lane whose source lane is off keeps its value.  s_nop 1: the two wait states a
@@ -673,14 +550,7 @@ template <int TIER> struct Fetch {
     template <class CT, class H> DFN_DEV void load(int slot, int fp, Stream& s, const CT& c, H&& hook) {
         using C = TierCfg<TIER>;
         constexpr int GAP = SLAB_FRAGS / C::LOADS_PER_SLAB;       // fragment reads between two DMA pieces
-        constexpr bool DEPH = CT::dephase && tier_is16(TIER);
-        if constexpr (DEPH) {
-            static_assert(!CT::dephase || use_asm_dma<TIER, CT>(), "the de-phased hand-over predicates the asm LDS-DMA");
-            if (fp % (SLAB_FRAGS / 2) == 0) {
-                slab_advance_dephased<TIER, true>(s, c.ring, c.wave, c.lane, fp % SLAB_FRAGS == 0, fp == 0);
-                if (fp % SLAB_FRAGS == 0) hook();
-            }
-        } else if (fp % SLAB_FRAGS == 0) {
+        if (fp % SLAB_FRAGS == 0) {
             slab_advance<TIER>(s, c.ring, c.wave, c.lane);
             hook();
         }
@@ -692,17 +562,7 @@ template <int TIER> struct Fetch {
             asm volatile("" ::"v"(dup));
         }
 #endif
-        if constexpr (DEPH) {
-            // the lead group's four pieces go out in the second half of its slab, the lag group's in the first half of its own
-            if (fp % 4 == 2) {
-                const int k = (fp % (SLAB_FRAGS / 2)) / 4;         // compile-time
-                const bool second = (fp % SLAB_FRAGS) >= SLAB_FRAGS / 2;
-                const bool on = (c.wave < 4) == second;            // wave-uniform; predicated, not branched (stream_issue_piece_if)
-                stream_issue_piece_if<TIER>(s, c.ring, c.wave, c.lane, k, on);
-                s.pf_owed -= on ? 1 : 0;
-                if (k == C::LOADS_PER_SLAB - 1) stream_cursor_next_if(s, on);
-            }
-        } else if (fp % GAP == GAP / 2) {                          // one piece of the slab two ahead
+        if (fp % GAP == GAP / 2) {                                 // one piece of the slab two ahead
             const int k = (fp % SLAB_FRAGS) / GAP;                 // compile-time
             stream_issue_piece<TIER, use_asm_dma<TIER, CT>()>(s, c.ring, c.wave, c.lane, k);
             --s.pf_owed;
@@ -711,8 +571,7 @@ template <int TIER> struct Fetch {
     }
     // start of a pass: fragments 0..PF_DEPTH-1
     template <class CT> DFN_DEV void prime(Stream& s, const CT& c) {
-        // (de-phased hand-over: the owed pieces go out behind the pass's first barrier, slab_advance_dephased)
-        if constexpr (!(CT::dephase && tier_is16(TIER))) stream_flush<TIER, use_asm_dma<TIER, CT>()>(s, c.ring, c.wave, c.lane);
+        stream_flush<TIER, use_asm_dma<TIER, CT>()>(s, c.ring, c.wave, c.lane);
         stream_pass_begin(s);
 #pragma unroll
         for (int i = 0; i < PF_DEPTH; ++i) load(i, i, s, c);
@@ -1192,11 +1051,7 @@ DFN_DEV MlpOut mlp_trunk(Vec<TIER, 8>& act, const Vec<TIER, NTP>& pvec, const Dh
     const auto blk_row = [&](int k) { return r_trunk + RecMap::T_A0 + 256 * (k + 1); };          // output of blocks[k]
     const auto blk_mask = [&](int k) { return m_trunk + (k < 4 ? RecMap::TM_A0 + 4 * (k + 1) : RecMap::TM_A5 + 4 * (k - 4)); };
     int f = f_l1;
-#ifndef DFN_TRAIN_TRUNK_UNROLL      // 1 (round 5): the RECORDING kernels run the straight-line form (their vector issue port is the scarce one)
-#define DFN_TRAIN_TRUNK_UNROLL 1
-#endif
-    constexpr bool STRAIGHT = (DFN_TRUNK_UNROLL != 0) || (CT::rec_on && tier_is16(TIER) && (DFN_TRAIN_TRUNK_UNROLL != 0));
-    if constexpr (STRAIGHT) {
+#if DFN_TRUNK_UNROLL
     // straight-line: seven layer bodies, the operand vectors alternate by name (no copies, no loop-carried vectors)
 #define DFN_PLAIN(OUT, IN, K) f = f_l1; layer<TIER, 8, P::KU_ACT, 8, true>(OUT, IN, blk_bias(K), f, fe, s, c, blk_row(K), blk_mask(K))
     DFN_PLAIN(nxt, act, 0);
@@ -1209,7 +1064,7 @@ DFN_DEV MlpOut mlp_trunk(Vec<TIER, 8>& act, const Vec<TIER, NTP>& pvec, const Dh
     DFN_PLAIN(act, nxt, 5);
     DFN_PLAIN(nxt, act, 6);
 #undef DFN_PLAIN
-    } else {
+#else
     // runtime loops (one layer body each): the 64-register copy after every layer is the price of the small code
     for (int l = 0; l < 3; ++l) {
         f = f_l1;
@@ -1227,11 +1082,11 @@ DFN_DEV MlpOut mlp_trunk(Vec<TIER, 8>& act, const Vec<TIER, NTP>& pvec, const Dh
                                            r_trunk + RecMap::T_A0 + 256 * (5 + l), m_trunk + RecMap::TM_A5 + 4 * l);
         act = nxt;
     }
-    }
+#endif
     // the trunk's output a7: in `nxt` after the straight-line form, in `act` after the loops; the other vector takes the
     // view layer's output
-    Vec<TIER, 8>& a7 = STRAIGHT ? nxt : act;
-    Vec<TIER, 8>& hid = STRAIGHT ? act : nxt;
+    Vec<TIER, 8>& a7 = DFN_TRUNK_UNROLL ? nxt : act;
+    Vec<TIER, 8>& hid = DFN_TRUNK_UNROLL ? act : nxt;
     // feat_view (+ sigma_out as row 0 of a 9th tile) on [act ; view PE]   (decoder.py:329-340)
     MlpOut o;
     {

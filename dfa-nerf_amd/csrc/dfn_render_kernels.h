@@ -169,22 +169,9 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
                              // the kernel sits at its power ceiling, DESIGN.md 4.6: a better schedule is paid back in clock)
 #define DFN_PIPE_TWO_HEAD 1
 #endif
-#ifndef DFN_DEPHASE_FWD       // 1: the training forward's waves 4-7 run the weight stream half a slab behind the waves 0-3 (dfn_mlp.h,
-                             // "de-phased hand-over"): one wave of a SIMD issues MFMAs while the other runs its recorder epilogue
-#define DFN_DEPHASE_FWD 1
-#endif
-#ifndef DFN_DEPHASE_TWO       // the same in the two-field INFERENCE kernel (whose torso passes have no registers for the pipelined layers)
-#define DFN_DEPHASE_TWO 0
-#endif
-#ifndef DFN_DEPHASE_ONE       // ... and in the head-only inference kernel (pipelined layers: its epilogue is hidden already)
-#define DFN_DEPHASE_ONE 0
-#endif
-    static_assert(!tier_is16(TIER) || ((P::H_FRAGS % SLAB_FRAGS == 0 || P::H_FRAGS % SLAB_FRAGS >= 15) && (P::T_FRAGS % SLAB_FRAGS == 0 || P::T_FRAGS % SLAB_FRAGS >= 15)),
-                  "de-phased hand-over: the lag group issues its pieces at fragments 2, 6, 10, 14 of every slab, the last one included");
-    constexpr bool DEPH = tier_is16(TIER) && (TRAIN != 0 ? (DFN_DEPHASE_FWD != 0) : TWO ? (DFN_DEPHASE_TWO != 0) : (DFN_DEPHASE_ONE != 0));
-    typedef CtxT<TRAIN != 0, TRAIN == 0, TRAIN != 0, (DFN_PIPE != 0) && TRAIN == 0 && (!TWO || DFN_PIPE_TWO != 0), TRAIN != 0 && ACT4, DEPH> CtxK;      // (fused step: act_T in MX-fp4 unless ACT4 is off)
+    typedef CtxT<TRAIN != 0, TRAIN == 0, TRAIN != 0, (DFN_PIPE != 0) && TRAIN == 0 && (!TWO || DFN_PIPE_TWO != 0), TRAIN != 0 && ACT4> CtxK;      // (fused step: act_T in MX-fp4 unless ACT4 is off)
     CtxK ctx = {lds, wave, lane, lane >> 5, {}};
-    typedef CtxT<TRAIN != 0, TRAIN == 0, TRAIN != 0, (DFN_PIPE != 0) && TRAIN == 0 && (!TWO || DFN_PIPE_TWO != 0 || DFN_PIPE_TWO_HEAD != 0), TRAIN != 0 && ACT4, DEPH> CtxH;   // the head's passes
+    typedef CtxT<TRAIN != 0, TRAIN == 0, TRAIN != 0, (DFN_PIPE != 0) && TRAIN == 0 && (!TWO || DFN_PIPE_TWO != 0 || DFN_PIPE_TWO_HEAD != 0), TRAIN != 0 && ACT4> CtxH;   // the head's passes
     constexpr bool two = TWO;
     const int NF = TRAIN == 1 ? 0 : F.n_fine;     // TRAIN == 1: the training forward is the reference's coarse renderer
     const bool hier = NF > 0;
@@ -273,7 +260,6 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
         zall[lane] = add_(mul_(F.z_near, sub_(1.0f, t)), mul_(F.z_far, t));
     }
     __syncthreads();     // bias blob + ray state visible (also drains the first two slab loads)
-    if constexpr (DEPH) dephase_begin<TIER>(wave);
 
     const bool cbg = F.concate_bg != 0;
     const DhatRef dref_h = {st + RS_DHAT_H, 1}, dref_t = {st + RS_DHAT_T, 1};
@@ -584,7 +570,6 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
             break;
         }
     }
-    if constexpr (DEPH) dephase_end(wave);       // barrier counts match again: the __syncthreads() of the loss epilogue pair up
 #ifdef DFN_TIMING
     if (valid && lane == 0 && A.z_out) {
         const unsigned long long T_end = __builtin_readcyclecounter();

@@ -6,20 +6,14 @@ north_star: "PSNR within 0.05 dB of reference" - the reference trains in fp32 (r
 (tests/test_gpu_train.py) bounds the per-step gradient error; THIS harness asks the question a user asks: does a model
 trained in the 16-bit tier come out as good as one trained in the exact tier?
 
-  teacher   a fixed synthetic scene: the five networks of synth.synth_all_states(0), F frames of poses / audio /
-            expression features (synth.bench_scene), rendered by the f32 tier (64 coarse samples, both fields: exactly
-            what the training step differentiates, MAIN:855-899) -> uint8 ground-truth frames (head, composite), as a
-            dataset on disk would hold them;
-  students  the teacher's networks with EVERY tensor of all five moved by `perturb` x rms(tensor) x N(0, 1) (a fixed seed): the
-            rendered frames start ~15-20 dB from the ground truth and training has to find the way back - all five networks
-            receive gradients, and the end of the run is where a quantised gradient matters most: close to an optimum, where
-            the true gradient is small against the rounding of its operands.  (A student initialised from scratch - torch's
-            default initialisation - is the other possible start; on THIS synthetic scene its head field's density dies in
-            the first steps - relu(sigma) = 0 on every ray, in every tier, the exact one included: the head image stays the
-            background, 10.94 dB, for 12,000 steps - so it measures nothing about the tiers: profiles/r05a_convergence_fresh_init.txt.)
-            Trained with the PRODUCTION step (run_nerf.train_step_loss_hip -> training.backward -> run_nerf.optimizer_steps:
-            device pixel sampler, uint8 targets gathered in the forward's epilogue, HipAdam, all five optimizers live) on the
-            first F_train frames, same start, same frame and pixel sequence in every tier;
+  teacher   a fixed synthetic scene: the five networks in torch's default initialisation (seed 7) with the density and colour
+            layers calibrated so that there is structure to learn (make_teacher), F frames of poses / audio / expression
+            features (synth.bench_scene), rendered by the f32 tier (64 coarse samples, both fields: exactly what the training
+            step differentiates, MAIN:855-899) -> uint8 ground-truth frames (head, composite), as a dataset on disk holds them;
+  students  fresh networks (torch's default initialisation, another seed), trained with the PRODUCTION step
+            (run_nerf.train_step_loss_hip -> training.backward -> run_nerf.optimizer_steps: device pixel sampler, uint8
+            targets gathered in the forward's epilogue, HipAdam, all five optimizers live) on the first F_train frames,
+            same start, same frame and pixel sequence in every tier;
   score     PSNR of the student's f32-tier renders against the ground truth, on the training frames and on the HELD-OUT
             frames (poses and audio the student never saw), head and composite images.
 Training trajectories are chaotic: two runs that differ in rounding only end at slightly different models.  The harness
@@ -47,24 +41,16 @@ def _t(x):
     return torch.from_numpy(np.asarray(x))
 
 
-def make_modules(dev, states=None, seed=None, perturb=None):
-    """the five networks: from a state dict set (the teacher), freshly initialised under `seed` (torch's default
-    initialisation), or - perturb = a - the state dicts with every tensor moved by a x rms(tensor) x N(0, 1) under `seed`"""
+def make_modules(dev, states=None, seed=None):
+    """the five networks: from a state dict set, or freshly initialised (torch's default initialisation) under `seed`"""
     if seed is not None:
         torch.manual_seed(seed)
     mods = {"decoder": Decoder(z_dim=256, hidden_size=256, dim_signal=96, use_deformation_field=True),
             "AudNet": nets.AudioNet_W2L(), "ExpNet": nets.ExpressionEnc(), "AudAttNet": nets.AudioAttNet(96, 4),
             "PoseAttNet": nets.AudioAttNet(42, 8)}
-    gen = torch.Generator().manual_seed(0 if seed is None else seed)
     for k, m in mods.items():
         if states is not None:
-            sd = {kk: _t(v).clone() for kk, v in states[k].items()}
-            if perturb:
-                for kk, v in sd.items():
-                    if v.dtype.is_floating_point:
-                        rms = float(v.double().pow(2).mean().sqrt())
-                        sd[kk] = v + perturb * rms * torch.randn(v.shape, generator=gen)
-            m.load_state_dict(sd)
+            m.load_state_dict({kk: _t(v) for kk, v in states[k].items()})
         m.to(dev)
     return mods
 
@@ -130,25 +116,30 @@ def score(scene, mods, gt8, split, tier="f32"):
     return {k: float(10.0 * np.log10(len(imgs) / v)) for k, v in se.items()}
 
 
-PERTURB = 0.2
+STUDENT_SIGMA_BIAS = 0.05
 
 
-def student_start(dev, init_seed=1234, perturb=PERTURB):
-    """the students' common start: the perturbed teacher (perturb > 0) or torch's default initialisation (perturb = None)"""
-    if perturb:
-        return make_modules(dev, states=synth.synth_all_states(0), seed=init_seed, perturb=perturb)
-    return make_modules(dev, seed=init_seed)
+def student_start(dev, init_seed=1234):
+    """the students' common start: torch's default initialisation under a fixed seed (not the teacher's seed), with ONE value
+    set by hand: sigma_out.bias = +0.05.  The default draw puts the raw density of a fresh decoder at -0.02 +- 0.0075 over the
+    whole frustum: relu(sigma) = 0 at every sample of every ray, no gradient reaches the density layer, and the field stays
+    empty for good - in every tier, the exact one included (profiles/r05c_convergence_scan.txt: the head image of all students
+    equals the bare background to four digits after 1,500 steps).  A small positive bias is a faint fog the loss can shape."""
+    mods = make_modules(dev, seed=init_seed)
+    with torch.no_grad():
+        mods["decoder"].sigma_out.bias.fill_(STUDENT_SIGMA_BIAS)
+    return mods
 
 
 def train_student(scene, gt8, tier, steps, act_format=None, init_seed=1234, pixel_seed=100, n_rand=2048, curve_every=0,
-                  log=None, perturb=PERTURB):
-    """`steps` production steps of a student on the F_TRAIN training frames.  -> (modules, info)"""
+                  log=None, lrate=5e-4):
+    """`steps` production steps of a fresh student on the F_TRAIN training frames.  -> (modules, info)"""
     dev, sc = scene.dev, scene.sc
-    mods = student_start(dev, init_seed, perturb)
+    mods = student_start(dev, init_seed)
     a = run_nerf.config_parser().parse_args(
         (f"--expname conv --concate_bg --N_rand={n_rand} --sample_rate=0 --smo_size=4 --smo_torse_size 8 --use_et_embed "
          "--dim_signal=96 --dim_aud=96 --n_object=1 --use_deformation_field --nosmo_iters 0 --noexp_iters 0 "
-         "--lrate 5e-4 --lrate_decay 500").split())
+         f"--lrate {lrate} --lrate_decay 500").split())
     ds = [{"auds": scene.aud[:F_TRAIN].contiguous(), "exp": scene.exp[:F_TRAIN].contiguous(),
            "poses": scene.poses[:F_TRAIN].contiguous(), "bc_img": (scene.bg8.float() / 255.0),
            "hwfcxy": [scene.H, scene.W, sc["focal"], sc["cx"], sc["cy"]], "near": sc["near"], "far": sc["far"]}]
@@ -194,25 +185,94 @@ def train_student(scene, gt8, tier, steps, act_format=None, init_seed=1234, pixe
     return mods, info
 
 
-def teacher_ground_truth(scene):
+def raw_outputs(scene, mods, frame=0, n_rays=2048, seed=5):
+    """raw decoder outputs (sigma_head, rgb_head[3], sigma_torso, rgb_torso[3]) [n_rays * 64, 8] of `mods` on random pixels of one
+    training frame: the exact tier's training forward (dfn_train_fwd), whose recorder leaves them per sample"""
+    import ctypes as C
+    from dfanerf._lib import check as chk, lib
+    from dfanerf.engine import _ptr, _stream
+    dev, sc = scene.dev, scene.sc
+    pk = engine.PackedDecoder(engine.flatten_state(mods["decoder"].state_dict(), dev), "f32", fields=(0, 1))
+    enc = engine.SignalEncoder(mods["AudNet"], mods["ExpNet"], mods["AudAttNet"], mods["PoseAttNet"],
+                               scene.aud[:F_TRAIN].contiguous(), scene.exp[:F_TRAIN].contiguous(), scene.poses[:F_TRAIN].contiguous())
+    s2, t2 = enc.encode([frame], 4, 8)
+    bias = pk.fold(s2[0], t2[0], scene.zs[0], scene.za[0])
+    rows = [chk(lib.dfn_train_rows(f, 0), "rows") for f in (0, 1)]
+    mrows = [chk(lib.dfn_train_rows(f, 2), "rows") for f in (0, 1)]
+    NP = n_rays * 64
+    act = [torch.empty(NP // 32, rows[f], 32, dtype=torch.float32, device=dev) for f in (0, 1)]
+    masks = [torch.empty(NP // 32, mrows[f], 64, dtype=torch.int32, device=dev) for f in (0, 1)]
+    samples = torch.empty(NP, 8, dtype=torch.float32, device=dev)
+    rgb = torch.empty(2, n_rays, 3, dtype=torch.float32, device=dev)
+    pix = torch.randperm(scene.H * scene.W, generator=torch.Generator().manual_seed(seed))[:n_rays].to(torch.int32).to(dev)
+    fr = engine.make_frame(scene.H, scene.W, sc["focal"], sc["cx"], sc["cy"], sc["poses"][frame], sc["pose_body"], sc["near"],
+                           sc["far"], ray_count=n_rays, n_fine=0, fields=2)
+    nh = pk.bias_floats(0)
+    chk(lib.dfn_train_fwd(0, C.byref(fr), _ptr(pk.packed[0]), _ptr(pk.packed[1]), _ptr(bias), C.c_void_p(bias.data_ptr() + 4 * nh),
+                          None, _ptr(scene.bg8), _ptr(pix), _ptr(rgb[0]), _ptr(rgb[1]), _ptr(samples), _ptr(act[0]), _ptr(masks[0]),
+                          _ptr(act[1]), _ptr(masks[1]), _stream()), "dfn_train_fwd(raw outputs)")
+    torch.cuda.synchronize()
+    return samples
+
+
+TEACHER_SIGMA_STD, TEACHER_SIGMA_MEAN, TEACHER_LOGIT_STD = 6.0, -1.0, 1.5
+
+
+def make_teacher(scene, seed=7):
+    """The teacher: the five networks in torch's default initialisation (seed 7) with the two output layers re-scaled so that the
+    scene is worth learning AND learnable - a freshly initialised decoder renders a uniform grey fog.  Calibrated on 2048 rays of
+    training frame 0: sigma_out's gain and bias such that the raw density over the sampled points has mean -1 and standard
+    deviation 6 (about 40 % of space carries density, up to ~15: translucent to opaque structures, smooth in space; head and
+    torso fields pooled: they share the layer), feat_out's gain such that the colour logits have standard deviation 1.5
+    (saturated and pale regions).  synth.synth_all_states(0) - the parity tests' network - is NOT used here: its density layer
+    (weights x 1.7, bias -27) is so steep that 1,500 Adam steps at the reference's learning rate push a student that STARTS
+    25.9 dB from the ground truth to an empty head field (loss 0.011 -> 0.105, in every tier: profiles/r05b_convergence_scan.txt)."""
+    mods = make_modules(scene.dev, seed=seed)
+    dec = mods["decoder"]
+    with torch.no_grad():
+        s = raw_outputs(scene, mods)
+        sig = torch.cat([s[:, 0], s[:, 4]]).double()
+        b_old = float(dec.sigma_out.bias[0])
+        mu, sd = float((sig - b_old).mean()), float((sig - b_old).std())
+        g = TEACHER_SIGMA_STD / max(sd, 1e-6)
+        dec.sigma_out.weight.mul_(g)
+        dec.sigma_out.bias.fill_(TEACHER_SIGMA_MEAN - g * mu)
+        y = torch.cat([s[:, 1:4], s[:, 5:8]]).double().clamp(1e-6, 1 - 1e-6)
+        logit = torch.log(y / (1 - y))
+        gc = TEACHER_LOGIT_STD / max(float((logit - logit.mean(0, keepdim=True)).std()), 1e-6)
+        dec.feat_out.weight.mul_(gc)
+    info = {"sigma_gain": g, "sigma_bias": float(dec.sigma_out.bias[0]), "rgb_gain": gc, "raw_sigma_mean_before": mu + b_old,
+            "raw_sigma_std_before": sd}
+    return mods, info
+
+
+def teacher_ground_truth(scene, teacher):
     """uint8 (head, com) frames [H*W,3] of the teacher for every frame (both splits), rendered in the exact tier"""
-    teacher = make_modules(scene.dev, states=synth.synth_all_states(0))
     imgs = scene.render(teacher, "f32", "train") + scene.render(teacher, "f32", "held")
     return [(to8b(rh), to8b(rc)) for rh, rc in imgs]
 
 
-def run(steps, variants, size=450, curve_every=0, log=None, with_inference_check=True, perturb=PERTURB):
+def run(steps, variants, size=450, curve_every=0, log=None, with_inference_check=True, lrate=5e-4):
     """variants: list of (name, tier, act_format, pixel_seed).  -> dict of per-variant scores and the pairwise differences"""
     dev = torch.device("cuda")
     scene = Scene(dev, size)
-    gt8 = teacher_ground_truth(scene)
-    res = {"steps": steps, "size": size, "frames_train": F_TRAIN, "frames_held_out": F_HELD, "perturb": perturb, "variants": {}}
-    # what the students' start scores (the scale of what training buys)
-    res["untrained"] = score(scene, student_start(dev, 1234, perturb), gt8, "held")
+    teacher, tinfo = make_teacher(scene)
+    gt8 = teacher_ground_truth(scene, teacher)
+    res = {"steps": steps, "size": size, "frames_train": F_TRAIN, "frames_held_out": F_HELD, "lrate": lrate, "teacher": tinfo,
+           "variants": {}}
+    # how far the teacher's frames are from the bare background (what there is to learn), and what the students' start scores
+    a, b = scene.split("held")
+    bgf = scene.bg8.double() / 255.0
+    res["teacher"]["held_out_psnr_of_the_bare_background"] = {
+        "head": float(10 * np.log10(1.0 / np.mean([float(((gt8[k][0].double() / 255.0 - bgf) ** 2).mean()) for k in range(a, b)]))),
+        "com": float(10 * np.log10(1.0 / np.mean([float(((gt8[k][1].double() / 255.0 - bgf) ** 2).mean()) for k in range(a, b)])))}
+    res["untrained"] = score(scene, student_start(dev, 1234), gt8, "held")
+    if log:
+        log(f"  teacher: {tinfo}; students' start scores {res['untrained']} on the held-out frames")
     keep = {}
     for name, tier, fmt, pseed in variants:
         mods, info = train_student(scene, gt8, tier, steps, act_format=fmt, pixel_seed=pseed, curve_every=curve_every, log=log,
-                                   perturb=perturb)
+                                   lrate=lrate)
         info["psnr_held_out"] = score(scene, mods, gt8, "held")
         info["psnr_train_frames"] = score(scene, mods, gt8, "train")
         res["variants"][name] = info

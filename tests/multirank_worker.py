@@ -129,6 +129,13 @@ def main():
     both = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(both, flat)
     same = all(bool(torch.equal(both[0], b)) for b in both[1:])          # every replica against rank 0's (world = 2 or 8)
+    if not same and rank == 0:                                            # which network, which rank, by how much
+        off = 0
+        for name, m in mods.items():
+            n = sum(p.numel() for p in m.parameters())
+            d = [float((both[0][off:off + n] - b[off:off + n]).abs().max()) for b in both[1:]]
+            print(f"MULTIRANK_DIFF {name}: max |rank 0 - rank r| for r = 1.. : {d}", flush=True)
+            off += n
     moved = bool((flat != torch.cat([t(v).reshape(-1).to(dev) for k in mods for v in
                                      [st[k][n] for n, _ in mods[k].named_parameters()]])).any())
     if rank == 0:

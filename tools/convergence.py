@@ -16,24 +16,23 @@ import convergence as CV      # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 12000
 every = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
-# third argument: the students' start - a number = the teacher perturbed by that fraction of every tensor's rms (default
-# convergence.PERTURB), "fresh" = torch's default initialisation, "scan" = a quick look at several perturbations (16-bit tier only)
-mode = sys.argv[3] if len(sys.argv) > 3 else str(CV.PERTURB)
+# third argument: learning rate (default 5e-4, scripts/train_obama.sh) or "scan" = a quick look at the scene (exact tier only)
+mode = sys.argv[3] if len(sys.argv) > 3 else "5e-4"
 log = lambda s: print(s, flush=True)
 if mode == "scan":
-    for a in (0.05, 0.1, 0.2, 0.4):
-        r = CV.run(steps, [("bf16_fp4", "bf16", "fp4", 100)], curve_every=every, log=log, with_inference_check=False, perturb=a)
-        i = r["variants"]["bf16_fp4"]
-        log(f"perturb {a}: start held-out head {r['untrained']['head']:.2f} com {r['untrained']['com']:.2f} dB -> after {steps} steps "
-            f"head {i['psnr_held_out']['head']:.2f} com {i['psnr_held_out']['com']:.2f} dB (loss {i['first_loss']:.5f} -> {i['last_loss']:.5f})")
+    for lr in (5e-4, 1e-4):
+        r = CV.run(steps, [("f32", "f32", None, 100), ("bf16_fp4", "bf16", "fp4", 100)], curve_every=every, log=log, with_inference_check=False, lrate=lr)
+        for k, i in r["variants"].items():
+            log(f"lr {lr} {k}: bare background {r['teacher']['held_out_psnr_of_the_bare_background']}, start {r['untrained']} -> after {steps} steps "
+                f"held-out head {i['psnr_held_out']['head']:.2f} com {i['psnr_held_out']['com']:.2f} dB (loss {i['first_loss']:.5f} -> {i['last_loss']:.5f})")
     sys.exit(0)
-perturb = None if mode == "fresh" else float(mode)
-log(f"# convergence of the training tiers: {steps} production steps of 2048 rays on {CV.F_TRAIN} training frames (450 x 450), scored on "
-    f"{CV.F_HELD} held-out frames; teacher = synth.synth_all_states(0) rendered in the f32 tier")
+lrate = float(mode)
+log(f"# convergence of the training tiers: {steps} production steps of 2048 rays (lr {lrate}) on {CV.F_TRAIN} training frames (450 x 450), scored on "
+    f"{CV.F_HELD} held-out frames; teacher = convergence.make_teacher (calibrated default-init networks) rendered in the f32 tier")
 variants = [("f32", "f32", None, 100), ("f32_other_pixels", "f32", None, 101), ("bf16_fp4", "bf16", "fp4", 100),
             ("bf16_e4m3", "bf16", "e4m3", 100)]
-log(f"# students start from: " + ("torch's default initialisation" if perturb is None else f"the teacher with every tensor moved by {perturb} x its rms x N(0,1)"))
-res = CV.run(steps, variants, curve_every=every, log=log, perturb=perturb)
+res = CV.run(steps, variants, curve_every=every, log=log, lrate=lrate)
+log(f"the bare background against the teacher's frames (held-out): {res['teacher']['held_out_psnr_of_the_bare_background']}")
 v = res["variants"]
 log("")
 log(f"the students' start (held-out): head {res['untrained']['head']:.3f} dB, com {res['untrained']['com']:.3f} dB")

@@ -5,9 +5,9 @@
 # on the kernels alone (tools/time_fwd.py, tools/time_dx.py) and on the whole step (bench.py --workload c4 / c4h).
 # Variant libraries (tools/build_variant.sh, VARIANT_UNITS="dfn_render_bf16 dfn_bwd_bf16"):
 #   exp_libs/base.so      everything off (= round 4's kernels)      exp_libs/nodeph.so    the three trims, no de-phasing
-#   exp_libs/dephonly.so  de-phasing only
+#   exp_libs/dephonly.so  de-phasing only        (LIBS="..." overrides the list; ROUNDS_C4 / ROUNDS_C4H the rounds)
 OUT="${1:-gpurun_out/r05b}"; mkdir -p "$OUT"
-LIBS="intree exp_libs/base.so exp_libs/nodeph.so exp_libs/dephonly.so"
+LIBS="${LIBS:-intree exp_libs/base.so exp_libs/nodeph.so exp_libs/dephonly.so}"
 {
 for r in 1 2; do
   for lib in $LIBS; do
@@ -18,8 +18,10 @@ for r in 1 2; do
   done
 done
 unset DFN_LIB
-V="new"
-for n in base nodeph dephonly; do [ -f exp_libs/$n.so ] && V="$V $n:DFN_LIB=exp_libs/$n.so"; done
-WL=c4 ROUNDS=3 STEPS=1000 tools/ab_c4.sh $V
-WL=c4h ROUNDS=2 STEPS=300 tools/ab_c4.sh $V
+V=""
+for lib in $LIBS; do
+  if [ "$lib" = intree ]; then V="$V new"; else n=$(basename $lib .so); [ -f $lib ] && V="$V $n:DFN_LIB=$lib"; fi
+done
+WL=c4 ROUNDS=${ROUNDS_C4:-3} STEPS=1000 tools/ab_c4.sh $V
+[ "${ROUNDS_C4H:-2}" -gt 0 ] && WL=c4h ROUNDS=${ROUNDS_C4H:-2} STEPS=300 tools/ab_c4.sh $V
 } 2>&1 | tee "$OUT/ab_train.txt"
