@@ -13,5 +13,11 @@ import os as _os
 # the step is gone (measured through RCCL on one MI355X: 1.36 -> 1.32 ms per step with eight queues; a single-rank process
 # is 2 % slower with eight, so it keeps the default).  Read by the runtime when it initialises, i.e. at the first GPU call:
 # this import has to come before it (bench.py and run_nerf.py import the package before they touch the device).
-if int(_os.environ.get("WORLD_SIZE", "1") or 1) > 1 or _os.environ.get("DFN_BENCH_RCCL_WORLD1"):
-    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# The functional modes that put EVERY rank on one GPU (DFN_ONE_GPU / DFN_BENCH_ONE_GPU: gloo, tests) share the device's queues:
+# eight processes x eight queues oversubscribe it - the CLI at world 8 then died in five runs of six with a GPU memory fault in
+# whatever kernel touched freshly allocated memory (an ATen fill / copy), and in none of three with two queues per process
+# (round 5, profiles/r05e_world8_queues.txt) - so they get 16 / world queues each, at least two.
+_world = int(_os.environ.get("WORLD_SIZE", "1") or 1)
+if _world > 1 or _os.environ.get("DFN_BENCH_RCCL_WORLD1"):
+    _shared = bool(_os.environ.get("DFN_ONE_GPU") or _os.environ.get("DFN_BENCH_ONE_GPU"))
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(2, 16 // _world)) if _shared else "8")

@@ -117,6 +117,16 @@ def score(scene, mods, gt8, split, tier="f32"):
 
 
 STUDENT_SIGMA_BIAS = 0.05
+# Learning rate of the harness: 1e-4.  scripts/train_obama.sh trains at 5e-4; on this synthetic scene the first few hundred Adam steps
+# at 5e-4 decide by chance whether the head field's faint starting density survives (profiles/r05d_convergence_scan.txt: after 2,000
+# steps the exact tier's head image is the bare background, 17.96 dB, and the 16-bit tier's is at 35.7 dB - and with another seed it
+# is the other way round): a coin toss is no yardstick.  At 1e-4 every tier's student learns both fields.
+LRATE = 1e-4
+# ... decayed by the reference's own schedule (MAIN:1081-1094: lrate x 0.1^(step / (lrate_decay x 1500))) with --lrate_decay =
+# steps / 3000, i.e. to 1 % over the run: at a CONSTANT rate the head field's density keeps collapsing and recovering (held-out head
+# PSNR of one and the same run: 34.4 dB at step 6,000, 17.96 dB = empty at 9,000, 34.6 dB at 12,000; two exact-tier runs that differ in
+# the pixel seed end 1.7 dB apart, profiles/r05f_convergence_constant_lr.txt) and the final score measures where in that cycle a run
+# was stopped.  A decayed rate lets every run settle.
 
 
 def student_start(dev, init_seed=1234):
@@ -132,14 +142,14 @@ def student_start(dev, init_seed=1234):
 
 
 def train_student(scene, gt8, tier, steps, act_format=None, init_seed=1234, pixel_seed=100, n_rand=2048, curve_every=0,
-                  log=None, lrate=5e-4):
+                  log=None, lrate=LRATE):
     """`steps` production steps of a fresh student on the F_TRAIN training frames.  -> (modules, info)"""
     dev, sc = scene.dev, scene.sc
     mods = student_start(dev, init_seed)
     a = run_nerf.config_parser().parse_args(
         (f"--expname conv --concate_bg --N_rand={n_rand} --sample_rate=0 --smo_size=4 --smo_torse_size 8 --use_et_embed "
          "--dim_signal=96 --dim_aud=96 --n_object=1 --use_deformation_field --nosmo_iters 0 --noexp_iters 0 "
-         f"--lrate {lrate} --lrate_decay 500").split())
+         f"--lrate {lrate} --lrate_decay {max(1, steps // 3000)}").split())
     ds = [{"auds": scene.aud[:F_TRAIN].contiguous(), "exp": scene.exp[:F_TRAIN].contiguous(),
            "poses": scene.poses[:F_TRAIN].contiguous(), "bc_img": (scene.bg8.float() / 255.0),
            "hwfcxy": [scene.H, scene.W, sc["focal"], sc["cx"], sc["cy"]], "near": sc["near"], "far": sc["far"]}]
@@ -252,7 +262,7 @@ def teacher_ground_truth(scene, teacher):
     return [(to8b(rh), to8b(rc)) for rh, rc in imgs]
 
 
-def run(steps, variants, size=450, curve_every=0, log=None, with_inference_check=True, lrate=5e-4):
+def run(steps, variants, size=450, curve_every=0, log=None, with_inference_check=True, lrate=LRATE):
     """variants: list of (name, tier, act_format, pixel_seed).  -> dict of per-variant scores and the pairwise differences"""
     dev = torch.device("cuda")
     scene = Scene(dev, size)

@@ -138,8 +138,10 @@ def main():
             off += n
     moved = bool((flat != torch.cat([t(v).reshape(-1).to(dev) for k in mods for v in
                                      [st[k][n] for n, _ in mods[k].named_parameters()]])).any())
+    # (finite: the parameters too - torch.equal is False on NaNs, so a non-finite gradient anywhere would read as "replicas differ")
+    finite = bool(all(np.isfinite(losses)) and torch.isfinite(flat).all())
     if rank == 0:
-        print(f"MULTIRANK_OK image={ok_img} replicas_identical={same} trained={moved} finite={all(np.isfinite(losses))}")
+        print(f"MULTIRANK_OK image={ok_img} replicas_identical={same} trained={moved} finite={finite}")
     dist.destroy_process_group()
 
 

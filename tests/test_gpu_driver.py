@@ -86,6 +86,9 @@ def _run2(root, extra, world=2):
                os.path.join(ROOT, "NeRFs", "DFANeRF", "run_nerf_com_trainExpLater.py")] + (COMMON + " " + extra).split()
         r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=1500,
                            env=dict(os.environ, DFN_ONE_GPU="1", OMP_NUM_THREADS="4"))
+        if os.environ.get("DFN_TEST_LOG_DIR"):          # (debugging aid: the ranks' complete output)
+            with open(os.path.join(os.environ["DFN_TEST_LOG_DIR"], f"run2_world{world}_{attempt}_rc{r.returncode}.txt"), "a") as f:
+                f.write(r.stdout + "\n==== stderr\n" + r.stderr)
         if r.returncode == 0:
             break
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

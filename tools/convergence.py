@@ -16,8 +16,8 @@ import convergence as CV      # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 12000
 every = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
-# third argument: learning rate (default 5e-4, scripts/train_obama.sh) or "scan" = a quick look at the scene (exact tier only)
-mode = sys.argv[3] if len(sys.argv) > 3 else "5e-4"
+# third argument: learning rate (default convergence.LRATE = 1e-4: see there) or "scan" = a quick look at the scene at two rates
+mode = sys.argv[3] if len(sys.argv) > 3 else str(CV.LRATE)
 log = lambda s: print(s, flush=True)
 if mode == "scan":
     for lr in (5e-4, 1e-4):
@@ -31,6 +31,9 @@ log(f"# convergence of the training tiers: {steps} production steps of 2048 rays
     f"{CV.F_HELD} held-out frames; teacher = convergence.make_teacher (calibrated default-init networks) rendered in the f32 tier")
 variants = [("f32", "f32", None, 100), ("f32_other_pixels", "f32", None, 101), ("bf16_fp4", "bf16", "fp4", 100),
             ("bf16_e4m3", "bf16", "e4m3", 100)]
+# the 16-bit tier is cheap (12 s per run): more pixel seeds of it, for a spread of its own
+variants += [("bf16_fp4_s101", "bf16", "fp4", 101), ("bf16_fp4_s102", "bf16", "fp4", 102), ("bf16_e4m3_s101", "bf16", "e4m3", 101),
+             ("bf16_e4m3_s102", "bf16", "e4m3", 102)]
 res = CV.run(steps, variants, curve_every=every, log=log, lrate=lrate)
 log(f"the bare background against the teacher's frames (held-out): {res['teacher']['held_out_psnr_of_the_bare_background']}")
 v = res["variants"]
@@ -43,10 +46,16 @@ for k, i in v.items():
 d = lambda a, b, s, im: v[a][s][im] - v[b][s][im]
 log("")
 log("differences against the exact tier (dB; + = better than f32):")
-for k in ("f32_other_pixels", "bf16_fp4", "bf16_e4m3"):
+for k in [k for k in v if k != "f32"]:
     log(f"  {k:<18} held-out head {d(k, 'f32', 'psnr_held_out', 'head'):+.3f} com {d(k, 'f32', 'psnr_held_out', 'com'):+.3f}   "
         f"training frames head {d(k, 'f32', 'psnr_train_frames', 'head'):+.3f} com {d(k, 'f32', 'psnr_train_frames', 'com'):+.3f}")
 log("  (f32_other_pixels = the exact tier again with another pixel-sampling seed: the noise floor of a training trajectory)")
+import numpy as np
+for grp, keys in (("f32 (2 seeds)", ["f32", "f32_other_pixels"]), ("bf16 / fp4 (3 seeds)", ["bf16_fp4", "bf16_fp4_s101", "bf16_fp4_s102"]),
+                  ("bf16 / e4m3 (3 seeds)", ["bf16_e4m3", "bf16_e4m3_s101", "bf16_e4m3_s102"])):
+    for im in ("head", "com"):
+        x = [v[k]["psnr_held_out"][im] for k in keys]
+        log(f"  {grp:<22} held-out {im:<4}: mean {np.mean(x):.3f} dB, min {min(x):.3f}, max {max(x):.3f}")
 log("")
 for k in ("bf16_fp4", "bf16_e4m3"):
     log(f"{k} rendered in the f16 inference tier vs the f32 tier (held-out frame 0, full frame): " +
