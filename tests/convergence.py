@@ -285,11 +285,16 @@ def run(steps, variants, size=450, curve_every=0, log=None, with_inference_check
                                    lrate=lrate)
         info["psnr_held_out"] = score(scene, mods, gt8, "held")
         info["psnr_train_frames"] = score(scene, mods, gt8, "train")
+        # the same held-out frames rendered in the ARITHMETIC THE 16-BIT TIER TRAINS IN (bf16 operands): a model is fitted to what
+        # its own forward renders, so scoring it in another arithmetic adds that arithmetic's distance (bf16 vs f32: 47 dB on a full
+        # frame) to its error - 10 log10(1 + 10^((P - 47) / 10)) dB at a P-dB model, 0.3 dB at 35.6 dB
+        info["psnr_held_out_bf16_render"] = score(scene, mods, gt8, "held", tier="bf16")
         res["variants"][name] = info
         keep[name] = mods
         if log:
             log(f"  {name}: {info['ms_per_step']:.3f} ms/step, loss {info['first_loss']:.5f} -> {info['last_loss']:.5f}, held-out "
-                f"head {info['psnr_held_out']['head']:.3f} dB com {info['psnr_held_out']['com']:.3f} dB, training frames head "
+                f"head {info['psnr_held_out']['head']:.3f} dB com {info['psnr_held_out']['com']:.3f} dB (rendered in bf16: head "
+                f"{info['psnr_held_out_bf16_render']['head']:.3f} com {info['psnr_held_out_bf16_render']['com']:.3f}), training frames head "
                 f"{info['psnr_train_frames']['head']:.3f} com {info['psnr_train_frames']['com']:.3f}")
     if with_inference_check:
         # the models the 16-bit tier trained, through the f16 INFERENCE tier: the full-frame accuracy clause (>= 49.4 dB against

@@ -39,10 +39,11 @@ log(f"the bare background against the teacher's frames (held-out): {res['teacher
 v = res["variants"]
 log("")
 log(f"the students' start (held-out): head {res['untrained']['head']:.3f} dB, com {res['untrained']['com']:.3f} dB")
-log(f"{'variant':<18}{'ms/step':>9}{'held head':>11}{'held com':>10}{'train head':>12}{'train com':>11}")
+log(f"{'variant':<18}{'ms/step':>9}{'held head':>11}{'held com':>10}{'train head':>12}{'train com':>11}{'held head, bf16 render':>24}{'com':>8}")
 for k, i in v.items():
     log(f"{k:<18}{i['ms_per_step']:>9.3f}{i['psnr_held_out']['head']:>11.3f}{i['psnr_held_out']['com']:>10.3f}"
-        f"{i['psnr_train_frames']['head']:>12.3f}{i['psnr_train_frames']['com']:>11.3f}")
+        f"{i['psnr_train_frames']['head']:>12.3f}{i['psnr_train_frames']['com']:>11.3f}"
+        f"{i['psnr_held_out_bf16_render']['head']:>24.3f}{i['psnr_held_out_bf16_render']['com']:>8.3f}")
 d = lambda a, b, s, im: v[a][s][im] - v[b][s][im]
 log("")
 log("differences against the exact tier (dB; + = better than f32):")
