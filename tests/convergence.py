@@ -225,7 +225,7 @@ def raw_outputs(scene, mods, frame=0, n_rays=2048, seed=5):
     return samples
 
 
-TEACHER_SIGMA_STD, TEACHER_SIGMA_MEAN, TEACHER_LOGIT_STD = 6.0, -1.0, 1.5
+TEACHER_SIGMA_STD, TEACHER_SIGMA_MEAN, TEACHER_LOGIT_STD, TEACHER_PE_DAMP = 6.0, -1.0, 1.5, 0.75
 
 
 def make_teacher(scene, seed=7):
@@ -240,6 +240,14 @@ def make_teacher(scene, seed=7):
     mods = make_modules(scene.dev, seed=seed)
     dec = mods["decoder"]
     with torch.no_grad():
+        # a SMOOTH scene: the weights that read octave i of the positional encoding (columns 6 i .. 6 i + 5 of every layer fed
+        # with PE(p), decoder.py:257-275) are damped by 2^(-0.75 i) - with the default initialisation all ten octaves weigh the
+        # same and the teacher's colour is noise at the pixel scale, which no student fits (the composite of the first long runs
+        # stayed at 19 dB in every tier, profiles/r05g_convergence.txt)
+        damp = torch.tensor([2.0 ** (-TEACHER_PE_DAMP * (c // 6)) for c in range(60)], device=scene.dev)
+        for lin in (dec.fc_in, dec.fc_p_skips[0], dec.fc_in_torso, dec.fc_p_skips_torso[0], dec.deform_net.blocks_embed[0],
+                    dec.deform_net.blocks_signal[0], dec.deform_net.fc_embed_skips[0]):
+            lin.weight[:, :60].mul_(damp)
         s = raw_outputs(scene, mods)
         sig = torch.cat([s[:, 0], s[:, 4]]).double()
         b_old = float(dec.sigma_out.bias[0])
