@@ -33,12 +33,13 @@ def test_16bit_tier_trains_as_good_a_model_as_the_exact_tier(result):
     held-out frames the pixel seed moves a run by +-0.5 dB and the 16-bit means are 0.07-0.14 dB below the f32 pair's - no systematic
     deficit.  Gates: the 16-bit model is not worse than the WORSE of the two f32 models by more than GATE_*_DB plus twice their spread."""
     v = result["variants"]
-    for im, gate in (("head", GATE_HEAD_DB), ("com", GATE_COM_DB)):
-        ref, other, got = (v[k]["psnr_held_out"][im] for k in ("f32", "f32_other_pixels", "bf16_fp4"))
-        noise = abs(other - ref)
-        print(f"held-out {im}: f32 {ref:.3f} dB, f32 (other pixels) {other:.3f} dB, 16-bit tier {got:.3f} dB "
-              f"(difference to their mean {got - 0.5 * (ref + other):+.3f}, spread of the two f32 runs {noise:.3f})")
-        assert got > min(ref, other) - gate - 2.0 * noise, (im, ref, other, got)
+    for which, key in (("held-out", "psnr_held_out"), ("training frames", "psnr_train_frames")):
+        for im, gate in (("head", GATE_HEAD_DB), ("com", GATE_COM_DB)):
+            ref, other, got = (v[k][key][im] for k in ("f32", "f32_other_pixels", "bf16_fp4"))
+            noise = abs(other - ref)
+            print(f"{which} {im}: f32 {ref:.3f} dB, f32 (other pixels) {other:.3f} dB, 16-bit tier {got:.3f} dB "
+                  f"(difference to their mean {got - 0.5 * (ref + other):+.3f}, spread of the two f32 runs {noise:.3f})")
+            assert got > min(ref, other) - gate - 2.0 * noise, (which, im, ref, other, got)
 
 
 def test_16bit_trained_model_holds_the_f16_inference_clause(result):
