@@ -31,6 +31,8 @@ Prints ONE JSON line on rank 0 (fields: see the driver contract), including
                  (coarse), c2_f32 (the exact tier: the one that meets "within 1e-4 PSNR"), c4 / c4h (training step, coarse and
                  hierarchical, 16-bit training tier - `dtype` spells out its operand formats) and c4_f32 (the training step
                  in the exact tier), so that they are driver-timed numbers too;
+  f16_range    - (N == 1, f16 tier) the range guard's calibration (dfanerf/f16guard.py) on the bench scene, after the timed loops: max
+                 |activation| over 256 rays of each frame in the exact tier and max |parameter| against half precision's 65504;
   parity_check - (N == 1) after the timed loops, 64 rays of the LAST timed frame rendered again in the timed configuration
                  and compared with the CPU oracle (outside the timed region): binds the timed launch to the parity suite.
 
