@@ -103,6 +103,21 @@ DFN_DEV void put(const BwdIO& io, int row0, const Vec<TIER, NT>& v, const CT& c)
 // Pin a finished vector where the source computes it.  The torso kernel's skip-path product (fc_p_skips_torso^T x g4) is
 // only consumed ~500 MFMAs later; left free, the scheduler sinks its 64 MFMAs down to that use and keeps their INPUTS alive
 // instead - 64 weight fragments copied from the LDS ring to scratch memory (256 spilled VGPRs).
+// f32 tier, torso kernel: the skip path's product (64 registers per lane) waits in LDS while the lower half of the trunk runs.
+// The f32 dX kernels run one wave per SIMD with all 512 registers; the head kernel needs 402, the torso kernel with this vector
+// alive across the four-layer loop needed 438 MORE than it has (1756 bytes of scratch per lane: 3.48 ms where the head kernel
+// takes 1.18 - round 5, profiles/r05l_c4_f32_kernel_stats.csv).  The ring leaves 64 KiB of the CU's 160: 4 waves x 64 x 64 floats.
+constexpr int PARK_BYTES_PER_WAVE = 64 * 64 * 4;
+template <class CT> DFN_DEV void park_store(const CT& c, const Vec<TIER_F32, 4>& v) {
+    lds_f32* p = (lds_f32*)(c.ring + RING_BYTES + c.wave * PARK_BYTES_PER_WAVE) + c.lane;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) p[64 * k] = v.v[k];
+}
+template <class CT> DFN_DEV void park_load(const CT& c, Vec<TIER_F32, 4>& v) {
+    const lds_f32* p = (const lds_f32*)(c.ring + RING_BYTES + c.wave * PARK_BYTES_PER_WAVE) + c.lane;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) v.v[k] = p[64 * k];
+}
 template <int TIER, int NT> DFN_DEV void pin_vec(Vec<TIER, NT>& v) {
     if constexpr (tier_is16(TIER)) {
 #pragma unroll
@@ -301,6 +316,7 @@ DFN_DEV void bwd_trunk(const BwdIn& in, Vec<TIER, 8>& dy0, Vec<TIER, 4>& gpd_ski
     if constexpr (TORSO) bwd_layer<TIER, 4, B::KU_ACT, 8>(gpd_skip, cur, -1, io, f, fe, s, c);   // fc_p_skips_torso^T
 #endif
     if constexpr (TORSO) pin_vec(gpd_skip);
+    if constexpr (TORSO && TIER == TIER_F32) park_store(c, gpd_skip);      // (read back by bwd_torso)
     // dy4 = g4 * [y4 > 0]
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -364,6 +380,7 @@ DFN_DEV void bwd_torso(const BwdIn& in, const BwdIO& io, Stream& s, const CT& c)
     // dL/d pd = fc_in_torso^T x dy0 + (skip path)
     Vec<TIER, 4> gpd;
     bwd_layer<TIER, 4, B::KU_ACT, 8>(gpd, dy0, -1, io, f, fe, s, c, DFN_TORSO_DY0_SPREAD ? GradMap::S_TRUNK + GradMap::T_DY0 : -1);
+    if constexpr (TIER == TIER_F32) park_load(c, gsk);
 #pragma unroll
     for (int L = 0; L < 64; ++L) gpd.set(L, gpd.get(L) + gsk.get(L));
     // pd = [out_embed(.) + pe ; out_signal(.) + signal]: the GEMM outputs get g_pd unchanged

@@ -86,7 +86,9 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
 
 template <int TIER, bool TORSO> inline hipError_t launch_mlp_bwd_t(const MlpBwdArgs& A, hipStream_t st) {
     using C = TierCfg<TIER>;
-    const int lds = RING_BYTES;
+    // (f32 torso kernel: + the parking area of the skip path's product, dfn_bwd.h: park_store)
+    const int lds = RING_BYTES + ((TIER == TIER_F32 && TORSO) ? C::WAVES * PARK_BYTES_PER_WAVE : 0);
+    static_assert(RING_BYTES + 4 * PARK_BYTES_PER_WAVE <= 160 * 1024, "LDS budget of the f32 torso dX kernel");
     static bool done = false;
     if (!done) {
         hipError_t e = hipFuncSetAttribute((const void*)mlp_bwd_kernel<TIER, TORSO>,
