@@ -86,7 +86,10 @@ struct WgradEntry {
     int ksplit_uploaded = 0;
 };
 WgradEntry g_wgrad[2];
-constexpr int WGRAD_KSPLIT = 32;
+#ifndef DFN_WGRAD_KSPLIT_F32
+#define DFN_WGRAD_KSPLIT_F32 32
+#endif
+constexpr int WGRAD_KSPLIT = DFN_WGRAD_KSPLIT_F32;
 constexpr long WGRAD_SMALL_NP = 196608;  // 16-bit tier: calls up to this many points use the split with more spare compute units
 
 constexpr int WS_KSPLIT_MAX = 32;       // slices the workspace is sized for (>= every tier's split)

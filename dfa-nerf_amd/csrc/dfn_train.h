@@ -78,7 +78,10 @@ hipError_t launch_mse_loss(const float* rgb_head, const float* rgb_com, const un
 constexpr int BIAS_GRAD_SLICES = 128;      // slices of the points in the streaming bias_grad_kernel
 // macro-tile of one wgrad wave, in 32x32 output tiles (dfn_api.hip sizes the work list with the same numbers)
 constexpr int WG_MT = 2, WG_NT = 4;
-constexpr int WG_PF = 4;      // register prefetch depth of wgrad_kernel (f32 tier), in 8-point steps
+#ifndef DFN_WG_PF
+#define DFN_WG_PF 4
+#endif
+constexpr int WG_PF = DFN_WG_PF;      // register prefetch depth of wgrad_kernel (f32 tier), in 8-point steps
 // streaming row sums: parts [BIAS_GRAD_SLICES][n] (workspace), then launch_reduce_bias
 hipError_t launch_bias_grad(int tier, int field, const int* e_of, const int* rows, int n, const void* dy_T, long NP,
                             float* parts, float* dbias, hipStream_t st);

@@ -356,52 +356,18 @@ hipError_t launch_composite_bwd_hier(const CompositeBwdArgs& A, hipStream_t st) 
 
 // ================================================================================================
 // weight gradients: C[M x N] += A[M x NP] * B[N x NP]^T, contraction over the sample points, split-K + atomics
-// ================================================================================================
-// One wave = one macro-tile of up to WG_MT x WG_NT 32x32 output tiles over a slice of the sample points: per
-// 32-point step it loads WG_MT A tiles + WG_NT B tiles (1 KiB each) for WG_MT*WG_NT tile products - 2.7x less
-// operand traffic than one tile per wave (the kernel is bound by operand reads out of L2/HBM, not by the MFMAs).
-// f32 tier only: the bf16 tier shares the operands of a whole GEMM through LDS (dfn_wgrad_bf16.hip).
-__global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, const int* work_prefix, const void* dy_T,
-                                                    const void* act_T, long n_tiles, int g_rows, int a_rows,
-                                                    int ksplit, float* C, long c_stride, const int* e_of, float* dbias,
-                                                    int n_bias) {
+// GEMM shapes that go through the LDS kernel (wgrad_full_kernel, below); everything else: wgrad_kernel
+// (Round 5: the other shapes were tried in it too - <8,4,4> <8,2,4> <8,1,4> <1,8,1> <2,2,2>, one launch per shape: both fields
+// 4.07 -> 4.68 ms.  A launch per small shape fills 32-416 workgroups of little work each, one after the other; wgrad_kernel runs
+// all of them side by side.)
+DFN_HD constexpr bool wgrad_lds_shape(int M, int N) { return M == 256 && N == 256; }
+// the point loop of wgrad_kernel (below) for one macro-tile
+template <bool FULL, bool BIAS>
+__device__ __forceinline__ void wgrad_loop(const float* a, const float* b, long t0, long t1, int g_rows, int a_rows, int h, int mt_n_,
+                                           int nt_n_, f32x16 (&acc)[WG_MT][WG_NT], f32x16 (&accb)[WG_MT]) {
     typedef float T;
-    const int lane = threadIdx.x & 63;
-    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= work_prefix[n_ops]) return;
-    int op = 0;
-    while (item >= work_prefix[op + 1]) ++op;
-    const WOp o = ops[op];
-    long loc = item - work_prefix[op];
-    const int mts = o.M / 32, nts = o.N / 32;
-    const int nb_n = max(1, (nts + WG_NT - 1) / WG_NT), mb_n = (mts + WG_MT - 1) / WG_MT;     // N = 0: row sums only
-    // row block fastest: the 4 waves of a workgroup then share the column block and the slice of points, i.e. they
-    // request the SAME B tiles at about the same time (one trip to L2 instead of four)
-    const int mb = (int)(loc % mb_n);
-    loc /= mb_n;
-    const int nb = (int)(loc % nb_n), ks = (int)(loc / nb_n);
-    const int mt_n = min(WG_MT, mts - WG_MT * mb), nt_n = min(WG_NT, nts - WG_NT * nb);     // wave-uniform
-    const long per = (n_tiles + ksplit - 1) / ksplit;
-    const long t0 = ks * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
-    // tile-major operands: row r of tile t starts at (t * rows + r) * 32
-    const int h = lane >> 5;
-    const T* a = (const T*)dy_T + (long)(o.a_row + 32 * WG_MT * mb + (lane & 31)) * 32;
-    const T* b = (const T*)act_T + (long)(o.b_row + 32 * WG_NT * nb + (lane & 31)) * 32;
-    // bias gradients for free: the first column block of the GEMM that owns these dy_T rows multiplies them by a tile of
-    // ones as well (2 more MFMAs per step, no extra memory traffic) -> row sums over the points
-    const bool do_bias = dbias && o.bias_owner && nb == 0;          // wave-uniform
-    f32x16 accb[WG_MT];
-#pragma unroll
-    for (int i = 0; i < WG_MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
-    f32x16 acc[WG_MT][WG_NT];
-#pragma unroll
-    for (int i = 0; i < WG_MT; ++i)
-#pragma unroll
-        for (int j = 0; j < WG_NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int mt_n = FULL ? WG_MT : mt_n_, nt_n = FULL ? WG_NT : nt_n_;
+    constexpr bool do_bias = BIAS;
     {
         // f32: v_mfma_f32_32x32x2_f32 takes A[row][k = half].  The contraction order is free, so MFMA m of a group of
         // four pairs k = m (lower half of the wave) with k = m + 4 (upper half): each lane then needs 4 CONSECUTIVE
@@ -448,6 +414,65 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
             }
         }
     }
+}
+
+// ================================================================================================
+// One wave = one macro-tile of up to WG_MT x WG_NT 32x32 output tiles over a slice of the sample points: per
+// 32-point step it loads WG_MT A tiles + WG_NT B tiles (1 KiB each) for WG_MT*WG_NT tile products - 2.7x less
+// operand traffic than one tile per wave (the kernel is bound by operand reads out of L2/HBM, not by the MFMAs).
+// f32 tier only: the bf16 tier shares the operands of a whole GEMM through LDS (dfn_wgrad_bf16.hip).
+__global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, const int* work_prefix, const void* dy_T,
+                                                    const void* act_T, long n_tiles, int g_rows, int a_rows,
+                                                    int ksplit, float* C, long c_stride, const int* e_of, float* dbias,
+                                                    int n_bias) {
+    typedef float T;
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= work_prefix[n_ops]) return;
+    int op = 0;
+    while (item >= work_prefix[op + 1]) ++op;
+    const WOp o = ops[op];
+    if (wgrad_lds_shape(o.M, o.N)) return;      // these shapes have their own kernel (wgrad_full_kernel, below): this one is the general fallback
+    long loc = item - work_prefix[op];
+    const int mts = o.M / 32, nts = o.N / 32;
+    const int nb_n = max(1, (nts + WG_NT - 1) / WG_NT), mb_n = (mts + WG_MT - 1) / WG_MT;     // N = 0: row sums only
+    // row block fastest: the 4 waves of a workgroup then share the column block and the slice of points, i.e. they
+    // request the SAME B tiles at about the same time (one trip to L2 instead of four)
+    const int mb = (int)(loc % mb_n);
+    loc /= mb_n;
+    const int nb = (int)(loc % nb_n), ks = (int)(loc / nb_n);
+    const int mt_n = min(WG_MT, mts - WG_MT * mb), nt_n = min(WG_NT, nts - WG_NT * nb);     // wave-uniform
+    const long per = (n_tiles + ksplit - 1) / ksplit;
+    const long t0 = ks * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
+    // tile-major operands: row r of tile t starts at (t * rows + r) * 32
+    const int h = lane >> 5;
+    const T* a = (const T*)dy_T + (long)(o.a_row + 32 * WG_MT * mb + (lane & 31)) * 32;
+    const T* b = (const T*)act_T + (long)(o.b_row + 32 * WG_NT * nb + (lane & 31)) * 32;
+    // bias gradients for free: the first column block of the GEMM that owns these dy_T rows multiplies them by a tile of
+    // ones as well (2 more MFMAs per step, no extra memory traffic) -> row sums over the points
+    const bool do_bias = dbias && o.bias_owner && nb == 0;          // wave-uniform
+    f32x16 accb[WG_MT];
+#pragma unroll
+    for (int i = 0; i < WG_MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+    f32x16 acc[WG_MT][WG_NT];
+#pragma unroll
+    for (int i = 0; i < WG_MT; ++i)
+#pragma unroll
+        for (int j = 0; j < WG_NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // FULL: the macro-tile is complete (mt_n == WG_MT, nt_n == WG_NT: every 256 x 256 GEMM) - no per-tile conditions, and BIAS as a
+    // compile-time flag: with the run-time conditions every load and every MFMA sat behind its own scalar branch (3.1 scalar
+    // instructions per MFMA, matrix pipe 54 % busy with ONE wave per SIMD - round 5, profiles/r05m_c4_f32_pmc.txt)
+    if (mt_n == WG_MT && nt_n == WG_NT) {
+        if (do_bias) wgrad_loop<true, true>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, accb);
+        else wgrad_loop<true, false>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, accb);
+    } else {
+        if (do_bias) wgrad_loop<false, true>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, accb);
+        else wgrad_loop<false, false>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, accb);
+    }
     if (do_bias && (lane & 31) == 0) {          // every column of accb holds the row sums: take column 0
 #pragma unroll
         for (int i = 0; i < WG_MT; ++i)
@@ -472,6 +497,125 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
                 }
             }
 }
+// ================================================================================================
+// f32 tier, the 256 x 256 GEMMs (most of a field's weight-gradient FLOPs): one workgroup of four waves owns the WHOLE output of
+// one GEMM for one slice of the points, the operands go through LDS once per workgroup.  (wgrad_kernel above reads every
+// operand tile from L2 / HBM once per macro-tile that needs it - a dy_T tile twice, an act_T tile four times, 32-byte pieces
+// of 128-byte lines per request - and ran at 46 % of the f32 MFMA peak with one wave per SIMD: round 5.)
+//   * wave w: output rows 64 w .. 64 w + 63 x all 256 columns = 2 x 8 accumulator tiles (256 registers);
+//   * a step = one 32-point tile: the 256 dy_T rows and the 256 act_T rows of the tile are 32 KiB each, CONTIGUOUS in memory
+//     (tile-major arrays) -> 64 LDS-DMA pieces of 1 KiB per step, 16 per wave, two stages of 64 KiB;
+//   * the LDS image is swizzled at the SOURCE (the DMA writes lane i's 16 bytes at base + 16 i; each lane chooses what it
+//     fetches): 16-byte chunk c of row r sits at slot 8 r + (c ^ ((r >> 1) & 7)) - the sixteen rows of a ds_read_b128 lane
+//     group then hit sixteen different slots of the 256-byte bank row (MI355X_MICROARCH.md, LDS);
+//   * same products in the same order per output element as wgrad_kernel (MFMA m of an 8-point group pairs point m with
+//     point m + 4): the partial sums of a slice are bit-identical to the old kernel's.
+// <MT, NT, RG> = GEMM of 32 MT x 32 NT outputs, the four waves as an RG x (4 / RG) grid over its tiles; instantiated for <8, 8, 4>,
+// the 256 x 256 GEMMs (wave w: 2 x 8 tiles).
+template <int MT, int NT, int RG>
+__global__ __launch_bounds__(256) void wgrad_full_kernel(const WOp* ops, int n_ops, const float* dy_T, const float* act_T,
+                                                         long n_tiles, int g_rows, int a_rows, int ksplit, float* C,
+                                                         long c_stride) {
+    constexpr int CG = 4 / RG, MW = MT / RG, NW = NT / CG;              // wave grid, tiles per wave
+    constexpr int PIECES = (MT + NT) * 4, PW = PIECES / 4;               // 1-KiB DMA pieces per stage (8 rows each), per wave
+    constexpr int STAGE = PIECES * 1024;
+    static_assert(MT % RG == 0 && NT % CG == 0 && PIECES % 4 == 0 && 2 * STAGE <= 160 * 1024, "shape");
+    extern __shared__ __attribute__((aligned(16))) char wf_smem[];
+    const int op = blockIdx.x / ksplit, ks = blockIdx.x % ksplit;
+    const WOp o = ops[op];
+    if (o.M != 32 * MT || o.N != 32 * NT) return;                        // (uniform over the workgroup)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rg = wave / CG, cg = wave % CG;
+    const long per = (n_tiles + ksplit - 1) / ksplit;
+    const long t0 = ks * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
+    lds_char* lds = (lds_char*)wf_smem;
+    // DMA piece p of a stage: 8 rows of the dy_T block (p < 4 MT) or of the act_T block; this wave issues pieces wave, wave + 4, ...
+    // lane i -> row 8 p' + (i >> 3) of its block, slot i & 7, source chunk (i & 7) ^ ((row >> 1) & 7)
+    auto issue = [&](int stage, long t) {
+#pragma unroll
+        for (int k = 0; k < PW; ++k) {
+            const int p = 4 * k + wave;                                  // wave-uniform
+            const bool isb = p >= 4 * MT;
+            const int r = 8 * (isb ? p - 4 * MT : p) + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            const float* base = isb ? act_T + (t * (long)a_rows + o.b_row) * 32 : dy_T + (t * (long)g_rows + o.a_row) * 32;
+            const gchar_c* sb = (const gchar_c*)uniform_ptr(base);
+            const unsigned voff = (unsigned)(r * 128 + c * 16);
+            const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)lds + (unsigned)(stage * STAGE + p * 1024));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(dst) : "memory", "m0");
+        }
+    };
+    f32x16 acc[MW][NW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int j = 0; j < NW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int rl = lane & 31, h = lane >> 5;
+    if (t0 < t1) issue(0, t0);
+    for (long t = t0; t < t1; ++t) {
+        const int st = (int)((t - t0) & 1);
+        if (t + 1 < t1) {
+            issue(st ^ 1, t + 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");    // this tile's pieces landed (the next tile's are younger)
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                                 // ... and everybody else's
+        const lds_char* sa = lds + st * STAGE;
+        const lds_char* sb_ = sa + MT * 32 * 128;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = 2 * q + h;
+            f32x4 av[MW], bv[NW];
+#pragma unroll
+            for (int i = 0; i < MW; ++i) {
+                const int r = 32 * (MW * rg + i) + rl;
+                av[i] = *(const lds_f32x4*)(sa + (r * 8 + (c ^ ((r >> 1) & 7))) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const int r = 32 * (NW * cg + j) + rl;
+                bv[j] = *(const lds_f32x4*)(sb_ + (r * 8 + (c ^ ((r >> 1) & 7))) * 16);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < MW; ++i)
+#pragma unroll
+                    for (int j = 0; j < NW; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][m], bv[j][m], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                                                 // the stage is free for the tile after the next
+    }
+    float* c = C + (long)ks * c_stride + o.c_off;
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+        for (int j = 0; j < NW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * (MW * rg + i) + tile_feat(h, r), col = 32 * (NW * cg + j) + rl;
+                c[(long)row * (32 * NT) + col] = acc[i][j][r];
+            }
+}
+template <int MT, int NT, int RG>
+static hipError_t launch_wgrad_shape(const WOp* ops_dev, int n_ops, const float* dy_T, const float* act_T, long n_tiles, int g_rows,
+                                     int a_rows, int ksplit, float* C, long c_stride, hipStream_t st) {
+    constexpr int lds = 2 * (MT + NT) * 4 * 1024;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_full_kernel<MT, NT, RG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    // one workgroup per (GEMM, slice); a workgroup of another shape's GEMM exits at once
+    hipLaunchKernelGGL((wgrad_full_kernel<MT, NT, RG>), dim3(n_ops * ksplit), dim3(256), lds, st, ops_dev, n_ops, dy_T, act_T, n_tiles,
+                       g_rows, a_rows, ksplit, C, c_stride);
+    return hipGetLastError();
+}
+
 hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, const int* prefix_dev, int total_items,
                         const void* dy_T, const void* act_T, long NP, int ksplit, float* C, long c_stride, const int* e_of,
                         float* dbias, int n_bias, hipStream_t st) {
@@ -479,6 +623,13 @@ hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, cons
     const bool torso = field == FIELD_TORSO;
     const int g_rows = torso ? GradMap::S_ROWS : GradMap::H_ROWS, a_rows = torso ? RecMap::S_ROWS : RecMap::H_ROWS;
     if (tier != TIER_F32) return hipErrorInvalidValue;          // bf16: launch_wgrad_bf16
+    // the 256 x 256 GEMMs through LDS (8 of a field's GEMMs, 89 % of its FLOPs), then the small shapes in the general kernel
+    const float *dy = (const float*)dy_T, *ac = (const float*)act_T;
+    hipError_t e1;
+#define DFN_WSHAPE(MT, NT, RG)                                                                                           \
+    if ((e1 = launch_wgrad_shape<MT, NT, RG>(ops_dev, n_ops, dy, ac, NP / 32, g_rows, a_rows, ksplit, C, c_stride, st)) != hipSuccess) return e1;
+    DFN_WSHAPE(8, 8, 4)
+#undef DFN_WSHAPE
     hipLaunchKernelGGL(wgrad_kernel, dim3(blocks), dim3(256), 0, st, ops_dev, n_ops, prefix_dev, dy_T, act_T, NP / 32,
                        g_rows, a_rows, ksplit, C, c_stride, e_of, dbias, n_bias);
     return hipGetLastError();
