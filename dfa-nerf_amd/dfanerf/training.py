@@ -40,6 +40,8 @@ _SIG_SET = os.environ.get("DFN_TRAIN_SIG_SET", "0") == "1"
 _SIG_KEEP = os.environ.get("DFN_TRAIN_SIG_KEEP", "1") == "1"
 # the main stream waits for the head's weight-gradient chain in front of the torso's REDUCTION (1) or in front of its GEMMs (0: A/B)
 _SPLIT_JOIN = os.environ.get("DFN_TRAIN_SPLIT_JOIN", "1") == "1"
+# the torso field's dX chain BEFORE the head field's (1; A/B): the fields' roles in the overlapped schedule swapped
+_TORSO_FIRST = os.environ.get("DFN_TRAIN_TORSO_FIRST", "0") == "1"
 # the step's loss from the training forward's epilogue (1: dfn_train_fwd*_loss) or from its own launch (0: dfn_mse_loss_u8; A/B)
 _LOSS_IN_FWD = os.environ.get("DFN_TRAIN_LOSS_IN_FWD", "1") == "1"
 
@@ -337,50 +339,52 @@ def _fused_backward(ctx, d_h, d_c):
             ev = getattr(tr, "_dsig_ev", None)
             if ev is None:
                 ev = tr._dsig_ev = (torch.cuda.Event(), torch.cuda.Event())
-        dx(0, st)
-        # ONE event behind the head's dX chain for both side chains (every record is a packet in the main queue in front of the
-        # torso's dX chain: two cost 14 us between the two dX kernels)
+        fa, fb = (1, 0) if _TORSO_FIRST else (0, 1)          # the field whose dX chain runs first / second
+        sig_st = {0: s_a, 1: s_p}
+        dx(fa, st)
+        # ONE event behind the first dX chain for both side chains (every record is a packet in the main queue in front of the
+        # second dX chain: two cost 14 us between the two dX kernels)
         e_dx = getattr(buf, "_ev_dx", None)
         if e_dx is None:
             e_dx = buf._ev_dx = torch.cuda.Event()
-        # (the head's d(signal) stays on the audio stream: on the main stream between the two dX chains - what pays for the
-        # torso's, below - the step was 40 us LONGER, 1.02 -> 1.06 ms: the main chain is the critical one)
+        # (the first field's d(signal) stays on its encoder's stream: on the main stream between the two dX chains - what pays
+        # for the second's, below - the step was 40 us LONGER, 1.02 -> 1.06 ms: the main chain is the critical one)
         e_dx.record(main)
-        s_a.wait_event(e_dx)
-        dsig(0, C.c_void_p(s_a.cuda_stream))
+        sig_st[fa].wait_event(e_dx)
+        dsig(fa, C.c_void_p(sig_st[fa].cuda_stream))
         if ev is not None:
-            ev[0].record(s_a)
+            ev[fa].record(sig_st[fa])
         if over:
             side.wait_event(e_dx)
-            dw(0, C.c_void_p(side.cuda_stream), g_flat, False)
+            dw(fa, C.c_void_p(side.cuda_stream), g_flat, False)
         else:
-            dw(0, st, g_flat, False)
-        dx(1, st)
+            dw(fa, st, g_flat, False)
+        dx(fb, st)
         if ev is not None and _SIG_FIRST:
-            # The torso's d(signal) (row sums, their reduction, the fold backward: three small kernels, ~30 us) ON the main
-            # stream, in front of the torso's weight-gradient GEMMs, not next to them on the pose network's stream: the GEMMs'
+            # The second field's d(signal) (row sums, their reduction, the fold backward: three small kernels, ~30 us) ON the main
+            # stream, in front of its weight-gradient GEMMs, not next to them on its encoder's stream: the GEMMs'
             # workgroups own the compute units (144 KiB of LDS each) until they finish, so a kernel launched next to them
             # starts when they end - the pose network's whole backward chain (row sums -> fold backward -> encoder backward ->
             # Adam -> the next step's encoder forward, ~130 us) then ran BEHIND the GEMMs and the next step's forward waited
             # for it.  On the main stream it also costs no cross-queue hand-over (a wait on another queue's event is 15-20 us:
-            # dX -> pose stream -> main was 59 us between the dX chain and the GEMMs).  The pose stream picks d(signal) up
-            # behind ev[1] (_SignalFn.backward).
-            dsig(1, st)
-            ev[1].record(main)
+            # dX -> pose stream -> main was 59 us between the dX chain and the GEMMs).  The encoder's stream picks d(signal) up
+            # behind ev[fb] (_SignalFn.backward).
+            dsig(fb, st)
+            ev[fb].record(main)
         else:
-            s_p.wait_stream(main)
-            dsig(1, C.c_void_p(s_p.cuda_stream))
+            sig_st[fb].wait_stream(main)
+            dsig(fb, C.c_void_p(sig_st[fb].cuda_stream))
             if ev is not None:
-                ev[1].record(s_p)
+                ev[fb].record(sig_st[fb])
         if over and _SPLIT_JOIN:
-            # the main stream joins the head's chain (GEMMs, reduction, fold backward on the side stream) in front of the torso's
-            # REDUCTION, not in front of its GEMMs: the cross-queue wait sat between d(signal) and a 130-us kernel that does
-            # not depend on it - 17 us of the critical path (profiles/r04g_c4_timeline.txt)
-            dw(1, st, g_flat, False, before_reduce=lambda: main.wait_stream(side))
+            # the main stream joins the first field's chain (GEMMs, reduction, fold backward on the side stream) in front of the
+            # second's REDUCTION, not in front of its GEMMs: the cross-queue wait sat between d(signal) and a 130-us kernel that
+            # does not depend on it - 17 us of the critical path (profiles/r04g_c4_timeline.txt)
+            dw(fb, st, g_flat, False, before_reduce=lambda: main.wait_stream(side))
         else:
             if over:
                 main.wait_stream(side)
-            dw(1, st, g_flat, False)
+            dw(fb, st, g_flat, False)
         if tr is None:          # torch autograd consumes d_sig on the main stream
             main.wait_stream(s_a)
             main.wait_stream(s_p)
@@ -624,6 +628,8 @@ class _SignalFn(torch.autograd.Function):
             s_p.wait_stream(main)
         elif s_p is not None and getattr(tr, "_dsig_ev", None) is not None:
             s_p.wait_event(tr._dsig_ev[1])          # (the torso's d(signal) may have been produced on the main stream: _SIG_FIRST)
+            if _TORSO_FIRST:
+                s_a.wait_event(tr._dsig_ev[0])      # (and then the head's is the one that may)
         st_a = st if s_a is None else C.c_void_p(s_a.cuda_stream)
         st_t = st if s_p is None else C.c_void_p(s_p.cuda_stream)
         def buffers(side, stream, nets):

@@ -142,14 +142,16 @@ def student_start(dev, init_seed=1234):
 
 
 def train_student(scene, gt8, tier, steps, act_format=None, init_seed=1234, pixel_seed=100, n_rand=2048, curve_every=0,
-                  log=None, lrate=LRATE):
-    """`steps` production steps of a fresh student on the F_TRAIN training frames.  -> (modules, info)"""
+                  log=None, lrate=LRATE, start_states=None, constant_lr=False):
+    """`steps` production steps of a fresh student on the F_TRAIN training frames.  -> (modules, info).
+    start_states (name -> state_dict): continue from these parameters instead (fresh Adam moments); constant_lr: no decay."""
     dev, sc = scene.dev, scene.sc
-    mods = student_start(dev, init_seed)
+    mods = student_start(dev, init_seed) if start_states is None else make_modules(dev, states=start_states)
+    decay = 10 ** 6 if constant_lr else max(1, steps // 3000)
     a = run_nerf.config_parser().parse_args(
         (f"--expname conv --concate_bg --N_rand={n_rand} --sample_rate=0 --smo_size=4 --smo_torse_size 8 --use_et_embed "
          "--dim_signal=96 --dim_aud=96 --n_object=1 --use_deformation_field --nosmo_iters 0 --noexp_iters 0 "
-         f"--lrate {lrate} --lrate_decay {max(1, steps // 3000)}").split())
+         f"--lrate {lrate} --lrate_decay {decay}").split())
     ds = [{"auds": scene.aud[:F_TRAIN].contiguous(), "exp": scene.exp[:F_TRAIN].contiguous(),
            "poses": scene.poses[:F_TRAIN].contiguous(), "bc_img": (scene.bg8.float() / 255.0),
            "hwfcxy": [scene.H, scene.W, sc["focal"], sc["cx"], sc["cy"]], "near": sc["near"], "far": sc["far"]}]
@@ -320,4 +322,32 @@ def run(steps, variants, size=450, curve_every=0, log=None, with_inference_check
                                                   for i in range(0, got[k].shape[0], 2500)),
                             "finite": bool(torch.isfinite(got[k]).all())}
             res["variants"][name]["f16_inference_vs_f32"] = chk
+    return res
+
+
+def run_continuation(base_steps, cont_steps, variants, cont_lrate=1e-5, size=450, log=None):
+    """The PAIRED form of the comparison: ONE student trained to convergence in the exact tier (base_steps), then continued for
+    cont_steps at a small constant rate from those very parameters (fresh Adam moments) by every variant (name, tier, act_format,
+    pixel_seed).  All continuations sit in the same basin, so what separates two fresh runs (which basin, where on the way: +-0.5 dB
+    between two exact-tier seeds) is gone and a format that biased the weight gradients would show as a drift of its
+    continuation away from the exact tier's.  -> base scores + per-variant scores"""
+    dev = torch.device("cuda")
+    scene = Scene(dev, size)
+    teacher, tinfo = make_teacher(scene)
+    gt8 = teacher_ground_truth(scene, teacher)
+    base, binfo = train_student(scene, gt8, "f32", base_steps, log=log)
+    states = {k: {kk: v.detach().cpu().clone() for kk, v in m.state_dict().items()} for k, m in base.items()}
+    res = {"base_steps": base_steps, "cont_steps": cont_steps, "cont_lrate": cont_lrate,
+           "base": {"psnr_held_out": score(scene, base, gt8, "held"), "psnr_train_frames": score(scene, base, gt8, "train"),
+                    "last_loss": binfo["last_loss"]}, "variants": {}}
+    if log:
+        log(f"  base (f32, {base_steps} steps): {res['base']}")
+    for name, tier, fmt, pseed in variants:
+        mods, info = train_student(scene, gt8, tier, cont_steps, act_format=fmt, pixel_seed=pseed, lrate=cont_lrate,
+                                   start_states=states, constant_lr=True)
+        info["psnr_held_out"] = score(scene, mods, gt8, "held")
+        info["psnr_train_frames"] = score(scene, mods, gt8, "train")
+        res["variants"][name] = info
+        if log:
+            log(f"  {name}: held-out {info['psnr_held_out']}, training frames {info['psnr_train_frames']}, loss -> {info['last_loss']:.6f}")
     return res

@@ -26,6 +26,43 @@ if mode == "scan":
             log(f"lr {lr} {k}: bare background {r['teacher']['held_out_psnr_of_the_bare_background']}, start {r['untrained']} -> after {steps} steps "
                 f"held-out head {i['psnr_held_out']['head']:.2f} com {i['psnr_held_out']['com']:.2f} dB (loss {i['first_loss']:.5f} -> {i['last_loss']:.5f})")
     sys.exit(0)
+if mode == "continue":
+    # the paired form (convergence.run_continuation): python tools/convergence.py 12000 0 continue [cont_steps=3000] [lr=1e-5] [pixel seeds=2]
+    cont = int(sys.argv[4]) if len(sys.argv) > 4 else 3000
+    clr = float(sys.argv[5]) if len(sys.argv) > 5 else 1e-5
+    log(f"# paired continuation: one exact-tier student trained {steps} steps, then continued {cont} steps at a constant {clr} from the "
+        f"same parameters by every variant; held-out / training-frame PSNR in the exact tier")
+    n_seeds = int(sys.argv[6]) if len(sys.argv) > 6 else 2
+    seeds = [200 + k for k in range(n_seeds)]
+    variants = []
+    for sd in seeds:
+        variants += [(f"f32_s{sd}", "f32", None, sd), (f"bf16_fp4_s{sd}", "bf16", "fp4", sd), (f"bf16_e4m3_s{sd}", "bf16", "e4m3", sd)]
+    r = CV.run_continuation(steps, cont, variants, cont_lrate=clr, log=log)
+    b, v = r["base"], r["variants"]
+    log("")
+    log(f"{'':<26}{'held head':>11}{'held com':>10}{'train head':>12}{'train com':>11}")
+    log(f"{'base (before)':<26}{b['psnr_held_out']['head']:>11.3f}{b['psnr_held_out']['com']:>10.3f}{b['psnr_train_frames']['head']:>12.3f}{b['psnr_train_frames']['com']:>11.3f}")
+    for k, i in v.items():
+        log(f"{k:<26}{i['psnr_held_out']['head']:>11.3f}{i['psnr_held_out']['com']:>10.3f}{i['psnr_train_frames']['head']:>12.3f}{i['psnr_train_frames']['com']:>11.3f}")
+    import numpy as np
+    log("")
+    log(f"paired differences against the exact tier's continuation on the SAME pixel sequence, over {n_seeds} pixel seeds (dB; + = better): mean +- standard error [min, max]")
+    cols = (("psnr_held_out", "head"), ("psnr_held_out", "com"), ("psnr_train_frames", "head"), ("psnr_train_frames", "com"))
+    for fmt in ("bf16_fp4", "bf16_e4m3"):
+        parts = []
+        for s_, im in cols:
+            d = np.array([v[f"{fmt}_s{sd}"][s_][im] - v[f"f32_s{sd}"][s_][im] for sd in seeds])
+            se = d.std(ddof=1) / np.sqrt(len(d)) if len(d) > 1 else float("nan")
+            parts.append(f"{s_[5:]} {im} {d.mean():+.3f} +- {se:.3f} [{d.min():+.3f}, {d.max():+.3f}]")
+        log(f"  {fmt:<10} " + "   ".join(parts))
+    parts = []
+    for s_, im in cols:
+        x = np.array([v[f"f32_s{sd}"][s_][im] for sd in seeds])
+        parts.append(f"{s_[5:]} {im} std {x.std(ddof=1) if len(x) > 1 else float('nan'):.3f} [{x.min():.3f}, {x.max():.3f}]")
+    log("  the exact tier's own continuations across the seeds: " + "   ".join(parts))
+    log("")
+    log(json.dumps(r, default=str))
+    sys.exit(0)
 lrate = float(mode)
 log(f"# convergence of the training tiers: {steps} production steps of 2048 rays (lr {lrate}) on {CV.F_TRAIN} training frames (450 x 450), scored on "
     f"{CV.F_HELD} held-out frames; teacher = convergence.make_teacher (calibrated default-init networks) rendered in the f32 tier")
