@@ -77,7 +77,13 @@ hipError_t launch_mse_loss(const float* rgb_head, const float* rgb_com, const un
                            hipStream_t st);
 constexpr int BIAS_GRAD_SLICES = 128;      // slices of the points in the streaming bias_grad_kernel
 // macro-tile of one wgrad wave, in 32x32 output tiles (dfn_api.hip sizes the work list with the same numbers)
-constexpr int WG_MT = 2, WG_NT = 4;
+#ifndef DFN_WG_MT
+#define DFN_WG_MT 2
+#endif
+#ifndef DFN_WG_NT
+#define DFN_WG_NT 4
+#endif
+constexpr int WG_MT = DFN_WG_MT, WG_NT = DFN_WG_NT;
 #ifndef DFN_WG_PF
 #define DFN_WG_PF 4
 #endif

@@ -16,6 +16,10 @@ TRAIN_ACT_E4M3 = 0x100      # or'ed into the tier of dfn_train_fwd*: e4m3 instea
 ACT_E4M3, ACT_E2M1 = 0, 1
 FIELD_HEAD, FIELD_TORSO, FIELD_LISTENER = 0, 1, 2
 N_DECODER_PARAMS = 955242
+# Linear layers the reference's Decoder registers with use_expression / use_wav2lip (decoder.py:219-228) and never evaluates for the
+# one person its scripts train (itr_obj 0: signal = [aud, None], MAIN:70; w2lnet is used nowhere): they are parameters of the
+# module (state_dict, checkpoints, optimizer) and no part of the kernels' flat parameter vector
+DECODER_UNUSED_PREFIXES = ("expnet.", "w2lnet.")
 
 
 class DfnFrame(C.Structure):

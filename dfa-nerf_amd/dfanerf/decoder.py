@@ -90,6 +90,8 @@ class Decoder(nn.Module):
             self.blocks_view = nn.ModuleList([nn.Linear(dim_embed_view + hidden_size, hidden_size)
                                               for _ in range(n_blocks_view - 1)])
         self._hip = {}            # tier -> (PackedDecoder, param version stamp)
+        from ._lib import DECODER_UNUSED_PREFIXES
+        self._dfn_flat_skip = DECODER_UNUSED_PREFIXES        # (training._FlatNet: not part of the flat parameter vector)
 
     # ---- positional encoding (decoder.py:257-275) ----------------------------------------------------------
     def transform_points(self, p, views=False):
@@ -102,8 +104,7 @@ class Decoder(nn.Module):
     def hip_supported(self):
         return (self.hidden_size == 256 and self.z_dim == 256 and self.n_blocks == 8 and list(self.skips) == [4] and
                 self.dim_signal == 96 and self.dim_et_embed == 42 and self.n_freq_posenc == 10 and
-                self.n_freq_posenc_views == 4 and self.use_deformation_field and not self.use_expression and
-                not self.use_wav2lip and self.use_viewdirs and self.n_blocks_view == 1 and
+                self.n_freq_posenc_views == 4 and self.use_deformation_field and self.use_viewdirs and self.n_blocks_view == 1 and
                 self.final_sigmoid_activation and self.downscale_p_by == 2.)
 
     def packed(self, tier="bf16"):
@@ -111,7 +112,9 @@ class Decoder(nn.Module):
         from . import engine
         if not self.hip_supported():
             raise NotImplementedError("the HIP path supports the scripts/test_obama.sh decoder configuration only")
-        params = list(self.state_dict().values())
+        from ._lib import DECODER_UNUSED_PREFIXES
+        # (use_expression / use_wav2lip: expnet / w2lnet are registered - checkpoint parity - and evaluated by nothing on this path)
+        params = [v for k, v in self.state_dict().items() if not k.startswith(DECODER_UNUSED_PREFIXES)]
         stamp = (tuple(p._version for p in params), params[0].device, params[0].data_ptr())
         hit = self._hip.get(tier)
         if hit is None or hit[1][1:] != stamp[1:]:
@@ -130,7 +133,9 @@ class Decoder(nn.Module):
             raise Exception('Do not give head or torso!!')
         if head_or_torso == 'head':
             if self.use_expression and signal[1] is not None:
-                raise NotImplementedError("expression branch (use_expression) is not enabled by the reference scripts")
+                raise NotImplementedError("use_expression with an expression signal (signal[1]) is the reference's branch for a second "
+                                          "person (itr_obj > 0, MAIN:72-75): the scripts train one (--n_object 1), whose "
+                                          "signal[1] is None; expnet is a registered, unused layer on this path")
             signal = signal[0]
         if ray_d is None or z_shape is None or z_app is None:
             raise ValueError("Decoder.forward needs ray_d, z_shape and z_app (the reference's random-latent default, "

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (DfnFrame, FIELD_HEAD, FIELD_LISTENER, FIELD_TORSO, N_DECODER_PARAMS, TIER_BF16, TIER_F16, TIER_F32,
+from ._lib import (DECODER_UNUSED_PREFIXES, DfnFrame, FIELD_HEAD, FIELD_LISTENER, FIELD_TORSO, N_DECODER_PARAMS, TIER_BF16, TIER_F16, TIER_F32,
                    check, lib)
 
 # "f16": v_mfma_f32_32x32x16_f16, the throughput tier (inference only); "bf16": also the 16-bit training tier
@@ -38,7 +38,7 @@ def require_gpu():
 
 def flatten_state(state, device):
     """decoder.state_dict() -> flat f32 device vector in registration order (dfn_layout.h:ParamId)."""
-    parts = [_f32c(v, device).reshape(-1) for v in state.values()]
+    parts = [_f32c(v, device).reshape(-1) for k, v in state.items() if not k.startswith(DECODER_UNUSED_PREFIXES)]
     flat = torch.cat(parts)
     if flat.numel() != N_DECODER_PARAMS:
         raise ValueError(f"decoder has {flat.numel()} parameters; the HIP path supports the "

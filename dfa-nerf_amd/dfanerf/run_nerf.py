@@ -719,8 +719,9 @@ def check_supported(args):
     bad = []
     if (args.n_feat, args.z_dim, args.dim_signal) != (256, 256, 96):
         bad.append(f"--n_feat {args.n_feat} --z_dim {args.z_dim} --dim_signal {args.dim_signal} (supported: 256 / 256 / 96)")
-    if not args.use_deformation_field or args.use_expression:
-        bad.append("--use_deformation_field is required and --use_expression is not supported")
+    # (--use_expression: accepted - with one person the reference's decoder registers expnet and never evaluates it, MAIN:70)
+    if not args.use_deformation_field:
+        bad.append("--use_deformation_field is required")
     if args.N_samples != 64:
         bad.append(f"--N_samples {args.N_samples} (supported: 64)")
     if getattr(args, "hierarchical", False) and args.N_importance not in (64, 128):

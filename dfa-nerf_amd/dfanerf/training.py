@@ -409,6 +409,9 @@ class _FlatNet:
     def __init__(self, module):
         self.module = module
         sd = module.state_dict(keep_vars=True)
+        skip = tuple(getattr(module, "_dfn_flat_skip", ()))      # (decoder: layers the kernels never evaluate, _lib.DECODER_UNUSED_PREFIXES)
+        if skip:
+            sd = {k: v for k, v in sd.items() if not k.startswith(skip)}
         self.names, self.params = list(sd.keys()), list(sd.values())
         # (owning sub-module, attribute name) of every entry, for the cheap identity check of of()
         self.slots = []

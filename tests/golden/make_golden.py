@@ -418,6 +418,49 @@ def main():
     mse = torch.tensor([1e-4, 0.01, 0.3])
     save("g10_to8b", x=x, y=HELP.to8b(x), mse=mse, psnr=HELP.mse2psnr(mse))
 
+    g13_optional_branches()
+
+
+def g13_optional_branches():
+    """G13: the decoder built with use_expression / use_wav2lip (decoder.py:219-228): the two extra Linear layers in the
+    state_dict (names, shapes, position), and - for the one person the scripts train (itr_obj 0: signal = [aud, None],
+    MAIN:70) - outputs that do not depend on them.  Runs alone too: python make_golden.py g13"""
+    import json as _json
+    sc = synth.bench_scene(0, n_frames=8)
+    H, W, focal, cx, cy = sc["H"], sc["W"], sc["focal"], sc["cx"], sc["cy"]
+    st = synth.synth_all_states(0)
+    z_shape, z_app = [t(v) for v in synth.synth_latents(0)]
+    dec = DEC.Decoder(z_dim=256, hidden_size=256, dim_signal=96, use_deformation_field=True, use_expression=True,
+                      use_wav2lip=True, use_aud_net=False)
+    extra = {"expnet.weight": t(synth.synth_tensor(0, "g13/expnet.weight", (256, 256), 0.1)),
+             "expnet.bias": t(synth.synth_tensor(0, "g13/expnet.bias", (256,), 0.1)),
+             "w2lnet.weight": t(synth.synth_tensor(0, "g13/w2lnet.weight", (256, 512), 0.1)),
+             "w2lnet.bias": t(synth.synth_tensor(0, "g13/w2lnet.bias", (256,), 0.1))}
+    sd = {k: t(v) for k, v in st["decoder"].items()}
+    sd.update(extra)
+    dec.load_state_dict(sd)
+    manifest = [[k, list(v.shape)] for k, v in dec.state_dict().items()]
+    with open(os.path.join(HERE, "g13_decoder_optional_keys.json"), "w") as f:
+        _json.dump(manifest, f, indent=0)
+    sig_aud = t(synth.synth_tensor(0, "g3/sig", (1, 96), 0.8))
+    sig_torso = t(synth.synth_tensor(0, "g3/sigt", (1, 42), 0.8))
+    ro, rd = HELP.get_rays(H, W, focal, t(sc["poses"][0])[:3, :4], cx, cy)
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    rays = np.array([0, 101234, 150000, H * W - 1])
+    tv = torch.linspace(0., 1., steps=64)
+    z = 0.3 * (1. - tv) + 0.9 * tv
+    p = (ro[rays, None, :] + rd[rays, None, :] * z[None, :, None]).reshape(1, -1, 3)
+    r = rd[rays, None, :].expand(len(rays), 64, 3).reshape(1, -1, 3)
+    with torch.no_grad():
+        fh, sh = dec(p, r, z_shape[:, 0], z_app[:, 0], [sig_aud, None], 'head')
+        ft, st_ = dec(p, r, z_shape[:, 1], z_app[:, 1], sig_torso, 'torso')
+    save("g13_decoder_optional", p=p, r=r, sig_aud=sig_aud, sig_torso=sig_torso, feat_head=fh, sigma_head=sh, feat_torso=ft,
+         sigma_torso=st_)          # (the extra layers' values: synth.synth_tensor(0, "g13/<key>", shape, 0.1), as above)
+    print("g13: ", len(manifest), "state_dict entries")
+
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["g13"]:
+        g13_optional_branches()
+    else:
+        main()

@@ -131,6 +131,49 @@ def test_run_network_and_create_nerf_dropin(dropin, states, scene, latents, gold
     assert embed_fn(torch.zeros(2, 3)).shape == (2, 21)
 
 
+def test_decoder_with_the_optional_layers_vs_reference_golden(dropin, states, latents, golden):
+    """use_expression / use_wav2lip (decoder.py:219-228): golden G13 = the REFERENCE decoder built with both flags (expnet, w2lnet
+    registered and, for the one person the scripts train, evaluated by nothing: MAIN:70), head and torso outputs on G3's points.  The
+    drop-in module built the same way: same outputs at the f32 tier's gates; in grad mode the two layers keep .grad = None (what
+    autograd leaves a parameter no forward used) and every other gradient equals the plain decoder's bit for bit."""
+    M, D = dropin
+    from dfanerf import synth
+    dev = torch.device("cuda")
+    g = golden("g13_decoder_optional")
+    sd = {k: t(v) for k, v in states["decoder"].items()}
+    plain = D.Decoder(z_dim=256, hidden_size=256, dim_signal=96, use_deformation_field=True)
+    plain.load_state_dict(sd)
+    plain.to(dev)
+    for k, sh in (("expnet.weight", (256, 256)), ("expnet.bias", (256,)), ("w2lnet.weight", (256, 512)), ("w2lnet.bias", (256,))):
+        sd[k] = t(synth.synth_tensor(0, "g13/" + k, sh, 0.1))
+    dec = D.Decoder(z_dim=256, hidden_size=256, dim_signal=96, use_deformation_field=True, use_expression=True, use_wav2lip=True)
+    dec.load_state_dict(sd)
+    dec.to(dev)
+    zs, za = [t(v).to(dev) for v in latents]
+    p, r = t(g["p"]).to(dev), t(g["r"]).to(dev)
+    sig_aud, sig_torso = t(g["sig_aud"]).to(dev), t(g["sig_torso"]).to(dev)
+    with torch.no_grad():
+        fh, sh_ = dec(p, r, zs[:, 0], za[:, 0], [sig_aud, None], 'head')
+        ft, st_ = dec(p, r, zs[:, 1], za[:, 1], sig_torso, 'torso')
+    for got, key, atol, rtol in ((fh, "feat_head", 1e-5, 0), (ft, "feat_torso", 1e-5, 0), (sh_, "sigma_head", 2e-4, 1e-5),
+                                 (st_, "sigma_torso", 2e-4, 1e-5)):
+        np.testing.assert_allclose(got.cpu().numpy(), g[key], atol=atol, rtol=rtol, err_msg=key)
+    grads = []
+    for m in (dec, plain):
+        m.zero_grad(set_to_none=True)
+        fh, sh_ = m(p, r, zs[:, 0], za[:, 0], [sig_aud, None], 'head')
+        ft, st_ = m(p, r, zs[:, 1], za[:, 1], sig_torso, 'torso')
+        (fh.sum() + 0.01 * sh_.sum() + ft.sum() + 0.01 * st_.sum()).backward()
+        torch.cuda.synchronize()
+        grads.append({k: (None if q.grad is None else q.grad.clone()) for k, q in m.named_parameters()})
+    assert all(grads[0][k] is None for k in ("expnet.weight", "expnet.bias", "w2lnet.weight", "w2lnet.bias"))
+    assert grads[1]["fc_in.weight"] is not None and float(grads[1]["fc_in.weight"].abs().max()) > 0
+    for k, gv in grads[1].items():
+        assert (gv is None) == (grads[0][k] is None), k
+        if gv is not None:
+            assert torch.equal(gv, grads[0][k]), k
+
+
 def test_signal_encoders_single_frame_beyond_sequence_length(states, scene):
     """before --nosmo_iters the reference indexes auds[img_i] directly (MAIN:59-61) - a training frame whose
     index is >= len(i_train) (the count left after the speak_frames filter) must NOT get a zero signal.  The window

@@ -69,9 +69,9 @@ COMMON = ("--config dataset/obama/HeadNeRF_config_ba.txt --last_dist=1e10 --data
           "--resume dataset/train_together/obama_TrainExpLater_smoMix/280000.tar")
 
 
-def _run(root, extra):
+def _run(root, extra, common=COMMON):
     cmd = [sys.executable, os.path.join(ROOT, "NeRFs", "DFANeRF", "run_nerf_com_trainExpLater.py")] + \
-        (COMMON + " " + extra).split()
+        (common + " " + extra).split()
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return r.stdout
@@ -192,6 +192,17 @@ def test_training_cli_writes_reference_checkpoint(dataset):
     hl = [ln for ln in open(hb / "loss.txt").read().strip().split("\n") if ln.startswith("[TRAIN]")]
     assert len(hl) >= 3 and all(np.isfinite(float(ln.split("Com Loss: ")[1].split()[0])) for ln in hl), hl[-3:]
     assert (hb / "280005.tar").exists()
+    # --use_expression (MAIN:412, decoder.py:219): the decoder then carries the expression layer the reference registers and, for
+    # the one person it trains, never evaluates - a fresh model (no checkpoint has the layer), three steps, and the new .tar holds
+    # it next to the layers that were trained
+    _run(root, "--N_rand=256 --N_iters=3 --i_weights=2 --i_print=1 --use_expression --expname expr_train",
+         common=COMMON[:COMMON.index("--resume")])
+    eb = root / "dataset" / "train_together" / "expr_train"
+    el = [ln for ln in open(eb / "loss.txt").read().strip().split("\n") if ln.startswith("[TRAIN]")]
+    assert len(el) >= 2 and all(np.isfinite(float(ln.split("Com Loss: ")[1].split()[0])) for ln in el), el[-3:]
+    ck = torch.load(eb / "000002.tar", weights_only=False)
+    sd = ck["network_decoder_state_dict"]
+    assert "expnet.weight" in sd and tuple(sd["expnet.weight"].shape) == (256, 256) and "fc_in.weight" in sd
 
 
 @pytest.mark.parametrize("world", [2, 8])

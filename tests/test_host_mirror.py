@@ -72,11 +72,38 @@ def test_unsupported_configurations_are_refused_at_parse_time():
         "--expname t --n_feat 256 --z_dim 256 --dim_signal 96 --n_object 1 --use_deformation_field".split())
     run_nerf.check_supported(ok)
     for extra in ("--n_feat 128", "--N_samples 32", "--dim_signal 128", "--hierarchical --N_importance 96", "--n_object 2",
-                  "--hip_tier fp8", "--use_expression", "--hip_train_act e2m3"):
+                  "--hip_tier fp8", "--hip_train_act e2m3"):
         a = run_nerf.config_parser().parse_args(
             ("--expname t --z_dim 256 --dim_signal 96 --n_object 1 --use_deformation_field --n_feat 256 " + extra).split())
         with pytest.raises(SystemExit, match="unsupported configuration"):
             run_nerf.check_supported(a)
+
+
+def test_decoder_optional_layers_are_registered_and_outside_the_flat_vector(states):
+    """use_expression / use_wav2lip (decoder.py:219-228): the reference registers expnet / w2lnet and, for the one person its scripts
+    train, evaluates neither (MAIN:70: signal = [aud, None]).  Golden G13 = the reference module's state_dict (names, shapes, order):
+    the mirror's equals it, --use_expression is accepted at parse time, and the kernels' flat parameter vector is the same 955,242
+    values with or without the two layers."""
+    import json
+    from dfanerf import engine, training
+    from dfanerf._lib import N_DECODER_PARAMS
+    want = [(k, tuple(sh)) for k, sh in json.load(open(os.path.join(GOLDEN, "g13_decoder_optional_keys.json")))]
+    dec = Decoder(z_dim=256, hidden_size=256, dim_signal=96, use_deformation_field=True, use_expression=True, use_wav2lip=True)
+    assert [(k, tuple(v.shape)) for k, v in dec.state_dict().items()] == want
+    assert dec.hip_supported()
+    sd = {k: t(v) for k, v in states["decoder"].items()}
+    dec.load_state_dict(sd, strict=False)
+    base = _modules(states)["decoder"]
+    assert torch.equal(engine.flatten_state(dec.state_dict(), "cpu"), engine.flatten_state(base.state_dict(), "cpu"))
+    assert engine.flatten_state(dec.state_dict(), "cpu").numel() == N_DECODER_PARAMS
+    fn = training._FlatNet(dec)
+    assert fn.flat.numel() == N_DECODER_PARAMS and not any(n.startswith(("expnet.", "w2lnet.")) for n in fn.names)
+    a = run_nerf.config_parser().parse_args(
+        "--expname t --n_feat 256 --z_dim 256 --dim_signal 96 --n_object 1 --use_deformation_field --use_expression".split())
+    run_nerf.check_supported(a)
+    with pytest.raises(NotImplementedError, match="second"):
+        dec(torch.zeros(1, 64, 3), torch.zeros(1, 64, 3), torch.zeros(1, 256), torch.zeros(1, 256),
+            [None, torch.zeros(1, 256)], 'head')
 
 
 def test_state_dict_manifest(states):

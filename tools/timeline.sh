@@ -7,7 +7,7 @@ for kv in "$@"; do export "$kv"; done
 mkdir -p "$REPO/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tl_$TAG
-rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$TAG -- python "$REPO/bench.py" --workload ${WL:-c4} --steps 30 --warmup 10 \
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$TAG -- python "$REPO/bench.py" --workload ${WL:-c4} ${TIER:+--tier $TIER} --steps ${STEPS:-30} --warmup 10 \
     --no-cpu-baseline --no-extra --sustain-seconds 0 > /tmp/tl_$TAG.log 2>&1
 f=$(find /tmp/tl_$TAG -name "*kernel_trace.csv" | head -1)
 python "$REPO/tools/timeline.py" "$f" -5 > "$REPO/gpurun_out/timeline_$TAG.txt"
