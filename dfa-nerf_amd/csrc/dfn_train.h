@@ -87,6 +87,9 @@ constexpr int WG_MT = DFN_WG_MT, WG_NT = DFN_WG_NT;
 #ifndef DFN_WG_PF
 #define DFN_WG_PF 4
 #endif
+#ifndef DFN_WG_TILE_PF
+#define DFN_WG_TILE_PF 0
+#endif
 constexpr int WG_PF = DFN_WG_PF;      // register prefetch depth of wgrad_kernel (f32 tier), in 8-point steps
 // streaming row sums: parts [BIAS_GRAD_SLICES][n] (workspace), then launch_reduce_bias
 hipError_t launch_bias_grad(int tier, int field, const int* e_of, const int* rows, int n, const void* dy_T, long NP,

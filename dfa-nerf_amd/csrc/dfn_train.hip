@@ -362,11 +362,12 @@ hipError_t launch_composite_bwd_hier(const CompositeBwdArgs& A, hipStream_t st) 
 // all of them side by side.)
 DFN_HD constexpr bool wgrad_lds_shape(int M, int N) { return M == 256 && N == 256; }
 // the point loop of wgrad_kernel (below) for one macro-tile
-template <bool FULL, bool BIAS>
+// <MTN, NTN>: the wave's macro-tile as compile-time numbers (0, 0: run-time mt_n_ x nt_n_, the general fallback)
+template <int MTN, int NTN, bool BIAS>
 __device__ __forceinline__ void wgrad_loop(const float* a, const float* b, long t0, long t1, int g_rows, int a_rows, int h, int mt_n_,
                                            int nt_n_, f32x16 (&acc)[WG_MT][WG_NT], f32x16 (&accb)[WG_MT]) {
     typedef float T;
-    const int mt_n = FULL ? WG_MT : mt_n_, nt_n = FULL ? WG_NT : nt_n_;
+    const int mt_n = MTN ? MTN : mt_n_, nt_n = MTN ? NTN : nt_n_;
     constexpr bool do_bias = BIAS;
     {
         // f32: v_mfma_f32_32x32x2_f32 takes A[row][k = half].  The contraction order is free, so MFMA m of a group of
@@ -402,6 +403,31 @@ __device__ __forceinline__ void wgrad_loop(const float* a, const float* b, long 
                         if (i < mt_n) accb[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i][m], 1.0f, accb[i], 0, 0, 0);
             }
         };
+#if DFN_WG_TILE_PF
+        // the four 8-point steps of a 32-point tile are fetched TOGETHER, one whole tile ahead (two register buffers of four
+        // steps): a lane's four 16-byte pieces of a tile sit in ONE 128-byte line (32 bytes apart), and issued a step apart
+        // each of them went to L2 on its own - the compute unit's L1 does not hold a step's 24 KiB per wave for four waves
+        static_assert(WG_PF == 8, "tile-granular prefetch: two buffers of four steps");
+        const long n_t = t1 - t0;
+        if (n_t > 0) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) load(s, s);
+        }
+        for (long t = 0; t < n_t; t += 2) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const long tt = t + half;
+                if (tt + 1 < n_t) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) load(4 * (half ^ 1) + s, 4 * (tt + 1) + s);
+                }
+                if (tt < n_t) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) mac(4 * half + s);
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int s = 0; s < WG_PF - 1; ++s)
             if (s < n_steps) load(s, s);
@@ -413,6 +439,7 @@ __device__ __forceinline__ void wgrad_loop(const float* a, const float* b, long 
                 if (qq < n_steps) mac(s);
             }
         }
+#endif
     }
 }
 
@@ -463,16 +490,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
         for (int j = 0; j < WG_NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // FULL: the macro-tile is complete (mt_n == WG_MT, nt_n == WG_NT: every 256 x 256 GEMM) - no per-tile conditions, and BIAS as a
-    // compile-time flag: with the run-time conditions every load and every MFMA sat behind its own scalar branch (3.1 scalar
-    // instructions per MFMA, matrix pipe 54 % busy with ONE wave per SIMD - round 5, profiles/r05m_c4_f32_pmc.txt)
-    if (mt_n == WG_MT && nt_n == WG_NT) {
-        if (do_bias) wgrad_loop<true, true>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, accb);
-        else wgrad_loop<true, false>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, accb);
-    } else {
-        if (do_bias) wgrad_loop<false, true>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, accb);
-        else wgrad_loop<false, false>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, accb);
+    // The macro-tile's shape as compile-time numbers, and BIAS as a compile-time flag: with run-time conditions every load and
+    // every MFMA sits behind its own scalar branch, and - what costs the time - the compiler can no longer count the loads in
+    // flight: it waits for ALL of them (vmcnt(0)) in front of every step, so the register prefetch hides nothing and a step
+    // takes a memory round trip (1.2 us, whatever its MFMA count: head and torso launches both 0.62 ms, with 2 x 2, 1 x 4 or
+    // 2 x 4 tiles per wave alike - round 5, profiles/r05t_wgrad_f32_macrotile.txt).  The decoder's GEMMs cut into 2 x 4 macro-tiles
+    // give four shapes; anything else takes the general loop.
+#define DFN_WG_CASE(M_, N_)                                                                                   \
+    if (mt_n == M_ && nt_n == N_) {                                                                           \
+        if (do_bias) wgrad_loop<M_, N_, true>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, accb);       \
+        else wgrad_loop<M_, N_, false>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, accb);              \
     }
+    DFN_WG_CASE(WG_MT, WG_NT)
+    else DFN_WG_CASE(2, 2)
+    else DFN_WG_CASE(1, 4)
+    else DFN_WG_CASE(2, 1)
+    else DFN_WG_CASE(1, 2)
+    else {
+        if (do_bias) wgrad_loop<0, 0, true>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, accb);
+        else wgrad_loop<0, 0, false>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, accb);
+    }
+#undef DFN_WG_CASE
     if (do_bias && (lane & 31) == 0) {          // every column of accb holds the row sums: take column 0
 #pragma unroll
         for (int i = 0; i < WG_MT; ++i)
