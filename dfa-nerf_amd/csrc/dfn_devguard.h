@@ -11,7 +11,7 @@
     defined(DFN_EXP_CONSTMASK) || defined(DFN_EXP_CLAMPCVT) || defined(DFN_REC8_NOAMAX) || defined(DFN_REC8_NOSTORE) ||       \
     defined(DFN_REC_NOMASK) || defined(DFN_REC_NOMASKSTORE) || defined(DFN_PUT_SMALL) || defined(DFN_PUT_EIGHTH) ||           \
     defined(DFN_NOMASK) || defined(DFN_NOPUT) || defined(DFN_WL_NOLDS) || defined(DFN_WL_NOMFMA) || defined(DFN_WL_TRACE) ||  \
-    defined(DFN_TIMING) || defined(DFN_PRIO_YOUNG)
+    defined(DFN_TIMING) || defined(DFN_PRIO_YOUNG) || defined(DFN_REC32_NOSTORE)
 #ifndef DFN_DEV_BUILD
 #error "a developer / timing switch (DFN_EXP_*, DFN_*_NO*, DFN_TIMING, DFN_WL_TRACE, ...) is defined without DFN_DEV_BUILD: such a build computes WRONG results or carries instrumentation - build it with DFN_DEV_BUILD=1 (build.sh) or tools/build_variant.sh, never as the product library"
 #endif

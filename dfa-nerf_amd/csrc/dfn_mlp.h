@@ -463,6 +463,9 @@ DFN_DEV void store_tiles_T(void* arr, int rows, long tile, int row0, const Vec<T
                     }
             }
     } else {
+#ifdef DFN_REC32_NOSTORE      // timing experiment (wrong results): the f32 recorder without its store instructions
+        return;
+#endif
 #pragma unroll
         for (int L = 0; L < 16 * NT; ++L)
             if ((L >> 4) >= t0 && (L >> 4) < t0 + n) {

@@ -52,6 +52,17 @@ def test_developer_switches_cannot_reach_the_product_library(tmp_path):
         r = subprocess.run(base + ["-D" + sw], capture_output=True, text=True)
         assert r.returncode != 0 and "DFN_DEV_BUILD" in r.stderr, (sw, r.stderr[-300:])
         assert subprocess.run(base + ["-D" + sw, "-DDFN_DEV_BUILD=1"], capture_output=True).returncode == 0, sw
+    # every switch the sources mark "wrong results" is one the guard knows
+    import glob
+    import re
+    guard = open(os.path.join(ROOT, "dfa-nerf_amd", "csrc", "dfn_devguard.h")).read()
+    marked = set()
+    for f in glob.glob(os.path.join(ROOT, "dfa-nerf_amd", "csrc", "*.h*")):
+        for ln in open(f):
+            m = re.match(r"\s*#\s*(?:ifdef|elif defined\(|if defined\()\s*(DFN_\w+).*wrong results", ln)
+            if m:
+                marked.add(m.group(1))
+    assert len(marked) >= 10 and all(f"defined({sw})" in guard for sw in marked), sorted(sw for sw in marked if f"defined({sw})" not in guard)
     r = subprocess.run(["bash", os.path.join(ROOT, "dfa-nerf_amd", "build.sh")], capture_output=True, text=True,
                        env=dict(os.environ, DFN_EXTRA_FLAGS="-DDFN_EXP_NOEPI"), timeout=60)
     assert r.returncode == 2 and "DFN_DEV_BUILD" in r.stderr, r.stderr[-300:]
