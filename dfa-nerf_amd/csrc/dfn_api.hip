@@ -787,22 +787,24 @@ static int weight_grad_impl(int tier, int field, int act_format, const void* dy_
         const int rc = ensure_eof(w, tier, field);
         if (rc != DFN_OK) return rc;
     }
-    // bf16 tier: the row sums ride along in the GEMMs (two cheap MFMAs per step).  f32 tier: an f32 MFMA costs 16x
-    // more, the streaming row-sum kernel is cheaper there (measured).
+    // The row sums (bias gradients) ride along in the GEMMs, partial per slice like the products: bf16 tier two cheap MFMAs
+    // per step; f32 tier on the vector ALU from the operand registers (round 5: a streaming row-sum kernel of its own read
+    // dy_T a second time, 0.27 ms per field).
     const bool fuse = dbias && tier == DFN_TIER_BF16;
+    const bool ride = dbias && tier == DFN_TIER_F32;
     if (!gemm) {
     } else if (tier == DFN_TIER_BF16)
         err = launch_wgrad_bf16(field, act_format == DFN_ACT_E2M1, w.ops_dev, w.items_dev[sc], w.n_items[sc], dy_T, act_T, NP, c_parts, W,
                                 fuse ? w.eof_dev : nullptr, fuse ? b_parts : nullptr, nb, st);
     else
         err = launch_wgrad(tier, field, w.ops_dev, (int)w.ops.size(), w.prefix_dev, w.prefix.back(), dy_T, act_T, NP, ks,
-                           c_parts, W, nullptr, nullptr, nb, st);
+                           c_parts, W, ride ? w.eof_dev : nullptr, ride ? b_parts : nullptr, nb, st);
     if (err != hipSuccess) return hip_fail(err, "wgrad_kernel");
-    if (gemm && dbias && !fuse) {          // f32 tier: the row sums are a separate streaming kernel (final values: no second stage)
-        err = launch_bias_grad(tier, field, w.eof_dev, w.rows_dev, nb, dy_T, NP, b_parts, dbias, st);
-        if (err != hipSuccess) return hip_fail(err, "bias_grad_kernel");
-    }
     if (!red) return DFN_OK;
+    if (ride) {
+        err = launch_reduce_bias(w.rows_dev, b_parts, nb, valid, dbias, st);
+        if (err != hipSuccess) return hip_fail(err, "reduce_bias_kernel");
+    }
     if (fuse) {
         err = launch_reduce_both(w.map_dev, c_parts, W, W, valid, grad_flat, w.rows_dev, b_parts, nb, dbias, w.blk_n_dev[sc],
                                  w.bias_n_dev[sc], units, st);

@@ -365,7 +365,7 @@ DFN_HD constexpr bool wgrad_lds_shape(int M, int N) { return M == 256 && N == 25
 // <MTN, NTN>: the wave's macro-tile as compile-time numbers (0, 0: run-time mt_n_ x nt_n_, the general fallback)
 template <int MTN, int NTN, bool BIAS>
 __device__ __forceinline__ void wgrad_loop(const float* a, const float* b, long t0, long t1, int g_rows, int a_rows, int h, int mt_n_,
-                                           int nt_n_, f32x16 (&acc)[WG_MT][WG_NT], f32x16 (&accb)[WG_MT]) {
+                                           int nt_n_, f32x16 (&acc)[WG_MT][WG_NT], float (&rs)[WG_MT]) {
     typedef float T;
     const int mt_n = MTN ? MTN : mt_n_, nt_n = MTN ? NTN : nt_n_;
     constexpr bool do_bias = BIAS;
@@ -395,12 +395,10 @@ __device__ __forceinline__ void wgrad_loop(const float* a, const float* b, long 
                     for (int j = 0; j < WG_NT; ++j)
                         if (i < mt_n && j < nt_n)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i][m], bv[s][j][m], acc[i][j], 0, 0, 0);
-            if (do_bias) {
+            if (do_bias) {      // row sums of the dy_T rows (bias gradients): this lane's four points of the step, on the vector ALU
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int i = 0; i < WG_MT; ++i)
-                        if (i < mt_n) accb[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i][m], 1.0f, accb[i], 0, 0, 0);
+                for (int i = 0; i < WG_MT; ++i)
+                    if (i < mt_n) rs[i] += (av[s][i][0] + av[s][i][1]) + (av[s][i][2] + av[s][i][3]);
             }
         };
 #if DFN_WG_TILE_PF
@@ -475,14 +473,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
     const int h = lane >> 5;
     const T* a = (const T*)dy_T + (long)(o.a_row + 32 * WG_MT * mb + (lane & 31)) * 32;
     const T* b = (const T*)act_T + (long)(o.b_row + 32 * WG_NT * nb + (lane & 31)) * 32;
-    // bias gradients for free: the first column block of the GEMM that owns these dy_T rows multiplies them by a tile of
-    // ones as well (2 more MFMAs per step, no extra memory traffic) -> row sums over the points
+    // bias gradients for free: the first column block of the GEMM that owns these dy_T rows also sums them over the points
+    // (the operand is in registers anyway: four adds per row tile and step, no extra memory traffic).  Lane (row, half) sums
+    // its own points in step order; the two halves of a row are added at the end: a fixed order, bit-reproducible.
     const bool do_bias = dbias && o.bias_owner && nb == 0;          // wave-uniform
-    f32x16 accb[WG_MT];
+    float rs[WG_MT];
 #pragma unroll
-    for (int i = 0; i < WG_MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+    for (int i = 0; i < WG_MT; ++i) rs[i] = 0.f;
     f32x16 acc[WG_MT][WG_NT];
 #pragma unroll
     for (int i = 0; i < WG_MT; ++i)
@@ -498,8 +495,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
     // give four shapes; anything else takes the general loop.
 #define DFN_WG_CASE(M_, N_)                                                                                   \
     if (mt_n == M_ && nt_n == N_) {                                                                           \
-        if (do_bias) wgrad_loop<M_, N_, true>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, accb);       \
-        else wgrad_loop<M_, N_, false>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, accb);              \
+        if (do_bias) wgrad_loop<M_, N_, true>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, rs);       \
+        else wgrad_loop<M_, N_, false>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, rs);              \
     }
     DFN_WG_CASE(WG_MT, WG_NT)
     else DFN_WG_CASE(2, 2)
@@ -507,18 +504,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
     else DFN_WG_CASE(2, 1)
     else DFN_WG_CASE(1, 2)
     else {
-        if (do_bias) wgrad_loop<0, 0, true>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, accb);
-        else wgrad_loop<0, 0, false>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, accb);
+        if (do_bias) wgrad_loop<0, 0, true>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, rs);
+        else wgrad_loop<0, 0, false>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, rs);
     }
 #undef DFN_WG_CASE
-    if (do_bias && (lane & 31) == 0) {          // every column of accb holds the row sums: take column 0
+    if (do_bias) {
 #pragma unroll
         for (int i = 0; i < WG_MT; ++i)
             if (i < mt_n) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int e = e_of[o.a_row + 32 * (WG_MT * mb + i) + tile_feat(lane >> 5, r)];
-                    if (e >= 0) dbias[(long)ks * n_bias + e] = accb[i][r];      // one writer per (slice, element)
+                const float tot = rs[i] + __shfl_xor(rs[i], 32);
+                if (h == 0) {
+                    const int e = e_of[o.a_row + 32 * (WG_MT * mb + i) + (lane & 31)];
+                    if (e >= 0) dbias[(long)ks * n_bias + e] = tot;             // one writer per (slice, element)
                 }
             }
     }
@@ -553,7 +550,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, c
 template <int MT, int NT, int RG>
 __global__ __launch_bounds__(256) void wgrad_full_kernel(const WOp* ops, int n_ops, const float* dy_T, const float* act_T,
                                                          long n_tiles, int g_rows, int a_rows, int ksplit, float* C,
-                                                         long c_stride) {
+                                                         long c_stride, const int* e_of, float* dbias, int n_bias) {
     constexpr int CG = 4 / RG, MW = MT / RG, NW = NT / CG;              // wave grid, tiles per wave
     constexpr int PIECES = (MT + NT) * 4, PW = PIECES / 4;               // 1-KiB DMA pieces per stage (8 rows each), per wave
     constexpr int STAGE = PIECES * 1024;
@@ -591,6 +588,11 @@ __global__ __launch_bounds__(256) void wgrad_full_kernel(const WOp* ops, int n_o
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int rl = lane & 31, h = lane >> 5;
+    // row sums of this GEMM's dy_T rows (bias gradients) on the way, as in wgrad_kernel: the waves of the first column group
+    const bool do_bias = dbias && o.bias_owner && cg == 0;               // wave-uniform
+    float rs[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) rs[i] = 0.f;
     if (t0 < t1) issue(0, t0);
     for (long t = t0; t < t1; ++t) {
         const int st = (int)((t - t0) & 1);
@@ -624,8 +626,22 @@ __global__ __launch_bounds__(256) void wgrad_full_kernel(const WOp* ops, int n_o
 #pragma unroll
                     for (int j = 0; j < NW; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][m], bv[j][m], acc[i][j], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < MW; ++i) rs[i] += (av[i][0] + av[i][1]) + (av[i][2] + av[i][3]);
+            }
         }
         __syncthreads();                                                 // the stage is free for the tile after the next
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < MW; ++i) {
+            const float tot = rs[i] + __shfl_xor(rs[i], 32);
+            if (h == 0) {
+                const int e = e_of[o.a_row + 32 * (MW * rg + i) + rl];
+                if (e >= 0) dbias[(long)ks * n_bias + e] = tot;                 // one writer per (slice, element)
+            }
+        }
     }
     float* c = C + (long)ks * c_stride + o.c_off;
 #pragma unroll
@@ -640,7 +656,8 @@ __global__ __launch_bounds__(256) void wgrad_full_kernel(const WOp* ops, int n_o
 }
 template <int MT, int NT, int RG>
 static hipError_t launch_wgrad_shape(const WOp* ops_dev, int n_ops, const float* dy_T, const float* act_T, long n_tiles, int g_rows,
-                                     int a_rows, int ksplit, float* C, long c_stride, hipStream_t st) {
+                                     int a_rows, int ksplit, float* C, long c_stride, const int* e_of, float* dbias, int n_bias,
+                                     hipStream_t st) {
     constexpr int lds = 2 * (MT + NT) * 4 * 1024;
     static bool attr_done = false;
     if (!attr_done) {
@@ -650,7 +667,7 @@ static hipError_t launch_wgrad_shape(const WOp* ops_dev, int n_ops, const float*
     }
     // one workgroup per (GEMM, slice); a workgroup of another shape's GEMM exits at once
     hipLaunchKernelGGL((wgrad_full_kernel<MT, NT, RG>), dim3(n_ops * ksplit), dim3(256), lds, st, ops_dev, n_ops, dy_T, act_T, n_tiles,
-                       g_rows, a_rows, ksplit, C, c_stride);
+                       g_rows, a_rows, ksplit, C, c_stride, e_of, dbias, n_bias);
     return hipGetLastError();
 }
 
@@ -665,7 +682,7 @@ hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, cons
     const float *dy = (const float*)dy_T, *ac = (const float*)act_T;
     hipError_t e1;
 #define DFN_WSHAPE(MT, NT, RG)                                                                                           \
-    if ((e1 = launch_wgrad_shape<MT, NT, RG>(ops_dev, n_ops, dy, ac, NP / 32, g_rows, a_rows, ksplit, C, c_stride, st)) != hipSuccess) return e1;
+    if ((e1 = launch_wgrad_shape<MT, NT, RG>(ops_dev, n_ops, dy, ac, NP / 32, g_rows, a_rows, ksplit, C, c_stride, e_of, dbias, n_bias, st)) != hipSuccess) return e1;
     DFN_WSHAPE(8, 8, 4)
 #undef DFN_WSHAPE
     hipLaunchKernelGGL(wgrad_kernel, dim3(blocks), dim3(256), 0, st, ops_dev, n_ops, prefix_dev, dy_T, act_T, NP / 32,
