@@ -92,7 +92,11 @@ WgradEntry g_wgrad[2];
 constexpr int WGRAD_KSPLIT = DFN_WGRAD_KSPLIT_F32;
 constexpr long WGRAD_SMALL_NP = 196608;  // 16-bit tier: calls up to this many points use the split with more spare compute units
 
-constexpr int WS_KSPLIT_MAX = 32;       // slices the workspace is sized for (>= every tier's split)
+#ifndef DFN_WS_KSPLIT_MAX
+#define DFN_WS_KSPLIT_MAX 32
+#endif
+constexpr int WS_KSPLIT_MAX = DFN_WS_KSPLIT_MAX;       // slices the workspace is sized for (>= every tier's split)
+static_assert(DFN_WGRAD_KSPLIT_F32 <= DFN_WS_KSPLIT_MAX, "the f32 tier's split fits the workspace");
 // head 16 / torso 18 (round 3, whole step, interleaved A/B over 600 steps x 4: torso 16 / 17 / 18 / 20 = 1.1056 / 1.1021 / 1.0975 /
 // 1.114 ms; head 19: worse).  Round 2: the kernel alone takes the same time for 16 ... 32 slices (0.81-0.82 ms for both fields, HBM-bound), the second stage
 // reads a third less and the whole training step is 1.2 % faster than with 24 (interleaved A/B, bench.py --workload c4)
