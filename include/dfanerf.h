@@ -289,8 +289,8 @@ int dfn_weight_bias_grad_fmt(int tier, int field, int act_format, const void* dy
  * stages must run one after the other (a fixed order: bit-reproducible sums) - their _partials stages need not: the training
  * step launches the torso's GEMMs without waiting for the head's reduction on the other stream (a cross-queue wait in front of a
  * 130-us kernel was 17 us of the step's critical path) and waits in front of the torso's reduction instead.  Same NP,
- * workspace and tier / field in both calls; f32 tier: dbias is written by _partials already (its row sums are a separate
- * streaming kernel) and _reduce ignores it. */
+ * workspace and tier / field in both calls; both tiers: the row sums ride in the GEMMs as per-slice partials in `workspace`,
+ * dbias is written by _reduce (pass the same dbias to both; _partials does not touch it). */
 int dfn_weight_bias_grad_partials(int tier, int field, int act_format, const void* dy_T, const void* act_T, long NP,
                                   float* workspace, float* dbias, void* stream);
 int dfn_weight_bias_grad_reduce(int tier, int field, long NP, float* workspace, float* grad_flat, float* dbias, void* stream);
