@@ -40,7 +40,9 @@ _SIG_SET = os.environ.get("DFN_TRAIN_SIG_SET", "0") == "1"
 _SIG_KEEP = os.environ.get("DFN_TRAIN_SIG_KEEP", "1") == "1"
 # the main stream waits for the head's weight-gradient chain in front of the torso's REDUCTION (1) or in front of its GEMMs (0: A/B)
 _SPLIT_JOIN = os.environ.get("DFN_TRAIN_SPLIT_JOIN", "1") == "1"
-# the torso field's dX chain BEFORE the head field's (1; A/B): the fields' roles in the overlapped schedule swapped
+# the torso field's dX chain BEFORE the head field's (1; A/B): the fields' roles in the overlapped schedule swapped.  Measured (interleaved,
+# two boxes, profiles/r05p_ab_schedule.txt): the hierarchical step -1 % on one box and +-0 on the other, the 64-sample step 7 % SLOWER (the
+# audio encoder's backward chain then starts behind the second dX chain and the next forward waits for it): off
 _TORSO_FIRST = os.environ.get("DFN_TRAIN_TORSO_FIRST", "0") == "1"
 # the step's loss from the training forward's epilogue (1: dfn_train_fwd*_loss) or from its own launch (0: dfn_mse_loss_u8; A/B)
 _LOSS_IN_FWD = os.environ.get("DFN_TRAIN_LOSS_IN_FWD", "1") == "1"
@@ -339,7 +341,10 @@ def _fused_backward(ctx, d_h, d_c):
             ev = getattr(tr, "_dsig_ev", None)
             if ev is None:
                 ev = tr._dsig_ev = (torch.cuda.Event(), torch.cuda.Event())
-        fa, fb = (1, 0) if _TORSO_FIRST else (0, 1)          # the field whose dX chain runs first / second
+        torso_first = _TORSO_FIRST
+        if tr is not None:
+            tr._torso_first = torso_first
+        fa, fb = (1, 0) if torso_first else (0, 1)           # the field whose dX chain runs first / second
         sig_st = {0: s_a, 1: s_p}
         dx(fa, st)
         # ONE event behind the first dX chain for both side chains (every record is a packet in the main queue in front of the
@@ -631,8 +636,8 @@ class _SignalFn(torch.autograd.Function):
             s_p.wait_stream(main)
         elif s_p is not None and getattr(tr, "_dsig_ev", None) is not None:
             s_p.wait_event(tr._dsig_ev[1])          # (the torso's d(signal) may have been produced on the main stream: _SIG_FIRST)
-            if _TORSO_FIRST:
-                s_a.wait_event(tr._dsig_ev[0])      # (and then the head's is the one that may)
+            if getattr(tr, "_torso_first", False):
+                s_a.wait_event(tr._dsig_ev[0])      # (the head's then: the torso's dX chain ran first, _TORSO_FIRST)
         st_a = st if s_a is None else C.c_void_p(s_a.cuda_stream)
         st_t = st if s_p is None else C.c_void_p(s_p.cuda_stream)
         def buffers(side, stream, nets):
