@@ -3,7 +3,7 @@
 step counts in fp32) - on the teacher scene of tests/convergence.py: one exact-tier run, the 16-bit tier in both recorded-activation
 formats on the same pixel sequence, and each format once more on another sequence.  Learning rate 1e-4 decayed to 1 % over the run.
 
-    python tools/convergence_long.py [steps=100000] > profiles/r05_convergence_100k.txt
+    python tools/convergence_long.py [steps=100000] [name:tier:format:seed ...] > profiles/r05_convergence_100k.txt
 """
 import json
 import os
@@ -19,7 +19,9 @@ log(f"# {steps} production steps of 2048 rays per variant, lr {CV.LRATE} decayed
     f"{CV.F_TRAIN} training frames, {CV.F_HELD} held-out frames; PSNR in the exact tier")
 variants = [("f32", "f32", None, 100), ("bf16_fp4", "bf16", "fp4", 100), ("bf16_e4m3", "bf16", "e4m3", 100),
             ("bf16_fp4_s101", "bf16", "fp4", 101), ("bf16_e4m3_s101", "bf16", "e4m3", 101)]
-res = CV.run(steps, variants, curve_every=max(1, steps // 10), log=log)
+if len(sys.argv) > 2:      # explicit variants: name:tier:format:pixel_seed ... (format "-" for the exact tier), compared against the first
+    variants = [(n, t, None if f == "-" else f, int(sd)) for n, t, f, sd in (a.split(":") for a in sys.argv[2:])]
+res = CV.run(steps, variants, curve_every=max(1, steps // 10), log=log, with_inference_check=len(sys.argv) <= 2)
 v = res["variants"]
 log("")
 log(f"{'variant':<18}{'ms/step':>9}{'finite':>8}{'last loss':>12}{'held head':>11}{'held com':>10}{'train head':>12}{'train com':>11}")
@@ -27,9 +29,10 @@ for k, i in v.items():
     log(f"{k:<18}{i['ms_per_step']:>9.3f}{str(i['finite']):>8}{i['last_loss']:>12.2e}{i['psnr_held_out']['head']:>11.3f}{i['psnr_held_out']['com']:>10.3f}"
         f"{i['psnr_train_frames']['head']:>12.3f}{i['psnr_train_frames']['com']:>11.3f}")
 log("")
-for k in [k for k in v if k != "f32"]:
-    d = lambda s_, im: v[k][s_][im] - v["f32"][s_][im]
-    log(f"  {k:<18} minus f32: held-out head {d('psnr_held_out', 'head'):+.3f} com {d('psnr_held_out', 'com'):+.3f}   "
+ref = "f32" if "f32" in v else next(iter(v))
+for k in [k for k in v if k != ref]:
+    d = lambda s_, im: v[k][s_][im] - v[ref][s_][im]
+    log(f"  {k:<18} minus {ref}: held-out head {d('psnr_held_out', 'head'):+.3f} com {d('psnr_held_out', 'com'):+.3f}   "
         f"training frames head {d('psnr_train_frames', 'head'):+.3f} com {d('psnr_train_frames', 'com'):+.3f}")
 log("")
 for k, i in v.items():
