@@ -68,12 +68,16 @@ struct WgradEntry {
     bool built = false;
     std::vector<WOpHost> ops;
     std::vector<int32_t> map, bias_rows;
-    std::vector<int> prefix;          // work items (WG_MT x WG_NT macro-tiles x k-splits) prefix per op
+    // f32 tier: the 256 x 256 GEMMs (wgrad_full_kernel) and the work items of every other GEMM (wgrad_narrow_kernel)
+    std::vector<int> full_ops;
+    std::vector<WNItem> nitems;
+    std::string plan_error;           // a GEMM shape the f32 kernels are not instantiated for
     WOp* ops_dev = nullptr;
     int32_t* map_dev = nullptr;
     int32_t* rows_dev = nullptr;
     int32_t* eof_dev = nullptr;      // dy_T row -> bias element
-    int* prefix_dev = nullptr;
+    int* full_ops_dev = nullptr;
+    WNItem* nitems_dev = nullptr;
     // 16-bit tier: one workgroup per (GEMM, slice of the points), the slice count PER GEMM (balanced split, see wgrad_items)
     // Two splits (WGRAD_SPLITS): [0] the reference's step (<= WGRAD_SMALL_NP points), [1] larger calls (the hierarchical step)
     WItem* items_dev[2] = {nullptr, nullptr};
@@ -176,10 +180,19 @@ WgradEntry& wgrad_of(int field) {
     WgradEntry& w = g_wgrad[field];
     if (!w.built) {
         build_wgrad_plan(field, w.ops, w.map, w.bias_rows);
-        w.prefix.assign(1, 0);
-        for (const WOpHost& o : w.ops)
-            w.prefix.push_back(w.prefix.back() +
-                               ((o.M / 32 + WG_MT - 1) / WG_MT) * std::max(1, (o.N / 32 + WG_NT - 1) / WG_NT) * WGRAD_KSPLIT);
+        // f32 tier: every GEMM is cut into WGRAD_KSPLIT slices of the points (one partial array per slice: the reduction adds
+        // the same number of slices for every element).  Items of the narrow launch: blocks of a shape's row tiles x slices,
+        // the shapes with the longest workgroups first (dfn_train.h: WN_4x4 < WN_4x2 < ... is that order)
+        for (int shape = 0; shape < WN_COUNT; ++shape)
+            for (size_t i = 0; i < w.ops.size(); ++i) {
+                const WOpHost& o = w.ops[i];
+                const int sh = wn_shape_of(o.M, o.N);
+                if (sh == -2) w.plan_error = "weight-gradient GEMM " + std::to_string(o.M) + " x " + std::to_string(o.N) + ": no f32 kernel for this shape";
+                if (sh == -1 && shape == 0) w.full_ops.push_back((int)i);
+                if (sh != shape) continue;
+                for (int m0 = 0; m0 < o.M / 32; m0 += wn_shape_mt(shape))
+                    for (int ks = 0; ks < WGRAD_KSPLIT; ++ks) w.nitems.push_back(WNItem{(int)i, ks, m0, shape});
+            }
         w.built = true;
     }
     return w;
@@ -694,6 +707,7 @@ static int weight_grad_impl(int tier, int field, int act_format, const void* dy_
         NP <= 0 || NP % 32)
         return fail(DFN_E_ARG, std::string(who) + ": bad argument (NP must be a multiple of 32)");
     WgradEntry& w = wgrad_of(field);
+    if (tier == DFN_TIER_F32 && !w.plan_error.empty()) return fail(DFN_E_ARG, std::string(who) + ": " + w.plan_error);
     hipStream_t st = (hipStream_t)stream;
     {
         std::lock_guard<std::mutex> lk(g_plan_mu);
@@ -744,12 +758,14 @@ static int weight_grad_impl(int tier, int field, int act_format, const void* dy_
             // ops_dev, and a later call must never launch with a table that is still null
             WOp* d_ops = nullptr;
             int32_t *d_map = nullptr, *d_rows = nullptr;
-            int* d_prefix = nullptr;
+            int* d_full = nullptr;
+            WNItem* d_nitems = nullptr;
             WItem* d_items[2] = {nullptr, nullptr};
             unsigned char *d_blk[2] = {nullptr, nullptr}, *d_bn[2] = {nullptr, nullptr};
             hipError_t e = upload(&d_ops, ops.data(), ops.size());
             if (e == hipSuccess) e = upload(&d_map, w.map.data(), w.map.size());
-            if (e == hipSuccess) e = upload(&d_prefix, w.prefix.data(), w.prefix.size());
+            if (e == hipSuccess && !w.full_ops.empty()) e = upload(&d_full, w.full_ops.data(), w.full_ops.size());
+            if (e == hipSuccess && !w.nitems.empty()) e = upload(&d_nitems, w.nitems.data(), w.nitems.size());
             if (e == hipSuccess && !w.rows_dev) e = upload(&d_rows, w.bias_rows.data(), w.bias_rows.size());
             for (int c = 0; c < 2; ++c) {
                 if (e == hipSuccess) e = upload(&d_items[c], items[c].data(), items[c].size());
@@ -757,12 +773,13 @@ static int weight_grad_impl(int tier, int field, int act_format, const void* dy_
                 if (e == hipSuccess) e = upload(&d_bn[c], bias_n[c].data(), bias_n[c].size());
             }
             if (e != hipSuccess) {
-                (void)hipFree(d_ops); (void)hipFree(d_map); (void)hipFree(d_prefix); (void)hipFree(d_rows);
+                (void)hipFree(d_ops); (void)hipFree(d_map); (void)hipFree(d_full); (void)hipFree(d_nitems); (void)hipFree(d_rows);
                 for (int c = 0; c < 2; ++c) { (void)hipFree(d_items[c]); (void)hipFree(d_blk[c]); (void)hipFree(d_bn[c]); }
                 return hip_fail(e, "upload(wgrad plan)");
             }
             w.map_dev = d_map;
-            w.prefix_dev = d_prefix;
+            w.full_ops_dev = d_full;
+            w.nitems_dev = d_nitems;
             if (d_rows) w.rows_dev = d_rows;
             for (int c = 0; c < 2; ++c) {
                 w.items_dev[c] = d_items[c];
@@ -801,8 +818,8 @@ static int weight_grad_impl(int tier, int field, int act_format, const void* dy_
         err = launch_wgrad_bf16(field, act_format == DFN_ACT_E2M1, w.ops_dev, w.items_dev[sc], w.n_items[sc], dy_T, act_T, NP, c_parts, W,
                                 fuse ? w.eof_dev : nullptr, fuse ? b_parts : nullptr, nb, st);
     else
-        err = launch_wgrad(tier, field, w.ops_dev, (int)w.ops.size(), w.prefix_dev, w.prefix.back(), dy_T, act_T, NP, ks,
-                           c_parts, W, ride ? w.eof_dev : nullptr, ride ? b_parts : nullptr, nb, st);
+        err = launch_wgrad(tier, field, w.ops_dev, w.full_ops_dev, (int)w.full_ops.size(), w.nitems_dev, (int)w.nitems.size(), dy_T, act_T,
+                           NP, ks, c_parts, W, ride ? w.eof_dev : nullptr, ride ? b_parts : nullptr, nb, st);
     if (err != hipSuccess) return hip_fail(err, "wgrad_kernel");
     if (!red) return DFN_OK;
     if (ride) {
@@ -824,6 +841,20 @@ static int weight_grad_impl(int tier, int field, int act_format, const void* dy_
     err = launch_reduce_scatter(w.map_dev, c_parts, W, W, valid, grad_flat, st);
     if (err != hipSuccess) return hip_fail(err, "reduce_scatter_kernel");
     return DFN_OK;
+}
+
+long dfn_wgrad_plan(int field, int what, int32_t* out, long capacity) {
+    if ((field != 0 && field != 1) || what < 0 || what > 2) return fail(DFN_E_ARG, "dfn_wgrad_plan: bad field / selector");
+    WgradEntry& w = wgrad_of(field);
+    std::vector<int32_t> ops;
+    if (what == 0)
+        for (const WOpHost& o : w.ops) ops.insert(ops.end(), {o.a_row, o.M, o.b_row, o.N, o.c_off, o.bias_owner});
+    const std::vector<int32_t>& v = what == 0 ? ops : what == 1 ? w.map : w.bias_rows;
+    if (out) {
+        if (capacity < (long)v.size()) return fail(DFN_E_SIZE, "dfn_wgrad_plan: capacity too small");
+        std::memcpy(out, v.data(), v.size() * sizeof(int32_t));
+    }
+    return (long)v.size();
 }
 
 // (the two entry points without a format argument consume what the FUSED step records: dfn_train_fwd / dfn_train_fwd_hier)

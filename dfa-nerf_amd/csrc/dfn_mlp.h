@@ -737,6 +737,9 @@ DFN_DEV void rec_vals(const CT& c, int row0, const Vec<TIER, NT>& out, int t0) {
 DFN_HD constexpr int mask_pos(int b) { return ((b & 1) << 4) | (b >> 1); }
 template <class CT>
 DFN_DEV void rec_mask_pair(const CT& c, int mask_dword, const f32x16 (&acc)[2]) {
+#ifdef DFN_REC_NOMASK         // timing experiment (wrong results): no ReLU bits at all (f32 route)
+    return;
+#endif
     if constexpr (CT::rec_on) {
         if (mask_dword >= 0) {
             unsigned bits = 0;

@@ -46,9 +46,23 @@ hipError_t launch_composite_bwd(const CompositeBwdArgs& A, hipStream_t st);
 hipError_t launch_composite_bwd_hier(const CompositeBwdArgs& A, hipStream_t st);      // n_fine in {64, 128}
 // Split-K partials: C [ksplit][c_stride] and dbias [ksplit][n_bias], one writer per element and slice (no atomics);
 // launch_reduce_scatter / launch_reduce_bias add the slices in index order (bit-reproducible gradients).
-hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, const int* prefix_dev, int total_items,
-                        const void* dy_T, const void* act_T, long NP, int ksplit, float* C, long c_stride, const int* e_of,
-                        float* dbias, int n_bias, hipStream_t st);
+// f32 tier: two launches per field, both with the operands through LDS (dfn_train.hip) -
+//   wgrad_full_kernel    the 256 x 256 GEMMs (`full_ops_dev`: their indices into ops_dev), one workgroup per (GEMM, slice);
+//   wgrad_narrow_kernel  every other GEMM, one workgroup per WNItem (below), all shapes side by side in ONE launch.
+struct WNItem {                 // slice `ks` of row tiles [m_tile0, m_tile0 + the shape's MT) of GEMM `op` (f32 tier, narrow shapes)
+    int op, ks, m_tile0, shape; // shape: WN_* (dfn_train.hip: the (MT, NT) instantiations of wgrad_lds_part)
+};
+enum WNShape : int { WN_4x4 = 0, WN_4x2, WN_1x8, WN_4x1, WN_2x2, WN_ROWS, WN_COUNT };
+// classification of a GEMM M x N (dy_T rows x act_T rows) for the f32 tier: WN_* and the number of row parts it is cut into
+// (-1: the 256 x 256 shape of wgrad_full_kernel; -2: a shape no kernel is instantiated for)
+DFN_HD constexpr int wn_shape_of(int M, int N) {
+    return (M == 256 && N == 256) ? -1 : (M == 256 && N == 128) ? WN_4x4 : (M == 256 && N == 64) ? WN_4x2 : (M == 32 && N == 256) ? WN_1x8
+         : (M == 256 && N == 32) ? WN_4x1 : (M == 64 && N == 64) ? WN_2x2 : (N == 0 && M > 0 && M % 32 == 0) ? WN_ROWS : -2;
+}
+DFN_HD constexpr int wn_shape_mt(int shape) { return shape == WN_1x8 ? 1 : (shape == WN_2x2 || shape == WN_ROWS) ? 2 : 4; }
+hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, const int* full_ops_dev, int n_full, const WNItem* nitems_dev,
+                        int n_nitems, const void* dy_T, const void* act_T, long NP, int ksplit, float* C, long c_stride,
+                        const int* e_of, float* dbias, int n_bias, hipStream_t st);
 // bf16 tier: one workgroup per (GEMM, slice of the points), operands through LDS (dfn_wgrad_bf16.hip); order = GEMMs by
 // decreasing size
 struct WItem {                  // one workgroup of the 16-bit tier's weight-gradient launch: slice `ks` of `n` of GEMM `op`
@@ -76,21 +90,6 @@ hipError_t launch_mse_loss(const float* rgb_head, const float* rgb_com, const un
                            const unsigned char* img_com, const int* pix, int n, float* losses, float* d_head, float* d_com,
                            hipStream_t st);
 constexpr int BIAS_GRAD_SLICES = 128;      // slices of the points in the streaming bias_grad_kernel
-// macro-tile of one wgrad wave, in 32x32 output tiles (dfn_api.hip sizes the work list with the same numbers)
-#ifndef DFN_WG_MT
-#define DFN_WG_MT 2
-#endif
-#ifndef DFN_WG_NT
-#define DFN_WG_NT 4
-#endif
-constexpr int WG_MT = DFN_WG_MT, WG_NT = DFN_WG_NT;
-#ifndef DFN_WG_PF
-#define DFN_WG_PF 4
-#endif
-#ifndef DFN_WG_TILE_PF
-#define DFN_WG_TILE_PF 0
-#endif
-constexpr int WG_PF = DFN_WG_PF;      // register prefetch depth of wgrad_kernel (f32 tier), in 8-point steps
 // streaming row sums: parts [BIAS_GRAD_SLICES][n] (workspace), then launch_reduce_bias
 hipError_t launch_bias_grad(int tier, int field, const int* e_of, const int* rows, int n, const void* dy_T, long NP,
                             float* parts, float* dbias, hipStream_t st);

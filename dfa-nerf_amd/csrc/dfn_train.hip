@@ -355,217 +355,55 @@ hipError_t launch_composite_bwd_hier(const CompositeBwdArgs& A, hipStream_t st) 
 }
 
 // ================================================================================================
-// weight gradients: C[M x N] += A[M x NP] * B[N x NP]^T, contraction over the sample points, split-K + atomics
-// GEMM shapes that go through the LDS kernel (wgrad_full_kernel, below); everything else: wgrad_kernel
-// (Round 5: the other shapes were tried in it too - <8,4,4> <8,2,4> <8,1,4> <1,8,1> <2,2,2>, one launch per shape: both fields
-// 4.07 -> 4.68 ms.  A launch per small shape fills 32-416 workgroups of little work each, one after the other; wgrad_kernel runs
-// all of them side by side.)
-DFN_HD constexpr bool wgrad_lds_shape(int M, int N) { return M == 256 && N == 256; }
-// the point loop of wgrad_kernel (below) for one macro-tile
-// <MTN, NTN>: the wave's macro-tile as compile-time numbers (0, 0: run-time mt_n_ x nt_n_, the general fallback)
-template <int MTN, int NTN, bool BIAS>
-__device__ __forceinline__ void wgrad_loop(const float* a, const float* b, long t0, long t1, int g_rows, int a_rows, int h, int mt_n_,
-                                           int nt_n_, f32x16 (&acc)[WG_MT][WG_NT], float (&rs)[WG_MT]) {
-    typedef float T;
-    const int mt_n = MTN ? MTN : mt_n_, nt_n = MTN ? NTN : nt_n_;
-    constexpr bool do_bias = BIAS;
-    {
-        // f32: v_mfma_f32_32x32x2_f32 takes A[row][k = half].  The contraction order is free, so MFMA m of a group of
-        // four pairs k = m (lower half of the wave) with k = m + 4 (upper half): each lane then needs 4 CONSECUTIVE
-        // points - one 16-byte load, nothing fetched twice, no selects - and a group covers 8 points.  Steps of 8
-        // points are double-buffered in registers like the bf16 path.
-        f32x4 av[WG_PF][WG_MT], bv[WG_PF][WG_NT];
-        const long n_steps = (t1 - t0) * 4;                    // 4 groups of 8 points per 32-point tile
-        auto load = [&](int s, long q) {
-            const long t = t0 + (q >> 2);
-            const int k8 = (int)(q & 3) * 8 + 4 * h;
-            const T* at = a + t * (long)g_rows * 32 + k8;
-            const T* bt = b + t * (long)a_rows * 32 + k8;
-#pragma unroll
-            for (int i = 0; i < WG_MT; ++i) if (i < mt_n) av[s][i] = *(const f32x4*)(at + i * 1024);
-#pragma unroll
-            for (int j = 0; j < WG_NT; ++j) if (j < nt_n) bv[s][j] = *(const f32x4*)(bt + j * 1024);
-        };
-        auto mac = [&](int s) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int i = 0; i < WG_MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < WG_NT; ++j)
-                        if (i < mt_n && j < nt_n)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i][m], bv[s][j][m], acc[i][j], 0, 0, 0);
-            if (do_bias) {      // row sums of the dy_T rows (bias gradients): this lane's four points of the step, on the vector ALU
-#pragma unroll
-                for (int i = 0; i < WG_MT; ++i)
-                    if (i < mt_n) rs[i] += (av[s][i][0] + av[s][i][1]) + (av[s][i][2] + av[s][i][3]);
-            }
-        };
-#if DFN_WG_TILE_PF
-        // the four 8-point steps of a 32-point tile are fetched TOGETHER, one whole tile ahead (two register buffers of four
-        // steps): a lane's four 16-byte pieces of a tile sit in ONE 128-byte line (32 bytes apart), and issued a step apart
-        // each of them went to L2 on its own - the compute unit's L1 does not hold a step's 24 KiB per wave for four waves
-        static_assert(WG_PF == 8, "tile-granular prefetch: two buffers of four steps");
-        const long n_t = t1 - t0;
-        if (n_t > 0) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) load(s, s);
-        }
-        for (long t = 0; t < n_t; t += 2) {
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const long tt = t + half;
-                if (tt + 1 < n_t) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) load(4 * (half ^ 1) + s, 4 * (tt + 1) + s);
-                }
-                if (tt < n_t) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) mac(4 * half + s);
-                }
-            }
-        }
-#else
-#pragma unroll
-        for (int s = 0; s < WG_PF - 1; ++s)
-            if (s < n_steps) load(s, s);
-        for (long q = 0; q < n_steps; q += WG_PF) {
-#pragma unroll
-            for (int s = 0; s < WG_PF; ++s) {
-                const long qq = q + s;
-                if (qq + WG_PF - 1 < n_steps) load((s + WG_PF - 1) % WG_PF, qq + WG_PF - 1);
-                if (qq < n_steps) mac(s);
-            }
-        }
-#endif
-    }
-}
-
+// weight gradients (f32 tier): C[M x N] = A[M x NP] * B[N x NP]^T, contraction over the sample points, split over slices of the
+// points (one partial array per slice, no atomics; launch_reduce_scatter adds the slices in index order).
+// Two kernels, both with the operands through LDS: wgrad_full_kernel (the 256 x 256 GEMMs, 89 % of a field's FLOPs) and
+// wgrad_narrow_kernel (everything else, all shapes in one launch).  Rounds 2-5 ran the narrow GEMMs in a kernel that read its
+// operands straight from L2 / HBM, one wave per 2 x 4-tile macro-tile, one wave per SIMD (420 registers): latency-bound,
+// 0.48 ms (head) / 0.64 ms (torso) for 11 % of the FLOPs (profiles/r05end_c4_f32_timeline.txt).
 // ================================================================================================
-// One wave = one macro-tile of up to WG_MT x WG_NT 32x32 output tiles over a slice of the sample points: per
-// 32-point step it loads WG_MT A tiles + WG_NT B tiles (1 KiB each) for WG_MT*WG_NT tile products - 2.7x less
-// operand traffic than one tile per wave (the kernel is bound by operand reads out of L2/HBM, not by the MFMAs).
-// f32 tier only: the bf16 tier shares the operands of a whole GEMM through LDS (dfn_wgrad_bf16.hip).
-__global__ __launch_bounds__(256) void wgrad_kernel(const WOp* ops, int n_ops, const int* work_prefix, const void* dy_T,
-                                                    const void* act_T, long n_tiles, int g_rows, int a_rows,
-                                                    int ksplit, float* C, long c_stride, const int* e_of, float* dbias,
-                                                    int n_bias) {
-    typedef float T;
-    const int lane = threadIdx.x & 63;
-    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= work_prefix[n_ops]) return;
-    int op = 0;
-    while (item >= work_prefix[op + 1]) ++op;
-    const WOp o = ops[op];
-    if (wgrad_lds_shape(o.M, o.N)) return;      // these shapes have their own kernel (wgrad_full_kernel, below): this one is the general fallback
-    long loc = item - work_prefix[op];
-    const int mts = o.M / 32, nts = o.N / 32;
-    const int nb_n = max(1, (nts + WG_NT - 1) / WG_NT), mb_n = (mts + WG_MT - 1) / WG_MT;     // N = 0: row sums only
-    // row block fastest: the 4 waves of a workgroup then share the column block and the slice of points, i.e. they
-    // request the SAME B tiles at about the same time (one trip to L2 instead of four)
-    const int mb = (int)(loc % mb_n);
-    loc /= mb_n;
-    const int nb = (int)(loc % nb_n), ks = (int)(loc / nb_n);
-    const int mt_n = min(WG_MT, mts - WG_MT * mb), nt_n = min(WG_NT, nts - WG_NT * nb);     // wave-uniform
-    const long per = (n_tiles + ksplit - 1) / ksplit;
-    const long t0 = ks * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
-    // tile-major operands: row r of tile t starts at (t * rows + r) * 32
-    const int h = lane >> 5;
-    const T* a = (const T*)dy_T + (long)(o.a_row + 32 * WG_MT * mb + (lane & 31)) * 32;
-    const T* b = (const T*)act_T + (long)(o.b_row + 32 * WG_NT * nb + (lane & 31)) * 32;
-    // bias gradients for free: the first column block of the GEMM that owns these dy_T rows also sums them over the points
-    // (the operand is in registers anyway: four adds per row tile and step, no extra memory traffic).  Lane (row, half) sums
-    // its own points in step order; the two halves of a row are added at the end: a fixed order, bit-reproducible.
-    const bool do_bias = dbias && o.bias_owner && nb == 0;          // wave-uniform
-    float rs[WG_MT];
-#pragma unroll
-    for (int i = 0; i < WG_MT; ++i) rs[i] = 0.f;
-    f32x16 acc[WG_MT][WG_NT];
-#pragma unroll
-    for (int i = 0; i < WG_MT; ++i)
-#pragma unroll
-        for (int j = 0; j < WG_NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // The macro-tile's shape as compile-time numbers, and BIAS as a compile-time flag: with run-time conditions every load and
-    // every MFMA sits behind its own scalar branch, and - what costs the time - the compiler can no longer count the loads in
-    // flight: it waits for ALL of them (vmcnt(0)) in front of every step, so the register prefetch hides nothing and a step
-    // takes a memory round trip (1.2 us, whatever its MFMA count: head and torso launches both 0.62 ms, with 2 x 2, 1 x 4 or
-    // 2 x 4 tiles per wave alike - round 5, profiles/r05t_wgrad_f32_macrotile.txt).  The decoder's GEMMs cut into 2 x 4 macro-tiles
-    // give four shapes; anything else takes the general loop.
-#define DFN_WG_CASE(M_, N_)                                                                                   \
-    if (mt_n == M_ && nt_n == N_) {                                                                           \
-        if (do_bias) wgrad_loop<M_, N_, true>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, rs);       \
-        else wgrad_loop<M_, N_, false>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, rs);              \
-    }
-    DFN_WG_CASE(WG_MT, WG_NT)
-    else DFN_WG_CASE(2, 2)
-    else DFN_WG_CASE(1, 4)
-    else DFN_WG_CASE(2, 1)
-    else DFN_WG_CASE(1, 2)
-    else {
-        if (do_bias) wgrad_loop<0, 0, true>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, rs);
-        else wgrad_loop<0, 0, false>(a, b, t0, t1, g_rows, a_rows, h, mt_n, nt_n, acc, rs);
-    }
-#undef DFN_WG_CASE
-    if (do_bias) {
-#pragma unroll
-        for (int i = 0; i < WG_MT; ++i)
-            if (i < mt_n) {
-                const float tot = rs[i] + __shfl_xor(rs[i], 32);
-                if (h == 0) {
-                    const int e = e_of[o.a_row + 32 * (WG_MT * mb + i) + (lane & 31)];
-                    if (e >= 0) dbias[(long)ks * n_bias + e] = tot;             // one writer per (slice, element)
-                }
-            }
-    }
-    float* c = C + (long)ks * c_stride + o.c_off;       // this wave's slice of the split-K partials (no atomics)
-#pragma unroll
-    for (int i = 0; i < WG_MT; ++i)
-#pragma unroll
-        for (int j = 0; j < WG_NT; ++j)
-            if (i < mt_n && j < nt_n) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = 32 * (WG_MT * mb + i) + tile_feat(lane >> 5, r), col = 32 * (WG_NT * nb + j) + (lane & 31);
-                    c[(long)row * o.N + col] = acc[i][j][r];
-                }
-            }
-}
-// ================================================================================================
-// f32 tier, the 256 x 256 GEMMs (most of a field's weight-gradient FLOPs): one workgroup of four waves owns the WHOLE output of
-// one GEMM for one slice of the points, the operands go through LDS once per workgroup.  (wgrad_kernel above reads every
-// operand tile from L2 / HBM once per macro-tile that needs it - a dy_T tile twice, an act_T tile four times, 32-byte pieces
-// of 128-byte lines per request - and ran at 46 % of the f32 MFMA peak with one wave per SIMD: round 5.)
-//   * wave w: output rows 64 w .. 64 w + 63 x all 256 columns = 2 x 8 accumulator tiles (256 registers);
-//   * a step = one 32-point tile: the 256 dy_T rows and the 256 act_T rows of the tile are 32 KiB each, CONTIGUOUS in memory
-//     (tile-major arrays) -> 64 LDS-DMA pieces of 1 KiB per step, 16 per wave, two stages of 64 KiB;
+// One GEMM (or a block of its row tiles) for one slice of the points, by one workgroup of four waves, the operands through LDS
+// once per workgroup (round 5, for the 256 x 256 GEMMs; before that a general kernel read every operand tile from L2 / HBM once
+// per wave macro-tile that needed it - 32-byte pieces of 128-byte lines, 46 % of the f32 MFMA peak with one wave per SIMD):
+//   * a step = one 32-point tile: the block's dy_T rows and act_T rows of the tile are CONTIGUOUS in memory (tile-major arrays)
+//     -> 1-KiB LDS-DMA pieces of 8 rows each, dealt round-robin to the four waves;
 //   * the LDS image is swizzled at the SOURCE (the DMA writes lane i's 16 bytes at base + 16 i; each lane chooses what it
 //     fetches): 16-byte chunk c of row r sits at slot 8 r + (c ^ ((r >> 1) & 7)) - the sixteen rows of a ds_read_b128 lane
 //     group then hit sixteen different slots of the 256-byte bank row (MI355X_MICROARCH.md, LDS);
-//   * same products in the same order per output element as wgrad_kernel (MFMA m of an 8-point group pairs point m with
-//     point m + 4): the partial sums of a slice are bit-identical to the old kernel's.
-// <MT, NT, RG> = GEMM of 32 MT x 32 NT outputs, the four waves as an RG x (4 / RG) grid over its tiles; instantiated for <8, 8, 4>,
-// the 256 x 256 GEMMs (wave w: 2 x 8 tiles).
-template <int MT, int NT, int RG>
-__global__ __launch_bounds__(256) void wgrad_full_kernel(const WOp* ops, int n_ops, const float* dy_T, const float* act_T,
-                                                         long n_tiles, int g_rows, int a_rows, int ksplit, float* C,
-                                                         long c_stride, const int* e_of, float* dbias, int n_bias) {
-    constexpr int CG = 4 / RG, MW = MT / RG, NW = NT / CG;              // wave grid, tiles per wave
-    constexpr int PIECES = (MT + NT) * 4, PW = PIECES / 4;               // 1-KiB DMA pieces per stage (8 rows each), per wave
+//   * the four waves as an RG x (4 / RG) grid over the block's MT x NT output tiles;
+//   * NS stages, ONE barrier per step: "tile t has landed" and "everybody is done with tile t - 1" are the same barrier, behind
+//     it the stage of tile t - 1 is refilled with tile t + NS - 1 (round 5 had two barriers per step around two stages).
+// wgrad_full_kernel: the 256 x 256 GEMMs (8 of a field's 13 / 26, 89 % of its FLOPs), <8, 8, 4, 2>: wave w owns output rows
+// 64 w .. 64 w + 63 x all 256 columns (256 accumulator registers), two 64-KiB stages, one workgroup per compute unit;
+// 8 GEMMs x 32 slices = 256 workgroups = one round: 1.04-1.1 ms per field, 0.83 of the f32 MFMA peak.
+//
+// wgrad_narrow_kernel: every GEMM that is NOT 256 x 256 (11 % of a field's weight-gradient FLOPs, but a third of its operand
+// bytes), all of them in ONE launch: one workgroup per WNItem = (GEMM, block of its row tiles, slice of the points).  (Round 5
+// tried one launch per narrow shape: 32-416 workgroups of little work each, one launch after the other - slower than the
+// general kernel.  Side by side in one launch they fill the chip.)  What the narrow shapes need on top:
+//   * 2-4 stages, as many as fit 72 KiB: a stage of a 64 x 64 GEMM is 16 KiB and its step 16 MFMAs per wave - two stages
+//     would leave the workgroup waiting for memory most of the time;
+//   * 72 KiB of LDS and < 128 registers: two workgroups per compute unit (the second hides the first's barriers and waits);
+//   * GEMMs with 256 dy_T rows are cut into two blocks of 128 rows (their act_T rows are read twice: 8-32 KiB per step): every
+//     item then holds at most 4 output tiles per wave and the launch's longest workgroup is 128 steps x 64 MFMAs;
+//   * a dy_T row block no GEMM reads (N = 0: its layer multiplies a per-frame constant) is summed straight from memory.
+// Same products in the same order per output element as before (MFMA m of an 8-point group pairs point m with point m + 4, groups
+// in point order), same row-sum order: the slices' partial sums are bit-identical to rounds 2-5.
+// (Shapes: dfn_train.h wn_shape_of; anything else is refused when the plan is built, dfn_api.hip.)
+template <int MT, int NT, int RG, int NS, int LDS_MAX = 72 * 1024>
+__device__ __forceinline__ void wgrad_lds_part(const WOp& o, int m_tile0, int ks, const float* dy_T, const float* act_T, long n_tiles,
+                                               int g_rows, int a_rows, int ksplit, float* C, long c_stride, const int* e_of,
+                                               float* dbias, int n_bias, lds_char* lds) {
+    constexpr int CG = 4 / RG, MW = MT / RG, NW = NT / CG;
+    constexpr int PIECES = (MT + NT) * 4, PW = PIECES / 4;
     constexpr int STAGE = PIECES * 1024;
-    static_assert(MT % RG == 0 && NT % CG == 0 && PIECES % 4 == 0 && 2 * STAGE <= 160 * 1024, "shape");
-    extern __shared__ __attribute__((aligned(16))) char wf_smem[];
-    const int op = blockIdx.x / ksplit, ks = blockIdx.x % ksplit;
-    const WOp o = ops[op];
-    if (o.M != 32 * MT || o.N != 32 * NT) return;                        // (uniform over the workgroup)
+    static_assert(MT % RG == 0 && NT % CG == 0 && NS >= 2 && NS <= 4 && NS * STAGE <= LDS_MAX && (NS - 1) * PW <= 63, "shape");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rg = wave / CG, cg = wave % CG;
     const long per = (n_tiles + ksplit - 1) / ksplit;
     const long t0 = ks * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
-    lds_char* lds = (lds_char*)wf_smem;
-    // DMA piece p of a stage: 8 rows of the dy_T block (p < 4 MT) or of the act_T block; this wave issues pieces wave, wave + 4, ...
-    // lane i -> row 8 p' + (i >> 3) of its block, slot i & 7, source chunk (i & 7) ^ ((row >> 1) & 7)
+    if (t0 >= t1) return;                                                // a slice without points: the reduction skips it
+    const int a_row0 = o.a_row + 32 * m_tile0;
     auto issue = [&](int stage, long t) {
 #pragma unroll
         for (int k = 0; k < PW; ++k) {
@@ -573,7 +411,7 @@ __global__ __launch_bounds__(256) void wgrad_full_kernel(const WOp* ops, int n_o
             const bool isb = p >= 4 * MT;
             const int r = 8 * (isb ? p - 4 * MT : p) + (lane >> 3);
             const int c = (lane & 7) ^ ((r >> 1) & 7);
-            const float* base = isb ? act_T + (t * (long)a_rows + o.b_row) * 32 : dy_T + (t * (long)g_rows + o.a_row) * 32;
+            const float* base = isb ? act_T + (t * (long)a_rows + o.b_row) * 32 : dy_T + (t * (long)g_rows + a_row0) * 32;
             const gchar_c* sb = (const gchar_c*)uniform_ptr(base);
             const unsigned voff = (unsigned)(r * 128 + c * 16);
             const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)lds + (unsigned)(stage * STAGE + p * 1024));
@@ -588,57 +426,65 @@ __global__ __launch_bounds__(256) void wgrad_full_kernel(const WOp* ops, int n_o
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int rl = lane & 31, h = lane >> 5;
-    // row sums of this GEMM's dy_T rows (bias gradients) on the way, as in wgrad_kernel: the waves of the first column group
     const bool do_bias = dbias && o.bias_owner && cg == 0;               // wave-uniform
     float rs[MW];
 #pragma unroll
     for (int i = 0; i < MW; ++i) rs[i] = 0.f;
-    if (t0 < t1) issue(0, t0);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (t0 + s < t1) issue(s, t0 + s);
+    int st = 0;                                                          // stage of tile t
     for (long t = t0; t < t1; ++t) {
-        const int st = (int)((t - t0) & 1);
-        if (t + 1 < t1) {
-            issue(st ^ 1, t + 1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");    // this tile's pieces landed (the next tile's are younger)
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();                                                 // ... and everybody else's
+        // this wave's pieces of tile t have landed once at most the pieces of the younger tiles in flight are outstanding
+        const long younger = (t1 - 1 - t < NS - 2) ? t1 - 1 - t : NS - 2;
+        if (NS >= 4 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+        else if (NS >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                     // ... and everybody else's; everybody is also done reading the stage of tile t - 1
+        if (t + NS - 1 < t1) issue(st == 0 ? NS - 1 : st - 1, t + NS - 1);
         const lds_char* sa = lds + st * STAGE;
         const lds_char* sb_ = sa + MT * 32 * 128;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        // the operands of 8-point group q + 1 are read while the MFMAs of group q issue (two register sets: left to itself the
+        // compiler reads a group's operands into the registers the previous group's last MFMA has just released, and the first
+        // MFMA of every group waits for LDS)
+        f32x4 av[2][MW], bv[2][NW];
+        auto fetch = [&](int q) {
             const int c = 2 * q + h;
-            f32x4 av[MW], bv[NW];
 #pragma unroll
             for (int i = 0; i < MW; ++i) {
                 const int r = 32 * (MW * rg + i) + rl;
-                av[i] = *(const lds_f32x4*)(sa + (r * 8 + (c ^ ((r >> 1) & 7))) * 16);
+                av[q & 1][i] = *(const lds_f32x4*)(sa + (r * 8 + (c ^ ((r >> 1) & 7))) * 16);
             }
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
                 const int r = 32 * (NW * cg + j) + rl;
-                bv[j] = *(const lds_f32x4*)(sb_ + (r * 8 + (c ^ ((r >> 1) & 7))) * 16);
+                bv[q & 1][j] = *(const lds_f32x4*)(sb_ + (r * 8 + (c ^ ((r >> 1) & 7))) * 16);
             }
+        };
+        fetch(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < 3) fetch(q + 1);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int i = 0; i < MW; ++i)
 #pragma unroll
                     for (int j = 0; j < NW; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][m], bv[j][m], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 1][i][m], bv[q & 1][j][m], acc[i][j], 0, 0, 0);
             if (do_bias) {
 #pragma unroll
-                for (int i = 0; i < MW; ++i) rs[i] += (av[i][0] + av[i][1]) + (av[i][2] + av[i][3]);
+                for (int i = 0; i < MW; ++i) rs[i] += (av[q & 1][i][0] + av[q & 1][i][1]) + (av[q & 1][i][2] + av[q & 1][i][3]);
             }
         }
-        __syncthreads();                                                 // the stage is free for the tile after the next
+        st = (st + 1 == NS) ? 0 : st + 1;
     }
     if (do_bias) {
 #pragma unroll
         for (int i = 0; i < MW; ++i) {
             const float tot = rs[i] + __shfl_xor(rs[i], 32);
             if (h == 0) {
-                const int e = e_of[o.a_row + 32 * (MW * rg + i) + rl];
+                const int e = e_of[a_row0 + 32 * (MW * rg + i) + rl];
                 if (e >= 0) dbias[(long)ks * n_bias + e] = tot;                 // one writer per (slice, element)
             }
         }
@@ -650,44 +496,105 @@ __global__ __launch_bounds__(256) void wgrad_full_kernel(const WOp* ops, int n_o
         for (int j = 0; j < NW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = 32 * (MW * rg + i) + tile_feat(h, r), col = 32 * (NW * cg + j) + rl;
-                c[(long)row * (32 * NT) + col] = acc[i][j][r];
+                const int row = 32 * (m_tile0 + MW * rg + i) + tile_feat(h, r), col = 32 * (NW * cg + j) + rl;
+                c[(long)row * o.N + col] = acc[i][j][r];
             }
 }
-template <int MT, int NT, int RG>
-static hipError_t launch_wgrad_shape(const WOp* ops_dev, int n_ops, const float* dy_T, const float* act_T, long n_tiles, int g_rows,
-                                     int a_rows, int ksplit, float* C, long c_stride, const int* e_of, float* dbias, int n_bias,
-                                     hipStream_t st) {
-    constexpr int lds = 2 * (MT + NT) * 4 * 1024;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad_full_kernel<MT, NT, RG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
+// row sums only (N = 0): up to 64 dy_T rows from row tile m_tile0 on, summed over the slice's points straight from memory.
+// Thread (row = tid & 63, quarter = tid >> 6) adds points 8 quarter .. 8 quarter + 7 of every tile in tile order, then the four
+// quarters are added in index order: a fixed order.
+__device__ __forceinline__ void wgrad_rows_part(const WOp& o, int m_tile0, int ks, const float* dy_T, long n_tiles, int g_rows, int ksplit,
+                                                const int* e_of, float* dbias, int n_bias, lds_char* lds) {
+    const long per = (n_tiles + ksplit - 1) / ksplit;
+    const long t0 = ks * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
+    if (t0 >= t1 || !dbias || !o.bias_owner) return;
+    const int row = threadIdx.x & 63, quarter = threadIdx.x >> 6;
+    const int r = 32 * m_tile0 + row;                                    // row inside the GEMM's block
+    float s = 0.f;
+    if (r < o.M) {
+        const float* p = dy_T + ((long)t0 * g_rows + o.a_row + r) * 32 + 8 * quarter;
+        for (long t = t0; t < t1; ++t, p += (long)g_rows * 32) {
+            const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+            s += ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
+        }
     }
-    // one workgroup per (GEMM, slice); a workgroup of another shape's GEMM exits at once
-    hipLaunchKernelGGL((wgrad_full_kernel<MT, NT, RG>), dim3(n_ops * ksplit), dim3(256), lds, st, ops_dev, n_ops, dy_T, act_T, n_tiles,
-                       g_rows, a_rows, ksplit, C, c_stride, e_of, dbias, n_bias);
-    return hipGetLastError();
+    lds_f32* red = (lds_f32*)lds;
+    red[quarter * 64 + row] = s;
+    __syncthreads();
+    if (quarter == 0 && r < o.M) {
+        const float tot = (red[row] + red[64 + row]) + (red[128 + row] + red[192 + row]);
+        const int e = e_of[o.a_row + r];
+        if (e >= 0) dbias[(long)ks * n_bias + e] = tot;
+    }
+}
+constexpr int WN_LDS_BYTES = 72 * 1024;
+__global__ __launch_bounds__(256, 2) void wgrad_narrow_kernel(const WOp* ops, const WNItem* items, const float* dy_T, const float* act_T,
+                                                              long n_tiles, int g_rows, int a_rows, int ksplit, float* C,
+                                                              long c_stride, const int* e_of, float* dbias, int n_bias) {
+    extern __shared__ __attribute__((aligned(16))) char wn_smem[];
+    lds_char* lds = (lds_char*)wn_smem;
+    const WNItem it = items[blockIdx.x];
+    const WOp o = ops[it.op];
+#define DFN_WN(MT, NT, RG, NS) \
+    wgrad_lds_part<MT, NT, RG, NS>(o, it.m_tile0, it.ks, dy_T, act_T, n_tiles, g_rows, a_rows, ksplit, C, c_stride, e_of, dbias, n_bias, lds)
+    switch (it.shape) {                                                  // (uniform over the workgroup)
+        case WN_4x4: DFN_WN(4, 4, 2, 2); break;                          // 128 x 128 of a 256 x 128 GEMM: wave = 2 x 2 tiles, 32-KiB stages
+        case WN_4x2: DFN_WN(4, 2, 4, 3); break;                          // 128 x 64 of a 256 x 64 GEMM: wave = 1 x 2 tiles, 24-KiB stages
+        case WN_1x8: DFN_WN(1, 8, 1, 2); break;                          // 32 x 256: wave = 1 x 2 tiles, 36-KiB stages
+        case WN_4x1: DFN_WN(4, 1, 4, 3); break;                          // 128 x 32 of a 256 x 32 GEMM: wave = 1 tile, 20-KiB stages
+        case WN_2x2: DFN_WN(2, 2, 2, 4); break;                          // 64 x 64: wave = 1 tile, 16-KiB stages
+        default: wgrad_rows_part(o, it.m_tile0, it.ks, dy_T, n_tiles, g_rows, ksplit, e_of, dbias, n_bias, lds); break;
+    }
+#undef DFN_WN
 }
 
-hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, int n_ops, const int* prefix_dev, int total_items,
-                        const void* dy_T, const void* act_T, long NP, int ksplit, float* C, long c_stride, const int* e_of,
-                        float* dbias, int n_bias, hipStream_t st) {
-    const int blocks = (total_items + 3) / 4;
+// the 256 x 256 GEMMs (two 64-KiB stages; `full_ops`: their indices in `ops`, dfn_api.hip)
+__global__ __launch_bounds__(256) void wgrad_full_kernel(const WOp* ops, const int* full_ops, const float* dy_T, const float* act_T,
+                                                          long n_tiles, int g_rows, int a_rows, int ksplit, float* C, long c_stride,
+                                                          const int* e_of, float* dbias, int n_bias) {
+    extern __shared__ __attribute__((aligned(16))) char wf1_smem[];
+    const WOp o = ops[full_ops[blockIdx.x / ksplit]];
+    wgrad_lds_part<8, 8, 4, 2, 128 * 1024>(o, 0, blockIdx.x % ksplit, dy_T, act_T, n_tiles, g_rows, a_rows, ksplit, C, c_stride, e_of, dbias,
+                                           n_bias, (lds_char*)wf1_smem);
+}
+
+// hipFuncSetAttribute once per (kernel, device): a second device of the process needs it too
+template <typename K> static hipError_t lds_attr_once(K kernel, int bytes, bool (&done)[64]) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !done[dev]) {
+        e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) done[dev] = true;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, const int* full_ops_dev, int n_full, const WNItem* nitems_dev,
+                        int n_nitems, const void* dy_T, const void* act_T, long NP, int ksplit, float* C, long c_stride,
+                        const int* e_of, float* dbias, int n_bias, hipStream_t st) {
     const bool torso = field == FIELD_TORSO;
     const int g_rows = torso ? GradMap::S_ROWS : GradMap::H_ROWS, a_rows = torso ? RecMap::S_ROWS : RecMap::H_ROWS;
     if (tier != TIER_F32) return hipErrorInvalidValue;          // bf16: launch_wgrad_bf16
-    // the 256 x 256 GEMMs through LDS (8 of a field's GEMMs, 89 % of its FLOPs), then the small shapes in the general kernel
     const float *dy = (const float*)dy_T, *ac = (const float*)act_T;
-    hipError_t e1;
-#define DFN_WSHAPE(MT, NT, RG)                                                                                           \
-    if ((e1 = launch_wgrad_shape<MT, NT, RG>(ops_dev, n_ops, dy, ac, NP / 32, g_rows, a_rows, ksplit, C, c_stride, e_of, dbias, n_bias, st)) != hipSuccess) return e1;
-    DFN_WSHAPE(8, 8, 4)
-#undef DFN_WSHAPE
-    hipLaunchKernelGGL(wgrad_kernel, dim3(blocks), dim3(256), 0, st, ops_dev, n_ops, prefix_dev, dy_T, act_T, NP / 32,
-                       g_rows, a_rows, ksplit, C, c_stride, e_of, dbias, n_bias);
-    return hipGetLastError();
+    hipError_t e;
+    if (n_full > 0) {           // the 256 x 256 GEMMs (8 of a field's GEMMs, 89 % of its FLOPs): one workgroup per (GEMM, slice)
+        constexpr int lds = 2 * (8 + 8) * 4 * 1024;
+        static bool done[64] = {};
+        if ((e = lds_attr_once(wgrad_full_kernel, lds, done)) != hipSuccess) return e;
+        hipLaunchKernelGGL(wgrad_full_kernel, dim3(n_full * ksplit), dim3(256), lds, st, ops_dev, full_ops_dev, dy, ac, NP / 32,
+                           g_rows, a_rows, ksplit, C, c_stride, e_of, dbias, n_bias);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (n_nitems > 0) {         // everything else, side by side in one launch
+        static bool done[64] = {};
+        if ((e = lds_attr_once(wgrad_narrow_kernel, WN_LDS_BYTES, done)) != hipSuccess) return e;
+        hipLaunchKernelGGL(wgrad_narrow_kernel, dim3(n_nitems), dim3(256), WN_LDS_BYTES, st, ops_dev, nitems_dev, dy, ac, NP / 32, g_rows,
+                           a_rows, ksplit, C, c_stride, e_of, dbias, n_bias);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // ================================================================================================

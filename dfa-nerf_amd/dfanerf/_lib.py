@@ -98,6 +98,7 @@ def _load():
         "dfn_composite_bwd": (i32, [C.POINTER(DfnFrame), ip, fp, vp, fp, fp, fp, fp, vp]),
         "dfn_composite_bwd_z": (i32, [C.POINTER(DfnFrame), ip, fp, vp, fp, fp, fp, fp, fp, lg, vp]),
         "dfn_mlp_bwd": (i32, [i32, i32, vp, fp, fp, vp, lg, vp, vp]),
+        "dfn_wgrad_plan": (lg, [i32, i32, ip, lg]),
         "dfn_weight_grad": (i32, [i32, i32, vp, vp, lg, fp, fp, vp]),
         "dfn_weight_bias_grad": (i32, [i32, i32, vp, vp, lg, fp, fp, fp, vp]),
         "dfn_weight_bias_grad_fmt": (i32, [i32, i32, i32, vp, vp, lg, fp, fp, fp, vp]),

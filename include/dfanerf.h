@@ -263,6 +263,13 @@ int dfn_composite_bwd_hier_z(const DfnFrame* frame, const int32_t* pix_index, co
                              const float* d_rgb_com, float* dsamples, float* zero_buf, long zero_floats, void* stream);
 int dfn_mlp_bwd(int tier, int field, const void* packed_T, const float* samples, const float* dsamples,
                 const uint32_t* masks, long NP, void* dy_T, void* stream);
+/* The weight-gradient plan of `field` (0 head, 1 torso), for tests and tools: what == 0 -> the GEMM list, 6 int32 per GEMM
+ * {a_row, M, b_row, N, c_off, bias_owner}: C[M x N] = dy_T rows [a_row, a_row + M) x act_T rows [b_row, b_row + N)^T summed over the
+ * points, stored row-major at c_off of the dense partial array; what == 1 -> map[i] = index into the flat decoder parameter vector
+ * the dense element i is added to (-1: structural padding); what == 2 -> bias_rows[e] = dy_T row whose sum over the points is the
+ * gradient of bias-blob element e (-1: none).  Returns the number of int32 (out may be NULL to ask), negative on error.
+ * (The backward of Decoder.forward, decoder.py:291-349: one GEMM per nn.Linear the field evaluates.) */
+long dfn_wgrad_plan(int field, int what, int32_t* out, long capacity);
 /* (16-bit tier: dfn_weight_grad / dfn_weight_bias_grad read act_T in the fused step's DEFAULT format, MX-fp4 - 16 bytes per row and
  * tile, dfn_train_rows(field, 6) bytes per tile, NP/32 + 1 tiles allocated, see above; for e4m3 arrays use the _fmt entry point) */
 int dfn_weight_grad(int tier, int field, const void* dy_T, const void* act_T, long NP, float* workspace,
