@@ -32,7 +32,9 @@ Prints ONE JSON line on rank 0 (fields: see the driver contract), including
                  hierarchical, 16-bit training tier - `dtype` spells out its operand formats) and c4_f32 (the training step
                  in the exact tier), so that they are driver-timed numbers too;
   f16_range    - (N == 1, f16 tier) the range guard's calibration (dfanerf/f16guard.py) on the bench scene, after the timed loops: max
-                 |activation| over 256 rays of each frame in the exact tier and max |parameter| against half precision's 65504;
+                 |activation| over 256 rays of each frame in the exact tier and max |parameter| against half precision's 65504; and
+                 the accuracy guard's numbers on the same sample: psnr_vs_f32_db (f16 images against the exact tier's, worse of
+                 head / composite), the worst frame, the gate "within 0.05 dB" implies for a 30-dB model;
   parity_check - (N == 1) after the timed loops, 64 rays of the LAST timed frame rendered again in the timed configuration
                  and compared with the CPU oracle (outside the timed region): binds the timed launch to the parity suite.
 
@@ -847,6 +849,26 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
             out["f16_range"] = {"max_activation": top, "max_parameter": pk.f16_weight_max, "f16_max": f16guard.F16_MAX,
                                 "margin": f16guard.MARGIN, "frames": F, "rays_per_frame": 256,
                                 "worst_layer": max(((v, f"{fld}: {ly}") for fld, d in b.items() for ly, v in d.items()))[1]}
+            # ... and its accuracy guard (round 6): the same 256 rays x F frames in the f16 tier AND the exact tier, both fields,
+            # the workload's n_fine - PSNR of the f16 images against the exact tier's, whole sample and worst frame, next to the
+            # gate the north star's "within 0.05 dB" needs for a 30-dB model (f16guard.psnr_gate)
+            pk32 = engine.PackedDecoder(flat, "f32")
+            gen, blocks = torch.Generator(device="cpu").manual_seed(0), []
+            with torch.no_grad():
+                for f in range(F):
+                    pix = torch.randperm(H * W, generator=gen)[:256].to(torch.int32).to(dev)
+                    img = {}
+                    for name, p_ in (("f16", pk), ("f32", pk32)):
+                        fr = engine.make_frame(H, W, sc["focal"], sc["cx"], sc["cy"], sc["poses"][f], sc["pose_body"], sc["near"],
+                                               sc["far"], ray_count=256, n_fine=n_fine, fields=2)
+                        img[name] = engine.render(p_, p_.fold(sh[f], stt[f], zs_d, za_d), fr, bg, pix_index=pix)
+                    blocks.append({"head": (img["f16"][0], img["f32"][0], None), "com": (img["f16"][1], img["f32"][1], None)})
+            acc = f16guard.accuracy_stats(blocks)
+            out["f16_range"].update({"psnr_vs_f32_db": round(min(a["psnr_db"] for a in acc.values()), 2),
+                                     "psnr_vs_f32_worst_frame_db": round(min(a["worst_block_db"] for a in acc.values()), 2),
+                                     "psnr_gate_db": round(f16guard.psnr_gate(f16guard.DEFAULT_MODEL_PSNR), 2),
+                                     "psnr_by_image": {k: round(a["psnr_db"], 2) for k, a in acc.items()},
+                                     "n_fine": int(n_fine)})
         except Exception as e:
             out["f16_range"] = {"error": f"{type(e).__name__}: {e}"}
     if check and world == 1:

@@ -1,4 +1,4 @@
-"""Range guard of the f16 inference tier.
+"""Range guard and accuracy guard of the f16 inference tier.
 
 The throughput tier carries the decoder's activations and weights as IEEE half precision (v_mfma_f32_32x32x16_f16:
 10 mantissa bits, 5 exponent bits).  The conversion at the end of every layer (v_cvt_pk_f16_f32) does not saturate: an
@@ -13,8 +13,21 @@ f16 tier renders a sequence it is CALIBRATED:
 
 check() refuses (F16RangeError, naming the layer) when a bound times MARGIN exceeds f16's largest value; the bounds stay
 with the packed decoder (PackedDecoder.f16_bounds) so that a caller can read them.  bf16 and f32 have f32's exponent range
-and need no guard.  Reference semantics of the path: decoder.py:277-349 (fp32 throughout upstream)."""
+and need no guard.  Reference semantics of the path: decoder.py:277-349 (fp32 throughout upstream).
+
+ACCURACY (round 6).  A checkpoint inside f16's RANGE can still lose the north star's clause - "PSNR within 0.05 dB of
+reference" - to f16's 10 mantissa bits: a sharper density field (larger sigma gain) amplifies the rounding of the last
+layers.  The clause is about the model's PSNR against ground truth; what can be measured without ground truth is the f16
+image against the exact tier's.  An error uncorrelated with the model's own adds in mean square: the model's PSNR moves by
+10 log10(1 + mse_f16 / mse_model) <= 0.05 dB  <=>  PSNR(f16 vs f32) >= PSNR(model) + 19.36 dB (psnr_gate: 49.4 dB for a
+30-dB model, 54.4 for a 35-dB one).  accuracy_stats() takes the SAME calibration sample - a few hundred rays of up to eight
+frames, rendered in both tiers with the production settings (two fields, the run's n_fine) - and reports the whole-sample
+and the worst-frame PSNR per image; check_accuracy() refuses (F16AccuracyError) under the gate.  The model's own PSNR is
+measured on the sample where ground truth exists (training / validation frames), a flag otherwise (--hip_f16_model_psnr,
+default 30 dB: the level the reference's lineage reports).  `--hip_tier auto` renders in f16 when both guards pass and in
+the exact tier when one refuses."""
 import ctypes as C
+import math
 
 import numpy as np
 import torch
@@ -27,8 +40,75 @@ F16_MAX = 65504.0
 MARGIN = 4.0          # an unseen frame may exceed the calibrated maximum; 4x still leaves f16 13 binades above a |h| of 13
 
 
+CLAUSE_DB = 0.05      # BASELINE.json north_star: "PSNR within 0.05 dB of reference"
+DEFAULT_MODEL_PSNR = 30.0
+BLOCK_SLACK_DB = 3.0  # a single frame's few hundred rays are 1/8 of the sample: its PSNR may sit this far under the gate
+
+
 class F16RangeError(RuntimeError):
     pass
+
+
+class F16AccuracyError(RuntimeError):
+    pass
+
+
+def psnr_gate(model_psnr_db, clause_db=CLAUSE_DB):
+    """PSNR (dB) of the f16 image against the exact tier's from which on the model's PSNR against ground truth cannot move by
+    more than clause_db (errors uncorrelated with the model's own add in mean square)."""
+    return float(model_psnr_db) + 10.0 * math.log10(1.0 / (10.0 ** (clause_db / 10.0) - 1.0))
+
+
+def _psnr(mse):
+    return float("inf") if mse <= 0.0 else -10.0 * math.log10(mse)
+
+
+def accuracy_stats(blocks):
+    """blocks: one dict per calibration frame, image name ("head" / "com") -> (rgb_f16 [n,3], rgb_f32 [n,3], gt [n,3] or None),
+    float tensors in [0, 1].  -> {"head": {...}, "com": {...}} with psnr_db (whole sample, f16 against f32), worst_block_db,
+    max_abs, n_rays, and model_psnr_db (f32 against ground truth, None without one)."""
+    out = {}
+    for name in sorted({k for b in blocks for k in b}):
+        mses, gts, top, n = [], [], 0.0, 0
+        for b in blocks:
+            if name not in b:
+                continue
+            lo, hi, gt = b[name]
+            d = lo.double() - hi.double()
+            mses.append(float((d * d).mean()))
+            top = max(top, float(d.abs().max()))
+            n += lo.shape[0]
+            if gt is not None:
+                e = hi.double() - gt.double()
+                gts.append(float((e * e).mean()))
+        if not mses:
+            continue
+        out[name] = {"psnr_db": _psnr(sum(mses) / len(mses)), "worst_block_db": _psnr(max(mses)), "max_abs": top, "n_rays": n,
+                     "blocks": len(mses), "model_psnr_db": _psnr(sum(gts) / len(gts)) if gts else None}
+    return out
+
+
+def check_accuracy(stats, model_psnr_db=None, what="the decoder"):
+    """raise F16AccuracyError if an image of the calibration sample is under the clause's gate; -> the gates used, per image.
+    model_psnr_db: the model's PSNR against ground truth where the sample had none (default DEFAULT_MODEL_PSNR); an image
+    whose sample came with ground truth is gated on its own measured PSNR."""
+    bad, gates = [], {}
+    for name, st in stats.items():
+        m = st.get("model_psnr_db")
+        if m is None:
+            m = DEFAULT_MODEL_PSNR if model_psnr_db is None else float(model_psnr_db)
+        g = gates[name] = psnr_gate(m)
+        if not (st["psnr_db"] >= g):
+            bad.append(f"{name} image: {st['psnr_db']:.1f} dB against the exact tier over {st['n_rays']} rays, the clause needs "
+                       f"{g:.1f} dB (model at {m:.1f} dB)")
+        elif not (st["worst_block_db"] >= g - BLOCK_SLACK_DB):
+            bad.append(f"{name} image: worst frame of the sample {st['worst_block_db']:.1f} dB against the exact tier, "
+                       f"{BLOCK_SLACK_DB:g} dB under the clause's {g:.1f} dB (model at {m:.1f} dB)")
+    if bad:
+        raise F16AccuracyError(
+            f"--hip_tier f16: {what} loses the accuracy clause (PSNR within {CLAUSE_DB} dB of the reference) in half precision: "
+            + "; ".join(bad) + ".  Use --hip_tier f32 (exact) or --hip_tier auto (f16 only where both guards pass)")
+    return gates
 
 
 # groups of act_T rows (csrc/dfn_mlp.h: RecMap): every GEMM input of a field, in recorder order

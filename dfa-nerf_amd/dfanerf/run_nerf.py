@@ -99,7 +99,10 @@ _FLAGS = [
 # --image_ext: file type of the rendered frames (upstream writes .jpg, MAIN:722-732; png = the kernel's uint8 output
 # losslessly, which is what the parity tests read back)
 # --hip_train_act: format of the activations the 16-bit training step records for its weight gradients (fp4 | e4m3)
-_EXTRA_FLAGS = [("hip_tier", str, 'f32'), ("hierarchical", None, None), ("image_ext", str, 'jpg'), ("hip_train_act", str, 'fp4')]
+# --hip_f16_model_psnr: the model's PSNR against ground truth, for the f16 tier's accuracy guard where the frames being rendered
+# have no ground truth (f16guard.py)
+_EXTRA_FLAGS = [("hip_tier", str, 'f32'), ("hierarchical", None, None), ("image_ext", str, 'jpg'), ("hip_train_act", str, 'fp4'),
+                ("hip_f16_model_psnr", float, 30.0)]
 _EXTRA_HELP = {
     "hip_tier": "precision tier of the HIP path: f32 (exact MFMA products, the parity tier; default) | f16 (throughput tier "
                 "for rendering: f16 MFMA operands, f32 accumulation) | bf16.  TRAINING with f16 or bf16 runs the 16-bit "
@@ -107,7 +110,10 @@ _EXTRA_HELP = {
                 "in MX block formats (one power-of-two scale per 64 features x 32 points): the pre-activation gradients as "
                 "MX-fp8 (e4m3; values below amax * 2^-17 of a block flush to zero), the layer inputs as MX-fp4 (e2m1: ONE "
                 "mantissa bit; --hip_train_act e4m3 records them in 8 bits instead) - the weight-gradient GEMMs run on them.  "
-                "Use f32 for a reference-exact training run",
+                "Use f32 for a reference-exact training run.  auto: render in f16 when the checkpoint passes the f16 tier's range "
+                "AND accuracy guards on a calibration sample of the frames (dfanerf/f16guard.py), in f32 otherwise; trains in f32",
+    "hip_f16_model_psnr": "f16 tier's accuracy guard: PSNR (dB) of the model against ground truth, used where the rendered frames "
+                          "have none (with ground truth it is measured); the f16 image must stay within 0.05 dB of it",
     "hip_train_act": "16-bit training tier: format of the recorded layer inputs that feed the weight gradients: fp4 (MX-fp4 "
                      "e2m1, default: half the bytes; a weight gradient sums >= 131,072 points and the rounding averages out - "
                      "tests/test_gpu_convergence.py trains to convergence in both) | e4m3 (MX-fp8, +5 % step time)",
@@ -337,6 +343,10 @@ class FrameRenderer:
         self.engine = engine
         self.decoder, self.args = decoder, args
         self.tier = tier or getattr(args, "hip_tier", "f32")
+        # auto: f16 where the checkpoint passes both guards of the f16 tier (check_f16), the exact tier otherwise
+        self.auto = self.tier == "auto"
+        if self.auto:
+            self.tier = "f16"
         H, W, focal, cx, cy = hwfcxy
         self.H, self.W, self.focal, self.cx, self.cy = int(H), int(W), float(focal), float(cx), float(cy)
         self.near, self.far = float(near), float(far)
@@ -370,6 +380,66 @@ class FrameRenderer:
         print(f"[dfanerf] f16 tier: calibrated on {len(pick)} frames x {n_rays} rays in the exact tier: max |activation| "
               f"{top:.4g}, max |parameter| {pk.f16_weight_max:.4g} (half precision holds {f16guard.F16_MAX:.0f}; margin x{f16guard.MARGIN:g})")
         return pk.f16_bounds
+
+    def check_f16_accuracy(self, poses, pose_body, signals, max_frames=8, n_rays=256, targets=None, model_psnr=None, seed=0):
+        """f16 tier only (no-op otherwise): the accuracy guard.  Renders `n_rays` random pixels of up to `max_frames` of the
+        frames about to be rendered in the f16 tier AND in the exact tier, with the production settings (both fields, this
+        renderer's n_fine, the frames' own poses and signals), and refuses (f16guard.F16AccuracyError) if the f16 images sit
+        under the PSNR the north star's clause needs (f16guard.psnr_gate).  targets(k) -> (head [H*W,3], com [H*W,3]) ground
+        truth (uint8 or float in [0,1], either may be None) where it exists: the model's own PSNR is then measured on the
+        sample; model_psnr (dB) otherwise.  The statistics stay on the packed decoder (`f16_accuracy`)."""
+        if self.tier != "f16" or len(poses) == 0:
+            return None
+        from . import f16guard
+        eng, dev = self.engine, self.bg.device
+        pick = sorted(set(np.linspace(0, len(poses) - 1, min(max_frames, len(poses))).astype(int).tolist()))
+        gen = torch.Generator(device="cpu").manual_seed(seed)
+        blocks = []
+        with torch.no_grad():
+            for k in pick:
+                a, b = signals(k)
+                pix = torch.randperm(self.H * self.W, generator=gen)[:n_rays].to(torch.int32).to(dev)
+                img = {}
+                for tier in ("f16", "f32"):
+                    pk = self.decoder.packed(tier)
+                    bias = pk.fold(a.reshape(-1), b.reshape(-1), self.zs, self.za)
+                    fr = eng.make_frame(self.H, self.W, self.focal, self.cx, self.cy, _host(poses[k]), _host(pose_body), self.near,
+                                        self.far, self.args.last_dist, 0, n_rays, self.args.N_samples, self.n_fine, 2,
+                                        self.args.concate_bg)
+                    img[tier] = eng.render(pk, bias, fr, self.bg, pix_index=pix)
+                gt = targets(k) if targets is not None else (None, None)
+                def at(t):
+                    if t is None:
+                        return None
+                    t = torch.as_tensor(t).reshape(-1, 3).to(dev)[pix.long()]
+                    return t.float() / 255.0 if t.dtype == torch.uint8 else t.float()
+                blocks.append({"head": (img["f16"][0], img["f32"][0], at(gt[0])), "com": (img["f16"][1], img["f32"][1], at(gt[1]))})
+        pk = self.decoder.packed("f16")
+        pk.f16_accuracy = f16guard.accuracy_stats(blocks)
+        mp = getattr(self.args, "hip_f16_model_psnr", None) if model_psnr is None else model_psnr
+        gates = f16guard.check_accuracy(pk.f16_accuracy, mp)
+        print("[dfanerf] f16 tier: accuracy on %d frames x %d rays against the exact tier: " % (len(pick), n_rays) +
+              ", ".join(f"{n} {st['psnr_db']:.1f} dB (worst frame {st['worst_block_db']:.1f}, gate {gates[n]:.1f})"
+                        for n, st in pk.f16_accuracy.items()))
+        return pk.f16_accuracy
+
+    def check_f16(self, poses, pose_body, signals, targets=None, max_frames=8, n_rays=256):
+        """Both guards of the f16 tier in front of a render loop (no-op in any other tier): range, then accuracy.  With
+        --hip_tier auto a refusal switches this renderer to the exact tier instead of raising.  -> the tier that will render."""
+        if self.auto:
+            self.tier = "f16"          # (every call decides again: the weights may have changed since the last one)
+        if self.tier != "f16":
+            return self.tier
+        from . import f16guard
+        try:
+            self.check_f16_range(poses, pose_body, signals, max_frames, n_rays)
+            self.check_f16_accuracy(poses, pose_body, signals, max_frames, n_rays, targets=targets)
+        except (f16guard.F16RangeError, f16guard.F16AccuracyError) as e:
+            if not self.auto:
+                raise
+            print(f"[dfanerf] --hip_tier auto: rendering in the exact tier (f32): {e}")
+            self.tier = "f32"
+        return self.tier
 
     def render(self, pose, pose_body, signal, signal_torso, ray_begin=0, ray_count=None, pix_index=None, fields=2,
                out_u8=False, out=None, bias=None):
@@ -728,8 +798,8 @@ def check_supported(args):
         bad.append(f"--hierarchical with --N_importance {args.N_importance} (supported: 64, 128)")
     if args.n_object != 1:
         bad.append(f"--n_object {args.n_object} (the scripts train one person: 1)")
-    if args.hip_tier not in ("f32", "f16", "bf16"):
-        bad.append(f"--hip_tier {args.hip_tier} (f32 | f16 | bf16)")
+    if args.hip_tier not in ("f32", "f16", "bf16", "auto"):
+        bad.append(f"--hip_tier {args.hip_tier} (f32 | f16 | bf16 | auto)")
     if getattr(args, "hip_train_act", "fp4") not in ("fp4", "e4m3"):
         bad.append(f"--hip_train_act {args.hip_train_act} (fp4 | e4m3)")
     if bad:
@@ -835,7 +905,12 @@ def train():
                     st_ = encode_signal_torso(datasets, itr_obj, img_i, nets.get("PoseAttNet"), global_step, args, len_sig,
                                               embed_fn=embed_fn)
                 return sg[0], st_
-            renderer.check_f16_range([poses_host[i] for i in frame_ids], body_host, sig_of)
+            # ... and the accuracy guard: the same sample in f16 AND the exact tier, production settings (f16guard.py, round 6)
+            renderer.check_f16([poses_host[i] for i in frame_ids], body_host, sig_of)
+            if pf is not None and pf.pk is not renderer.decoder.packed(renderer.tier):       # (auto fell back to the exact tier)
+                pf = engine.FramePrefetcher(enc, renderer.decoder.packed(renderer.tier), renderer.zs, renderer.za,
+                                            args.smo_size if smoothed else 0, args.smo_torse_size if smoothed else 0, fields=2,
+                                            length=len_sig)
         for k, img_i in enumerate(frame_ids):
             with torch.no_grad():
                 if pf is not None:
@@ -885,6 +960,7 @@ def train():
     from . import training
     # the 16-bit training tier is bf16 (f16, the inference throughput tier, has too little exponent range for gradients)
     tier = getattr(args, "hip_tier", "f32")
+    tier = "f32" if tier == "auto" else tier        # (auto = the fastest tier that keeps the accuracy clause: training is exact)
     train_buf = training.TrainBuffers("bf16" if tier == "f16" else tier, args.N_rand, dev,
                                       n_fine=args.N_importance if getattr(args, "hierarchical", False) else 0,
                                       act_format=getattr(args, "hip_train_act", None))
@@ -951,6 +1027,23 @@ def train():
                 enc_t = engine.SignalEncoder(nets["AudNet"], nets["ExpNet"], nets["AudAttNet"], nets["PoseAttNet"],
                                              ds['auds'], ds['exp'], ds['poses'])
             smoothed = global_step >= args.nosmo_iters
+            def test_signals(img_id):
+                with torch.no_grad():
+                    if enc_t is not None:
+                        s2, t2 = enc_t.encode([img_id], args.smo_size if smoothed else 0,
+                                              args.smo_torse_size if smoothed else 0, length=len(i_train) + len(i_val))
+                        return s2[0], t2[0]
+                    sg = encode_signal(datasets, itr_obj, img_id, args.dim_aud, nets["AudNet"], nets["ExpNet"], nets["AudAttNet"],
+                                       global_step, args, len(i_train) + len(i_val), embed_fn=embed_fn)
+                    st_ = encode_signal_torso(datasets, itr_obj, img_id, nets.get("PoseAttNet"), global_step, args,
+                                              len(i_train) + len(i_val), embed_fn=embed_fn)
+                    return sg[0], st_
+            test_ids = [i_val[t] for t in range(0, len(i_val), 100)]
+            if renderer.tier == "f16" and test_ids:
+                # the weights change every step: both guards of the f16 tier again on the frames about to be rendered, the model's
+                # own PSNR measured against their ground truth (this render used to run unguarded)
+                renderer.check_f16([poses_host[j] for j in test_ids], poses_host[0], lambda k: test_signals(test_ids[k]),
+                                   targets=lambda k: (_imread(ds['imgs'][test_ids[k]]), _imread(ds['imgs_com'][test_ids[k]])))
             for testimg_i in range(0, len(i_val), 100):
                 img_id = i_val[testimg_i]
                 with torch.no_grad():

@@ -285,7 +285,8 @@ def test_render_hierarchical_f32_vs_reference_golden(eng, packed, scene, latents
     # and 71-80 % of the rays identical; the sampler itself is bit-exact given the coarse weights
     # (test_hierarchical_sampler_is_bit_exact_given_the_coarse_weights), so what moves a depth is the ~1e-7 difference
     # of the coarse weights at sample_pdf's `denom < 1e-5` switch
-    assert clean.mean() > 0.65 and (dz > 2e-6).mean() < 0.003
+    # (round 6: the gate follows the measurement - 0.70, was 0.65; the box-to-box spread of the share is the coarse weights' 1e-7)
+    assert clean.mean() >= 0.70 and (dz > 2e-6).mean() < 0.003
     np.testing.assert_allclose(rh[clean], g[f"rgb_head_f{fields}"][clean], atol=5e-5, rtol=0)      # (1)
     if fields == 2:
         np.testing.assert_allclose(rc.cpu().numpy()[clean], g[f"rgb_com_f{fields}"][clean], atol=5e-5, rtol=0)
@@ -299,6 +300,12 @@ def test_render_hierarchical_f32_vs_reference_golden(eng, packed, scene, latents
           f"on the rays with a moved depth: max {d_all[~clean].max() if (~clean).any() else 0.0:.2e}; PSNR {psnr(final, ref):.1f} dB")
     # measured: head image max 3.1e-4 / 94.8 dB, two-field composite 2.2e-6 / 136.9 dB
     assert d_all.max() <= 1e-3 and psnr(final, ref) >= 85.0
+    # ... and as the uint8 image the reference writes (to8b, run_nerf_helpers.py:17: truncation): never more than one level
+    # off, one level on at most 0.5 % of the values ("identical except +-1 LSB")
+    to8 = lambda x: (255.0 * np.clip(x, 0.0, 1.0)).astype(np.uint8).astype(np.int32)
+    d8 = np.abs(to8(final) - to8(ref))
+    print(f"fields={fields}: uint8 image vs golden: {(d8 > 0).mean() * 100:.3f}% of the values differ, max {d8.max()} level(s)")
+    assert d8.max() <= 1 and (d8 > 0).mean() <= 0.005
     # (3)
     P = O.params_to_torch(states["decoder"])
     zs, za = [t(v) for v in latents]

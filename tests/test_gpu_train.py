@@ -136,6 +136,21 @@ def test_training_step_hip_vs_golden(states, scene, latents, golden, tier, step,
                         # tensor's rms + 10 % relative
                 np.testing.assert_allclose(samp, g[f"gsamp_{step}/{tag}/{k}"], rtol=1e-1, atol=2e-1 * rms + 1e-9)
     print(f"{tier} step {step}: worst relative gradient-norm error {worst:.2e}")
+    # the DIRECTION of every tensor's gradient (a norm cannot see a rotated gradient; G8 stores norms and 8 entries per tensor):
+    # cosine against the same step under torch CPU autograd through the oracle - which G8's own numbers pin above
+    ref_loss, ref_g = _oracle_full_step(states, scene, latents, sel, tgt_h.cpu(), tgt_c.cpu(), step)
+    np.testing.assert_allclose(ref_loss, g[f"loss_{step}"], rtol=3e-5)
+    worst_cos = 1.0
+    for tag, m in mods.items():
+        for k, p in m.named_parameters():
+            ref = ref_g[f"{tag}/{k}"]
+            if ref is None or float(ref.abs().max()) == 0.0:
+                continue
+            a, b = p.grad.detach().cpu().double().reshape(-1), ref.double().reshape(-1)
+            cos = float(a @ b / (a.norm() * b.norm()))
+            worst_cos = min(worst_cos, cos)
+            assert cos >= (1.0 - 1e-6 if tier == "f32" else 0.995), (tag, k, cos)
+    print(f"{tier} step {step}: worst per-tensor cosine against the oracle gradient {worst_cos:.6f}")
 
 
 _FULL = {}
@@ -218,6 +233,8 @@ def test_training_step_full_size_vs_oracle_autograd(states, scene, latents, tier
             assert abs(gn - rn) <= rel * rn + 1e-9, (tag, k, gn, rn)
             d = float((g - ref).double().norm()) / rn
             worst_dir = max(worst_dir, d)
+            cos = float(g.double().reshape(-1) @ ref.double().reshape(-1)) / (gn * rn)
+            assert cos >= (1.0 - 1e-6 if tier == "f32" else 0.995), (tag, k, cos)
             assert d <= (5e-4 if tier == "f32" else 1.0e-1), (tag, k, d)       # (measured round 4: 6.4e-5 / 6.9e-2; until round 3 the gates were 2e-3 / 1.5e-1)
             gs, rs_ = g.reshape(-1), ref.reshape(-1)
             stride = max(1, gs.numel() // 8)

@@ -45,7 +45,7 @@ def test_cli_flags_match_reference():
             if f["type"]:
                 assert a.type.__name__ == f["type"], f
     extra = set(acts) - {f["name"] for f in want} - {"help"}
-    assert extra == {"hip_tier", "hierarchical", "image_ext", "hip_train_act"}
+    assert extra == {"hip_tier", "hierarchical", "image_ext", "hip_train_act", "hip_f16_model_psnr"}
 
 
 def test_config_file_and_script_flags(tmp_path):
