@@ -160,27 +160,33 @@ def cpu_baseline(args, sc, st, zs, za, n_fine, fields):
     mp_runs = []
     if not os.environ.get("DFN_BENCH_NO_CPU_MP"):
         import subprocess
-        for T in (16, 32):
+        # (round 6: THREE repetitions of TWO whole 2048-ray chunks per process - every chunk is the complete path of its rays,
+        # coarse pass, sample_pdf, fine pass, compositing - and the MEDIAN repetition is the figure; round 5 timed one chunk per
+        # process once and moved by +-5 % from run to run.  One thread count per run: 16 where the host has 32+ cores.)
+        REPS, CHUNKS = 3, 2
+        for T in ((16,) if int(cores) // 16 >= 2 else (32, 8, 4)):
             n_proc = int(cores) // T
             if n_proc < 2:
                 continue
             try:
-                per_proc = max(out["single_process_value"] / n_proc * 1.3, 20.0)       # expected rays/s of one of P processes
-                chunks_each = max(1, int(round(args.cpu_seconds / 2 / (chunk / per_proc))))
-                span = H * W - chunks_each * chunk
+                span = H * W - CHUNKS * REPS * chunk
                 procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker",
-                                           f"{(i * chunks_each * chunk) % span},{chunks_each},{T},{n_fine},{fields}"],
+                                           f"{(i * CHUNKS * REPS * chunk) % span},{CHUNKS},{T},{n_fine},{fields},{REPS}"],
                                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
                                           env=dict(os.environ, OMP_NUM_THREADS=str(T), MKL_NUM_THREADS=str(T)))
                          for i in range(n_proc)]
                 res = []
                 for pr in procs:
-                    o, _ = pr.communicate(timeout=600)
+                    o, _ = pr.communicate(timeout=900)
                     res.append(json.loads([ln for ln in o.splitlines() if ln.startswith("{")][-1]))
-                rays = sum(r["rays"] for r in res)
-                secs = max(r["seconds"] for r in res)
-                mp_runs.append({"value": rays / secs, "unit": "rays/s", "processes": n_proc, "threads_per_process": T,
-                                "cores": n_proc * T, "seconds": secs, "chunks_per_process": chunks_each})
+                # the processes run the same amount of work side by side: a repetition's rate = the sum of the processes' rates
+                rates = sorted(sum(r["rays"] / r["seconds"][k] for r in res) for k in range(REPS))
+                secs = max(sum(r["seconds"]) for r in res)
+                mp_runs.append({"value": rates[len(rates) // 2], "unit": "rays/s", "processes": n_proc, "threads_per_process": T,
+                                "cores": n_proc * T, "seconds": secs, "chunks_per_process": CHUNKS * REPS, "repetitions": REPS,
+                                "repetition_rates": [round(v, 1) for v in rates],
+                                "spread": round((rates[-1] - rates[0]) / rates[len(rates) // 2], 4)})
+                break
             except Exception as e:                      # a reported extra: never lose the line to it
                 mp_runs.append({"error": f"{type(e).__name__}: {e}", "threads_per_process": T})
     good = [m for m in mp_runs if "value" in m]
@@ -191,8 +197,10 @@ def cpu_baseline(args, sc, st, zs, za, n_fine, fields):
         if top["value"] > out["value"]:
             out["value"], out["cores"] = top["value"], int(top["cores"])
             out["sample"] = (f"{top['processes']} processes x {top['threads_per_process']} threads = {top['cores']} of the host's "
-                             f"{int(cores)} physical cores, each process {top['chunks_per_process']} chunks of 2048 rays of frame 0 "
-                             f"concurrently ({top['seconds']:.1f} s), same workload, fp32, torch {torch.__version__} CPU: the oracle on "
+                             f"{int(cores)} physical cores, each process {top['repetitions']} repetitions of {top['chunks_per_process'] // top['repetitions']} "
+                             f"whole 2048-ray chunks of frame 0 (coarse pass, sample_pdf, fine pass, compositing) concurrently "
+                             f"({top['seconds']:.1f} s), median repetition (spread {top['spread'] * 100:.1f} %), same workload, fp32, "
+                             f"torch {torch.__version__} CPU: the oracle on "
                              f"every host core.  One process alone: {out['single_process_value']:.0f} rays/s at {best} threads, the "
                              "best of the thread sweep (torch's intra-op parallelism on 2048-ray chunks stops scaling at 8-32 threads)")
     elif mp_runs:
@@ -202,7 +210,7 @@ def cpu_baseline(args, sc, st, zs, za, n_fine, fields):
 
 def cpu_worker(spec):
     """one process of cpu_baseline.multi_process: `chunks` 2048-ray chunks of frame 0 from ray `begin` on `threads` threads"""
-    begin, chunks, threads, n_fine, fields = [int(v) for v in spec.split(",")]
+    begin, chunks, threads, n_fine, fields, reps = ([int(v) for v in spec.split(",")] + [1])[:6]
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import dfa_oracle as O
     from dfanerf import synth
@@ -225,7 +233,7 @@ def cpu_worker(spec):
                            torch.from_numpy(zs), torch.from_numpy(za), sig, sigt, 64, n_fine, fields, 2048, ray_begin=b, ray_count=n)
             return time.perf_counter() - t0
         run(0, 256)
-        secs = sum(run(begin + 2048 * c, 2048) for c in range(chunks))
+        secs = [sum(run(begin + 2048 * (chunks * k + c), 2048) for c in range(chunks)) for k in range(reps)]
     print(json.dumps({"rays": 2048 * chunks, "seconds": secs}))
 
 
@@ -382,7 +390,7 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
         flop_ray = 3 * S * (FLOP_PT_HEAD + FLOP_PT_TORSO)          # fwd + 2x bwd, SURVEY.md 8(d) (C4: 481.5 MFLOP/ray)
         ach = flop_ray * N_RAND * world * steps / dt / 1e12
         # SURVEY.md 8(d) prices the training step as MFMA-bound: `frac` is the MFMA fraction.  What actually bounds the step
-        # today is the traffic of what the forward records for the backward: `traffic` = bytes the DESIGN moves
+        # today is the traffic of what the forward records for the backward (LABNOTES.md 7): `traffic` = bytes the DESIGN moves
         # per step and GPU - the forward writes the GEMM inputs act_T, the dX chain the pre-activation gradients dy_T, the
         # weight-gradient GEMMs read both (rows from dfn_train_rows, NP = S * N_rand points, element = the tier's type) -
         # next to the ALGORITHMIC bytes of the step (pixel ids, targets, background, the four weight streams, the parameter
@@ -508,7 +516,7 @@ def power_ceiling(pk, tier, dev, kernel_tflops):
     B operands = post-ReLU-like activations (half zeros, |N(0,1)| otherwise) in the tier's type.  `bare_chain` = MFMAs only
     (operands in registers), `renderer_mix` = + one 1-KiB LDS fragment read per MFMA and two convert / max instructions per
     MFMA (what the decoder's epilogue cannot avoid).  The 2.5 PFLOP/s peak needs 2.4 GHz, which the part only holds when the
-    multipliers do not toggle (tools/vendor_gemm_ceiling.py calibrates the same ceiling with hipBLASLt)."""
+    multipliers do not toggle (LABNOTES.md 4.6; tools/vendor_gemm_ceiling.py calibrates the same ceiling with hipBLASLt)."""
     import ctypes as C
     from dfanerf._lib import check as chk, lib
     from dfanerf.engine import TIERS
@@ -852,13 +860,13 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
             # ... and its accuracy guard (round 6): the same 256 rays x F frames in the f16 tier AND the exact tier, both fields,
             # the workload's n_fine - PSNR of the f16 images against the exact tier's, whole sample and worst frame, next to the
             # gate the north star's "within 0.05 dB" needs for a 30-dB model (f16guard.psnr_gate)
-            pk32 = engine.PackedDecoder(flat, "f32")
+            pk16, pk32 = engine.PackedDecoder(flat, "f16"), engine.PackedDecoder(flat, "f32")     # (both fields, whatever the workload packs)
             gen, blocks = torch.Generator(device="cpu").manual_seed(0), []
             with torch.no_grad():
                 for f in range(F):
                     pix = torch.randperm(H * W, generator=gen)[:256].to(torch.int32).to(dev)
                     img = {}
-                    for name, p_ in (("f16", pk), ("f32", pk32)):
+                    for name, p_ in (("f16", pk16), ("f32", pk32)):
                         fr = engine.make_frame(H, W, sc["focal"], sc["cx"], sc["cy"], sc["poses"][f], sc["pose_body"], sc["near"],
                                                sc["far"], ray_count=256, n_fine=n_fine, fields=2)
                         img[name] = engine.render(p_, p_.fold(sh[f], stt[f], zs_d, za_d), fr, bg, pix_index=pix)

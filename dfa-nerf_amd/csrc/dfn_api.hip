@@ -38,6 +38,11 @@ bool tier_ok(int tier) { return tier == DFN_TIER_F32 || tier == DFN_TIER_BF16 ||
 bool train_tier_ok(int tier) { return tier == DFN_TIER_F32 || tier == DFN_TIER_BF16; }
 bool field_ok(int field) { return field >= 0 && field <= 2; }
 int prog_field(int field) { return field == DFN_FIELD_TORSO ? FIELD_TORSO : FIELD_HEAD; }
+// training entry points: head, torso and (round 6) the listener, i.e. the head's program on fc_in_listener / fc_p_skips_listener
+// (decoder.py:306-307, 322-323: `signal is None`).  Its dX chain IS the head's: the head's backward stream holds no input layer
+// (the positional encoding gets no gradient), so the transposed weight stream and the kernel are shared (bwd_field).
+bool train_field_ok(int field) { return field == DFN_FIELD_HEAD || field == DFN_FIELD_TORSO || field == DFN_FIELD_LISTENER; }
+int bwd_field(int field) { return field == DFN_FIELD_TORSO ? 1 : 0; }
 
 // cached pack plans: host copy + lazily uploaded device copy (per device the first caller uses)
 struct PlanEntry {
@@ -63,7 +68,7 @@ struct BwdPlanEntry {
     long n_frags = 0;
     int32_t* dev = nullptr;
 };
-BwdPlanEntry g_bwd_plans[2][2];
+BwdPlanEntry g_bwd_plans[2][2];     // [tier][bwd_field]
 struct WgradEntry {
     bool built = false;
     std::vector<WOpHost> ops;
@@ -89,7 +94,7 @@ struct WgradEntry {
     int n_sig = 0;
     int ksplit_uploaded = 0;
 };
-WgradEntry g_wgrad[2];
+WgradEntry g_wgrad[3];               // head, torso, listener
 #ifndef DFN_WGRAD_KSPLIT_F32
 #define DFN_WGRAD_KSPLIT_F32 32
 #endif
@@ -308,9 +313,11 @@ static int render_fwd_impl(int tier, const DfnFrame* frame, const void* packed_h
     if (!tier_ok(tier) || !frame || !packed_head || !bias_head || !rgb_head)
         return fail(DFN_E_ARG, "dfn_render_fwd: bad argument");
     const DfnFrame& F = *frame;
-    if (F.n_coarse != 64) return fail(DFN_E_ARG, "dfn_render_fwd: n_coarse must be 64");
+    // --N_samples (MAIN:612-619): 32, 64 or 128 coarse samples; the hierarchical sampler (a 64-lane wave program) needs 64
+    if (F.n_coarse != 32 && F.n_coarse != 64 && F.n_coarse != 128) return fail(DFN_E_ARG, "dfn_render_fwd: n_coarse must be 32, 64 or 128");
     if (F.n_fine != 0 && F.n_fine != 64 && F.n_fine != 128)
         return fail(DFN_E_ARG, "dfn_render_fwd: n_fine must be 0, 64 or 128");
+    if (F.n_fine != 0 && F.n_coarse != 64) return fail(DFN_E_ARG, "dfn_render_fwd: the hierarchical mode (n_fine > 0) needs n_coarse = 64");
     if (F.fields != 1 && F.fields != 2) return fail(DFN_E_ARG, "dfn_render_fwd: fields must be 1 or 2");
     if (F.fields == 2 && (!packed_torso || !bias_torso || !rgb_com))
         return fail(DFN_E_ARG, "dfn_render_fwd: torso inputs / rgb_com missing for fields == 2");
@@ -370,7 +377,7 @@ int dfn_render_fwd_u8(int tier, const DfnFrame* frame, const void* packed_head, 
 
 // ---- training ---------------------------------------------------------------------------------------------------
 long dfn_train_rows(int field, int what) {
-    if (field != DFN_FIELD_HEAD && field != DFN_FIELD_TORSO) return fail(DFN_E_ARG, "dfn_train_rows: bad field");
+    if (!train_field_ok(field)) return fail(DFN_E_ARG, "dfn_train_rows: bad field");
     const bool t = field == DFN_FIELD_TORSO;
     switch (what) {
     case 0: return t ? 64 + 640 + 128 + 9 * 256 + 32 : 64 + 9 * 256 + 32;          // activation rows (RecMap)
@@ -393,9 +400,9 @@ long dfn_train_rows(int field, int what) {
 }
 
 long dfn_packed_bwd_bytes(int tier, int field) {
-    if (!train_tier_ok(tier) || (field != 0 && field != 1)) return fail(DFN_E_ARG, "dfn_packed_bwd_bytes: bad tier/field");
+    if (!train_tier_ok(tier) || !train_field_ok(field)) return fail(DFN_E_ARG, "dfn_packed_bwd_bytes: bad tier/field");
     ProgramInfo pi;
-    bwd_program_info(tier, field, &pi);
+    bwd_program_info(tier, bwd_field(field), &pi);
     return (long)pi.n_slabs * SLAB_BYTES;
 }
 
@@ -421,11 +428,11 @@ static int bwd_plan_dev(int tier, int field, const int32_t** dev, long* n_out) {
 }
 
 int dfn_pack_weights_bwd(int tier, int field, const float* params, void* packed_T, void* stream) {
-    if (!train_tier_ok(tier) || (field != 0 && field != 1) || !params || !packed_T)
+    if (!train_tier_ok(tier) || !train_field_ok(field) || !params || !packed_T)
         return fail(DFN_E_ARG, "dfn_pack_weights_bwd: bad argument");
     const int32_t* plan;
     long n;
-    const int rc = bwd_plan_dev(tier, field, &plan, &n);
+    const int rc = bwd_plan_dev(tier, bwd_field(field), &plan, &n);
     if (rc != DFN_OK) return rc;
     hipError_t err = launch_pack(plan, params, packed_T, n, tier, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "pack_kernel(bwd)");
@@ -479,14 +486,14 @@ static int train_fwd_impl(int tier, const DfnFrame* frame, const void* packed_he
         !rgb_com || !samples || !act_head || !masks_head || !act_torso || !masks_torso || (hier && (!z_all || !ranks)))
         return fail(DFN_E_ARG, std::string(who) + ": bad argument");
     const DfnFrame& F = *frame;
-    if (!hier && (F.n_coarse != 64 || F.n_fine != 0 || F.fields != 2))
+    if (!hier && ((F.n_coarse != 32 && F.n_coarse != 64 && F.n_coarse != 128) || F.n_fine != 0 || F.fields != 2))
         return fail(DFN_E_ARG, "dfn_train_fwd: the training step is coarse-only (64 samples), two fields (MAIN:855-899); "
                                "dfn_train_fwd_hier is the hierarchical variant");
     if (hier && (F.n_coarse != 64 || (F.n_fine != 64 && F.n_fine != 128) || F.fields != 2))
         return fail(DFN_E_ARG, "dfn_train_fwd_hier: 64 coarse + 64 or 128 fine samples, two fields");
     if (!bg_f32 && !bg_u8) return fail(DFN_E_ARG, std::string(who) + ": no background given");
     if (F.ray_count <= 0) return DFN_OK;
-    const long NP = (long)F.ray_count * (64 + F.n_fine);
+    const long NP = (long)F.ray_count * (F.n_coarse + F.n_fine);
     if (dfn_train_rows(1, 0) * NP >= (1L << 32)) return fail(DFN_E_ARG, std::string(who) + ": too many rays per call");
     ProgramInfo ph, pt;
     program_info(tier, FIELD_HEAD, &ph);
@@ -586,7 +593,8 @@ static int composite_bwd_impl(const DfnFrame* frame, const int32_t* pix_index, c
                               float* zero_buf, long zero_floats, void* stream) {
     if (!frame || !samples || !d_rgb_head || !dsamples || (!bg_f32 && !bg_u8))
         return fail(DFN_E_ARG, "dfn_composite_bwd: bad argument");
-    if (frame->n_coarse != 64 || frame->n_fine != 0) return fail(DFN_E_ARG, "dfn_composite_bwd: 64 coarse samples only");
+    if ((frame->n_coarse != 32 && frame->n_coarse != 64 && frame->n_coarse != 128) || frame->n_fine != 0)
+        return fail(DFN_E_ARG, "dfn_composite_bwd: 32, 64 or 128 coarse samples, no fine ones (dfn_composite_bwd_hier)");
     if (frame->ray_count <= 0) return DFN_OK;
     CompositeBwdArgs A;
     A.frame = *frame;
@@ -660,9 +668,10 @@ int dfn_composite_bwd_hier_z(const DfnFrame* frame, const int32_t* pix_index, co
 
 int dfn_mlp_bwd(int tier, int field, const void* packed_T, const float* samples, const float* dsamples,
                 const uint32_t* masks, long NP, void* dy_T, void* stream) {
-    if (!train_tier_ok(tier) || (field != 0 && field != 1) || !packed_T || !samples || !dsamples || !masks || !dy_T ||
+    if (!train_tier_ok(tier) || !train_field_ok(field) || !packed_T || !samples || !dsamples || !masks || !dy_T ||
         NP <= 0 || NP % 32)
         return fail(DFN_E_ARG, "dfn_mlp_bwd: bad argument");
+    field = bwd_field(field);
     ProgramInfo pi;
     bwd_program_info(tier, field, &pi);
     MlpBwdArgs A;
@@ -703,7 +712,7 @@ static int weight_grad_impl(int tier, int field, int act_format, const void* dy_
     const bool gemm = stages & 1, red = stages & 2;
     if (act_format != DFN_ACT_E4M3 && act_format != DFN_ACT_E2M1)
         return fail(DFN_E_ARG, std::string(who) + ": act_format must be DFN_ACT_E4M3 or DFN_ACT_E2M1");
-    if (!train_tier_ok(tier) || (field != 0 && field != 1) || (gemm && (!dy_T || !act_T)) || !workspace || (red && !grad_flat) ||
+    if (!train_tier_ok(tier) || !train_field_ok(field) || (gemm && (!dy_T || !act_T)) || !workspace || (red && !grad_flat) ||
         NP <= 0 || NP % 32)
         return fail(DFN_E_ARG, std::string(who) + ": bad argument (NP must be a multiple of 32)");
     WgradEntry& w = wgrad_of(field);
@@ -844,7 +853,7 @@ static int weight_grad_impl(int tier, int field, int act_format, const void* dy_
 }
 
 long dfn_wgrad_plan(int field, int what, int32_t* out, long capacity) {
-    if ((field != 0 && field != 1) || what < 0 || what > 2) return fail(DFN_E_ARG, "dfn_wgrad_plan: bad field / selector");
+    if (!train_field_ok(field) || what < 0 || what > 2) return fail(DFN_E_ARG, "dfn_wgrad_plan: bad field / selector");
     WgradEntry& w = wgrad_of(field);
     std::vector<int32_t> ops;
     if (what == 0)
@@ -890,7 +899,7 @@ int dfn_weight_bias_grad_reduce(int tier, int field, long NP, float* workspace, 
 }
 
 int dfn_bias_grad(int tier, int field, const void* dy_T, long NP, float* workspace, float* dbias, void* stream) {
-    if (!train_tier_ok(tier) || (field != 0 && field != 1) || !dy_T || !workspace || !dbias || NP <= 0)
+    if (!train_tier_ok(tier) || !train_field_ok(field) || !dy_T || !workspace || !dbias || NP <= 0)
         return fail(DFN_E_ARG, "dfn_bias_grad: bad argument");
     WgradEntry& w = wgrad_of(field);
     {
@@ -1088,9 +1097,9 @@ int dfn_decoder_fwd(int tier, int field, const void* packed, const float* bias, 
 int dfn_decoder_train_fwd(int tier, int field, const void* packed, const float* bias, const float* points,
                           const float* dirs, long n, float* feat, float* sigma, float* samples, void* act_T,
                           uint32_t* masks, void* stream) {
-    if (!train_tier_ok(tier) || (field != DFN_FIELD_HEAD && field != DFN_FIELD_TORSO) || !packed || !bias || !points ||
+    if (!train_tier_ok(tier) || !train_field_ok(field) || !packed || !bias || !points ||
         !dirs || !feat || !sigma || !samples || !act_T || !masks)
-        return fail(DFN_E_ARG, "dfn_decoder_train_fwd: bad argument (tiers f32 / bf16, fields head / torso)");
+        return fail(DFN_E_ARG, "dfn_decoder_train_fwd: bad argument (tiers f32 / bf16, fields head / torso / listener)");
     if (n <= 0) return DFN_OK;
     const long NP = (n + 31) / 32 * 32;
     if (dfn_train_rows(1, 0) * NP >= (1L << 32)) return fail(DFN_E_ARG, "dfn_decoder_train_fwd: too many points per call");

@@ -99,7 +99,7 @@ template <int TIER, bool TORSO> inline hipError_t launch_mlp_bwd_t(const MlpBwdA
     const long n_tiles = A.NP / 32;
     int blocks = (int)((n_tiles + C::WAVES - 1) / C::WAVES);
 #ifndef DFN_BWD_PERSIST
-#define DFN_BWD_PERSIST 0      // measured: 213 -> 212 us (head), 237 -> 238 us (torso): the kernel is power-bound
+#define DFN_BWD_PERSIST 0      // measured: 213 -> 212 us (head), 237 -> 238 us (torso): the kernel is power-bound (LABNOTES.md 7)
 #endif
     if (DFN_BWD_PERSIST) {
         static int cus = 0;

@@ -614,7 +614,7 @@ hipError_t launch_zero_words(unsigned* p, long n, hipStream_t st) {
 }
 
 // ---- power-ceiling probe (dfn_debug_mfma_chain) -----------------------------------------------------------------------------
-// render_kernel's inner loop reduced to its cost drivers (tools/mfma_power_probe.hip is the stand-alone original):
+// render_kernel's inner loop reduced to its cost drivers (tools/mfma_power_probe.hip is the stand-alone original, LABNOTES.md 4.6):
 // 8 waves per workgroup, one workgroup per compute unit (150 KiB of LDS requested), every wave issuing the tier's 32x32x16 MFMA
 // on two alternating accumulator sets with LDS2 1-KiB fragment reads and VALU2 convert / max instructions per TWO MFMAs, on the
 // caller's operands.  (0, 0) = the bare chain: what the matrix pipe sustains on those operands under the chip's power limit;

@@ -30,7 +30,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define DFN_DEV __device__ __forceinline__
 // 1: in the bf16 inference render kernels the fragment reads and the LDS-DMA are inline asm with counted lgkmcnt waits
-// (-2.2 % on C2).  The build checks the generated ISA with tools/check_inflight.py: no instruction may
+// (-2.2 % on C2; LABNOTES.md 4.5).  The build checks the generated ISA with tools/check_inflight.py: no instruction may
 // touch an asm read's destination before the wait that retires it.  0 = everything through the compiler.
 #ifndef DFN_ASM_FETCH
 #define DFN_ASM_FETCH 1

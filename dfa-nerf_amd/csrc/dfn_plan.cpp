@@ -209,8 +209,11 @@ void build_wgrad_plan(int field, std::vector<WOpHost>& ops, std::vector<int32_t>
     const RowFn sig_rows = [](int r) { return r == 0 ? Src{P_SIGMA_W, 0} : Src{-1, 0}; };
     const RowFn out_rows = [](int r) { return r < 3 ? Src{P_FEATO_W, r} : Src{-1, 0}; };
     if (!torso) {
-        add(gt + GM::T_DY0, 256, RM::H_PE, 64, rows_of(P_FCIN_W), pe);
-        add(gt + GM::T_G4, 256, RM::H_PE, 64, rows_of(P_FCPSK_W), pe);
+        // head: the positional-encoding columns of fc_in / fc_p_skips (the signal columns multiply a per-frame constant: their
+        // gradient comes out of the fold's backward); listener (field 2, decoder.py:306-307, 322-323): its own two layers
+        const bool lis = field == 2;
+        add(gt + GM::T_DY0, 256, RM::H_PE, 64, rows_of(lis ? P_FCINL_W : P_FCIN_W), pe);
+        add(gt + GM::T_G4, 256, RM::H_PE, 64, rows_of(lis ? P_FCPSKL_W : P_FCPSK_W), pe);
     } else {
         const int dE[5] = {GM::S_DE0, GM::S_DE1, GM::S_DE2, GM::S_DE3, GM::S_DE4};
         const int dS[5] = {GM::S_DS0, GM::S_DS1, GM::S_DS2, GM::S_DS3, GM::S_DS4};

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
 #ifndef DFN_PIPE_TWO_HEAD    // 1: in the two-field kernel the HEAD's passes run the pipelined layers, the torso's (whose deformation
                              // field and skip input hold the registers the second accumulator set needs) the plain ones: 256
                              // VGPRs, nothing spilled, the same bits; C3 70.62 -> 70.24-70.36 ms (-0.4 %, interleaved, three rounds -
-                             // the kernel sits at its power ceiling, DESIGN.md 4.6: a better schedule is paid back in clock)
+                             // the kernel sits at its power ceiling, LABNOTES.md 4.6: a better schedule is paid back in clock)
 #define DFN_PIPE_TWO_HEAD 1
 #endif
     typedef CtxT<TRAIN != 0, TRAIN == 0, TRAIN != 0, (DFN_PIPE != 0) && TRAIN == 0 && (!TWO || DFN_PIPE_TWO != 0), TRAIN != 0 && ACT4> CtxK;      // (fused step: act_T in MX-fp4 unless ACT4 is off)
@@ -176,15 +176,19 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
     const int NF = TRAIN == 1 ? 0 : F.n_fine;     // TRAIN == 1: the training forward is the reference's coarse renderer
     const bool hier = NF > 0;
     const int KF = NF / 32;                        // fine tiles
-    const int S = 64 + NF;
+    // coarse samples per ray (--N_samples, MAIN:612-619): 64 in the scripts; 32 and 128 too when there is no fine pass (round 6:
+    // the coarse loop walks NC / 32 tiles; the hierarchical sampler is a 64-lane wave program and keeps NC = 64, dfn_api.hip)
+    const int NC = hier ? 64 : F.n_coarse;
+    const int S = NC + NF;
 
     Stream s;
     s.base0 = A.wblob[0];
     s.base1 = A.wblob[1];
     s.nslab0 = A.nslab[0];
     s.nslab1 = A.nslab[1];
-    // coarse: H T H T; fine: KF x H, then KF x T
-    s.sched = two ? (0xAu | (((1u << KF) - 1u) << (4 + KF))) : 0u;
+    // coarse: H T per coarse tile (NC / 32 of them: H T H T for the scripts' 64); fine: KF x H, then KF x T
+    const int KC = (F.n_fine > 0 && TRAIN != 1) ? 2 : F.n_coarse / 32;
+    s.sched = two ? ((0xAAu & ((1u << (2 * KC)) - 1u)) | (((1u << KF) - 1u) << (2 * KC + KF))) : 0u;
 #ifdef DFN_TIMING
     s.t_wait = s.t_bar = s.t_issue = 0;
     unsigned long long T_mlp = 0, T_pdf = 0;
@@ -256,8 +260,10 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
             for (int k = 0; k < 3; ++k) st[RS_RGB_H + k] = st[RS_RGB_C + k] = 0.f;
         }
         // coarse z: near*(1-t) + far*t (run_nerf_com_trainExpLater.py:617-618)
-        const float t = linspace01(lane, 64);
-        zall[lane] = add_(mul_(F.z_near, sub_(1.0f, t)), mul_(F.z_far, t));
+        for (int i = lane; i < NC; i += 64) {
+            const float t = linspace01(i, NC);
+            zall[i] = add_(mul_(F.z_near, sub_(1.0f, t)), mul_(F.z_far, t));
+        }
     }
     __syncthreads();     // bias blob + ray state visible (also drains the first two slab loads)
 
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
                 so[4] = b.sigma; so[5] = b.r; so[6] = b.g; so[7] = b.b;
             }
             // results live in lanes 0..31; mirror them so that both halves run the same arithmetic
-            const bool last = (si == 63);
+            const bool last = (si == NC - 1);
             const float znext = ((volatile lds_f32*)zall)[last ? si : si + 1];
             const float dz = last ? F.last_dist : sub_(znext, z);
             const float sg_h = __shfl(a.sigma, n);
@@ -391,11 +397,11 @@ __global__ __launch_bounds__(TierCfg<TIER>::THREADS, TierCfg<TIER>::THREADS / 25
             if (hier) {
                 if (lane < 32) tmp[si] = two ? w_c : w_h;
             } else if (valid && lane < 32) {
-                if (A.w_head) A.w_head[(size_t)r_raw * 64 + si] = w_h;
-                if (A.w_com && two) A.w_com[(size_t)r_raw * 64 + si] = w_c;
-                if (A.z_out) A.z_out[(size_t)r_raw * 64 + si] = z;
+                if (A.w_head) A.w_head[(size_t)r_raw * NC + si] = w_h;
+                if (A.w_com && two) A.w_com[(size_t)r_raw * NC + si] = w_c;
+                if (A.z_out) A.z_out[(size_t)r_raw * NC + si] = z;
             }
-            if (++tile < 2) continue;
+            if (++tile < NC / 32) continue;
             if (!hier) break;
 #ifdef DFN_TIMING
             const unsigned long long tp0 = __builtin_readcyclecounter();

@@ -53,20 +53,6 @@ __device__ __forceinline__ float wave_suffix_sum_excl(float v, int lane) {      
 struct WB {
     float w, ds;
 };
-__device__ __forceinline__ WB weights_bwd(float sigma, float dist, float q, int lane) {
-    const float e = expf(-((fmaxf(sigma, 0.f) + 1e-6f) * dist));
-    const float a = 1.0f - e;
-    const float v = 1.0f - a + 1e-10f;
-    const float T = wave_excl_prod(v, lane);
-    const float w = a * T;
-    const float suf = wave_suffix_sum_excl(w * q, lane);
-    const float da = T * q - suf / v;
-    WB r;
-    r.w = w;
-    r.ds = da * dist * e;             // d a / d sigma = dist * exp(-(sigma + 1e-6) dist)
-    return r;
-}
-
 __device__ __forceinline__ void composite_zero_fill(const CompositeBwdArgs& A) {
     if (!A.zero_buf) return;
     const long n4 = A.zero_floats >> 2, stride = (long)gridDim.x * blockDim.x;
@@ -74,12 +60,47 @@ __device__ __forceinline__ void composite_zero_fill(const CompositeBwdArgs& A) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (blockIdx.x == 0 && threadIdx.x < (A.zero_floats & 3)) A.zero_buf[(n4 << 2) + threadIdx.x] = 0.f;
 }
+// KL consecutive samples per lane (KL = 1: --N_samples 32 / 64, lanes beyond the ray's samples idle; KL = 2: 128), round 6.
+// Sample i = lane KL + k.  The scans run over the lanes' local products / sums and are carried across a lane's KL positions;
+// with KL = 1 and 64 samples the arithmetic is the round 1-5 kernel's.
+template <int KL>
+__device__ __forceinline__ void weights_bwd_n(const float (&sigma)[KL], const float (&dist)[KL], const float (&q)[KL],
+                                              const bool (&live)[KL], int lane, WB (&out)[KL]) {
+    float e[KL], a[KL], v[KL], T[KL], wq[KL];
+    float lp = 1.0f;
+#pragma unroll
+    for (int k = 0; k < KL; ++k) {
+        e[k] = expf(-((fmaxf(sigma[k], 0.f) + 1e-6f) * dist[k]));
+        a[k] = live[k] ? 1.0f - e[k] : 0.f;
+        v[k] = live[k] ? 1.0f - a[k] + 1e-10f : 1.0f;
+        lp *= v[k];
+    }
+    float Tb = wave_excl_prod(KL == 1 ? v[0] : lp, lane);
+    float ls = 0.f;
+#pragma unroll
+    for (int k = 0; k < KL; ++k) {
+        T[k] = Tb;
+        Tb *= v[k];
+        out[k].w = a[k] * T[k];
+        wq[k] = out[k].w * q[k];
+        ls += wq[k];
+    }
+    float suf = wave_suffix_sum_excl(KL == 1 ? wq[0] : ls, lane);      // over the lanes behind this one
+#pragma unroll
+    for (int k = KL - 1; k >= 0; --k) {
+        const float da = T[k] * q[k] - suf / v[k];
+        out[k].ds = da * dist[k] * e[k];             // d a / d sigma = dist * exp(-(sigma + 1e-6) dist)
+        suf += wq[k];
+    }
+}
+template <int KL>
 __global__ void composite_bwd_kernel(const CompositeBwdArgs A) {
     composite_zero_fill(A);
     const int lane = threadIdx.x & 63;
     const long ray = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= A.frame.ray_count) return;
     const DfnFrame& F = A.frame;
+    const int NC = F.n_coarse;
     const int pix = A.pix_index ? A.pix_index[ray] : F.ray_begin + (int)ray;
     // geometry (same arithmetic as the forward)
     const int y = pix / F.W, x = pix - y * F.W;
@@ -97,24 +118,37 @@ __global__ void composite_bwd_kernel(const CompositeBwdArgs A) {
         }
         nrm[b] = sqrtf(acc);
     }
-    const float step = __fdiv_rn(1.0f, 63.0f);
-    auto tval = [&](int i) { return (i < 32) ? __fmul_rn(step, (float)i) : fmaf(-step, (float)(63 - i), 1.0f); };
+    const float step = __fdiv_rn(1.0f, (float)(NC - 1));
+    auto tval = [&](int i) { return (i < NC / 2) ? __fmul_rn(step, (float)i) : fmaf(-step, (float)(NC - 1 - i), 1.0f); };
     auto zval = [&](int i) {
         const float t = tval(i);
         return __fadd_rn(__fmul_rn(F.z_near, __fsub_rn(1.0f, t)), __fmul_rn(F.z_far, t));
     };
-    const bool last = lane == 63;
-    const float dz = last ? F.last_dist : __fsub_rn(zval(lane + 1), zval(lane));
     const bool cbg = F.concate_bg != 0;
-    const float* sm = A.samples + (ray * 64 + lane) * 8;
-    float* out = A.dsamples + (ray * 64 + lane) * 8;
-    const float sg_h = sm[0], sg_t_raw = sm[4];
-    float ch[3] = {sm[1], sm[2], sm[3]}, ct[3] = {sm[5], sm[6], sm[7]};
-    const bool h_is_bg = cbg && last;
-    if (h_is_bg) {
+    bool live[KL], last[KL], h_is_bg[KL];
+    float dz[KL], sg_h[KL], sg_t_raw[KL], ch[KL][3], ct[KL][3], sh[KL];
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            ch[k] = A.bg_u8 ? __fdiv_rn((float)A.bg_u8[(size_t)pix * 3 + k], 255.0f) : A.bg_f32[(size_t)pix * 3 + k];
+    for (int k = 0; k < KL; ++k) {
+        const int i = lane * KL + k;
+        live[k] = i < NC;
+        const int ii = live[k] ? i : NC - 1;
+        last[k] = ii == NC - 1;
+        dz[k] = last[k] ? F.last_dist : __fsub_rn(zval(ii + 1), zval(ii));
+        const float* sm = A.samples + (ray * NC + ii) * 8;
+        sg_h[k] = sm[0];
+        sg_t_raw[k] = sm[4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ch[k][c] = sm[1 + c];
+            ct[k][c] = sm[5 + c];
+        }
+        h_is_bg[k] = cbg && last[k];
+        if (h_is_bg[k]) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                ch[k][c] = A.bg_u8 ? __fdiv_rn((float)A.bg_u8[(size_t)pix * 3 + c], 255.0f) : A.bg_f32[(size_t)pix * 3 + c];
+        }
+        sh[k] = fmaxf(sg_h[k], 0.f);
     }
     float Gh[3], Gc[3];
 #pragma unroll
@@ -122,61 +156,90 @@ __global__ void composite_bwd_kernel(const CompositeBwdArgs A) {
         Gh[k] = A.d_rgb_head[ray * 3 + k];
         Gc[k] = A.d_rgb_com ? A.d_rgb_com[ray * 3 + k] : 0.f;
     }
+    float d_sg_h[KL], d_ch[KL][3], d_sg_t[KL], d_ct[KL][3];
     // ---- head-only image: s = relu(sg_h) (+1e-6 at the last sample), colour ch
-    const float sh = fmaxf(sg_h, 0.f);
-    float d_sg_h = 0.f, d_ch[3] = {0, 0, 0}, d_sg_t = 0.f, d_ct[3] = {0, 0, 0};
     {
-        const float s1 = h_is_bg ? sh + 1e-6f : sh;
-        const float q = ch[0] * Gh[0] + ch[1] * Gh[1] + ch[2] * Gh[2];
-        const WB r = weights_bwd(s1, dz * nrm[0], q, lane);
-        if (sg_h > 0.f) d_sg_h += r.ds;
-        if (!h_is_bg)
+        float s1[KL], dist[KL], q[KL];
+        WB r[KL];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) d_ch[k] += r.w * Gh[k];
+        for (int k = 0; k < KL; ++k) {
+            s1[k] = h_is_bg[k] ? sh[k] + 1e-6f : sh[k];
+            dist[k] = dz[k] * nrm[0];
+            q[k] = ch[k][0] * Gh[0] + ch[k][1] * Gh[1] + ch[k][2] * Gh[2];
+        }
+        weights_bwd_n<KL>(s1, dist, q, live, lane, r);
+#pragma unroll
+        for (int k = 0; k < KL; ++k) {
+            d_sg_h[k] = (sg_h[k] > 0.f) ? r[k].ds : 0.f;
+            d_sg_t[k] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                d_ch[k][c] = h_is_bg[k] ? 0.f : r[k].w * Gh[c];
+                d_ct[k][c] = 0.f;
+            }
+        }
     }
     // ---- composite image (run_nerf_com_trainExpLater.py:146-166)
     if (A.frame.fields == 2) {
-        const float sg_t = (cbg && last) ? 0.f : sg_t_raw;
-        float st = fmaxf(sg_t, 0.f);
-        if (cbg && last) st += 1e-6f;
-        const float ssum = sh + st;
-        const bool zero = ssum == 0.f;
-        const float den = zero ? 1e-4f : ssum;
-        const float wh = sh / den, wt = st / den;
-        float cm[3];
+        float ssum[KL], dist[KL], q[KL], sg_t[KL], st[KL], den[KL], wh[KL], wt[KL];
+        bool zero[KL];
+        WB r[KL];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) cm[k] = ch[k] * wh + ct[k] * wt;
-        const float q = cm[0] * Gc[0] + cm[1] * Gc[1] + cm[2] * Gc[2];
-        const WB r = weights_bwd(ssum, dz * nrm[1], q, lane);
-        const float gch = ch[0] * Gc[0] + ch[1] * Gc[1] + ch[2] * Gc[2];
-        const float gct = ct[0] * Gc[0] + ct[1] * Gc[1] + ct[2] * Gc[2];
-        const float dwh = r.w * gch, dwt = r.w * gct;
-        // wh = sh/den, wt = st/den, den = sh + st (or the constant 1e-4)
-        float dsh = r.ds + dwh / den, dst = r.ds + dwt / den;
-        if (!zero) {
-            const float common = (dwh * sh + dwt * st) / (den * den);
-            dsh -= common;
-            dst -= common;
+        for (int k = 0; k < KL; ++k) {
+            sg_t[k] = (cbg && last[k]) ? 0.f : sg_t_raw[k];
+            st[k] = fmaxf(sg_t[k], 0.f);
+            if (cbg && last[k]) st[k] += 1e-6f;
+            ssum[k] = sh[k] + st[k];
+            zero[k] = ssum[k] == 0.f;
+            den[k] = zero[k] ? 1e-4f : ssum[k];
+            wh[k] = sh[k] / den[k];
+            wt[k] = st[k] / den[k];
+            float cm[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) cm[c] = ch[k][c] * wh[k] + ct[k][c] * wt[k];
+            q[k] = cm[0] * Gc[0] + cm[1] * Gc[1] + cm[2] * Gc[2];
+            dist[k] = dz[k] * nrm[1];
         }
-        if (sg_h > 0.f) d_sg_h += dsh;
-        if (sg_t > 0.f && !(cbg && last)) d_sg_t += dst;
+        weights_bwd_n<KL>(ssum, dist, q, live, lane, r);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (!h_is_bg) d_ch[k] += r.w * Gc[k] * wh;
-            d_ct[k] += r.w * Gc[k] * wt;
+        for (int k = 0; k < KL; ++k) {
+            const float gch = ch[k][0] * Gc[0] + ch[k][1] * Gc[1] + ch[k][2] * Gc[2];
+            const float gct = ct[k][0] * Gc[0] + ct[k][1] * Gc[1] + ct[k][2] * Gc[2];
+            const float dwh = r[k].w * gch, dwt = r[k].w * gct;
+            // wh = sh/den, wt = st/den, den = sh + st (or the constant 1e-4)
+            float dsh = r[k].ds + dwh / den[k], dst = r[k].ds + dwt / den[k];
+            if (!zero[k]) {
+                const float common = (dwh * sh[k] + dwt * st[k]) / (den[k] * den[k]);
+                dsh -= common;
+                dst -= common;
+            }
+            if (sg_h[k] > 0.f) d_sg_h[k] += dsh;
+            if (sg_t[k] > 0.f && !(cbg && last[k])) d_sg_t[k] += dst;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (!h_is_bg[k]) d_ch[k][c] += r[k].w * Gc[c] * wh[k];
+                d_ct[k][c] += r[k].w * Gc[c] * wt[k];
+            }
         }
     }
-    out[0] = d_sg_h;
-    out[4] = d_sg_t;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        out[1 + k] = d_ch[k];
-        out[5 + k] = d_ct[k];
+    for (int k = 0; k < KL; ++k) {
+        if (!live[k]) continue;
+        float* out = A.dsamples + (ray * NC + lane * KL + k) * 8;
+        out[0] = d_sg_h[k];
+        out[4] = d_sg_t[k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            out[1 + c] = d_ch[k][c];
+            out[5 + c] = d_ct[k][c];
+        }
     }
 }
 hipError_t launch_composite_bwd(const CompositeBwdArgs& A, hipStream_t st) {
     const int blocks = (A.frame.ray_count + 3) / 4;
-    hipLaunchKernelGGL(composite_bwd_kernel, dim3(blocks), dim3(256), 0, st, A);
+    if (A.frame.n_coarse == 128) hipLaunchKernelGGL(composite_bwd_kernel<2>, dim3(blocks), dim3(256), 0, st, A);
+    else if (A.frame.n_coarse == 64 || A.frame.n_coarse == 32) hipLaunchKernelGGL(composite_bwd_kernel<1>, dim3(blocks), dim3(256), 0, st, A);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -161,7 +161,7 @@ _STREAMS = {}
 
 def side_stream(device, high=False, role=None):
     """A side stream by ROLE ("wgrad", "sig_a", "sig_p"), one per device and role for the whole process: the device runs four
-    hardware queues, and every further stream shares one with another stream and serialises with it - a second
+    hardware queues, and every further stream shares one with another stream and serialises with it (LABNOTES.md 7) - a second
     TrainBuffers / SignalTrainer / FramePrefetcher in the same process (bench.py's other workloads, the test renders of a
     training run, a second model) must reuse the first one's streams instead of creating more."""
     if role is None:

@@ -62,10 +62,26 @@ def broadcast_replicas(nets, opts, extra=(), src=0, group=None):
     averages gradients, so replicas that start different stay different."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return list(extra)
+    # gloo (the functional modes: every rank on one GPU over gloo, the CPU tests) is handed HOST tensors only.  Given device
+    # tensors, c10d's gloo backend stages them through pinned buffers with copies on streams of its own - and with eight ranks on
+    # ONE device and eight hardware queues per process that start-up phase died in 2 of 3 runs with a GPU memory fault inside one
+    # of those copies (an ATen elementwise copy of a 256 x 256 weight), caching allocator on or off; staged through the host by
+    # us it passed 3 of 3 on the same box (round 6, profiles/r06g_world8_bcast.txt; plain PyTorch processes with the same
+    # process / queue counts and no gloo never fault: tools/queue_oversub_repro.py).  Production ranks use RCCL, which takes
+    # device tensors.  DFN_BCAST_HOST=0: the old route (developer switch).
+    via_host = os.environ.get("DFN_BCAST_HOST", "1") == "1" and dist.get_backend(group) == "gloo"
+
+    def bcast(t):
+        if via_host and t.is_cuda:
+            h = t.detach().cpu()
+            dist.broadcast(h, src=src, group=group)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=src, group=group)
     with torch.no_grad():
         for k in sorted(nets):
             for t in list(nets[k].parameters()) + list(nets[k].buffers()):
-                dist.broadcast(t.data, src=src, group=group)
+                bcast(t.data)
         for k in sorted(opts):
             # through the HOST: a pickled device tensor unpickles onto the SOURCE rank's device on every receiver (each rank
             # would open a context and allocate on GPU `src`); load_state_dict casts to the parameters' device
@@ -77,7 +93,7 @@ def broadcast_replicas(nets, opts, extra=(), src=0, group=None):
         out = []
         for t in extra:
             t = t.contiguous()
-            dist.broadcast(t, src=src, group=group)
+            bcast(t)
             out.append(t)
     return out
 

@@ -784,7 +784,7 @@ def update_lrate(opts, global_step, args):
 
 
 def check_supported(args):
-    """The HIP path implements the configuration scripts/{train,test}_obama.sh build: say so when
+    """The HIP path implements the configuration scripts/{train,test}_obama.sh build (LABNOTES.md section 1): say so when
     the arguments are parsed, not at the first kernel launch."""
     bad = []
     if (args.n_feat, args.z_dim, args.dim_signal) != (256, 256, 96):
@@ -792,12 +792,16 @@ def check_supported(args):
     # (--use_expression: accepted - with one person the reference's decoder registers expnet and never evaluates it, MAIN:70)
     if not args.use_deformation_field:
         bad.append("--use_deformation_field is required")
-    if args.N_samples != 64:
-        bad.append(f"--N_samples {args.N_samples} (supported: 64)")
+    if args.N_samples not in (32, 64, 128):
+        bad.append(f"--N_samples {args.N_samples} (supported: 32, 64, 128)")
+    if getattr(args, "hierarchical", False) and args.N_samples != 64:
+        bad.append(f"--hierarchical with --N_samples {args.N_samples} (the fused fine sampler works on 64 coarse samples)")
     if getattr(args, "hierarchical", False) and args.N_importance not in (64, 128):
         bad.append(f"--hierarchical with --N_importance {args.N_importance} (supported: 64, 128)")
-    if args.n_object != 1:
-        bad.append(f"--n_object {args.n_object} (the scripts train one person: 1)")
+    if args.n_object < 1:
+        bad.append(f"--n_object {args.n_object}")
+    # (--n_object > 1, the flag's default: accepted like upstream - and like upstream the run stops in the setup loop over the
+    # persons, train(): the reference builds ONE dataset, `datadir = [args.datadir]` (MAIN:449), and indexes it per person)
     if args.hip_tier not in ("f32", "f16", "bf16", "auto"):
         bad.append(f"--hip_tier {args.hip_tier} (f32 | f16 | bf16 | auto)")
     if getattr(args, "hip_train_act", "fp4") not in ("fp4", "e4m3"):
@@ -832,9 +836,18 @@ def train():
     datasets = [ds]
     batch_size = 1
     basedir = os.path.join('dataset/train_together', args.expname)
-    imgdir = [os.path.join(basedir, args.datadir.split('/')[-1])]
+    # MAIN:449, 495-501: one output directory per person out of a ONE-element `datadir` list - with the flag's default
+    # (--n_object 2) upstream stops right here with IndexError('list index out of range'); the scripts pass --n_object 1.
+    # Reproduced as is: what a second person WOULD evaluate (the listener input layers, MAIN:72-75, decoder.py:306-307) exists
+    # on this path - Decoder.forward(signal=[None, ...]) renders and trains in HIP (field 2) - but no dataset reaches it.
+    datadir = [args.datadir]
+    imgdir = []
+    for k in range(args.n_object):
+        i_dir = os.path.join(basedir, datadir[k].split('/')[-1])
+        if rank == 0:
+            os.makedirs(os.path.join(i_dir, 'person'), exist_ok=True)
+        imgdir.append(i_dir)
     if rank == 0:
-        os.makedirs(os.path.join(imgdir[0], 'person'), exist_ok=True)
         with open(os.path.join(basedir, 'args.txt'), 'w') as f:
             for arg in sorted(vars(args)):
                 f.write('{} = {}\n'.format(arg, getattr(args, arg)))
@@ -963,7 +976,7 @@ def train():
     tier = "f32" if tier == "auto" else tier        # (auto = the fastest tier that keeps the accuracy clause: training is exact)
     train_buf = training.TrainBuffers("bf16" if tier == "f16" else tier, args.N_rand, dev,
                                       n_fine=args.N_importance if getattr(args, "hierarchical", False) else 0,
-                                      act_format=getattr(args, "hip_train_act", None))
+                                      act_format=getattr(args, "hip_train_act", None), n_coarse=args.N_samples)
     if "PoseAttNet" in nets and _hip_signals_ok(args):
         train_buf.signal_trainer = training.SignalTrainer(nets["AudNet"], nets["ExpNet"], nets["AudAttNet"],
                                                           nets["PoseAttNet"], ds['auds'], ds['exp'], ds['poses'])

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import engine
-from ._lib import ACT_E2M1, ACT_E4M3, FIELD_HEAD, FIELD_TORSO, TRAIN_ACT_E4M3, DfnTrainLoss, check, lib
+from ._lib import ACT_E2M1, ACT_E4M3, FIELD_HEAD, FIELD_LISTENER, FIELD_TORSO, TRAIN_ACT_E4M3, DfnTrainLoss, check, lib
 from .engine import TIERS, _ptr, _stream
 
 
@@ -111,7 +111,7 @@ class TrainBuffers:
     """Device buffers of one training step, sized for `n_rays` rays of 64 + n_fine samples (reused across steps).
     n_fine = 0: the reference's coarse step (MAIN:855-899); 64 / 128: the hierarchical variant (dfn_train_fwd_hier)."""
 
-    def __init__(self, tier, n_rays, device, n_fine=0, act_format=None):
+    def __init__(self, tier, n_rays, device, n_fine=0, act_format=None, n_coarse=64):
         """act_format (16-bit tier): 'fp4' = the fused step records its GEMM inputs as MX-fp4 (e2m1, the default), 'e4m3' = as
         MX-fp8 (twice the bytes, 3 mantissa bits instead of 1): the run-time opt-out, one switch for an A/B of the two on real
         data (--hip_train_act, or DFN_TRAIN_ACT in the environment when the argument is None)."""
@@ -123,7 +123,10 @@ class TrainBuffers:
                              "underflow its exponent range)")
         if n_fine not in (0, 64, 128):
             raise ValueError("TrainBuffers: n_fine must be 0, 64 or 128")
-        self.n_fine, self.S = int(n_fine), 64 + int(n_fine)
+        if n_coarse not in (32, 64, 128) or (n_fine and n_coarse != 64):
+            raise ValueError("TrainBuffers: n_coarse (--N_samples) must be 32, 64 or 128, and 64 in the hierarchical step")
+        self.n_coarse = int(n_coarse)
+        self.n_fine, self.S = int(n_fine), int(n_coarse) + int(n_fine)
         self.n_rays, self.NP = n_rays, n_rays * self.S
         assert self.NP % 512 == 0, "N_rand must be a multiple of 8"
         rows = lambda f, w: check(lib.dfn_train_rows(f, w), "dfn_train_rows")
@@ -275,7 +278,7 @@ def _fused_backward(ctx, d_h, d_c):
     main = torch.cuda.current_stream(dev)
     # (with more than one rank RCCL brings a fifth stream; the package asks the runtime for eight hardware queues then
     # (dfanerf/__init__.py) - on the default four the weight-gradient stream shares the main stream's queue and this overlap
-    # is lost: 1.32 -> 1.36 ms per step through RCCL on one GPU)
+    # is lost: 1.32 -> 1.36 ms per step through RCCL on one GPU, LABNOTES.md 6)
     over = _OVERLAP and _WGRAD_SIDE
     if over and getattr(buf, "_side", None) is None:
         buf._side = _side_stream(dev, role="wgrad")
@@ -475,13 +478,13 @@ _LISTENER = ("fc_in_listener.", "fc_p_skips_listener.")
 
 
 def _decoder_touched(net, fields):
-    """Per parameter of the decoder: does a forward through `fields` (0 head, 1 torso) use it?  (decoder.py:297-325)"""
+    """Per parameter of the decoder: does a forward through `fields` (0 head, 1 torso, 2 listener) use it?  (decoder.py:297-325)"""
     key = ("touched", tuple(fields))
     hit = net.__dict__.get(key)
     if hit is None:
         def used(name):
             if name.startswith(_LISTENER):
-                return False
+                return 2 in fields
             if name.startswith(_HEAD_ONLY):
                 return 0 in fields
             if name.startswith(_TORSO_ONLY):
@@ -709,9 +712,9 @@ def render_train(dec, buf, frame, bg, pix_index, sig_head, sig_torso, z_shape, z
     if frame.ray_count != buf.n_rays or (pix_index is not None and pix_index.numel() != buf.n_rays):
         raise ValueError(f"render_train: the buffers were sized for {buf.n_rays} rays, the frame has {frame.ray_count}"
                          f" (pix_index {None if pix_index is None else pix_index.numel()})")
-    if frame.n_fine != buf.n_fine or frame.fields != 2:
-        raise ValueError(f"render_train: the buffers were sized for n_fine = {buf.n_fine}, the frame asks for "
-                         f"{frame.n_fine} (fields {frame.fields}: the training step renders both fields)")
+    if frame.n_fine != buf.n_fine or frame.n_coarse != buf.n_coarse or frame.fields != 2:
+        raise ValueError(f"render_train: the buffers were sized for {buf.n_coarse} + {buf.n_fine} samples, the frame asks for "
+                         f"{frame.n_coarse} + {frame.n_fine} (fields {frame.fields}: the training step renders both fields)")
     buf.bind(dec)
     if not sig_head.requires_grad:      # keep the Function in the graph even when no conditioning net trains
         sig_head = sig_head.detach().requires_grad_(True)
@@ -730,8 +733,9 @@ def render_train_loss(dec, buf, frame, bg, pix_index, sig_head, sig_torso, z_sha
     (FusedTrainLossFn): -> loss (= loss_com + loss_head), loss_head, loss_com, rgb_head, rgb_com."""
     if frame.ray_count != buf.n_rays or pix_index is None or pix_index.numel() != buf.n_rays:
         raise ValueError(f"render_train_loss: the buffers were sized for {buf.n_rays} rays, the frame has {frame.ray_count}")
-    if frame.n_fine != buf.n_fine or frame.fields != 2:
-        raise ValueError(f"render_train_loss: the buffers were sized for n_fine = {buf.n_fine}, the frame asks for {frame.n_fine}")
+    if frame.n_fine != buf.n_fine or frame.n_coarse != buf.n_coarse or frame.fields != 2:
+        raise ValueError(f"render_train_loss: the buffers were sized for {buf.n_coarse} + {buf.n_fine} samples, the frame asks for "
+                         f"{frame.n_coarse} + {frame.n_fine}")
     buf.bind(dec)
     if not sig_head.requires_grad:
         sig_head = sig_head.detach().requires_grad_(True)
@@ -925,7 +929,7 @@ class DecoderTrainFn(torch.autograd.Function):
     def forward(ctx, signal, net, pb, pts, dirs, zs, za):
         t, f, st = pb.tier, pb.field, _stream()
         flat, dev = net.flat, net.flat.device
-        sg = signal.detach().reshape(-1).float().contiguous()
+        sg = signal.detach().reshape(-1).float().contiguous() if signal.numel() else None      # (listener: no signal)
         check(lib.dfn_fold_bias(t, f, _ptr(flat), _ptr(sg), _ptr(zs), _ptr(za), _ptr(pb.bias), st), "dfn_fold_bias")
         check(lib.dfn_pack_weights(t, f, _ptr(flat), _ptr(pb.packed), st), "dfn_pack_weights")
         check(lib.dfn_pack_weights_bwd(t, f, _ptr(flat), _ptr(pb.packed_T), st), "dfn_pack_weights_bwd")
@@ -941,7 +945,7 @@ class DecoderTrainFn(torch.autograd.Function):
     def backward(ctx, d_feat, d_sigma):
         net, pb, (sg, zs, za, _, _), st = ctx.net, ctx.pb, ctx.keep, _stream()
         t, f, dev = pb.tier, pb.field, net.flat.device
-        o = 4 * f
+        o = 4 if f == FIELD_TORSO else 0          # (the listener is the head's program: the head's output slots)
         ds = torch.zeros(pb.NP, 8, dtype=torch.float32, device=dev)
         ds[:pb.n, o] = d_sigma.reshape(-1)
         ds[:pb.n, o + 1:o + 4] = d_feat.reshape(-1, 3)
@@ -949,21 +953,21 @@ class DecoderTrainFn(torch.autograd.Function):
                               st), "dfn_mlp_bwd")
         g_flat = _grad_buffer(net, "_g_flat", net.flat, net.params)
         g_bias = torch.empty(pb.nb, dtype=torch.float32, device=dev)
-        d_sig = torch.zeros(sg.numel(), dtype=torch.float32, device=dev)
+        d_sig = torch.zeros(0 if sg is None else sg.numel(), dtype=torch.float32, device=dev)
         check(lib.dfn_weight_bias_grad_fmt(t, f, 0, _ptr(pb.dy), _ptr(pb.act), pb.NP, _ptr(pb.ws), _ptr(g_flat), _ptr(g_bias),
                                            st), "dfn_weight_bias_grad_fmt")       # (0 = DFN_ACT_E4M3)
         check(lib.dfn_fold_bias_bwd(t, f, _ptr(net.flat), _ptr(sg), _ptr(zs), _ptr(za), _ptr(g_bias), _ptr(g_flat),
-                                    _ptr(d_sig), st), "dfn_fold_bias_bwd")
+                                    _ptr(d_sig) if sg is not None else None, st), "dfn_fold_bias_bwd")
         net.deposit(g_flat, touched=_decoder_touched(net, (f,)))
         return d_sig.reshape(ctx.sig_shape), None, None, None, None, None, None
 
 
 def decoder_train(dec, field, p_in, ray_d, z_shape, z_app, signal, tier="f32"):
     """Decoder.forward(p_in [B,N,3], ray_d [B,N,3], ...) under autograd, in HIP: -> feat [B,N,3], sigma [B,N].
-    field: 0 head, 1 torso.  Gradients flow to the decoder's parameters (deposited into .grad) and to `signal`."""
-    if field not in (FIELD_HEAD, FIELD_TORSO):
-        raise NotImplementedError("training the listener input layers (signal None) is not supported: the reference "
-                                  "driver never evaluates them (decoder.py:306-307, 322-323)")
+    field: 0 head, 1 torso, 2 listener (`signal` None: the head's program on fc_in_listener / fc_p_skips_listener,
+    decoder.py:306-307, 322-323).  Gradients flow to the decoder's parameters (deposited into .grad) and to `signal`."""
+    if field not in (FIELD_HEAD, FIELD_TORSO, FIELD_LISTENER):
+        raise ValueError(f"decoder_train: field {field}")
     if not dec.hip_supported():
         raise NotImplementedError("the HIP path supports the scripts/test_obama.sh decoder configuration only")
     t = TIERS["bf16" if tier in ("f16", 2) else tier]
@@ -977,7 +981,10 @@ def decoder_train(dec, field, p_in, ray_d, z_shape, z_app, signal, tier="f32"):
     pb = _PointBuffers(t, field, n, dev)
     zs = z_shape.detach().reshape(-1)[:256].to(dev, torch.float32).contiguous()
     za = z_app.detach().reshape(-1)[:256].to(dev, torch.float32).contiguous()
-    if not signal.requires_grad:
+    if field == FIELD_LISTENER:
+        # no conditioning signal: an anchor keeps the node in the graph (its "gradient" is empty)
+        signal = torch.zeros(0, dtype=torch.float32, device=dev, requires_grad=True)
+    elif not signal.requires_grad:
         signal = signal.detach().requires_grad_(True)
     feat, sigma = DecoderTrainFn.apply(signal, net, pb, pts, dirs, zs, za)
     return feat.reshape(p_in.shape[0], -1, 3), sigma.reshape(p_in.shape[0], -1)

@@ -58,7 +58,7 @@ typedef struct DfnFrame {
     float last_dist;       /* --last_dist, MAIN:171 */
     int ray_begin;         /* first ray (y*W+x) rendered when pix_index == NULL */
     int ray_count;         /* number of rays rendered by this call */
-    int n_coarse;          /* --N_samples; must be 64 */
+    int n_coarse;          /* --N_samples (MAIN:612-619): 32, 64 or 128; 64 when n_fine > 0 */
     int n_fine;            /* 0 (live reference renderer) or 64/128 */
     int fields;            /* 1 = head only, 2 = head + torso composite (MAIN:681-709) */
     int concate_bg;        /* --concate_bg, MAIN:669-671, 678-679, 692-694 */
@@ -283,7 +283,7 @@ int dfn_weight_bias_grad(int tier, int field, const void* dy_T, const void* act_
 /* The same with the format of act_T as an argument (16-bit tier; ignored in the f32 tier).  The FUSED step (dfn_train_fwd /
  * dfn_train_fwd_hier) records its activations as MX-fp4 - e2m1 nibbles, 16 bytes per row and tile: dfn_train_rows(field, 6)
  * bytes per tile, and the caller allocates one tile more than NP / 32 (1-KiB DMA pieces) - because a weight gradient of that
- * step sums >= 131,072 points and the rounding averages out.  dfn_decoder_train_fwd (Decoder.forward on
+ * step sums >= 131,072 points and the rounding averages out (LABNOTES.md 7, round 4).  dfn_decoder_train_fwd (Decoder.forward on
  * explicit points under autograd: any number of points) records e4m3 - 32 bytes per row and tile, dfn_train_rows(field, 8).
  * dfn_weight_grad / dfn_weight_bias_grad take the fused step's format. */
 #define DFN_ACT_E4M3 0

@@ -297,7 +297,7 @@ def run(steps, variants, size=450, curve_every=0, log=None, with_inference_check
         info["psnr_train_frames"] = score(scene, mods, gt8, "train")
         # the same held-out frames rendered in the ARITHMETIC THE 16-BIT TIER TRAINS IN (bf16 operands): a model is fitted to what
         # its own forward renders, so scoring it in another arithmetic adds that arithmetic's distance (bf16 vs f32: 47 dB on a full
-        # frame) to its error - 10 log10(1 + 10^((P - 47) / 10)) dB at a P-dB model, 0.3 dB at 35.6 dB
+        # frame, LABNOTES.md 3) to its error - 10 log10(1 + 10^((P - 47) / 10)) dB at a P-dB model, 0.3 dB at 35.6 dB
         info["psnr_held_out_bf16_render"] = score(scene, mods, gt8, "held", tier="bf16")
         res["variants"][name] = info
         keep[name] = mods
@@ -308,7 +308,7 @@ def run(steps, variants, size=450, curve_every=0, log=None, with_inference_check
                 f"{info['psnr_train_frames']['head']:.3f} com {info['psnr_train_frames']['com']:.3f}")
     if with_inference_check:
         # the models the 16-bit tier trained, through the f16 INFERENCE tier: the full-frame accuracy clause (>= 49.4 dB against
-        # the exact tier) on TRAINED weights - configs[1] (head, 64 + 128) and configs[2] (two fields)
+        # the exact tier, LABNOTES.md 3) on TRAINED weights - configs[1] (head, 64 + 128) and configs[2] (two fields)
         for name, mods in keep.items():
             if res["variants"][name]["tier"] != "bf16":
                 continue
@@ -329,7 +329,7 @@ def run_continuation(base_steps, cont_steps, variants, cont_lrate=1e-5, size=450
     """The PAIRED form of the comparison: ONE student trained to convergence in the exact tier (base_steps), then continued for
     cont_steps at a small constant rate from those very parameters (fresh Adam moments) by every variant (name, tier, act_format,
     pixel_seed).  All continuations sit in the same basin, so what separates two fresh runs (which basin, where on the way: +-0.5 dB
-    between two exact-tier seeds) is gone and a format that biased the weight gradients would show as a drift of its
+    between two exact-tier seeds, LABNOTES.md 9.2) is gone and a format that biased the weight gradients would show as a drift of its
     continuation away from the exact tier's.  -> base scores + per-variant scores"""
     dev = torch.device("cuda")
     scene = Scene(dev, size)

@@ -66,7 +66,12 @@ def build_ref_modules(seed=0):
     return dec, aud, exp, att, patt
 
 
+ONLY = None      # name of the one fixture to (re)write; None: all of them
+
+
 def save(name, **arrs):
+    if ONLY is not None and name != ONLY:
+        return
     out = {}
     for k, v in arrs.items():
         if isinstance(v, torch.Tensor):
@@ -262,6 +267,18 @@ def main():
          w_head_first8=w_h[:8], w_com_first8=w_c[:8],
          rgb8_head=HELP.to8b(rgb_h.numpy()), rgb8_com=HELP.to8b(rgb_c.numpy()),
          signal=signal[0], signal_torso=signal_torso)
+
+    # ---- G15 (round 6): the same loop with --N_samples 32 and 128, coarse only (MAIN:612-619: the flag is free upstream)
+    sub15 = np.arange(5, H * W, 811)
+    g15 = {"ray_idx": sub15, "frame": np.array([2]), "signal": signal[0], "signal_torso": signal_torso}
+    for S15 in (32, 128):
+        tv15 = torch.linspace(0., 1., steps=S15)
+        with torch.no_grad():
+            z15 = (0.3 * (1. - tv15) + 0.9 * tv15)[None].expand(len(sub15), S15)
+            rh15, rc15, wh15, wc15, _, _ = ref_chunk(sub15, z15)
+        g15.update({f"rgb_head_{S15}": rh15, f"rgb_com_{S15}": rc15, f"w_head_{S15}": wh15, f"w_com_{S15}": wc15,
+                    f"z_{S15}": z15[0]})
+    save("g15_coarse_nsamples", **g15)
 
     # row H composed from the reference's own functions (sample_pdf, decoder, composite, weights)
     subh = np.arange(0, H * W, 397)[:512]
@@ -459,7 +476,47 @@ def g13_optional_branches():
     print("g13: ", len(manifest), "state_dict entries")
 
 
+def g14_listener_backward():
+    """G14 (round 6): Decoder.forward with `signal is None` - the listener input layers fc_in_listener / fc_p_skips_listener
+    (decoder.py:306-307, 322-323: what the reference's second person evaluates, MAIN:72-75) - UNDER AUTOGRAD in the reference's
+    own module: a weighted sum of the outputs at 4 rays x 64 points (G3's points), the gradient of every parameter it reaches:
+    norms for all, 8 sampled entries each, the two listener weight matrices in full."""
+    g3 = np.load(os.path.join(HERE, "g3_decoder.npz"))
+    dec = build_ref_modules(0)[0]
+    z_shape, z_app = [t(v) for v in synth.synth_latents(0)]
+    p, r = t(g3["p_64"]), t(g3["r_64"])
+    n = p.shape[1]
+    w_f = t(np.abs(synth.synth_tensor(0, "g14/wf", (1, n, 3), 1.0)))
+    w_s = t(np.abs(synth.synth_tensor(0, "g14/ws", (1, n), 0.1)))
+    feat, sigma = dec(p, r, z_shape[:, 0], z_app[:, 0], [None, None], 'head')
+    assert np.array_equal(feat.detach().numpy(), g3["feat_listener_64"])
+    loss = (feat * w_f).sum() + (sigma * w_s).sum()
+    loss.backward()
+    out = {"w_f": w_f, "w_s": w_s, "loss": loss.detach()}
+    names = []
+    for k, q in dec.named_parameters():
+        if q.grad is None:
+            continue
+        names.append(k)
+        g = q.grad.reshape(-1)
+        out["gnorm/" + k] = g.double().norm()
+        out["gsamp/" + k] = g[:: max(1, g.numel() // 8)][:8]
+    for k in ("fc_in_listener.weight", "fc_p_skips_listener.0.weight"):
+        out["gfull/" + k] = dict(dec.named_parameters())[k].grad
+    assert "fc_in_listener.weight" in names and "fc_in.weight" not in names and "fc_in_torso.weight" not in names
+    with open(os.path.join(HERE, "g14_listener_touched.txt"), "w") as f:
+        f.write("\n".join(names) + "\n")
+    save("g14_listener_backward", **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "g14":
+        g14_listener_backward()
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[1] == "only":       # everything is computed, one fixture is written
+        ONLY = sys.argv[2]
+        main()
+        sys.exit(0)
     if sys.argv[1:] == ["g13"]:
         g13_optional_branches()
     else:

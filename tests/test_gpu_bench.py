@@ -29,7 +29,7 @@ def test_single_gpu_line_has_the_contract_and_the_parity_binding():
         assert k in out, k
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["dtype"] == "f16" and "workload" in out["config"]
     assert 0.0 < out["roofline"]["frac"] < 1.0 and out["roofline"]["bound"] == "mfma"
-    # 64 rays of the last timed frame against the oracle, in the timed tier (f16: the 49.4 dB clause of DESIGN.md 3)
+    # 64 rays of the last timed frame against the oracle, in the timed tier (f16: the 49.4 dB clause of LABNOTES.md 3)
     pc = out["parity_check"]
     assert "error" not in pc, pc
     assert pc["rays"] == 64 and pc["psnr_db"] >= 49.4 and pc["max_abs_rgb"] < 2e-2, pc

@@ -28,7 +28,7 @@ def test_students_learn_the_scene(result):
 def test_16bit_tier_trains_as_good_a_model_as_the_exact_tier(result):
     """PSNR of the 16-bit-trained student on the held-out frames (rendered in the exact tier) against the f32-trained students'.
     Two trajectories that differ in rounding - or in the pixel seed - end at slightly different models: the second f32 run measures
-    that spread.  Measured on 12,000-step runs with three seeds per 16-bit format (profiles/r05j_convergence.txt): on
+    that spread.  Measured on 12,000-step runs with three seeds per 16-bit format (profiles/r05j_convergence.txt; LABNOTES.md 9.2): on
     the training frames the 16-bit models are 0.14-0.26 dB better on the head image (49 dB) and within 0.02 dB on the composite; on the
     held-out frames the pixel seed moves a run by +-0.5 dB and the 16-bit means are 0.07-0.14 dB below the f32 pair's - no systematic
     deficit.  Gates: the 16-bit model is not worse than the WORSE of the two f32 models by more than GATE_*_DB plus twice their spread."""
@@ -44,7 +44,7 @@ def test_16bit_tier_trains_as_good_a_model_as_the_exact_tier(result):
 
 def test_16bit_trained_model_holds_the_f16_inference_clause(result):
     """the model the 16-bit tier trained, rendered in the f16 INFERENCE tier: >= 49.4 dB against the exact tier on the full frame
-    and on every 2,500-ray block (the north star's 0.05 dB at a 30 dB model) - on TRAINED weights, configs[1]
+    and on every 2,500-ray block (the north star's 0.05 dB at a 30 dB model, LABNOTES.md 3) - on TRAINED weights, configs[1]
     (head, 64 + 128), configs[2] (two fields) and the coarse renderer"""
     chk = result["variants"]["bf16_fp4"]["f16_inference_vs_f32"]
     for tag, c in chk.items():
@@ -52,7 +52,7 @@ def test_16bit_trained_model_holds_the_f16_inference_clause(result):
         assert c["finite"] and c["psnr_db"] >= 49.4 and c["worst_block_db"] >= 49.4, (tag, c)
 
 
-# set from the measured runs (profiles/r05j_convergence.txt, r05j_convergence_test.txt): the students start at 7.4 dB and
+# set from the measured runs (profiles/r05j_convergence.txt, r05j_convergence_test.txt; LABNOTES.md 9.2): the students start at 7.4 dB and
 # reach 28-30 dB on both held-out images in 3,000 steps
 GAIN_DB = 8.0
 GATE_HEAD_DB = 0.5

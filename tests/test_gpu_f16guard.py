@@ -39,7 +39,7 @@ def test_calibration_of_the_synthetic_network_passes(states, scene, latents):
     assert b is pk.f16_bounds and set(b) == {"head", "torso"} and pk.f16_weight_max < 100.0
     assert len(b["head"]) == 11 and len(b["torso"]) == 22
     top = max(v for d in b.values() for v in d.values())
-    assert 2.0 < top < 200.0, top                                  # (the synthetic network peaks at ~13)
+    assert 2.0 < top < 200.0, top                                  # (LABNOTES.md 8.1: the synthetic network peaks at ~13)
     for f in ("head", "torso"):
         assert b[f]["positional encoding"] <= 1.0 + 1e-6 and b[f]["view encoding"] <= 1.0 + 1e-6      # sin / cos
         assert all(np.isfinite(v) and v >= 0 for v in b[f].values())

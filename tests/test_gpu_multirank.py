@@ -1,5 +1,5 @@
 """The multi-rank code paths on hardware, on a box with ONE GPU: two and eight processes on GPU 0 over gloo (tests/multirank_worker.py).
-What only an 8-GPU node can show - RCCL over xGMI, the scaling curve - is the driver's to measure."""
+What only an 8-GPU node can show - RCCL over xGMI, the scaling curve - is the driver's to measure (LABNOTES.md section 6)."""
 import os
 import subprocess
 import sys

@@ -226,16 +226,44 @@ def test_decoder_ragged_sizes(eng, packed, golden, latents):
 
 # ---------------------------------------------------------------------------------------------------------
 def _render_subset(eng, packed, scene, latents, signal, signal_torso, ray_idx, tier, n_fine, fields, frame_i=2,
-                   want_weights=False, want_z=False):
+                   want_weights=False, want_z=False, n_coarse=64):
     zs, za = latents
     pk = packed[tier]
     bias = pk.fold(signal, signal_torso if fields == 2 else None, zs[0], za[0])
     fr = eng.make_frame(scene["H"], scene["W"], scene["focal"], scene["cx"], scene["cy"], scene["poses"][frame_i],
                         scene["pose_body"], scene["near"], scene["far"], ray_count=len(ray_idx), n_fine=n_fine,
-                        fields=fields)
+                        fields=fields, n_coarse=n_coarse)
     bg = (t(scene["bg"]).float() / 255.0).reshape(-1, 3).cuda()
     return eng.render(pk, bias, fr, bg, pix_index=t(np.asarray(ray_idx, np.int32)).cuda(), want_weights=want_weights,
                       want_z=want_z)
+
+
+@pytest.mark.parametrize("n_coarse", [32, 128])
+def test_render_coarse_other_sample_counts_vs_reference_golden(eng, packed, scene, latents, golden, n_coarse):
+    """--N_samples 32 / 128 (MAIN:612-619; round 5 refused everything but 64): the coarse renderer against golden G15, the
+    reference's own loop at those counts - depths bitwise, weights 2e-6, RGB 2e-5 in the exact tier; the f16 tier at its
+    image gate; the hierarchical mode keeps 64 coarse samples and says so."""
+    g = golden("g15_coarse_nsamples")
+    S = n_coarse
+    out = _render_subset(eng, packed, scene, latents, g["signal"][0], g["signal_torso"].reshape(-1), g["ray_idx"], "f32", 0, 2,
+                         want_weights=True, want_z=True, n_coarse=S)
+    rh, rc, wh, wc, z = [o.cpu().numpy() for o in out]
+    assert z.shape == (len(g["ray_idx"]), S) and np.array_equal(z[0], g[f"z_{S}"]) and (z == z[0]).all()
+    np.testing.assert_allclose(wh, g[f"w_head_{S}"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(wc, g[f"w_com_{S}"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(rh, g[f"rgb_head_{S}"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(rc, g[f"rgb_com_{S}"], atol=2e-5, rtol=0)
+    rh1, rc1 = _render_subset(eng, packed, scene, latents, g["signal"][0], None, g["ray_idx"], "f32", 0, 1, n_coarse=S)
+    assert rc1 is None
+    np.testing.assert_allclose(rh1.cpu().numpy(), rh, atol=1e-6, rtol=0)
+    for tier, gate in (("f16", 55.0), ("bf16", 42.0)):
+        th, tc = _render_subset(eng, packed, scene, latents, g["signal"][0], g["signal_torso"].reshape(-1), g["ray_idx"], tier, 0, 2,
+                                n_coarse=S)
+        ph, pc = psnr(th.cpu().numpy(), g[f"rgb_head_{S}"]), psnr(tc.cpu().numpy(), g[f"rgb_com_{S}"])
+        print(f"N_samples {S}, {tier}: head {ph:.1f} dB, com {pc:.1f} dB against the reference")
+        assert min(ph, pc) >= gate
+    with pytest.raises(Exception, match="n_coarse = 64"):
+        _render_subset(eng, packed, scene, latents, g["signal"][0], None, g["ray_idx"][:8], "f32", 128, 1, n_coarse=S)
 
 
 def test_render_coarse_f32_vs_reference_golden(eng, packed, scene, latents, golden):

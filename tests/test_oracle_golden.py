@@ -1,5 +1,7 @@
 """Pin the CPU oracle (oracle/dfa_oracle.py) against vectors produced by the
 imported reference (tests/golden/make_golden.py).  CPU only."""
+import os
+
 import numpy as np
 import torch
 
@@ -60,6 +62,28 @@ def test_g3_decoder(golden, states, latents):
     assert np.array_equal(O.posenc(t(g["p_big"]), 10).numpy(), g["pe_big"])
     d = t(g["r_64"][:, :8])
     assert np.array_equal(O.posenc(d / torch.norm(d, dim=-1, keepdim=True), 4).numpy(), g["pe_v"])
+
+
+def test_g14_listener_backward(golden, states, latents):
+    """the listener input layers (signal None: decoder.py:306-307, 322-323) under autograd: the oracle's gradients against the
+    reference module's (G14) - which parameters get one, their norms, sampled entries, the two listener matrices in full"""
+    g, g3 = golden("g14_listener_backward"), golden("g3_decoder")
+    P = {k: v.clone().requires_grad_(True) for k, v in O.params_to_torch(states["decoder"]).items()}
+    zs, za = [t(v) for v in latents]
+    feat, sigma = O.decoder_forward(P, t(g3["p_64"]), t(g3["r_64"]), zs[:, 0], za[:, 0], [None, None], 'head')
+    loss = (feat * t(g["w_f"])).sum() + (sigma * t(g["w_s"])).sum()
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-5)
+    loss.backward()
+    touched = open(os.path.join(os.path.dirname(__file__), "golden", "g14_listener_touched.txt")).read().split()
+    assert sorted(k for k, v in P.items() if v.grad is not None and float(v.grad.abs().max()) > 0) == sorted(touched)
+    for k in touched:
+        gr = P[k].grad.reshape(-1)
+        ref = float(g["gnorm/" + k])
+        assert abs(float(gr.double().norm()) - ref) <= 1e-4 * ref, k
+        np.testing.assert_allclose(gr[:: max(1, gr.numel() // 8)][:8].numpy(), g["gsamp/" + k], rtol=2e-3, atol=1e-5 * ref)
+    for k in ("fc_in_listener.weight", "fc_p_skips_listener.0.weight"):
+        d = (P[k].grad - t(g["gfull/" + k])).double().norm() / float(g["gnorm/" + k])
+        assert float(d) < 1e-5, (k, float(d))
 
 
 def test_g4_composite_weights(golden):
@@ -128,6 +152,21 @@ def test_g7_frame_coarse(golden, states, scene, latents):
     for got, ref in ((rh, "rgb8_head"), (rc, "rgb8_com")):
         d = np.abs(O.to8b(got.numpy()).astype(int) - g[ref].astype(int))
         assert d.max() <= 1 and (d > 0).mean() <= 1e-3
+
+
+def test_g15_coarse_other_sample_counts(golden, states, scene, latents):
+    """--N_samples 32 and 128 (MAIN:612-619: the flag is free upstream), coarse only: the oracle's loop against the reference's"""
+    g = golden("g15_coarse_nsamples")
+    P, zs, za, rays, bg = _frame_inputs(states, scene, latents, g)
+    for S in (32, 128):
+        with torch.no_grad():
+            rh, rc, aux = O.render_rays_chunk(P, *rays, bg, 0.3, 0.9, zs, za, [t(g["signal"]), None], t(g["signal_torso"]), S, 0, 2,
+                                              return_aux=True)
+        assert np.array_equal(O.coarse_z(0.3, 0.9, S).numpy(), g[f"z_{S}"])
+        np.testing.assert_allclose(rh.numpy(), g[f"rgb_head_{S}"], atol=2e-6, rtol=0)
+        np.testing.assert_allclose(rc.numpy(), g[f"rgb_com_{S}"], atol=2e-6, rtol=0)
+        np.testing.assert_allclose(aux["w_head"].numpy(), g[f"w_head_{S}"], atol=1e-6, rtol=0)
+        np.testing.assert_allclose(aux["w_com"].numpy(), g[f"w_com_{S}"], atol=1e-6, rtol=0)
 
 
 def test_g7_frame_hier(golden, states, scene, latents):

@@ -101,7 +101,7 @@ def test_error_paths_without_gpu():
     assert L.dfn_packed_bytes(2, 0) == L.dfn_packed_bytes(1, 0) > 0 and L.dfn_bias_floats(2, 1) == L.dfn_bias_floats(1, 1)
     assert L.dfn_packed_bwd_bytes(2, 0) == -1 and L.dfn_weight_grad(2, 0, one, one, 64, one, one, N) == -1
     assert L.dfn_decoder_train_fwd(2, 0, one, one, one, one, 32, one, one, one, one, one, N) == -1
-    assert L.dfn_decoder_train_fwd(1, 2, one, one, one, one, 32, one, one, one, one, one, N) == -1        # listener
+    assert L.dfn_decoder_train_fwd(1, 3, one, one, one, one, 32, one, one, one, one, one, N) == -1        # no such field (2 = listener: trains since round 6)
     assert L.dfn_decoder_fwd(1, 0, one, one, N, one, 4, one, one, N) == -1
     assert L.dfn_adam_multi(N, N, 4, 1e-3, 0.9, 0.999, 1e-8, 0.1, 0.03, N) == -1                          # no tables
     assert L.dfn_adam_multi(one, one, 4, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0.03, N) == -1                      # t = 0: bias_c1 = 0

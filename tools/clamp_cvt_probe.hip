@@ -1,6 +1,6 @@
 // Developer probe (GPU box): does the CLAMP bit of the packed f32 -> f16 / bf16 conversions saturate the RESULT to [0, 1] on gfx950?
 // (If it does, conversion + ReLU of activations pre-scaled into [0, 1] is ONE instruction per two values instead of two:
-// DESIGN.md 8 "Open (0)", tools/power_mix_sweep.py.)   hipcc --offload-arch=gfx950 tools/clamp_cvt_probe.hip -o tools/clamp_cvt_probe.bin
+// LABNOTES.md 8 "Open (0)", tools/power_mix_sweep.py.)   hipcc --offload-arch=gfx950 tools/clamp_cvt_probe.hip -o tools/clamp_cvt_probe.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>

@@ -4,7 +4,7 @@
 VERDICT r02 item 3 asks for one decisive experiment on the headline kernel: bf16 MFMA operands for the seven trunk layers
 (the bf16 instruction stream clocks ~5 % higher than the f16 one under the power limit) and f16 only "where the error
 enters" (PE input layer + skip, sigma / rgb heads) - to be kept only if the full-frame PSNR against the exact tier stays
->= 49.4 dB (the north star's 0.05 dB clause).  Before building that kernel this script measures what it could
+>= 49.4 dB (the north star's 0.05 dB clause, LABNOTES.md 3).  Before building that kernel this script measures what it could
 deliver: the row-H pipeline of the oracle (coarse pass -> sample_pdf -> merged pass -> compositing; C2 geometry, head field,
 64 + 128) with the decoder's GEMM operands (activations AND weights) rounded per layer to bf16 / f16 exactly as the kernel's
 tiers do (f32 accumulation, f32 folded biases), on a strided subset of the 450 x 450 frame; PSNR against the same pipeline

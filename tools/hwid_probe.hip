@@ -2,7 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O2 tools/hwid_probe.hip -o tools/hwid_probe.bin && tools/hwid_probe.bin
 // Reads HW_REG_HW_ID (gfx9 layout: WAVE_ID [3:0], SIMD_ID [5:4], PIPE_ID [7:6], CU_ID [11:8], SH_ID [12], SE_ID [15:13]) in
 // every wave of workgroups that hold a compute unit alone (96 KiB of LDS, like the training kernels): the question behind
-// the de-phased hand-over - are waves w and w + 4 the two waves of one SIMD, or w and w + 1?
+// the de-phased hand-over (LABNOTES.md 7, round 5) - are waves w and w + 4 the two waves of one SIMD, or w and w + 1?
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __global__ __launch_bounds__(512, 2) void k(unsigned* out) {

@@ -1,6 +1,6 @@
 // l2_atomic_probe.hip - what does it cost to accumulate weight-gradient partials in the XCD's own L2?
 //
-// Design question behind it: a backward kernel that forms dW inside the dX chain has to flush a
+// Design question behind it (LABNOTES.md §7): a backward kernel that forms dW inside the dX chain has to flush a
 // 256 x 256 f32 accumulator tile (256 KB) per 256 sample points and layer.  If every XCD owns one private copy of
 // the gradient buffer (2.3 MB per field: L2-resident) and its workgroups add into it with atomics that are resolved
 // in that L2, no partial ever goes to HBM.  This probe measures the rate of exactly that flush pattern:
