@@ -233,6 +233,8 @@ def cpu_worker(spec):
                            torch.from_numpy(zs), torch.from_numpy(za), sig, sigt, 64, n_fine, fields, 2048, ray_begin=b, ray_count=n)
             return time.perf_counter() - t0
         run(0, 256)
+        if reps > 1:
+            run(begin, 2048)          # one whole untimed chunk: the repetitions of a run rose by 4-5 % each from a cold start (round 6)
         secs = [sum(run(begin + 2048 * (chunks * k + c), 2048) for c in range(chunks)) for k in range(reps)]
     print(json.dumps({"rays": 2048 * chunks, "seconds": secs}))
 
