@@ -903,7 +903,7 @@ def train():
             pf = engine.FramePrefetcher(enc, renderer.decoder.packed(renderer.tier), renderer.zs, renderer.za,
                                         args.smo_size if smoothed else 0, args.smo_torse_size if smoothed else 0, fields=2,
                                         length=len_sig)
-        if renderer.tier == "f16" and frame_ids:
+        if (renderer.tier == "f16" or renderer.auto) and frame_ids:
             # range guard of the f16 tier (f16guard.py): a few hundred rays of up to eight of these frames through the exact
             # tier, with their own poses and signals; refuses a checkpoint whose activations half precision cannot hold
             def sig_of(k):
@@ -1052,7 +1052,7 @@ def train():
                                               len(i_train) + len(i_val), embed_fn=embed_fn)
                     return sg[0], st_
             test_ids = [i_val[t] for t in range(0, len(i_val), 100)]
-            if renderer.tier == "f16" and test_ids:
+            if (renderer.tier == "f16" or renderer.auto) and test_ids:
                 # the weights change every step: both guards of the f16 tier again on the frames about to be rendered, the model's
                 # own PSNR measured against their ground truth (this render used to run unguarded)
                 renderer.check_f16([poses_host[j] for j in test_ids], poses_host[0], lambda k: test_signals(test_ids[k]),

@@ -259,3 +259,10 @@ def test_f16_tier_refuses_an_out_of_range_checkpoint_loudly(dataset, states, lat
     assert not res.exists() or not os.listdir(res)
     _run(root, base.replace("--hip_tier f16", "--hip_tier bf16") + " --expname big_acts --resume dataset/train_together/big_acts/280000.tar")
     assert len(os.listdir(res)) == F_VAL
+    # --hip_tier auto (round 6): the same checkpoint is rendered - in the exact tier, and the run says why; the in-range one stays in f16
+    for f in os.listdir(res):
+        os.remove(res / f)
+    out = _run(root, base.replace("--hip_tier f16", "--hip_tier auto") + " --expname big_acts --resume dataset/train_together/big_acts/280000.tar")
+    assert "--hip_tier auto: rendering in the exact tier" in out and len(os.listdir(res)) == F_VAL
+    out = _run(root, base.replace("--hip_tier f16", "--hip_tier auto"))
+    assert "rendering in the exact tier" not in out and "f16 tier: accuracy on" in out
