@@ -208,9 +208,9 @@ extern "C" {
 
 const char* dfn_last_error(void) { return g_err.c_str(); }
 #ifdef DFN_DEV_BUILD      // (dfn_devguard.h: a library built with developer switches says so, and dfanerf._lib refuses it in-tree)
-const char* dfn_version(void) { return "dfanerf 0.1 gfx950 DEV"; }
+const char* dfn_version(void) { return "dfanerf 0.2 gfx950 DEV"; }
 #else
-const char* dfn_version(void) { return "dfanerf 0.1 gfx950"; }
+const char* dfn_version(void) { return "dfanerf 0.2 gfx950"; }
 #endif
 
 long dfn_packed_bytes(int tier, int field) {

@@ -45,7 +45,10 @@ extern "C" {
 #define DFN_N_DECODER_PARAMS 955242
 
 const char* dfn_last_error(void);
-/* library build info: "dfanerf <version> gfx950" */
+/* library build info: "dfanerf <version> gfx950".  ABI notes - 0.2 (round 6): + dfn_wgrad_plan; DFN_FIELD_LISTENER accepted by the
+ * training entry points; DfnFrame.n_coarse 32 / 64 / 128.  Since round 5 (still "0.1" then): dfn_weight_bias_grad_partials only fills
+ * the workspace's per-slice partials in EVERY tier - dbias is written by dfn_weight_bias_grad_reduce (a caller of _partials alone gets
+ * no bias gradient; tests/test_gpu_wgrad.py holds the pair to the one-call form bit for bit). */
 const char* dfn_version(void);
 
 /* ---- geometry of one frame (host struct, passed by value inside the calls below) -------------------- */

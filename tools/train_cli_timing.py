@@ -2,7 +2,7 @@
 """Developer tool (GPU box): step time of the REAL training CLI (NeRFs/DFANeRF/run_nerf_com_trainExpLater.py with the
 flag bundle of scripts/train_obama.sh) on a synthetic 450x450 dataset written in the reference's on-disk format, next to
 `bench.py --workload c4` - the input stage (frames.py) must keep the loop GPU-bound: no image decode, no host-to-device
-copy per step once the frames are resident.   python tools/train_cli_timing.py [steps]"""
+copy per step once the frames are resident.   python tools/train_cli_timing.py [steps] [bf16|f32]"""
 import json
 import os
 import subprocess
@@ -19,6 +19,7 @@ from dfanerf import nets, run_nerf, synth
 from dfanerf.decoder import Decoder
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+tier = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 H = W = 450
 F_TRAIN, F_VAL = 12, 2
 root = tempfile.mkdtemp(prefix="dfn_cli_")
@@ -57,7 +58,7 @@ flags = ("--config dataset/obama/HeadNeRF_config_ba.txt --last_dist=1e10 --datad
          "--smo_torse_size 8 --train_together --i_weights=100000000 --all_speaker --sample_rate_mouth=0 --lrate_decay=500 "
          "--lrate=5e-4 --use_et_embed --nosmo_iters=300000 --dim_signal=96 --dim_aud=96 --n_object=1 "
          "--expname=obama_TrainExpLater_smoMix --aud_file=obama_aud.pt --use_deformation_field --exp_file=obama_64_32.pt "
-         "--use_ba --noexp_iters 400000 --hip_tier bf16 "
+         f"--use_ba --noexp_iters 400000 --hip_tier {tier} "
          "--resume dataset/train_together/obama_TrainExpLater_smoMix/300000.tar").split()
 script = os.path.join(ROOT, "NeRFs", "DFANeRF", "run_nerf_com_trainExpLater.py")
 res = {}
@@ -67,7 +68,7 @@ for n in (100, 100, 100 + steps):                  # a discarded warm-up run (fi
     res[n] = time.perf_counter() - t0
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
 ms = (res[100 + steps] - res[100]) / steps * 1e3
-print(json.dumps({"train_cli_ms_per_step": ms, "steps": steps, "N_rand": 2048, "tier": "bf16",
+print(json.dumps({"train_cli_ms_per_step": ms, "steps": steps, "N_rand": 2048, "tier": tier,
                   "wall_s": {str(k): round(v, 2) for k, v in res.items()},
                   "note": "scripts/train_obama.sh flag bundle, 450x450 synthetic dataset, steady-state steps = the "
                           "difference of two run lengths (start-up, frame decode and the checkpoint load cancel)"}))
