@@ -95,7 +95,7 @@ def _run2(root, extra, world=2):
     return r.stdout
 
 
-def _oracle_frame_u8(root, sc, states, latents, k):
+def _oracle_frame_u8(root, sc, states, latents, k, n_coarse=64):
     """val frame k of the dataset through the oracle's frame loop -> uint8 (head, com) images"""
     from PIL import Image
     P = O.params_to_torch(states["decoder"])
@@ -107,7 +107,7 @@ def _oracle_frame_u8(root, sc, states, latents, k):
         sig = O.encode_signal(nets_o, auds, exps, k, 280000, 300000, 4, F_VAL)
         sigt = O.encode_signal_torso(nets_o, poses, k, 280000, 300000, 8, F_VAL)
         rh, rc = O.render_frame(P, H, W, 150.0, W / 2.0, H / 2.0, poses[k].numpy(), pose_body, bg, 0.3, 0.9,
-                                t(latents[0]), t(latents[1]), sig, sigt, 64, 0, 2)
+                                t(latents[0]), t(latents[1]), sig, sigt, n_coarse, 0, 2)
     return O.to8b(rh.reshape(H, W, 3).numpy()), O.to8b(rc.reshape(H, W, 3).numpy())
 
 
@@ -134,6 +134,13 @@ def test_render_person_cli(dataset, states, latents):
     img = np.asarray(Image.open(out / "render_com" / "test_000001.jpg")).astype(np.float32)
     ref = np.asarray(Image.open(out / "render_com" / "test_000001.png").convert("RGB")).astype(np.float32)
     assert np.abs(img - ref).mean() < 6.0                    # JPEG quality 95 of the same image (noisy background)
+    # --N_samples is free upstream (MAIN:612-619); round 6: 32 and 128 render too - the CLI's frame against the oracle's loop at 32
+    _run(root, "--render_person --test_file transforms_val_ba.json --N_rand=2048 --N_iters=600000 --image_ext png --N_samples 32")
+    ref_h, ref_c = _oracle_frame_u8(root, sc, states, latents, 1, n_coarse=32)
+    for sub, ref in (("render_com", ref_c), ("render_head", ref_h)):
+        img = np.asarray(Image.open(out / sub / "test_000001.png").convert("RGB"))
+        d = np.abs(img.astype(int) - ref.astype(int))
+        assert d.max() <= 1 and (d > 0).mean() <= 2e-3, ("N_samples 32", sub, int(d.max()), float((d > 0).mean()))
 
 
 def test_render_person_cli_on_a_generate_test_jsons_file(dataset):
