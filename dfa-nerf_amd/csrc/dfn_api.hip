@@ -1126,8 +1126,14 @@ int dfn_decoder_train_fwd(int tier, int field, const void* packed, const float* 
 
 int dfn_get_rays(int H, int W, float focal, float cx, float cy, const float* c2w_host, float* rays_o,
                  float* rays_d, void* stream) {
-    if (H <= 0 || W <= 0 || !c2w_host || !rays_o || !rays_d) return fail(DFN_E_ARG, "dfn_get_rays: bad argument");
-    hipError_t err = launch_get_rays(H, W, focal, cx, cy, c2w_host, rays_o, rays_d, (hipStream_t)stream);
+    return dfn_get_rays_strided(H, W, 1, focal, cx, cy, c2w_host, rays_o, rays_d, stream);
+}
+
+int dfn_get_rays_strided(int H, int W, int stride, float focal, float cx, float cy, const float* c2w_host, float* rays_o,
+                         float* rays_d, void* stream) {
+    if (H <= 0 || W <= 0 || stride <= 0 || H / stride <= 0 || W / stride <= 0 || !c2w_host || !rays_o || !rays_d)
+        return fail(DFN_E_ARG, "dfn_get_rays: bad argument");
+    hipError_t err = launch_get_rays(H, W, stride, focal, cx, cy, c2w_host, rays_o, rays_d, (hipStream_t)stream);
     if (err != hipSuccess) return hip_fail(err, "get_rays_kernel");
     return DFN_OK;
 }

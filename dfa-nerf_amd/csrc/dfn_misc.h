@@ -19,7 +19,7 @@ hipError_t launch_fold_bwd_sig(int field, const float* params, const float* dbia
 int sig_term_elements(int field, int* out);      // <= 512 bias-blob elements whose fold carries a signal term
 hipError_t launch_fold(int field, const float* params, const float* sig, const float* zs, const float* za,
                        float* out, int n, hipStream_t st);
-hipError_t launch_get_rays(int H, int W, float focal, float cx, float cy, const float* c2w_host, float* ro,
+hipError_t launch_get_rays(int H, int W, int stride, float focal, float cx, float cy, const float* c2w_host, float* ro,
                            float* rd, hipStream_t st);
 hipError_t launch_ndc_rays(int H, int W, float focal, float z_near, const float* ro, const float* rd, long n,
                            float* oo, float* od, hipStream_t st);

@@ -313,12 +313,21 @@ int sig_term_elements(int field, int* out) {
 
 // ---- get_rays / ndc_rays ----------------------------------------------------------------------------------------
 struct Pose12 { float m[12]; };
-__global__ void get_rays_kernel(int H, int W, float focal, float cx, float cy, Pose12 c2w, float* ro, float* rd) {
+// torch.linspace(0, end, n)[i] in f32 (ATen linspace_kernel; oracle/dfa_oracle.py: linspace): step = end / (n - 1); lower half step * i,
+// upper half end - step * (n - 1 - i) as ONE fused multiply-add.  n = end + 1 (stride 1): the integers, exactly.
+__device__ __forceinline__ float linspace0(int i, int n, float end) {
+    if (n <= 1) return 0.f;
+    const float step = __fdiv_rn(end, (float)(n - 1));
+    return (i < n / 2) ? __fmul_rn(step, (float)i) : fmaf(-step, (float)(n - 1 - i), end);
+}
+// H, W: the image; Hn x Wn = (H / stride) x (W / stride) rays through linspace(0, W - 1, Wn) x linspace(0, H - 1, Hn) (HELP:451)
+__global__ void get_rays_kernel(int H, int W, int Hn, int Wn, float focal, float cx, float cy, Pose12 c2w, float* ro, float* rd) {
     const int pix = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= H * W) return;
-    const int y = pix / W, x = pix - y * W;
-    const float dx = __fdiv_rn(__fsub_rn((float)x, cx), focal);
-    const float dy = __fdiv_rn(-__fsub_rn((float)y, cy), focal);
+    if (pix >= Hn * Wn) return;
+    const int yi = pix / Wn, xi = pix - yi * Wn;
+    const float x = linspace0(xi, Wn, (float)(W - 1)), y = linspace0(yi, Hn, (float)(H - 1));
+    const float dx = __fdiv_rn(__fsub_rn(x, cx), focal);
+    const float dy = __fdiv_rn(-__fsub_rn(y, cy), focal);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, c2w.m[4 * k]), __fmul_rn(dy, c2w.m[4 * k + 1])),
@@ -327,11 +336,12 @@ __global__ void get_rays_kernel(int H, int W, float focal, float cx, float cy, P
         ro[(size_t)pix * 3 + k] = c2w.m[4 * k + 3];
     }
 }
-hipError_t launch_get_rays(int H, int W, float focal, float cx, float cy, const float* c2w_host, float* ro,
+hipError_t launch_get_rays(int H, int W, int stride, float focal, float cx, float cy, const float* c2w_host, float* ro,
                            float* rd, hipStream_t st) {
     Pose12 p;
     for (int i = 0; i < 12; ++i) p.m[i] = c2w_host[i];
-    hipLaunchKernelGGL(get_rays_kernel, dim3((H * W + 255) / 256), dim3(256), 0, st, H, W, focal, cx, cy, p, ro, rd);
+    const int Hn = H / stride, Wn = W / stride;
+    hipLaunchKernelGGL(get_rays_kernel, dim3((Hn * Wn + 255) / 256), dim3(256), 0, st, H, W, Hn, Wn, focal, cx, cy, p, ro, rd);
     return hipGetLastError();
 }
 

@@ -70,6 +70,7 @@ def _load():
         "dfn_decoder_fwd": (i32, [i32, i32, vp, fp, fp, fp, lg, fp, fp, vp]),
         "dfn_decoder_train_fwd": (i32, [i32, i32, vp, fp, fp, fp, lg, fp, fp, fp, vp, vp, vp]),
         "dfn_get_rays": (i32, [i32, i32, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), fp, fp, vp]),
+        "dfn_get_rays_strided": (i32, [i32, i32, i32, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), fp, fp, vp]),
         "dfn_ndc_rays": (i32, [i32, i32, C.c_float, C.c_float, fp, fp, lg, fp, fp, vp]),
         "dfn_sample_pdf": (i32, [fp, fp, lg, i32, i32, fp, fp, vp]),
         "dfn_composite": (i32, [fp, fp, i32, lg, fp, fp, vp]),

@@ -337,16 +337,17 @@ def decoder_forward(packed, field, bias, points, dirs):
 
 
 # ---- building blocks ------------------------------------------------------------------------------------------
-def get_rays(H, W, focal, c2w, cx=None, cy=None, device="cuda"):
+def get_rays(H, W, focal, c2w, cx=None, cy=None, device="cuda", stride=1):
     require_gpu()
     cx = W * .5 if cx is None else cx
     cy = H * .5 if cy is None else cy
     m = (c2w.detach().cpu().numpy() if isinstance(c2w, torch.Tensor) else np.asarray(c2w)).astype(np.float32)
     m = np.ascontiguousarray(m[:3, :4]).reshape(-1)
     arr = (C.c_float * 12)(*[float(v) for v in m])
-    ro = torch.empty(H, W, 3, dtype=torch.float32, device=device)
-    rd = torch.empty(H, W, 3, dtype=torch.float32, device=device)
-    check(lib.dfn_get_rays(int(H), int(W), float(focal), float(cx), float(cy), arr, _ptr(ro), _ptr(rd), _stream()),
+    stride = int(stride)
+    ro = torch.empty(H // stride, W // stride, 3, dtype=torch.float32, device=device)
+    rd = torch.empty(H // stride, W // stride, 3, dtype=torch.float32, device=device)
+    check(lib.dfn_get_rays_strided(int(H), int(W), stride, float(focal), float(cx), float(cy), arr, _ptr(ro), _ptr(rd), _stream()),
           "dfn_get_rays")
     return ro, rd
 

@@ -35,14 +35,12 @@ def _device_of(c2w):
 
 def get_rays(H, W, focal, c2w, cx=None, cy=None, stride=1):
     """rays_o, rays_d [H//stride, W//stride, 3]; ray (y, x) through pixel centre (x*?, y) like the reference
-    (linspace(0, W-1, W//stride)).  Runs dfn_get_rays on the GPU; stride != 1 is never used by the driver."""
-    if stride != 1:
-        raise NotImplementedError("get_rays(stride != 1) is not used by the reference driver")
+    (linspace(0, W-1, W//stride)).  Runs dfn_get_rays[_strided] on the GPU; stride != 1 is never used by the driver (golden G1c)."""
     dev = _device_of(c2w)
     if dev is None:
         raise RuntimeError("get_rays runs on the GPU (no CPU fallback)")
     from . import engine
-    return engine.get_rays(int(H), int(W), float(focal), c2w, cx, cy, device=dev)
+    return engine.get_rays(int(H), int(W), float(focal), c2w, cx, cy, device=dev, stride=int(stride))
 
 
 def get_rays_np(H, W, focal, c2w, cx=None, cy=None):

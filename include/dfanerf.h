@@ -361,6 +361,11 @@ int dfn_decoder_train_fwd(int tier, int field, const void* packed, const float* 
 /* get_rays, HELP:449-465: rays_o, rays_d [H*W,3] for c2w (3x4, host memory, 12 floats). */
 int dfn_get_rays(int H, int W, float focal, float cx, float cy, const float* c2w_host, float* rays_o,
                  float* rays_d, void* stream);
+/* ... with HELP:449's `stride`: (H / stride) x (W / stride) rays through the pixel positions torch.linspace(0, W - 1, W / stride) x
+ * torch.linspace(0, H - 1, H / stride) (not integers for stride > 1); rays_o, rays_d [(H / stride) * (W / stride), 3].  Dead upstream
+ * (every caller passes stride 1); kept for the signature. */
+int dfn_get_rays_strided(int H, int W, int stride, float focal, float cx, float cy, const float* c2w_host, float* rays_o,
+                         float* rays_d, void* stream);
 /* ndc_rays, HELP:484-503 (n rays). */
 int dfn_ndc_rays(int H, int W, float focal, float z_near, const float* rays_o, const float* rays_d, long n,
                  float* out_o, float* out_d, void* stream);

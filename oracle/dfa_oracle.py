@@ -45,14 +45,28 @@ def params_to_torch(state):
 # --------------------------------------------------------------------------
 # A1 / A2: rays
 # --------------------------------------------------------------------------
-def get_rays(H, W, focal, c2w, cx=None, cy=None):
+def linspace0(end, n):
+    """torch.linspace(0, end, n) restated like linspace01 below (ATen linspace_kernel): f32 step end/(n-1), lower half step*i, upper
+    half end - step*(n-1-i) as one fused multiply-add.  n = end + 1 gives the integers exactly."""
+    if n <= 1:
+        return torch.zeros(max(n, 0), dtype=torch.float32)
+    step = np.float64(np.float32(end) / np.float32(n - 1))
+    i = np.arange(n)
+    lo = (step * i).astype(np.float32)
+    hi = (np.float64(np.float32(end)) - step * (n - 1 - i)).astype(np.float32)
+    return torch.from_numpy(np.where(i < n // 2, lo, hi).astype(np.float32))
+
+
+def get_rays(H, W, focal, c2w, cx=None, cy=None, stride=1):
     """HELP:449-465.  x = column, y = row; ray index y*W+x after reshape(-1,3).
-    rays_d[k] = (dx*R[k,0] + dy*R[k,1]) + dz*R[k,2], separate f32 roundings."""
+    rays_d[k] = (dx*R[k,0] + dy*R[k,1]) + dz*R[k,2], separate f32 roundings.  stride (dead upstream): W//stride x H//stride rays
+    through linspace(0, W-1, W//stride) x linspace(0, H-1, H//stride)."""
     c2w = T(c2w).float()
     cx = W * .5 if cx is None else cx
     cy = H * .5 if cy is None else cy
-    xs = torch.arange(W, dtype=torch.float32)[None, :].expand(H, W)
-    ys = torch.arange(H, dtype=torch.float32)[:, None].expand(H, W)
+    Hn, Wn = H // stride, W // stride
+    xs = linspace0(W - 1, Wn)[None, :].expand(Hn, Wn)
+    ys = linspace0(H - 1, Hn)[:, None].expand(Hn, Wn)
     dx = (xs - cx) / focal
     dy = -(ys - cy) / focal
     dz = -torch.ones_like(dx)

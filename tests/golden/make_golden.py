@@ -113,6 +113,19 @@ def main():
     ro, rd = HELP.get_rays(8, 6, 100.0, t(sc["poses"][1])[:3, :4])
     g1["small_rays_d"] = rd
     save("g1_rays", **g1)
+    # G1c (round 6): get_rays' `stride` argument (HELP:449-451; dead in the driver): 225 x 225 and 150 x 150 rays, 3 and 7 with sizes
+    # that do not divide (450 // 7 = 64)
+    g1c = {"hwfcxy": np.array([H, W, focal, cx, cy], np.float64), "pose": sc["poses"][5]}
+    for stride in (2, 3, 7):
+        ro, rd = HELP.get_rays(H, W, focal, t(sc["poses"][5])[:3, :4], cx, cy, stride=stride)
+        n = rd.shape[0] * rd.shape[1]
+        pick = np.unique(np.concatenate([[0, rd.shape[1] - 1, n - rd.shape[1], n - 1], np.random.RandomState(stride).randint(0, n, 250)]))
+        g1c[f"idx_{stride}"] = pick.astype(np.int64)
+        g1c[f"shape_{stride}"] = np.array(rd.shape[:2])
+        g1c[f"rays_d_{stride}"] = rd.reshape(-1, 3)[pick]
+        g1c[f"rays_o_{stride}"] = ro.reshape(-1, 3)[pick]
+        g1c[f"sum_d_{stride}"] = rd.double().sum((0, 1))
+    save("g1c_rays_stride", **g1c)
 
     # ---- G2: z_vals --------------------------------------------------------------
     g2 = {}

@@ -65,6 +65,16 @@ def test_get_rays_bitwise_full_frame(eng, scene, golden):
         np.testing.assert_allclose(nd.cpu().numpy()[idx], g["ndc_d_" + tag], rtol=2e-6, atol=1e-6)
     _, rd = eng.get_rays(8, 6, 100.0, scene["poses"][1][:3, :4])
     assert np.array_equal(rd.cpu().numpy(), g["small_rays_d"])
+    # the `stride` argument (HELP:449-451; round 5 raised NotImplementedError): every ray bitwise against the oracle, the golden's
+    # rays bitwise against the reference - through the drop-in helper
+    from dfanerf import helpers
+    gc = golden("g1c_rays_stride")
+    for s in (2, 3, 7):
+        ro, rd = helpers.get_rays(H, W, scene["focal"], t(gc["pose"][:3, :4]).cuda(), scene["cx"], scene["cy"], stride=s)
+        oro, ord_ = O.get_rays(H, W, scene["focal"], gc["pose"][:3, :4], scene["cx"], scene["cy"], stride=s)
+        assert tuple(rd.shape) == (H // s, W // s, 3) and np.array_equal(rd.cpu().numpy(), ord_.numpy())
+        assert np.array_equal(ro.cpu().numpy(), oro.numpy())
+        assert np.array_equal(rd.reshape(-1, 3)[t(gc[f"idx_{s}"]).cuda()].cpu().numpy(), gc[f"rays_d_{s}"])
 
 
 def _assert_samples_match(got, bins, w, n, u=None):

@@ -64,6 +64,18 @@ def test_g3_decoder(golden, states, latents):
     assert np.array_equal(O.posenc(d / torch.norm(d, dim=-1, keepdim=True), 4).numpy(), g["pe_v"])
 
 
+def test_g1c_get_rays_stride_bitwise(golden):
+    """get_rays' `stride` argument (HELP:449-451: non-integer pixel positions from torch.linspace; dead in the driver), all rays bitwise"""
+    g = golden("g1c_rays_stride")
+    H, W, focal, cx, cy = g["hwfcxy"]
+    for s in (2, 3, 7):
+        ro, rd = O.get_rays(int(H), int(W), focal, g["pose"][:3, :4], cx, cy, stride=s)
+        assert tuple(rd.shape[:2]) == tuple(g[f"shape_{s}"]) == (int(H) // s, int(W) // s)
+        idx = g[f"idx_{s}"]
+        assert np.array_equal(rd.reshape(-1, 3)[idx].numpy(), g[f"rays_d_{s}"]) and np.array_equal(ro.reshape(-1, 3)[idx].numpy(), g[f"rays_o_{s}"])
+        assert np.array_equal(rd.double().sum((0, 1)).numpy(), g[f"sum_d_{s}"])
+
+
 def test_g14_listener_backward(golden, states, latents):
     """the listener input layers (signal None: decoder.py:306-307, 322-323) under autograd: the oracle's gradients against the
     reference module's (G14) - which parameters get one, their norms, sampled entries, the two listener matrices in full"""
