@@ -138,19 +138,25 @@ def weight_bound(flat_params):
     return float(flat_params.detach().abs().max())
 
 
-def activation_bounds(flat_params, frames, sig_heads, sig_torsos, z_shape, z_app, bg, n_rays=256, seed=0):
-    """max |GEMM input| per layer and field over n_rays random pixels of every frame in `frames` (engine.make_frame objects with
-    fields = 2, n_fine = 0; ray_count is overwritten), with that frame's conditioning signals sig_heads[k] [96] /
-    sig_torsos[k] [42].  -> {"head": {layer: max}, "torso": {...}}.  Runs in the EXACT tier (f32 MFMAs, f32 recording)."""
+def activation_bounds(flat_params, frames, sig_heads, sig_torsos, z_shape, z_app, bg, n_rays=256, seed=0, n_fine=0):
+    """max |GEMM input| per layer and field over n_rays random pixels of every frame in `frames` (engine.make_frame objects;
+    ray_count / n_fine / fields are overwritten), with that frame's conditioning signals sig_heads[k] [96] / sig_torsos[k] [42].
+    n_fine = 64 / 128: the hierarchical forward (dfn_train_fwd_hier) - the fine samples cluster at the surfaces, where the
+    activations are largest, and the production render evaluates them.  -> {"head": {layer: max}, "torso": {...}}.
+    Runs in the EXACT tier (f32 MFMAs, f32 recording)."""
     dev = flat_params.device
     pk = engine.PackedDecoder(flat_params, "f32", fields=(FIELD_HEAD, FIELD_TORSO))
     rows = [_chk(lib.dfn_train_rows(f, 0), "dfn_train_rows") for f in (0, 1)]
     mrows = [_chk(lib.dfn_train_rows(f, 2), "dfn_train_rows") for f in (0, 1)]
-    NP = n_rays * 64
+    n_coarse = 64 if n_fine else int(frames[0].n_coarse)      # (--N_samples 32 / 128 render coarse only)
+    S = n_coarse + int(n_fine)
+    NP = n_rays * S
     act = [torch.empty(NP // 32, rows[f], 32, dtype=torch.float32, device=dev) for f in (0, 1)]
     masks = [torch.empty(NP // 32, mrows[f], 64, dtype=torch.int32, device=dev) for f in (0, 1)]
     samples = torch.empty(NP, 8, dtype=torch.float32, device=dev)
     rgb = torch.empty(2, n_rays, 3, dtype=torch.float32, device=dev)
+    z_all = torch.empty(n_rays, S, dtype=torch.float32, device=dev) if n_fine else None
+    ranks = torch.empty(n_rays, S, dtype=torch.uint8, device=dev) if n_fine else None
     gen = torch.Generator(device="cpu").manual_seed(seed)
     top = [torch.zeros(rows[f], dtype=torch.float32, device=dev) for f in (0, 1)]
     nh = pk.bias_floats(FIELD_HEAD)
@@ -159,11 +165,17 @@ def activation_bounds(flat_params, frames, sig_heads, sig_torsos, z_shape, z_app
     for k, fr in enumerate(frames):
         pix = torch.randperm(fr.H * fr.W, generator=gen)[:n_rays].to(torch.int32).to(dev)
         bias = pk.fold(sig_heads[k], sig_torsos[k], z_shape, z_app)
-        fr.ray_begin, fr.ray_count, fr.n_fine, fr.fields = 0, n_rays, 0, 2
-        _chk(lib.dfn_train_fwd(0, C.byref(fr), _ptr(pk.packed[FIELD_HEAD]), _ptr(pk.packed[FIELD_TORSO]), _ptr(bias),
-                               C.c_void_p(bias.data_ptr() + 4 * nh), _ptr(bg_f32), _ptr(bg_u8), _ptr(pix), _ptr(rgb[0]),
-                               _ptr(rgb[1]), _ptr(samples), _ptr(act[0]), _ptr(masks[0]), _ptr(act[1]), _ptr(masks[1]),
-                               _stream()), "dfn_train_fwd(calibration)")
+        fr.ray_begin, fr.ray_count, fr.n_coarse, fr.n_fine, fr.fields = 0, n_rays, n_coarse, int(n_fine), 2
+        if n_fine:
+            _chk(lib.dfn_train_fwd_hier(0, C.byref(fr), _ptr(pk.packed[FIELD_HEAD]), _ptr(pk.packed[FIELD_TORSO]), _ptr(bias),
+                                        C.c_void_p(bias.data_ptr() + 4 * nh), _ptr(bg_f32), _ptr(bg_u8), _ptr(pix), _ptr(rgb[0]),
+                                        _ptr(rgb[1]), _ptr(samples), _ptr(act[0]), _ptr(masks[0]), _ptr(act[1]), _ptr(masks[1]),
+                                        _ptr(z_all), _ptr(ranks), _stream()), "dfn_train_fwd_hier(calibration)")
+        else:
+            _chk(lib.dfn_train_fwd(0, C.byref(fr), _ptr(pk.packed[FIELD_HEAD]), _ptr(pk.packed[FIELD_TORSO]), _ptr(bias),
+                                   C.c_void_p(bias.data_ptr() + 4 * nh), _ptr(bg_f32), _ptr(bg_u8), _ptr(pix), _ptr(rgb[0]),
+                                   _ptr(rgb[1]), _ptr(samples), _ptr(act[0]), _ptr(masks[0]), _ptr(act[1]), _ptr(masks[1]),
+                                   _stream()), "dfn_train_fwd(calibration)")
         for f in (0, 1):
             top[f] = torch.maximum(top[f], act[f].abs().amax(dim=(0, 2)))
     out = {}

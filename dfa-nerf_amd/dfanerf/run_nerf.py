@@ -375,7 +375,8 @@ class FrameRenderer:
                                               self.near, self.far, self.args.last_dist, 0, n_rays, self.args.N_samples, 0, 2,
                                               self.args.concate_bg))
         with torch.no_grad():
-            pk.f16_bounds = f16guard.activation_bounds(pk.flat, frs, sh, stt, self.zs, self.za, self.bg, n_rays=n_rays)
+            pk.f16_bounds = f16guard.activation_bounds(pk.flat, frs, sh, stt, self.zs, self.za, self.bg, n_rays=n_rays,
+                                                       n_fine=self.n_fine if self.args.N_samples == 64 else 0)
         top = f16guard.check(pk.f16_bounds, pk.f16_weight_max)
         print(f"[dfanerf] f16 tier: calibrated on {len(pick)} frames x {n_rays} rays in the exact tier: max |activation| "
               f"{top:.4g}, max |parameter| {pk.f16_weight_max:.4g} (half precision holds {f16guard.F16_MAX:.0f}; margin x{f16guard.MARGIN:g})")
