@@ -854,7 +854,7 @@ def bench_render(args, workload, tier, steps, warmup, world, rank, dev, sustain_
                 sh.append(s2[0])
                 stt.append(t2[0])
                 frs.append(engine.make_frame(H, W, sc["focal"], sc["cx"], sc["cy"], sc["poses"][f], sc["pose_body"], sc["near"], sc["far"]))
-            b = f16guard.activation_bounds(flat, frs, sh, stt, zs_d, za_d, bg)
+            b = f16guard.activation_bounds(flat, frs, sh, stt, zs_d, za_d, bg, n_fine=n_fine)
             top = f16guard.check(b, pk.f16_weight_max)
             out["f16_range"] = {"max_activation": top, "max_parameter": pk.f16_weight_max, "f16_max": f16guard.F16_MAX,
                                 "margin": f16guard.MARGIN, "frames": F, "rays_per_frame": 256,
