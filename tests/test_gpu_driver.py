@@ -238,6 +238,23 @@ def test_cli_with_several_ranks_on_one_gpu(dataset, world):
     assert lines and np.isfinite(float(lines[-1].split("Com Loss: ")[1].split()[0]))
 
 
+def test_cli_eight_ranks_with_eight_hardware_queues_each(dataset, monkeypatch):
+    """the functional one-GPU modes cap the hardware queues per process (16 / world) because eight ranks x eight
+    queues on ONE device died in start-up copies of c10d-gloo's device-tensor broadcast.  Round 6 stages the replicas through the host
+    under gloo (parallel.broadcast_replicas): with EIGHT queues per process forced, the eight-rank render + training run must pass too
+    (before: 3 of 4 boxes failed; after: 8 of 8 runs passed, profiles/r06g_world8_bcast.txt, r06p_world8_q8_soak.txt)."""
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    root, sc = dataset
+    out = root / "dataset" / "train_together" / "obama_TrainExpLater_smoMix" / "obama" / "person"
+    _run2(root, "--render_person --test_file transforms_val_ba.json --N_rand=2048 --N_iters=600000 --image_ext png", 8)
+    for sub in ("render_com", "render_head"):
+        assert sorted(f for f in os.listdir(out / sub) if f.endswith(".png")) == [f"test_{k:06d}.png" for k in range(F_VAL)]
+    log = _run2(root, "--N_rand=256 --N_iters=280004 --i_weights=3 --hip_tier bf16", 8)
+    lines = [ln for ln in open(root / "dataset" / "train_together" / "obama_TrainExpLater_smoMix" / "loss.txt").read().split("\n")
+             if ln.startswith("[TRAIN] Iter: 280004")]
+    assert lines and np.isfinite(float(lines[-1].split("Com Loss: ")[1].split()[0])), log[-1500:]
+
+
 def test_f16_tier_refuses_an_out_of_range_checkpoint_loudly(dataset, states, latents):
     """--hip_tier f16 on a checkpoint whose activations exceed half precision: the CLI stops with the guard's message before it
     writes a frame (it used to render NaN frames silently); the same command on the in-range checkpoint reports its calibration."""
