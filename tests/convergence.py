@@ -322,6 +322,26 @@ def run(steps, variants, size=450, curve_every=0, log=None, with_inference_check
                                                   for i in range(0, got[k].shape[0], 2500)),
                             "finite": bool(torch.isfinite(got[k]).all())}
             res["variants"][name]["f16_inference_vs_f32"] = chk
+            # ... and what the f16 tier's ACCURACY GUARD (dfanerf/f16guard.py, round 6) says about these trained weights: every held-out
+            # frame in f16 and f32 (64 + 128 samples, both fields), the model's own PSNR against the scene's ground truth measured
+            # on the same frames -> the gate the 0.05-dB clause implies for THIS model, and the margin to it
+            from dfanerf import f16guard
+            lo = scene.render(mods, "f16", "held", n_fine=128, fields=2)
+            hi = scene.render(mods, "f32", "held", n_fine=128, fields=2)
+            a0, _ = scene.split("held")
+            blocks = [{"head": (lo[k][0], hi[k][0], gt8[a0 + k][0].float() / 255.0), "com": (lo[k][1], hi[k][1], gt8[a0 + k][1].float() / 255.0)}
+                      for k in range(len(lo))]
+            st = f16guard.accuracy_stats(blocks)
+            for im, q in st.items():
+                q["gate_db"] = f16guard.psnr_gate(q["model_psnr_db"])
+                q["margin_db"] = q["psnr_db"] - q["gate_db"]
+                q["worst_frame_margin_db"] = q["worst_block_db"] - (q["gate_db"] - f16guard.BLOCK_SLACK_DB)
+            try:
+                f16guard.check_accuracy(st)
+                verdict = "accepted"
+            except f16guard.F16AccuracyError as e:
+                verdict = "refused: " + str(e)[:200]
+            res["variants"][name]["f16_accuracy_guard"] = {"verdict": verdict, **st}
     return res
 
 

@@ -50,6 +50,14 @@ def test_16bit_trained_model_holds_the_f16_inference_clause(result):
     for tag, c in chk.items():
         print(f"{tag}: f16 vs f32 on the 16-bit-trained student: {c['psnr_db']:.2f} dB, worst block {c['worst_block_db']:.2f} dB")
         assert c["finite"] and c["psnr_db"] >= 49.4 and c["worst_block_db"] >= 49.4, (tag, c)
+    # the tier's accuracy guard (round 6) on the same weights, gated at what the clause implies for THIS model's own PSNR against the
+    # scene's ground truth (measured on the held-out frames): accepted, with its margins printed
+    g = result["variants"]["bf16_fp4"]["f16_accuracy_guard"]
+    for im in ("head", "com"):
+        q = g[im]
+        print(f"accuracy guard, {im}: f16 vs f32 {q['psnr_db']:.2f} dB (worst frame {q['worst_block_db']:.2f}), model {q['model_psnr_db']:.2f} dB "
+              f"-> gate {q['gate_db']:.2f} dB, margin {q['margin_db']:+.2f} dB")
+    assert g["verdict"] == "accepted", g["verdict"]
 
 
 # set from the measured runs (profiles/r05j_convergence.txt, r05j_convergence_test.txt; LABNOTES.md 9.2): the students start at 7.4 dB and

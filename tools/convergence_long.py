@@ -21,7 +21,8 @@ variants = [("f32", "f32", None, 100), ("bf16_fp4", "bf16", "fp4", 100), ("bf16_
             ("bf16_fp4_s101", "bf16", "fp4", 101), ("bf16_e4m3_s101", "bf16", "e4m3", 101)]
 if len(sys.argv) > 2:      # explicit variants: name:tier:format:pixel_seed ... (format "-" for the exact tier), compared against the first
     variants = [(n, t, None if f == "-" else f, int(sd)) for n, t, f, sd in (a.split(":") for a in sys.argv[2:])]
-res = CV.run(steps, variants, curve_every=max(1, steps // 10), log=log, with_inference_check=len(sys.argv) <= 2)
+res = CV.run(steps, variants, curve_every=max(1, steps // 10), log=log,
+             with_inference_check=len(sys.argv) <= 2 or os.environ.get("DFN_CONV_INFERENCE_CHECK") == "1")
 v = res["variants"]
 log("")
 log(f"{'variant':<18}{'ms/step':>9}{'finite':>8}{'last loss':>12}{'held head':>11}{'held com':>10}{'train head':>12}{'train com':>11}")
@@ -38,5 +39,7 @@ log("")
 for k, i in v.items():
     if "f16_inference_vs_f32" in i:
         log(f"  {k} through the f16 inference tier vs the exact tier: {i['f16_inference_vs_f32']}")
+    if "f16_accuracy_guard" in i:
+        log(f"  {k}: the f16 tier's accuracy guard on these weights: {json.dumps(i['f16_accuracy_guard'])}")
 log("")
 log(json.dumps(res, default=str))
