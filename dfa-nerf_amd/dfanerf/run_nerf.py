@@ -844,6 +844,9 @@ def train():
     datadir = [args.datadir]
     imgdir = []
     for k in range(args.n_object):
+        if k >= len(datadir):      # the same exception at the same place as upstream, with the reason spelled out
+            raise IndexError(f"list index out of range (--n_object {args.n_object}: like upstream, one dataset is loaded - datadir = "
+                             "[args.datadir], MAIN:449 - and person %d has none; the scripts pass --n_object 1)" % k)
         i_dir = os.path.join(basedir, datadir[k].split('/')[-1])
         if rank == 0:
             os.makedirs(os.path.join(i_dir, 'person'), exist_ok=True)
