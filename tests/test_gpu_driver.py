@@ -238,6 +238,20 @@ def test_cli_with_several_ranks_on_one_gpu(dataset, world):
     assert lines and np.isfinite(float(lines[-1].split("Com Loss: ")[1].split()[0]))
 
 
+def test_n_object_default_stops_where_upstream_stops(dataset):
+    """--n_object 2 is the flag's default (MAIN:378): upstream builds ONE dataset (`datadir = [args.datadir]`, MAIN:449) and stops
+    in the per-person setup loop (`datadir[i]`, MAIN:499) with IndexError - before a frame is rendered.  Accepted at parse time
+    (round 5 refused it) and reproduced: same exception, same place, nothing rendered."""
+    root, _ = dataset
+    cmd = [sys.executable, os.path.join(ROOT, "NeRFs", "DFANeRF", "run_nerf_com_trainExpLater.py")] + \
+        (COMMON + " --render_person --test_file transforms_val_ba.json --N_iters=600000 --expname two_persons --n_object=2").split()
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "IndexError: list index out of range" in r.stderr and "--n_object 2" in r.stderr, r.stderr[-1500:]
+    assert "unsupported configuration" not in r.stderr
+    res = root / "dataset" / "train_together" / "two_persons" / "obama" / "person" / "render_com"
+    assert not res.exists() or not os.listdir(res)
+
+
 def test_cli_eight_ranks_with_eight_hardware_queues_each(dataset, monkeypatch):
     """the functional one-GPU modes cap the hardware queues per process (16 / world) because eight ranks x eight
     queues on ONE device died in start-up copies of c10d-gloo's device-tensor broadcast.  Round 6 stages the replicas through the host
