@@ -435,7 +435,7 @@ def bench_training(args, workload, steps, warmup, world, rank, dev, sustain_s=0.
             "config": {"workload": desc, "H": H, "W": W, "N_rand_per_gpu": N_RAND, "n_coarse": 64, "n_fine": n_fine,
                        "recorded_activation_format": (("e2m1 (MX-fp4)" if buf.act_format == 1 else "e4m3 (MX-fp8)") if tier == "bf16" else "f32"),
                        "fields": 2, "parallelism": f"dp{world}, three in-place all_reduces per step, each on the stream its gradients are produced on: audio-side networks (180,785 floats), PoseAttNet (2,629), decoder (955,242)"},
-            "roofline": {"bound": "mfma", "kernel": "whole step (render_kernel<train>, mlp_bwd, wgrad_mx)",
+            "roofline": {"bound": "mfma", "kernel": "whole step (render_kernel<train>, mlp_bwd, " + ("wgrad_mx)" if tier == "bf16" else "wgrad_full + wgrad_narrow)"),
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "flop_per_ray": flop_ray,
                          "traffic": traffic, "traffic_source": traffic_src, "recorded_bytes_per_step": step_bytes,
                          "algorithmic_bytes": alg_bytes, "traffic_over_algorithmic": traffic / alg_bytes,
