@@ -102,7 +102,7 @@ class Decoder(nn.Module):
 
     # ---- HIP plumbing ------------------------------------------------------------------------------------------
     def hip_supported(self):
-        return (self.hidden_size == 256 and self.z_dim == 256 and self.n_blocks == 8 and list(self.skips) == [4] and
+        return (self.hidden_size == 256 and 0 < self.z_dim <= 256 and self.n_blocks == 8 and list(self.skips) == [4] and
                 self.dim_signal == 96 and self.dim_et_embed == 42 and self.n_freq_posenc == 10 and
                 self.n_freq_posenc_views == 4 and self.use_deformation_field and self.use_viewdirs and self.n_blocks_view == 1 and
                 self.final_sigmoid_activation and self.downscale_p_by == 2.)
@@ -119,9 +119,9 @@ class Decoder(nn.Module):
         hit = self._hip.get(tier)
         if hit is None or hit[1][1:] != stamp[1:]:
             flat = engine.flatten_state(self.state_dict(), params[0].device)
-            hit = (engine.PackedDecoder(flat, tier, fields=(0, 1, 2)), stamp)
+            hit = (engine.PackedDecoder(flat, tier, fields=(0, 1, 2), z_dim=self.z_dim), stamp)
         elif hit[1][0] != stamp[0]:
-            hit[0].flat.copy_(torch.cat([p.detach().reshape(-1).float() for p in params]))
+            hit[0].flat.copy_(engine.flatten_state(self.state_dict(), params[0].device))
             hit[0].repack()
             hit = (hit[0], stamp)
         self._hip[tier] = hit
@@ -148,6 +148,9 @@ class Decoder(nn.Module):
         needs_grad = torch.is_grad_enabled() and (
             any(p.requires_grad for p in self.parameters()) or (signal is not None and signal.requires_grad))
         if needs_grad:
+            if self.z_dim != 256:
+                raise NotImplementedError(f"training with z_dim = {self.z_dim}: the HIP training path is built for the scripts' z_dim = 256 "
+                                          "(a decoder with a narrower latent code RENDERS: call it under torch.no_grad())")
             from . import training
             return training.decoder_train(self, field, p_in, ray_d, z_shape, z_app, signal, tier)
         pk = self.packed(tier)

@@ -36,9 +36,22 @@ def require_gpu():
         raise RuntimeError("dfanerf: no HIP device visible; the render path has no CPU fallback")
 
 
+Z_WEIGHTS = ("fc_z.weight", "fc_z_skips.0.weight", "fc_z_view.weight")     # [256, z_dim]: the layers fed by the latent codes
+
+
 def flatten_state(state, device):
-    """decoder.state_dict() -> flat f32 device vector in registration order (dfn_layout.h:ParamId)."""
-    parts = [_f32c(v, device).reshape(-1) for k, v in state.items() if not k.startswith(DECODER_UNUSED_PREFIXES)]
+    """decoder.state_dict() -> flat f32 device vector in registration order (dfn_layout.h:ParamId).
+    --z_dim < 256 (round 6, rendering only): the three layers the latent codes feed are [256, z_dim] and act on per-frame constants
+    only (the fold, dfn_fold_bias) - they enter the library's [256, 256] slots padded with zero columns, and the codes are padded with
+    zeros to match (pad_z): W_pad . z_pad = W . z exactly (zero products add nothing in any summation order)."""
+    parts = []
+    for k, v in state.items():
+        if k.startswith(DECODER_UNUSED_PREFIXES):
+            continue
+        v = _f32c(v, device)
+        if k in Z_WEIGHTS and v.shape[1] < 256:
+            v = torch.nn.functional.pad(v, (0, 256 - v.shape[1]))
+        parts.append(v.reshape(-1))
     flat = torch.cat(parts)
     if flat.numel() != N_DECODER_PARAMS:
         raise ValueError(f"decoder has {flat.numel()} parameters; the HIP path supports the "
@@ -49,8 +62,11 @@ def flatten_state(state, device):
 class PackedDecoder:
     """Kernel-ready weight streams of one decoder, per (tier, field).  Call repack() after an optimizer step."""
 
-    def __init__(self, flat_params, tier="bf16", fields=(FIELD_HEAD, FIELD_TORSO)):
+    def __init__(self, flat_params, tier="bf16", fields=(FIELD_HEAD, FIELD_TORSO), z_dim=256):
         require_gpu()
+        if not 0 < int(z_dim) <= 256:
+            raise ValueError(f"PackedDecoder: z_dim {z_dim} (1 ... 256)")
+        self.z_dim = int(z_dim)         # width of the latent codes fold() is handed (padded with zeros to the library's 256)
         self.tier = TIERS[tier]
         self.flat = flat_params
         self.device = flat_params.device
@@ -83,8 +99,7 @@ class PackedDecoder:
         nt = self.bias_floats(FIELD_TORSO) if sig_torso is not None else 0
         if out is None:
             out = torch.empty(nh + nt, dtype=torch.float32, device=dev)
-        zs = _f32c(z_shape, dev).reshape(-1, 256)
-        za = _f32c(z_app, dev).reshape(-1, 256)
+        zs, za = self.pad_z(z_shape), self.pad_z(z_app)
         sh = None if sig_head is None else _f32c(sig_head, dev).reshape(-1)
         check(lib.dfn_fold_bias(self.tier, head_field, _ptr(self.flat), _ptr(sh), _ptr(zs[0]), _ptr(za[0]),
                                 _ptr(out), _stream()), "dfn_fold_bias(head)")
@@ -95,14 +110,19 @@ class PackedDecoder:
                                     C.c_void_p(out.data_ptr() + 4 * nh), _stream()), "dfn_fold_bias(torso)")
         return out
 
+    def pad_z(self, z):
+        """latent code(s) [..., z_dim] -> [rows, 256] f32 on the device, zero-padded (flatten_state pads the weights to match)"""
+        z = _f32c(z, self.device).reshape(-1, self.z_dim)
+        return z if self.z_dim == 256 else torch.nn.functional.pad(z, (0, 256 - self.z_dim)).contiguous()
+
     def fold_single(self, field, signal, z_shape, z_app):
         dev = self.device
         out = torch.empty(self.bias_floats(field), dtype=torch.float32, device=dev)
         # keep every temporary alive until the launch is enqueued (the caching allocator would otherwise
         # hand the same block to the next temporary)
         sg = None if signal is None else _f32c(signal, dev).reshape(-1)
-        zs = _f32c(z_shape, dev).reshape(-1)
-        za = _f32c(z_app, dev).reshape(-1)
+        zs = self.pad_z(z_shape).reshape(-1)
+        za = self.pad_z(z_app).reshape(-1)
         check(lib.dfn_fold_bias(self.tier, field, _ptr(self.flat), _ptr(sg), _ptr(zs), _ptr(za), _ptr(out),
                                 _stream()), "dfn_fold_bias")
         return out

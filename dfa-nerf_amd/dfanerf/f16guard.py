@@ -138,14 +138,14 @@ def weight_bound(flat_params):
     return float(flat_params.detach().abs().max())
 
 
-def activation_bounds(flat_params, frames, sig_heads, sig_torsos, z_shape, z_app, bg, n_rays=256, seed=0, n_fine=0):
+def activation_bounds(flat_params, frames, sig_heads, sig_torsos, z_shape, z_app, bg, n_rays=256, seed=0, n_fine=0, z_dim=256):
     """max |GEMM input| per layer and field over n_rays random pixels of every frame in `frames` (engine.make_frame objects;
     ray_count / n_fine / fields are overwritten), with that frame's conditioning signals sig_heads[k] [96] / sig_torsos[k] [42].
     n_fine = 64 / 128: the hierarchical forward (dfn_train_fwd_hier) - the fine samples cluster at the surfaces, where the
     activations are largest, and the production render evaluates them.  -> {"head": {layer: max}, "torso": {...}}.
     Runs in the EXACT tier (f32 MFMAs, f32 recording)."""
     dev = flat_params.device
-    pk = engine.PackedDecoder(flat_params, "f32", fields=(FIELD_HEAD, FIELD_TORSO))
+    pk = engine.PackedDecoder(flat_params, "f32", fields=(FIELD_HEAD, FIELD_TORSO), z_dim=z_dim)
     rows = [_chk(lib.dfn_train_rows(f, 0), "dfn_train_rows") for f in (0, 1)]
     mrows = [_chk(lib.dfn_train_rows(f, 2), "dfn_train_rows") for f in (0, 1)]
     n_coarse = 64 if n_fine else int(frames[0].n_coarse)      # (--N_samples 32 / 128 render coarse only)

@@ -376,7 +376,7 @@ class FrameRenderer:
                                               self.args.concate_bg))
         with torch.no_grad():
             pk.f16_bounds = f16guard.activation_bounds(pk.flat, frs, sh, stt, self.zs, self.za, self.bg, n_rays=n_rays,
-                                                       n_fine=self.n_fine if self.args.N_samples == 64 else 0)
+                                                       n_fine=self.n_fine if self.args.N_samples == 64 else 0, z_dim=pk.z_dim)
         top = f16guard.check(pk.f16_bounds, pk.f16_weight_max)
         print(f"[dfanerf] f16 tier: calibrated on {len(pick)} frames x {n_rays} rays in the exact tier: max |activation| "
               f"{top:.4g}, max |parameter| {pk.f16_weight_max:.4g} (half precision holds {f16guard.F16_MAX:.0f}; margin x{f16guard.MARGIN:g})")
@@ -788,8 +788,12 @@ def check_supported(args):
     """The HIP path implements the configuration scripts/{train,test}_obama.sh build (LABNOTES.md section 1): say so when
     the arguments are parsed, not at the first kernel launch."""
     bad = []
-    if (args.n_feat, args.z_dim, args.dim_signal) != (256, 256, 96):
-        bad.append(f"--n_feat {args.n_feat} --z_dim {args.z_dim} --dim_signal {args.dim_signal} (supported: 256 / 256 / 96)")
+    if (args.n_feat, args.dim_signal) != (256, 96):
+        bad.append(f"--n_feat {args.n_feat} --dim_signal {args.dim_signal} (supported: 256 / 96)")
+    # --z_dim: 256 trains and renders; 1 ... 255 render (--render_person: the three layers the latent codes feed act on per-frame
+    # constants only and enter the library zero-padded, engine.flatten_state)
+    if not 0 < args.z_dim <= 256 or (args.z_dim != 256 and not args.render_person):
+        bad.append(f"--z_dim {args.z_dim} (supported: 256; 1 ... 255 with --render_person)")
     # (--use_expression: accepted - with one person the reference's decoder registers expnet and never evaluates it, MAIN:70)
     if not args.use_deformation_field:
         bad.append("--use_deformation_field is required")

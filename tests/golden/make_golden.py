@@ -489,6 +489,21 @@ def g13_optional_branches():
     print("g13: ", len(manifest), "state_dict entries")
 
 
+def g16_z_dim_64():
+    """G16 (round 6): --z_dim is free upstream (MAIN:372; Decoder(z_dim=args.z_dim), MAIN:518): the reference's Decoder with z_dim = 64
+    - weights and 64-wide latent codes from the same closed-form generators - head, torso and listener outputs at G3's 4 x 64 points."""
+    g3 = np.load(os.path.join(HERE, "g3_decoder.npz"))
+    dec = DEC.Decoder(z_dim=64, hidden_size=256, dim_signal=96, use_deformation_field=True, use_expression=False, use_aud_net=False)
+    dec.load_state_dict({k: t(v) for k, v in synth.synth_decoder_state(0, z_dim=64).items()})
+    z_shape, z_app = [t(v) for v in synth.synth_latents(0, z_dim=64)]
+    p, r = t(g3["p_64"]), t(g3["r_64"])
+    with torch.no_grad():
+        fh, sh = dec(p, r, z_shape[:, 0], z_app[:, 0], [t(g3["sig_aud"]), None], 'head')
+        ft, st_ = dec(p, r, z_shape[:, 1], z_app[:, 1], t(g3["sig_torso"]), 'torso')
+        fl, sl = dec(p, r, z_shape[:, 0], z_app[:, 0], [None, None], 'head')
+    save("g16_z_dim_64", feat_head=fh, sigma_head=sh, feat_torso=ft, sigma_torso=st_, feat_listener=fl, sigma_listener=sl)
+
+
 def g14_listener_backward():
     """G14 (round 6): Decoder.forward with `signal is None` - the listener input layers fc_in_listener / fc_p_skips_listener
     (decoder.py:306-307, 322-323: what the reference's second person evaluates, MAIN:72-75) - UNDER AUTOGRAD in the reference's
@@ -525,6 +540,9 @@ def g14_listener_backward():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g14":
         g14_listener_backward()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g16":
+        g16_z_dim_64()
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "only":       # everything is computed, one fixture is written
         ONLY = sys.argv[2]

@@ -248,6 +248,56 @@ def _render_subset(eng, packed, scene, latents, signal, signal_torso, ray_idx, t
                       want_z=want_z)
 
 
+def test_decoder_with_a_narrower_latent_code_vs_reference_golden(scene, golden):
+    """--z_dim is free upstream (MAIN:372; Decoder(z_dim=args.z_dim), MAIN:518); round 5 refused everything but 256.  A decoder with
+    z_dim = 64 RENDERS: the three layers the latent codes feed act on per-frame constants only, so they enter the library's 256-wide
+    slots zero-padded (engine.flatten_state / PackedDecoder.pad_z).  The drop-in module against golden G16 - the reference's own
+    Decoder(z_dim=64) - head, torso, listener at 1e-5 in the exact tier; a frame through FrameRenderer equals the one rendered from
+    hand-padded 256-wide weights bit for bit; training is refused with the reason."""
+    from dfanerf import run_nerf
+    from dfanerf.decoder import Decoder
+    dev = torch.device("cuda")
+    g, g3 = golden("g16_z_dim_64"), golden("g3_decoder")
+    st = synth.synth_decoder_state(0, z_dim=64)
+    dec = Decoder(z_dim=64, hidden_size=256, dim_signal=96, use_deformation_field=True)
+    dec.load_state_dict({k: t(v) for k, v in st.items()})
+    dec.to(dev)
+    zs, za = [t(v).to(dev) for v in synth.synth_latents(0, z_dim=64)]
+    p, r = t(g3["p_64"]).to(dev), t(g3["r_64"]).to(dev)
+    sa, stt = t(g3["sig_aud"]).to(dev), t(g3["sig_torso"]).to(dev)
+    with torch.no_grad():
+        out = {"head": dec(p, r, zs[:, 0], za[:, 0], [sa, None], "head"), "torso": dec(p, r, zs[:, 1], za[:, 1], stt, "torso"),
+               "listener": dec(p, r, zs[:, 0], za[:, 0], [None, None], "head")}
+    for k, (f, s) in out.items():
+        np.testing.assert_allclose(f.cpu().numpy(), g["feat_" + k], atol=1e-5, rtol=0)
+        np.testing.assert_allclose(s.cpu().numpy(), g["sigma_" + k], rtol=1e-5, atol=2e-4)        # (the gates of golden G3's test)
+    with pytest.raises(NotImplementedError, match="z_dim = 64"):
+        dec(p, r, zs[:, 0], za[:, 0], [sa.clone().requires_grad_(True), None], "head")
+    # the frame renderer: 64-wide codes and weights = the same network written out 256 wide by hand
+    args = run_nerf.config_parser().parse_args("--expname t --concate_bg --dim_signal=96 --n_object=1 --use_deformation_field --z_dim 64 "
+                                               "--render_person --hierarchical --N_importance 128".split())
+    run_nerf.check_supported(args)
+    bg = (t(scene["bg"]).float() / 255.0).to(dev)
+    geo = [scene["H"], scene["W"], scene["focal"], scene["cx"], scene["cy"]]
+    R = run_nerf.FrameRenderer(dec, zs, za, bg, geo, scene["near"], scene["far"], args)
+    st256 = dict(st)
+    for k in ("fc_z.weight", "fc_z_skips.0.weight", "fc_z_view.weight"):
+        st256[k] = np.pad(st[k], ((0, 0), (0, 192)))
+    dec256 = Decoder(z_dim=256, hidden_size=256, dim_signal=96, use_deformation_field=True)
+    dec256.load_state_dict({k: t(v) for k, v in st256.items()})
+    dec256.to(dev)
+    pad = lambda z: torch.nn.functional.pad(z, (0, 192))
+    args256 = run_nerf.config_parser().parse_args("--expname t --concate_bg --dim_signal=96 --n_object=1 --use_deformation_field "
+                                                  "--render_person --hierarchical --N_importance 128".split())
+    R256 = run_nerf.FrameRenderer(dec256, pad(zs), pad(za), bg, geo, scene["near"], scene["far"], args256)
+    a = R.render(scene["poses"][1], scene["pose_body"], [sa, None], stt[0], ray_begin=80000, ray_count=4096)
+    b = R256.render(scene["poses"][1], scene["pose_body"], [sa, None], stt[0], ray_begin=80000, ray_count=4096)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and float(a[1].std()) > 0.01
+    with pytest.raises(SystemExit, match="z_dim 64"):
+        run_nerf.check_supported(run_nerf.config_parser().parse_args(
+            "--expname t --dim_signal=96 --n_object=1 --use_deformation_field --z_dim 64".split()))       # training: 256 only
+
+
 @pytest.mark.parametrize("n_coarse", [32, 128])
 def test_render_coarse_other_sample_counts_vs_reference_golden(eng, packed, scene, latents, golden, n_coarse):
     """--N_samples 32 / 128 (MAIN:612-619; round 5 refused everything but 64): the coarse renderer against golden G15, the

@@ -76,6 +76,21 @@ def test_g1c_get_rays_stride_bitwise(golden):
         assert np.array_equal(rd.double().sum((0, 1)).numpy(), g[f"sum_d_{s}"])
 
 
+def test_g16_z_dim_64(golden):
+    """--z_dim is free upstream (MAIN:372, 518): the oracle's decoder with 64-wide latent codes against the reference's (G16)"""
+    g, g3 = golden("g16_z_dim_64"), golden("g3_decoder")
+    P = O.params_to_torch(synth.synth_decoder_state(0, z_dim=64))
+    zs, za = [t(v) for v in synth.synth_latents(0, z_dim=64)]
+    p, r = t(g3["p_64"]), t(g3["r_64"])
+    with torch.no_grad():
+        out = {"head": O.decoder_forward(P, p, r, zs[:, 0], za[:, 0], [t(g3["sig_aud"]), None], 'head'),
+               "torso": O.decoder_forward(P, p, r, zs[:, 1], za[:, 1], t(g3["sig_torso"]), 'torso'),
+               "listener": O.decoder_forward(P, p, r, zs[:, 0], za[:, 0], [None, None], 'head')}
+    for k, (f, s) in out.items():
+        np.testing.assert_allclose(f.numpy(), g["feat_" + k], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(s.numpy(), g["sigma_" + k], rtol=1e-5, atol=2e-5)
+
+
 def test_g14_listener_backward(golden, states, latents):
     """the listener input layers (signal None: decoder.py:306-307, 322-323) under autograd: the oracle's gradients against the
     reference module's (G14) - which parameters get one, their norms, sampled entries, the two listener matrices in full"""
