@@ -37,14 +37,19 @@ def require_gpu():
 
 
 Z_WEIGHTS = ("fc_z.weight", "fc_z_skips.0.weight", "fc_z_view.weight")     # [256, z_dim]: the layers fed by the latent codes
+N_DEFORM_PARAMS = 59750         # deform_net.* (decoder.py:84-105): the first 28 tensors of the flat vector (dfn_layout.h: P_DE0_W .. P_DSSK_B)
 
 
 def flatten_state(state, device):
     """decoder.state_dict() -> flat f32 device vector in registration order (dfn_layout.h:ParamId).
     --z_dim < 256 (round 6, rendering only): the three layers the latent codes feed are [256, z_dim] and act on per-frame constants
     only (the fold, dfn_fold_bias) - they enter the library's [256, 256] slots padded with zero columns, and the codes are padded with
-    zeros to match (pad_z): W_pad . z_pad = W . z exactly (zero products add nothing in any summation order)."""
+    zeros to match (pad_z): W_pad . z_pad = W . z exactly (zero products add nothing in any summation order).
+    A decoder WITHOUT --use_deformation_field (rendering only): the torso evaluates `deform(p) + p` (decoder.py:297-299) with an all-zero
+    deformation network - every layer of it returns exactly 0 (relu(0) = 0, bias 0), so `p` passes unchanged, bit for bit."""
     parts = []
+    if not any(k.startswith("deform_net.") for k in state):
+        parts.append(torch.zeros(N_DEFORM_PARAMS, dtype=torch.float32, device=device))
     for k, v in state.items():
         if k.startswith(DECODER_UNUSED_PREFIXES):
             continue

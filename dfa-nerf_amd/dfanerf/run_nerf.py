@@ -795,8 +795,8 @@ def check_supported(args):
     if not 0 < args.z_dim <= 256 or (args.z_dim != 256 and not args.render_person):
         bad.append(f"--z_dim {args.z_dim} (supported: 256; 1 ... 255 with --render_person)")
     # (--use_expression: accepted - with one person the reference's decoder registers expnet and never evaluates it, MAIN:70)
-    if not args.use_deformation_field:
-        bad.append("--use_deformation_field is required")
+    if not args.use_deformation_field and not args.render_person:
+        bad.append("--use_deformation_field is required for training (without it the decoder renders: --render_person)")
     if args.N_samples not in (32, 64, 128):
         bad.append(f"--N_samples {args.N_samples} (supported: 32, 64, 128)")
     if getattr(args, "hierarchical", False) and args.N_samples != 64:

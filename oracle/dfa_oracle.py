@@ -162,8 +162,8 @@ def deformation_field(P, x, dim_embed=60, dim_signal=42):
 
 def decoder_forward(P, p_in, ray_d, z_shape, z_app, signal, head_or_torso,
                     return_intermediate=False):
-    """DEC:277-349 with use_deformation_field=True, use_expression=False,
-    use_viewdirs=True, final sigmoid.
+    """DEC:277-349 with use_expression=False, use_viewdirs=True, final sigmoid; use_deformation_field = whether `P` holds the
+    deform_net tensors (DEC:297: `if self.use_deformation_field and head_or_torso == 'torso'`).
     p_in, ray_d [1,N,3]; z_* [1,z_dim]; signal: [aud[1,96], None] for 'head',
     [1,42] or [42] for 'torso'.  Returns feat [1,N,3], sigma [1,N] (raw)."""
     if head_or_torso == 'head':
@@ -175,7 +175,8 @@ def decoder_forward(P, p_in, ray_d, z_shape, z_app, signal, head_or_torso,
     else:
         p = pe
     if head_or_torso == 'torso':
-        p = deformation_field(P, p) + p
+        if any(k.startswith("deform_net.") for k in P):
+            p = deformation_field(P, p) + p
         in_name, skip_name = "fc_in_torso", "fc_p_skips_torso.0"
     elif head_or_torso == 'head':
         if signal is not None:

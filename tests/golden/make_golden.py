@@ -504,6 +504,21 @@ def g16_z_dim_64():
     save("g16_z_dim_64", feat_head=fh, sigma_head=sh, feat_torso=ft, sigma_torso=st_, feat_listener=fl, sigma_listener=sl)
 
 
+def g17_no_deformation_field():
+    """G17 (round 6): the reference's Decoder WITHOUT --use_deformation_field (a store_true flag, MAIN:411: off unless given) - the
+    torso is then the plain 8-layer MLP on [PE, pose signal] (decoder.py:297-299 skipped): torso outputs at G3's 4 x 64 points, same
+    weights minus the deform_net tensors."""
+    g3 = np.load(os.path.join(HERE, "g3_decoder.npz"))
+    dec = DEC.Decoder(z_dim=256, hidden_size=256, dim_signal=96, use_deformation_field=False, use_expression=False, use_aud_net=False)
+    dec.load_state_dict({k: t(v) for k, v in synth.synth_decoder_state(0).items() if not k.startswith("deform_net.")})
+    z_shape, z_app = [t(v) for v in synth.synth_latents(0)]
+    with torch.no_grad():
+        ft, st_ = dec(t(g3["p_64"]), t(g3["r_64"]), z_shape[:, 1], z_app[:, 1], t(g3["sig_torso"]), 'torso')
+        fh, sh = dec(t(g3["p_64"]), t(g3["r_64"]), z_shape[:, 0], z_app[:, 0], [t(g3["sig_aud"]), None], 'head')
+    assert np.array_equal(fh.numpy(), g3["feat_head_64"]) and not np.allclose(ft.numpy(), g3["feat_torso_64"], atol=1e-3)
+    save("g17_no_deformation_field", feat_torso=ft, sigma_torso=st_)
+
+
 def g14_listener_backward():
     """G14 (round 6): Decoder.forward with `signal is None` - the listener input layers fc_in_listener / fc_p_skips_listener
     (decoder.py:306-307, 322-323: what the reference's second person evaluates, MAIN:72-75) - UNDER AUTOGRAD in the reference's
@@ -543,6 +558,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g16":
         g16_z_dim_64()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g17":
+        g17_no_deformation_field()
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "only":       # everything is computed, one fixture is written
         ONLY = sys.argv[2]

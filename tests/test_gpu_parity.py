@@ -298,6 +298,34 @@ def test_decoder_with_a_narrower_latent_code_vs_reference_golden(scene, golden):
             "--expname t --dim_signal=96 --n_object=1 --use_deformation_field --z_dim 64".split()))       # training: 256 only
 
 
+def test_decoder_without_deformation_field_vs_reference_golden(states, latents, golden):
+    """--use_deformation_field is a store_true flag upstream (MAIN:411); without it the torso skips decoder.py:297-299.  Round 5
+    required it.  Rendering now takes such a decoder: the fused torso program evaluates `deform(p) + p` with an all-zero deformation
+    network (engine.flatten_state), which returns p exactly.  Against golden G17 (the reference's own Decoder without the flag), all
+    three tiers; training is refused with the reason."""
+    from dfanerf.decoder import Decoder
+    dev = torch.device("cuda")
+    g, g3 = golden("g17_no_deformation_field"), golden("g3_decoder")
+    dec = Decoder(z_dim=256, hidden_size=256, dim_signal=96, use_deformation_field=False)
+    dec.load_state_dict({k: t(v) for k, v in states["decoder"].items() if not k.startswith("deform_net.")})
+    dec.to(dev)
+    assert not any(k.startswith("deform_net.") for k in dec.state_dict())
+    zs, za = [t(v).to(dev) for v in latents]
+    p, r, stt = t(g3["p_64"]).to(dev), t(g3["r_64"]).to(dev), t(g3["sig_torso"]).to(dev)
+    with torch.no_grad():
+        f, s = dec(p, r, zs[:, 1], za[:, 1], stt, "torso", tier="f32")
+        fh, _ = dec(p, r, zs[:, 0], za[:, 0], [t(g3["sig_aud"]).to(dev), None], "head", tier="f32")
+    np.testing.assert_allclose(f.cpu().numpy(), g["feat_torso"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(s.cpu().numpy(), g["sigma_torso"], rtol=1e-5, atol=2e-4)
+    np.testing.assert_allclose(fh.cpu().numpy(), g3["feat_head_64"], atol=1e-5, rtol=0)              # the head never saw the flag
+    for tier, tol in (("f16", 3e-3), ("bf16", 3e-2)):
+        with torch.no_grad():
+            ft, _ = dec(p, r, zs[:, 1], za[:, 1], stt, "torso", tier=tier)
+        assert float((ft.cpu() - t(g["feat_torso"])).abs().max()) < tol, tier
+    with pytest.raises(NotImplementedError, match="use_deformation_field = False"):
+        dec(p, r, zs[:, 1], za[:, 1], stt.clone().requires_grad_(True), "torso")
+
+
 @pytest.mark.parametrize("n_coarse", [32, 128])
 def test_render_coarse_other_sample_counts_vs_reference_golden(eng, packed, scene, latents, golden, n_coarse):
     """--N_samples 32 / 128 (MAIN:612-619; round 5 refused everything but 64): the coarse renderer against golden G15, the

@@ -91,6 +91,18 @@ def test_g16_z_dim_64(golden):
         np.testing.assert_allclose(s.numpy(), g["sigma_" + k], rtol=1e-5, atol=2e-5)
 
 
+def test_g17_no_deformation_field(golden, states, latents):
+    """without --use_deformation_field (MAIN:411) the torso is the plain MLP on [PE, pose signal] (DEC:297 skipped): the oracle
+    without the deform_net tensors against the reference's Decoder(use_deformation_field=False)"""
+    g, g3 = golden("g17_no_deformation_field"), golden("g3_decoder")
+    P = O.params_to_torch({k: v for k, v in states["decoder"].items() if not k.startswith("deform_net.")})
+    zs, za = [t(v) for v in latents]
+    with torch.no_grad():
+        f, s = O.decoder_forward(P, t(g3["p_64"]), t(g3["r_64"]), zs[:, 1], za[:, 1], t(g3["sig_torso"]), 'torso')
+    np.testing.assert_allclose(f.numpy(), g["feat_torso"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(s.numpy(), g["sigma_torso"], rtol=1e-5, atol=2e-5)
+
+
 def test_g14_listener_backward(golden, states, latents):
     """the listener input layers (signal None: decoder.py:306-307, 322-323) under autograd: the oracle's gradients against the
     reference module's (G14) - which parameters get one, their norms, sampled entries, the two listener matrices in full"""
