@@ -102,7 +102,7 @@ class Decoder(nn.Module):
 
     # ---- HIP plumbing ------------------------------------------------------------------------------------------
     def hip_supported(self):
-        return (self.hidden_size == 256 and 0 < self.z_dim <= 256 and self.n_blocks == 8 and list(self.skips) == [4] and
+        return (0 < self.hidden_size <= 256 and 0 < self.z_dim <= 256 and self.n_blocks == 8 and list(self.skips) == [4] and
                 self.dim_signal == 96 and self.dim_et_embed == 42 and self.n_freq_posenc == 10 and
                 self.n_freq_posenc_views == 4 and self.use_viewdirs and self.n_blocks_view == 1 and
                 self.final_sigmoid_activation and self.downscale_p_by == 2.)
@@ -148,10 +148,11 @@ class Decoder(nn.Module):
         needs_grad = torch.is_grad_enabled() and (
             any(p.requires_grad for p in self.parameters()) or (signal is not None and signal.requires_grad))
         if needs_grad:
-            if self.z_dim != 256 or not self.use_deformation_field:
-                raise NotImplementedError(f"training with z_dim = {self.z_dim}, use_deformation_field = {self.use_deformation_field}: the HIP "
-                                          "training path is built for the scripts' configuration (z_dim 256, deformation field on); a decoder "
-                                          "with a narrower latent code or without the deformation field RENDERS: call it under torch.no_grad()")
+            if self.z_dim != 256 or self.hidden_size != 256 or not self.use_deformation_field:
+                raise NotImplementedError(f"training with hidden_size = {self.hidden_size}, z_dim = {self.z_dim}, use_deformation_field = "
+                                          f"{self.use_deformation_field}: the HIP training path is built for the scripts' configuration (256 / "
+                                          "256, deformation field on); a narrower decoder, or one without the deformation field, RENDERS: "
+                                          "call it under torch.no_grad()")
             from . import training
             return training.decoder_train(self, field, p_in, ray_d, z_shape, z_app, signal, tier)
         pk = self.packed(tier)

@@ -788,12 +788,14 @@ def check_supported(args):
     """The HIP path implements the configuration scripts/{train,test}_obama.sh build (LABNOTES.md section 1): say so when
     the arguments are parsed, not at the first kernel launch."""
     bad = []
-    if (args.n_feat, args.dim_signal) != (256, 96):
-        bad.append(f"--n_feat {args.n_feat} --dim_signal {args.dim_signal} (supported: 256 / 96)")
-    # --z_dim: 256 trains and renders; 1 ... 255 render (--render_person: the three layers the latent codes feed act on per-frame
-    # constants only and enter the library zero-padded, engine.flatten_state)
+    if args.dim_signal != 96:
+        bad.append(f"--dim_signal {args.dim_signal} (supported: 96 - what the signal encoders emit, upstream too)")
+    # --z_dim / --n_feat: 256 trains and renders; 1 ... 255 render (--render_person: the network enters the library written out 256
+    # wide with zero rows / columns - the same function exactly, engine.flatten_state)
     if not 0 < args.z_dim <= 256 or (args.z_dim != 256 and not args.render_person):
         bad.append(f"--z_dim {args.z_dim} (supported: 256; 1 ... 255 with --render_person)")
+    if not 0 < args.n_feat <= 256 or (args.n_feat != 256 and not args.render_person):
+        bad.append(f"--n_feat {args.n_feat} (supported: 256; 1 ... 255 with --render_person)")
     # (--use_expression: accepted - with one person the reference's decoder registers expnet and never evaluates it, MAIN:70)
     if not args.use_deformation_field and not args.render_person:
         bad.append("--use_deformation_field is required for training (without it the decoder renders: --render_person)")

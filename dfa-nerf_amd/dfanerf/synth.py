@@ -128,10 +128,10 @@ def synth_state(shapes, seed, prefix, gain=1.0, overrides=None):
     return out
 
 
-def synth_decoder_state(seed=0, z_dim=Z_DIM):
+def synth_decoder_state(seed=0, z_dim=Z_DIM, hidden=HIDDEN):
     """sigma_out is scaled up so that relu(sigma) spans roughly [0, 30] on the
     bench frustum: otherwise every ray is pure background."""
-    shapes = decoder_shapes(z_dim=z_dim)
+    shapes = decoder_shapes(hidden=hidden, z_dim=z_dim)
     ov = {"sigma_out.weight": SIGMA_W, "sigma_out.bias": (0.0, SIGMA_B),
           "feat_out.weight": FEAT_W}
     return synth_state(shapes, seed, "decoder", overrides=ov)

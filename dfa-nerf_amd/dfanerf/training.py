@@ -167,9 +167,10 @@ class TrainBuffers:
         """Parameter list of `dec` in state_dict order and the matching views of one flat buffer (_FlatNet.of: one per
         module, shared by every consumer): the kernels read the flat buffer, which becomes the parameters' own storage
         (_sync_flat), and write gradients into a flat buffer whose slices become the parameters' .grad."""
-        if getattr(dec, "z_dim", 256) != 256 or not getattr(dec, "use_deformation_field", True):
-            raise NotImplementedError(f"training with z_dim = {dec.z_dim}, use_deformation_field = {dec.use_deformation_field}: the HIP training "
-                                      "path is built for the scripts' configuration (such decoders render: engine.flatten_state)")
+        if getattr(dec, "z_dim", 256) != 256 or getattr(dec, "hidden_size", 256) != 256 or not getattr(dec, "use_deformation_field", True):
+            raise NotImplementedError(f"training with hidden_size = {dec.hidden_size}, z_dim = {dec.z_dim}, use_deformation_field = "
+                                      f"{dec.use_deformation_field}: the HIP training path is built for the scripts' configuration (such "
+                                      "decoders render: engine.flatten_state)")
         fn = _FlatNet.of(dec)
         fn.refresh()
         self.net, self.flat, self.params, self.offsets = fn, fn.flat, fn.params, fn.offsets

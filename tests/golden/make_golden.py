@@ -504,6 +504,21 @@ def g16_z_dim_64():
     save("g16_z_dim_64", feat_head=fh, sigma_head=sh, feat_torso=ft, sigma_torso=st_, feat_listener=fl, sigma_listener=sl)
 
 
+def g18_n_feat_128():
+    """G18 (round 6): --n_feat is free upstream (MAIN:374; Decoder(hidden_size=args.n_feat), MAIN:518; 128 is the class's own default):
+    the reference's Decoder(hidden_size=128, z_dim=64) - head, torso (deformation field on), listener at G3's 4 x 64 points."""
+    g3 = np.load(os.path.join(HERE, "g3_decoder.npz"))
+    dec = DEC.Decoder(z_dim=64, hidden_size=128, dim_signal=96, use_deformation_field=True, use_expression=False, use_aud_net=False)
+    dec.load_state_dict({k: t(v) for k, v in synth.synth_decoder_state(0, z_dim=64, hidden=128).items()})
+    z_shape, z_app = [t(v) for v in synth.synth_latents(0, z_dim=64)]
+    p, r = t(g3["p_64"]), t(g3["r_64"])
+    with torch.no_grad():
+        fh, sh = dec(p, r, z_shape[:, 0], z_app[:, 0], [t(g3["sig_aud"]), None], 'head')
+        ft, st_ = dec(p, r, z_shape[:, 1], z_app[:, 1], t(g3["sig_torso"]), 'torso')
+        fl, sl = dec(p, r, z_shape[:, 0], z_app[:, 0], [None, None], 'head')
+    save("g18_n_feat_128", feat_head=fh, sigma_head=sh, feat_torso=ft, sigma_torso=st_, feat_listener=fl, sigma_listener=sl)
+
+
 def g17_no_deformation_field():
     """G17 (round 6): the reference's Decoder WITHOUT --use_deformation_field (a store_true flag, MAIN:411: off unless given) - the
     torso is then the plain 8-layer MLP on [PE, pose signal] (decoder.py:297-299 skipped): torso outputs at G3's 4 x 64 points, same
@@ -558,6 +573,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g16":
         g16_z_dim_64()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "g18":
+        g18_n_feat_128()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g17":
         g17_no_deformation_field()

@@ -91,6 +91,21 @@ def test_g16_z_dim_64(golden):
         np.testing.assert_allclose(s.numpy(), g["sigma_" + k], rtol=1e-5, atol=2e-5)
 
 
+def test_g18_n_feat_128(golden):
+    """--n_feat is free upstream (MAIN:374, 518): the oracle's decoder at hidden width 128, latent width 64 against the reference's (G18)"""
+    g, g3 = golden("g18_n_feat_128"), golden("g3_decoder")
+    P = O.params_to_torch(synth.synth_decoder_state(0, z_dim=64, hidden=128))
+    zs, za = [t(v) for v in synth.synth_latents(0, z_dim=64)]
+    p, r = t(g3["p_64"]), t(g3["r_64"])
+    with torch.no_grad():
+        out = {"head": O.decoder_forward(P, p, r, zs[:, 0], za[:, 0], [t(g3["sig_aud"]), None], 'head'),
+               "torso": O.decoder_forward(P, p, r, zs[:, 1], za[:, 1], t(g3["sig_torso"]), 'torso'),
+               "listener": O.decoder_forward(P, p, r, zs[:, 0], za[:, 0], [None, None], 'head')}
+    for k, (f, s) in out.items():
+        np.testing.assert_allclose(f.numpy(), g["feat_" + k], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(s.numpy(), g["sigma_" + k], rtol=1e-5, atol=2e-5)
+
+
 def test_g17_no_deformation_field(golden, states, latents):
     """without --use_deformation_field (MAIN:411) the torso is the plain MLP on [PE, pose signal] (DEC:297 skipped): the oracle
     without the deform_net tensors against the reference's Decoder(use_deformation_field=False)"""
