@@ -107,6 +107,18 @@ class Decoder(nn.Module):
                 self.n_freq_posenc_views == 4 and self.use_viewdirs and self.n_blocks_view == 1 and
                 self.final_sigmoid_activation and self.downscale_p_by == 2.)
 
+    def _dfn_flat_layout(self):
+        """training._FlatNet hook: None for the scripts' decoder (its flat parameter vector IS the library's); otherwise (first
+        offset, padded shape per tensor of the flat vector): a narrower decoder, or one without the deformation field, trains inside
+        the library's 256-wide layout (engine.padded_shape) - padded entries start at zero, get zero gradients and stay zero."""
+        if self.hidden_size == 256 and self.z_dim == 256 and self.use_deformation_field:
+            return None
+        from . import engine
+        from ._lib import DECODER_UNUSED_PREFIXES
+        names = [k for k in self.state_dict().keys() if not k.startswith(DECODER_UNUSED_PREFIXES)]
+        sd = self.state_dict(keep_vars=True)
+        return (0 if self.use_deformation_field else engine.N_DEFORM_PARAMS), [engine.padded_shape(k, sd[k].shape) for k in names]
+
     def packed(self, tier="bf16"):
         """Kernel-ready weights for `tier`, repacked whenever a parameter has changed in place."""
         from . import engine
@@ -148,11 +160,6 @@ class Decoder(nn.Module):
         needs_grad = torch.is_grad_enabled() and (
             any(p.requires_grad for p in self.parameters()) or (signal is not None and signal.requires_grad))
         if needs_grad:
-            if self.z_dim != 256 or self.hidden_size != 256 or not self.use_deformation_field:
-                raise NotImplementedError(f"training with hidden_size = {self.hidden_size}, z_dim = {self.z_dim}, use_deformation_field = "
-                                          f"{self.use_deformation_field}: the HIP training path is built for the scripts' configuration (256 / "
-                                          "256, deformation field on); a narrower decoder, or one without the deformation field, RENDERS: "
-                                          "call it under torch.no_grad()")
             from . import training
             return training.decoder_train(self, field, p_in, ray_d, z_shape, z_app, signal, tier)
         pk = self.packed(tier)

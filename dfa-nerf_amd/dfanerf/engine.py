@@ -44,30 +44,40 @@ _HID_COLS = ("blocks.", "sigma_out.", "feat_view.", "feat_out.")
 N_DEFORM_PARAMS = 59750         # deform_net.* (decoder.py:84-105): the first 28 tensors of the flat vector (dfn_layout.h: P_DE0_W .. P_DSSK_B)
 
 
+def padded_shape(name, shape):
+    """shape of decoder tensor `name` in the library's 256-wide layout: hidden rows / columns and latent-code columns padded to 256"""
+    shape = list(shape)
+    if name in Z_WEIGHTS:
+        shape[1] = 256
+    if name.startswith(_HID_COLS) and name.endswith(".weight"):
+        shape[1] = 256
+    if name.startswith(_HID_ROWS):
+        shape[0] = 256
+    return tuple(shape)
+
+
 def flatten_state(state, device):
     """decoder.state_dict() -> flat f32 device vector in registration order (dfn_layout.h:ParamId).
-    --z_dim < 256 (round 6, rendering only): the three layers the latent codes feed are [256, z_dim] and act on per-frame constants
+    --z_dim < 256 (round 6): the three layers the latent codes feed are [256, z_dim] and act on per-frame constants
     only (the fold, dfn_fold_bias) - they enter the library's [256, 256] slots padded with zero columns, and the codes are padded with
     zeros to match (pad_z): W_pad . z_pad = W . z exactly (zero products add nothing in any summation order).
-    --n_feat < 256 (rendering only): a hidden unit with zero weights and zero bias outputs relu(0) = 0 and feeds zero columns - the
+    --n_feat < 256: a hidden unit with zero weights and zero bias outputs relu(0) = 0 and feeds zero columns - the
     network written out 256 wide is the same function, exactly (at the 256-wide network's cost).
-    A decoder WITHOUT --use_deformation_field (rendering only): the torso evaluates `deform(p) + p` (decoder.py:297-299) with an all-zero
+    (Training such decoders: training._FlatNet keeps the same padded layout; the padded entries get zero gradients - relu'(0) = 0 -
+    and stay zero.)  A decoder WITHOUT --use_deformation_field: the torso evaluates `deform(p) + p` (decoder.py:297-299) with an all-zero
     deformation network - every layer of it returns exactly 0 (relu(0) = 0, bias 0), so `p` passes unchanged, bit for bit."""
     parts = []
-    hid = int(state["blocks.0.weight"].shape[0])
     if not any(k.startswith("deform_net.") for k in state):
         parts.append(torch.zeros(N_DEFORM_PARAMS, dtype=torch.float32, device=device))
     for k, v in state.items():
         if k.startswith(DECODER_UNUSED_PREFIXES):
             continue
         v = _f32c(v, device)
-        if k in Z_WEIGHTS and v.shape[1] < 256:
-            v = torch.nn.functional.pad(v, (0, 256 - v.shape[1]))
-        if hid < 256:
-            if k.startswith(_HID_COLS) and k.endswith(".weight"):
-                v = torch.nn.functional.pad(v, (0, 256 - v.shape[1]))
-            if k.startswith(_HID_ROWS):
-                v = torch.nn.functional.pad(v, (0, 0, 0, 256 - v.shape[0])) if v.dim() == 2 else torch.nn.functional.pad(v, (0, 256 - v.shape[0]))
+        want = padded_shape(k, v.shape)
+        if want != tuple(v.shape):
+            full = torch.zeros(want, dtype=torch.float32, device=device)
+            full[tuple(slice(0, n) for n in v.shape)] = v
+            v = full
         parts.append(v.reshape(-1))
     flat = torch.cat(parts)
     if flat.numel() != N_DECODER_PARAMS:

@@ -790,15 +790,15 @@ def check_supported(args):
     bad = []
     if args.dim_signal != 96:
         bad.append(f"--dim_signal {args.dim_signal} (supported: 96 - what the signal encoders emit, upstream too)")
-    # --z_dim / --n_feat: 256 trains and renders; 1 ... 255 render (--render_person: the network enters the library written out 256
-    # wide with zero rows / columns - the same function exactly, engine.flatten_state)
-    if not 0 < args.z_dim <= 256 or (args.z_dim != 256 and not args.render_person):
-        bad.append(f"--z_dim {args.z_dim} (supported: 256; 1 ... 255 with --render_person)")
-    if not 0 < args.n_feat <= 256 or (args.n_feat != 256 and not args.render_person):
-        bad.append(f"--n_feat {args.n_feat} (supported: 256; 1 ... 255 with --render_person)")
+    # --z_dim / --n_feat 1 ... 256 (upstream: free): a narrower network lives in the library's 256-wide layout with zero rows / columns -
+    # the same function exactly, forward and backward (engine.flatten_state, training._FlatNet) - at the 256-wide network's cost
+    if not 0 < args.z_dim <= 256:
+        bad.append(f"--z_dim {args.z_dim} (supported: 1 ... 256)")
+    if not 0 < args.n_feat <= 256:
+        bad.append(f"--n_feat {args.n_feat} (supported: 1 ... 256)")
     # (--use_expression: accepted - with one person the reference's decoder registers expnet and never evaluates it, MAIN:70)
-    if not args.use_deformation_field and not args.render_person:
-        bad.append("--use_deformation_field is required for training (without it the decoder renders: --render_person)")
+    # (without --use_deformation_field, a store_true flag upstream: the fused torso program runs an all-zero deformation network that
+    # nothing ever steps - deform(p) + p = p exactly)
     if args.N_samples not in (32, 64, 128):
         bad.append(f"--N_samples {args.N_samples} (supported: 32, 64, 128)")
     if getattr(args, "hierarchical", False) and args.N_samples != 64:

@@ -62,9 +62,15 @@ def _sync_flat(params, views):
         return
     with torch.no_grad():
         torch._foreach_copy_(views, [p.detach() for p in params])
-        if all(p.dtype == torch.float32 and p.is_contiguous() and p.device == v.device for p, v in zip(params, views)):
+        if all(p.dtype == torch.float32 and p.is_contiguous() and v.is_contiguous() and p.device == v.device for p, v in zip(params, views)):
             for p, v in zip(params, views):
                 p.data = v
+
+
+def _pad_z(z, rows):
+    """latent codes [rows, z_dim] -> [rows, 256] f32, zero-padded (a narrower code meets zero-padded weight columns: engine.flatten_state)"""
+    z = z.detach().reshape(rows, -1).float()
+    return (z if z.shape[1] == 256 else torch.nn.functional.pad(z, (0, 256 - z.shape[1]))).contiguous()
 
 
 def _grad_buffer(owner, name, like, params):
@@ -167,10 +173,6 @@ class TrainBuffers:
         """Parameter list of `dec` in state_dict order and the matching views of one flat buffer (_FlatNet.of: one per
         module, shared by every consumer): the kernels read the flat buffer, which becomes the parameters' own storage
         (_sync_flat), and write gradients into a flat buffer whose slices become the parameters' .grad."""
-        if getattr(dec, "z_dim", 256) != 256 or getattr(dec, "hidden_size", 256) != 256 or not getattr(dec, "use_deformation_field", True):
-            raise NotImplementedError(f"training with hidden_size = {dec.hidden_size}, z_dim = {dec.z_dim}, use_deformation_field = "
-                                      f"{dec.use_deformation_field}: the HIP training path is built for the scripts' configuration (such "
-                                      "decoders render: engine.flatten_state)")
         fn = _FlatNet.of(dec)
         fn.refresh()
         self.net, self.flat, self.params, self.offsets = fn, fn.flat, fn.params, fn.offsets
@@ -204,8 +206,7 @@ def _fused_forward(ctx, sig_head, sig_torso, buf, frame, bg, pix_index, z_shape,
     dev = flat.device
     sh = sig_head.detach().reshape(-1).float().contiguous()
     stt = sig_torso.detach().reshape(-1).float().contiguous()
-    zs = z_shape.detach().reshape(2, 256).float().contiguous()
-    za = z_app.detach().reshape(2, 256).float().contiguous()
+    zs, za = _pad_z(z_shape, 2), _pad_z(z_app, 2)
     bias = buf.bias
     bias_t = C.c_void_p(bias.data_ptr() + 4 * buf.nb[0])
     # both folds and the four packed weight streams in one launch (six launches back to back cost 37 us of the step)
@@ -432,6 +433,25 @@ class _FlatNet:
             self.slots.append((module.get_submodule(mod) if mod else module, key))
         self._dep = None
         dev = self.params[0].device
+        # A module may ask for a PADDED layout (Decoder._dfn_flat_layout: a narrower decoder, or one without the deformation field,
+        # inside the library's 256-wide flat vector): the flat buffer is then a zero-filled vector of the library's size, every
+        # parameter a strided corner of its padded slot - copied in before a step (refresh), its gradient copied out after it (deposit);
+        # the padded entries stay zero (relu'(0) = 0: their gradients are zero, and nothing ever steps them).
+        lay = getattr(module, "_dfn_flat_layout", None)
+        lay = lay() if callable(lay) else None
+        self.padded = lay is not None
+        if self.padded:
+            from ._lib import N_DECODER_PARAMS
+            o, self.shapes = lay
+            assert len(self.shapes) == len(self.params)
+            self.flat = torch.zeros(N_DECODER_PARAMS, dtype=torch.float32, device=dev)
+            self.offsets, self.views = [], []
+            for p, shp in zip(self.params, self.shapes):
+                self.offsets.append(o)
+                self.views.append(self._corner(self.flat, o, shp, p))
+                o += int(np.prod(shp))
+            assert o == N_DECODER_PARAMS, (o, N_DECODER_PARAMS)
+            return
         n = sum(p.numel() for p in self.params)
         self.flat = torch.empty(n, dtype=torch.float32, device=dev)
         self.offsets, o = [], 0
@@ -439,6 +459,11 @@ class _FlatNet:
             self.offsets.append(o)
             o += p.numel()
         self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
+
+    @staticmethod
+    def _corner(flat, o, shp, p):
+        """parameter p's values inside its padded slot [o, o + prod(shp)) of `flat`: the leading corner of the slot viewed as `shp`"""
+        return flat[o:o + int(np.prod(shp))].view(shp)[tuple(slice(0, n) for n in p.shape)]
 
     @staticmethod
     def of(module):
@@ -465,6 +490,23 @@ class _FlatNet:
         forward never used (the listener layers; the other field's layers when one field is evaluated)."""
         # the same view OBJECTS while the buffer and the selection stay (optim.HipAdam recognises an unchanged step by them)
         key = (grad_flat.data_ptr(), id(touched))
+        if self.padded:
+            # gradients of the padded layout: one multi-tensor copy of the parameters' corners into contiguous tensors of their own
+            # (the same ones every step while the buffer and the selection stay: optim.HipAdam keeps its table)
+            if self._dep is None or self._dep[0] != key:
+                sel = [(p, self._corner(grad_flat, o, shp, p)) for i, (p, o, shp) in enumerate(zip(self.params, self.offsets, self.shapes))
+                       if p.requires_grad and (touched is None or touched[i])]
+                self._dep = (key, [p for p, _ in sel], [c for _, c in sel], [torch.empty_like(p) for p, _ in sel], grad_flat)
+            _, ps, corners, own, _ = self._dep
+            fresh = [i for i, p in enumerate(ps) if p.grad is None]
+            if fresh:
+                torch._foreach_copy_([own[i] for i in fresh], [corners[i] for i in fresh])
+            for i, p in enumerate(ps):
+                if p.grad is None:
+                    p.grad = own[i]
+                else:
+                    p.grad.add_(corners[i])
+            return
         if self._dep is None or self._dep[0] != key:
             views = [(p, grad_flat[o:o + p.numel()].view_as(p)) for i, (p, o) in enumerate(zip(self.params, self.offsets))
                      if p.requires_grad and (touched is None or touched[i])]
@@ -983,8 +1025,8 @@ def decoder_train(dec, field, p_in, ray_d, z_shape, z_app, signal, tier="f32"):
     n = pts.shape[0]
     # a fresh set of buffers per call: several forwards may be alive before their backwards run (head, then torso)
     pb = _PointBuffers(t, field, n, dev)
-    zs = z_shape.detach().reshape(-1)[:256].to(dev, torch.float32).contiguous()
-    za = z_app.detach().reshape(-1)[:256].to(dev, torch.float32).contiguous()
+    zs = _pad_z(z_shape.detach().reshape(-1)[:dec.z_dim].to(dev), 1).reshape(-1)
+    za = _pad_z(z_app.detach().reshape(-1)[:dec.z_dim].to(dev), 1).reshape(-1)
     if field == FIELD_LISTENER:
         # no conditioning signal: an anchor keeps the node in the graph (its "gradient" is empty)
         signal = torch.zeros(0, dtype=torch.float32, device=dev, requires_grad=True)

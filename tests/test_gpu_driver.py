@@ -238,6 +238,28 @@ def test_cli_with_several_ranks_on_one_gpu(dataset, world):
     assert lines and np.isfinite(float(lines[-1].split("Com Loss: ")[1].split()[0]))
 
 
+def test_cli_trains_and_renders_a_narrower_decoder_without_the_deformation_field(dataset):
+    """--n_feat, --z_dim and --use_deformation_field are free upstream (MAIN:372-375, 411); round 5's CLI took one combination.
+    From scratch: four training steps of a 128-wide decoder with 64-wide latent codes and no deformation field (exact tier), a
+    checkpoint in the reference's format with the NARROW shapes, and --render_person from it in the f16 tier (both guards pass)."""
+    root, _ = dataset
+    common = COMMON.split(" --resume ")[0].replace("--use_deformation_field ", "").replace("--expname=obama_TrainExpLater_smoMix", "--expname=narrow")
+    assert "--resume" not in common and "--use_deformation_field" not in common
+    _run(root, "--N_rand=256 --N_iters=4 --i_weights=2 --n_feat 128 --z_dim 64 --hip_tier f32", common=common)
+    base = root / "dataset" / "train_together" / "narrow"
+    ck = torch.load(base / "000004.tar", map_location="cpu", weights_only=False)
+    sd = ck["network_decoder_state_dict"]
+    assert tuple(sd["blocks.3.weight"].shape) == (128, 128) and tuple(sd["fc_z.weight"].shape) == (128, 64) and \
+        tuple(sd["fc_in.weight"].shape) == (128, 156) and not any(k.startswith("deform_net.") for k in sd)
+    log = [ln for ln in open(base / "loss.txt").read().strip().split("\n") if ln.startswith("[TRAIN]")]
+    assert len(log) == 4 and all(np.isfinite(float(ln.split("Com Loss: ")[1].split()[0])) for ln in log)
+    out = _run(root, "--render_person --test_file transforms_val_ba.json --N_iters=600000 --image_ext png --n_feat 128 --z_dim 64 "
+                     "--hip_tier f16 --hierarchical --N_importance 128 --resume dataset/train_together/narrow/000004.tar", common=common)
+    assert "f16 tier: accuracy on" in out
+    frames = sorted(os.listdir(base / "obama" / "person" / "render_com"))
+    assert frames == [f"test_{k:06d}.png" for k in range(F_VAL)]
+
+
 def test_n_object_default_stops_where_upstream_stops(dataset):
     """--n_object 2 is the flag's default (MAIN:378): upstream builds ONE dataset (`datadir = [args.datadir]`, MAIN:449) and stops
     in the per-person setup loop (`datadir[i]`, MAIN:499) with IndexError - before a frame is rendered.  Accepted at parse time

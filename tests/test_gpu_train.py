@@ -532,6 +532,102 @@ def test_training_step_other_sample_counts_vs_oracle_autograd(states, scene, lat
     print(f"N_samples {n_coarse}, {tier}, {n} rays: worst whole-tensor gradient error against oracle autograd {worst:.2e}, d(signal) {e_sig[0]:.2e} / {e_sig[1]:.2e}")
 
 
+@pytest.mark.parametrize("kind", ["narrow", "no_deform"])
+def test_narrower_and_plainer_decoders_train_in_the_padded_layout(states, scene, latents, kind):
+    """--n_feat / --z_dim below 256 and a missing --use_deformation_field are free upstream (MAIN:372-375, 411, 518); round 5 trained
+    one configuration.  Such a decoder trains INSIDE the library's 256-wide layout (training._FlatNet: every parameter a corner of its
+    zero-padded slot, copied in before the step, its gradient copied out after it): the fused two-field step (f32 tier, 64 rays)
+    against torch CPU autograd through the oracle on the SAME narrow network - loss, d(signal), every parameter's gradient; then
+    two Adam steps: the padded entries of the flat vector are still exactly zero, the parameters moved, and `Decoder.forward` under
+    grad (head) agrees with the torch-op twin."""
+    from dfanerf import engine, training
+    from dfanerf.decoder import Decoder
+    from dfanerf.run_nerf import make_adam
+    dev = torch.device("cuda")
+    if kind == "narrow":
+        hid, zd, deform = 128, 64, True
+        st = synth.synth_decoder_state(0, z_dim=zd, hidden=hid)
+    else:
+        hid, zd, deform = 256, 256, False
+        st = {k: v for k, v in states["decoder"].items() if not k.startswith("deform_net.")}
+    zs, za = synth.synth_latents(0, z_dim=zd)
+    dec = Decoder(z_dim=zd, hidden_size=hid, dim_signal=96, use_deformation_field=deform)
+    dec.load_state_dict({k: t(v) for k, v in st.items()})
+    dec.to(dev)
+    n = 64
+    idx = np.arange(11, scene["H"] * scene["W"], 3163)[:n].astype(np.int32)
+    sig = synth.synth_tensor(0, "g3/sig", (96,), 0.8)
+    sigt = synth.synth_tensor(0, "g3/sigt", (42,), 0.8)
+    buf = training.TrainBuffers("f32", n, dev)
+    fr = engine.make_frame(scene["H"], scene["W"], scene["focal"], scene["cx"], scene["cy"], scene["poses"][0], scene["pose_body"],
+                           scene["near"], scene["far"], ray_count=n, n_fine=0, fields=2)
+    bg = (t(scene["bg"]).float() / 255.0).reshape(-1, 3)
+    tgt = t(np.linspace(0.1, 0.9, n * 3, dtype=np.float32).reshape(n, 3))
+    sh = t(sig)[None].to(dev).requires_grad_(True)
+    stt = t(sigt).to(dev).requires_grad_(True)
+    rh, rc = training.render_train(dec, buf, fr, bg.to(dev), t(idx).to(dev), sh, stt, t(zs[0]).to(dev), t(za[0]).to(dev))
+    assert buf.net.padded and buf.flat.numel() == 955242
+    loss = ((rh - tgt.to(dev)) ** 2).mean() + ((rc - tgt.to(dev)) ** 2).mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    P = {k: v.clone().requires_grad_(True) for k, v in O.params_to_torch(st).items()}
+    o_h, d_h = O.get_rays(scene["H"], scene["W"], scene["focal"], scene["poses"][0][:3, :4], scene["cx"], scene["cy"])
+    o_t, d_t = O.get_rays(scene["H"], scene["W"], scene["focal"], scene["pose_body"][:3, :4], scene["cx"], scene["cy"])
+    rays = [x.reshape(-1, 3)[idx] for x in (o_h, d_h, o_t, d_t)]
+    sh_o, st_o = t(sig)[None].requires_grad_(True), t(sigt)[None].requires_grad_(True)
+    oh, oc = O.render_rays_chunk(P, *rays, bg[idx], scene["near"], scene["far"], t(zs), t(za), [sh_o, None], st_o, 64, 0, 2)
+    lo = ((oh - tgt) ** 2).mean() + ((oc - tgt) ** 2).mean()
+    lo.backward()
+    np.testing.assert_allclose(loss.item(), lo.item(), rtol=1e-5)
+    np.testing.assert_allclose(rh.detach().cpu().numpy(), oh.detach().numpy(), atol=2e-5, rtol=0)
+    rel = lambda a, b: float((a.detach().cpu().double().reshape(-1) - b.double().reshape(-1)).norm() / (b.double().norm() + 1e-30))
+    assert rel(sh.grad, sh_o.grad) < 2e-3 and rel(stt.grad, st_o.grad) < 2e-3
+    worst, seen = 0.0, 0
+    for k, q in dec.named_parameters():
+        ref = P[k].grad
+        if ref is None or float(ref.abs().max()) == 0.0:
+            assert q.grad is None or float(q.grad.abs().max()) == 0.0, k
+            continue
+        assert q.grad is not None and q.grad.shape == q.shape and q.grad.is_contiguous(), k
+        worst, seen = max(worst, rel(q.grad, ref)), seen + 1
+        assert rel(q.grad, ref) < 2e-3, (k, rel(q.grad, ref))
+    print(f"{kind}: worst whole-tensor gradient error against oracle autograd {worst:.2e} over {seen} tensors")
+    # two optimizer steps: only the parameters move; everything else of the library's flat vector is still exactly zero
+    before = {k: q.detach().clone() for k, q in dec.named_parameters()}
+    opt = make_adam(dec.parameters(), 5e-4)
+    for _ in range(2):
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        rh, rc = training.render_train(dec, buf, fr, bg.to(dev), t(idx).to(dev), sh.detach().requires_grad_(True), stt.detach().requires_grad_(True),
+                                       t(zs[0]).to(dev), t(za[0]).to(dev))
+        (((rh - tgt.to(dev)) ** 2).mean() + ((rc - tgt.to(dev)) ** 2).mean()).backward()
+    torch.cuda.synchronize()
+    moved = [k for k, q in dec.named_parameters() if q.grad is not None and not torch.equal(q.detach(), before[k])]
+    assert len(moved) >= seen - 2, (len(moved), seen)
+    probe = torch.zeros(955242, dtype=torch.float32, device=dev)
+    for o_, shp, p_ in zip(buf.net.offsets, buf.net.shapes, buf.net.params):
+        training._FlatNet._corner(probe, o_, shp, p_).fill_(1.0)
+    occupied = probe > 0
+    assert int(occupied.sum()) == sum(q.numel() for q in buf.net.params) < 955242
+    assert float(buf.flat[~occupied].abs().max()) == 0.0
+    # Decoder.forward under grad (the reference-shaped loop's entry) on the same decoder against the torch-op twin
+    rs = np.random.RandomState(5)
+    p = t((rs.rand(1, 500, 3).astype(np.float32) - 0.5) * 1.2).to(dev)
+    d = t(rs.randn(1, 500, 3).astype(np.float32)).to(dev)
+    res = {}
+    for which in ("hip", "twin"):
+        dec.zero_grad(set_to_none=True)
+        s2 = t(sig)[None].to(dev).requires_grad_(True)
+        zz, aa = t(zs[:, 0]).to(dev), t(za[:, 0]).to(dev)
+        f_, s_ = dec(p, d, zz, aa, [s2, None], "head", tier="f32") if which == "hip" else twins.decoder_forward_aten(dec, p, d, zz, aa, [s2, None], "head")
+        (f_.sum() + 0.1 * s_.sum()).backward()
+        res[which] = (s2.grad.clone(), {k: q.grad.clone() for k, q in dec.named_parameters() if q.grad is not None})
+    assert rel(res["hip"][0].cpu(), res["twin"][0].cpu()) < 1e-3 and set(res["hip"][1]) == set(res["twin"][1])
+    for k, gtw in res["twin"][1].items():
+        if float(gtw.abs().max()) > 0:
+            assert rel(res["hip"][1][k].cpu(), gtw.cpu()) < 1e-3, k
+
+
 @pytest.mark.parametrize("tier", ["f32"])
 def test_listener_layers_train_through_the_hip_path_vs_reference_golden(states, latents, golden, tier):
     """Decoder.forward with `signal is None` (the listener input layers fc_in_listener / fc_p_skips_listener, decoder.py:306-307,
