@@ -453,30 +453,38 @@ hipError_t launch_composite_bwd_hier(const CompositeBwdArgs& A, hipStream_t st) 
 // Same products in the same order per output element as before (MFMA m of an 8-point group pairs point m with point m + 4, groups
 // in point order), same row-sum order: the slices' partial sums are bit-identical to rounds 2-5.
 // (Shapes: dfn_train.h wn_shape_of; anything else is refused when the plan is built, dfn_api.hip.)
-template <int MT, int NT, int RG, int NS, int LDS_MAX = 72 * 1024>
+template <int MT, int NT, int RG, int NS, int LDS_MAX = 72 * 1024, int PT = 32>
 __device__ __forceinline__ void wgrad_lds_part(const WOp& o, int m_tile0, int ks, const float* dy_T, const float* act_T, long n_tiles,
                                                int g_rows, int a_rows, int ksplit, float* C, long c_stride, const int* e_of,
                                                float* dbias, int n_bias, lds_char* lds) {
+    // PT = points per step: 32 (a whole tile: 128-byte rows, 8 rows per 1-KiB DMA piece) or 16 (half a tile: 64-byte half rows,
+    // 16 rows per piece, chunk c of row r at slot 4 r + (c ^ ((r >> 2) & 3)) - the same sixteen-different-slots rule)
     constexpr int CG = 4 / RG, MW = MT / RG, NW = NT / CG;
-    constexpr int PIECES = (MT + NT) * 4, PW = PIECES / 4;
+    constexpr int HP = 32 / PT, CH = PT / 4, RP = 256 / PT, QN = PT / 8;
+    constexpr int PIECES = (MT + NT) * 32 / RP, PA = MT * 32 / RP, PW = PIECES / 4;
     constexpr int STAGE = PIECES * 1024;
+    static_assert((PT == 32 || PT == 16) && PIECES % 4 == 0, "step");
     static_assert(MT % RG == 0 && NT % CG == 0 && NS >= 2 && NS <= 4 && NS * STAGE <= LDS_MAX && (NS - 1) * PW <= 63, "shape");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rg = wave / CG, cg = wave % CG;
     const long per = (n_tiles + ksplit - 1) / ksplit;
     const long t0 = ks * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
     if (t0 >= t1) return;                                                // a slice without points: the reduction skips it
+    const long n_steps = (t1 - t0) * HP;
     const int a_row0 = o.a_row + 32 * m_tile0;
-    auto issue = [&](int stage, long t) {
+    auto swz = [](int r) { return PT == 32 ? (r >> 1) & 7 : (r >> 2) & 3; };
+    auto issue = [&](int stage, long u) {
+        const long t = t0 + u / HP;
+        const int half = (int)(u % HP);
 #pragma unroll
         for (int k = 0; k < PW; ++k) {
             const int p = 4 * k + wave;                                  // wave-uniform
-            const bool isb = p >= 4 * MT;
-            const int r = 8 * (isb ? p - 4 * MT : p) + (lane >> 3);
-            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            const bool isb = p >= PA;
+            const int r = RP * (isb ? p - PA : p) + lane / CH;
+            const int c = (lane % CH) ^ swz(r);
             const float* base = isb ? act_T + (t * (long)a_rows + o.b_row) * 32 : dy_T + (t * (long)g_rows + a_row0) * 32;
             const gchar_c* sb = (const gchar_c*)uniform_ptr(base);
-            const unsigned voff = (unsigned)(r * 128 + c * 16);
+            const unsigned voff = (unsigned)(r * 128 + half * (PT * 4) + c * 16);
             const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)lds + (unsigned)(stage * STAGE + p * 1024));
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(dst) : "memory", "m0");
         }
@@ -495,18 +503,18 @@ __device__ __forceinline__ void wgrad_lds_part(const WOp& o, int m_tile0, int ks
     for (int i = 0; i < MW; ++i) rs[i] = 0.f;
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
-        if (t0 + s < t1) issue(s, t0 + s);
-    int st = 0;                                                          // stage of tile t
-    for (long t = t0; t < t1; ++t) {
-        // this wave's pieces of tile t have landed once at most the pieces of the younger tiles in flight are outstanding
-        const long younger = (t1 - 1 - t < NS - 2) ? t1 - 1 - t : NS - 2;
+        if (s < n_steps) issue(s, s);
+    int st = 0;                                                          // stage of step u
+    for (long u = 0; u < n_steps; ++u) {
+        // this wave's pieces of step u have landed once at most the pieces of the younger steps in flight are outstanding
+        const long younger = (n_steps - 1 - u < NS - 2) ? n_steps - 1 - u : NS - 2;
         if (NS >= 4 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
         else if (NS >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                     // ... and everybody else's; everybody is also done reading the stage of tile t - 1
-        if (t + NS - 1 < t1) issue(st == 0 ? NS - 1 : st - 1, t + NS - 1);
+        __syncthreads();                     // ... and everybody else's; everybody is also done reading the stage of step u - 1
+        if (u + NS - 1 < n_steps) issue(st == 0 ? NS - 1 : st - 1, u + NS - 1);
         const lds_char* sa = lds + st * STAGE;
-        const lds_char* sb_ = sa + MT * 32 * 128;
+        const lds_char* sb_ = sa + PA * 1024;
         // the operands of 8-point group q + 1 are read while the MFMAs of group q issue (two register sets: left to itself the
         // compiler reads a group's operands into the registers the previous group's last MFMA has just released, and the first
         // MFMA of every group waits for LDS)
@@ -516,18 +524,18 @@ __device__ __forceinline__ void wgrad_lds_part(const WOp& o, int m_tile0, int ks
 #pragma unroll
             for (int i = 0; i < MW; ++i) {
                 const int r = 32 * (MW * rg + i) + rl;
-                av[q & 1][i] = *(const lds_f32x4*)(sa + (r * 8 + (c ^ ((r >> 1) & 7))) * 16);
+                av[q & 1][i] = *(const lds_f32x4*)(sa + (r * CH + (c ^ swz(r))) * 16);
             }
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
                 const int r = 32 * (NW * cg + j) + rl;
-                bv[q & 1][j] = *(const lds_f32x4*)(sb_ + (r * 8 + (c ^ ((r >> 1) & 7))) * 16);
+                bv[q & 1][j] = *(const lds_f32x4*)(sb_ + (r * CH + (c ^ swz(r))) * 16);
             }
         };
         fetch(0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (q < 3) fetch(q + 1);
+        for (int q = 0; q < QN; ++q) {
+            if (q < QN - 1) fetch(q + 1);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -617,8 +625,13 @@ __global__ __launch_bounds__(256) void wgrad_full_kernel(const WOp* ops, const i
                                                           const int* e_of, float* dbias, int n_bias) {
     extern __shared__ __attribute__((aligned(16))) char wf1_smem[];
     const WOp o = ops[full_ops[blockIdx.x / ksplit]];
+#ifdef DFN_WF_HALF
+    wgrad_lds_part<8, 8, 4, DFN_WF_HALF, DFN_WF_HALF * 32 * 1024, 16>(o, 0, blockIdx.x % ksplit, dy_T, act_T, n_tiles, g_rows, a_rows, ksplit, C,
+                                                                      c_stride, e_of, dbias, n_bias, (lds_char*)wf1_smem);
+#else
     wgrad_lds_part<8, 8, 4, 2, 128 * 1024>(o, 0, blockIdx.x % ksplit, dy_T, act_T, n_tiles, g_rows, a_rows, ksplit, C, c_stride, e_of, dbias,
                                            n_bias, (lds_char*)wf1_smem);
+#endif
 }
 
 // hipFuncSetAttribute once per (kernel, device): a second device of the process needs it too
@@ -642,8 +655,32 @@ hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, const int* full
     if (tier != TIER_F32) return hipErrorInvalidValue;          // bf16: launch_wgrad_bf16
     const float *dy = (const float*)dy_T, *ac = (const float*)act_T;
     hipError_t e;
+    hipStream_t ns = st;
+#ifdef DFN_WG_FORK
+    // beside the 256 x 256 GEMMs, on a stream of its own (they write disjoint pieces of the partial arrays)
+    static hipStream_t side[64][3] = {};
+    static hipEvent_t ev[64][3][2] = {};
+    static const bool fork = [] { const char* v = getenv("DFN_WGRAD_FORK"); return !v || atoi(v) != 0; }();
+    int dev = 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    const bool forked = fork && n_full > 0 && n_nitems > 0 && dev >= 0 && dev < 64 && field >= 0 && field < 3;
+    if (forked) {
+        if (!side[dev][field]) {
+            if ((e = hipStreamCreateWithFlags(&side[dev][field], hipStreamNonBlocking)) != hipSuccess) return e;
+            for (int k = 0; k < 2; ++k)
+                if ((e = hipEventCreateWithFlags(&ev[dev][field][k], hipEventDisableTiming)) != hipSuccess) return e;
+        }
+        ns = side[dev][field];
+        if ((e = hipEventRecord(ev[dev][field][0], st)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(ns, ev[dev][field][0], 0)) != hipSuccess) return e;
+    }
+#endif
     if (n_full > 0) {           // the 256 x 256 GEMMs (8 of a field's GEMMs, 89 % of its FLOPs): one workgroup per (GEMM, slice)
+#ifdef DFN_WF_HALF
+        constexpr int lds = DFN_WF_HALF * 32 * 1024;
+#else
         constexpr int lds = 2 * (8 + 8) * 4 * 1024;
+#endif
         static bool done[64] = {};
         if ((e = lds_attr_once(wgrad_full_kernel, lds, done)) != hipSuccess) return e;
         hipLaunchKernelGGL(wgrad_full_kernel, dim3(n_full * ksplit), dim3(256), lds, st, ops_dev, full_ops_dev, dy, ac, NP / 32,
@@ -653,9 +690,15 @@ hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, const int* full
     if (n_nitems > 0) {         // everything else, side by side in one launch
         static bool done[64] = {};
         if ((e = lds_attr_once(wgrad_narrow_kernel, WN_LDS_BYTES, done)) != hipSuccess) return e;
-        hipLaunchKernelGGL(wgrad_narrow_kernel, dim3(n_nitems), dim3(256), WN_LDS_BYTES, st, ops_dev, nitems_dev, dy, ac, NP / 32, g_rows,
+        hipLaunchKernelGGL(wgrad_narrow_kernel, dim3(n_nitems), dim3(256), WN_LDS_BYTES, ns, ops_dev, nitems_dev, dy, ac, NP / 32, g_rows,
                            a_rows, ksplit, C, c_stride, e_of, dbias, n_bias);
         if ((e = hipGetLastError()) != hipSuccess) return e;
+#ifdef DFN_WG_FORK
+        if (forked) {
+            if ((e = hipEventRecord(ev[dev][field][1], ns)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(st, ev[dev][field][1], 0)) != hipSuccess) return e;
+        }
+#endif
     }
     return hipSuccess;
 }

@@ -628,6 +628,46 @@ def test_narrower_and_plainer_decoders_train_in_the_padded_layout(states, scene,
             assert rel(res["hip"][1][k].cpu(), gtw.cpu()) < 1e-3, k
 
 
+def test_narrower_decoder_trains_in_the_16_bit_tier_too(scene):
+    """the padded layout under the 16-bit training tier (bf16 MFMAs, MX-fp8 / MX-fp4 recorded arrays: a zero stays a zero in every
+    block format): 512 rays of a 128-wide / 64-code decoder - the loss against the exact tier's, finite gradients of the narrow
+    shapes, and after an Adam step every padded entry of the flat vector still exactly zero"""
+    from dfanerf import engine, training
+    from dfanerf.decoder import Decoder
+    from dfanerf.run_nerf import make_adam
+    dev = torch.device("cuda")
+    st = synth.synth_decoder_state(0, z_dim=64, hidden=128)
+    zs, za = synth.synth_latents(0, z_dim=64)
+    n = 512
+    idx = np.arange(3, scene["H"] * scene["W"], 389)[:n].astype(np.int32)
+    bg = (t(scene["bg"]).float() / 255.0).reshape(-1, 3).to(dev)
+    tgt = t(np.linspace(0.1, 0.9, n * 3, dtype=np.float32).reshape(n, 3)).to(dev)
+    losses = {}
+    for tier in ("f32", "bf16"):
+        dec = Decoder(z_dim=64, hidden_size=128, dim_signal=96, use_deformation_field=True)
+        dec.load_state_dict({k: t(v) for k, v in st.items()})
+        dec.to(dev)
+        buf = training.TrainBuffers(tier, n, dev)
+        fr = engine.make_frame(scene["H"], scene["W"], scene["focal"], scene["cx"], scene["cy"], scene["poses"][0], scene["pose_body"],
+                               scene["near"], scene["far"], ray_count=n, n_fine=0, fields=2)
+        sh = t(synth.synth_tensor(0, "g3/sig", (96,), 0.8))[None].to(dev).requires_grad_(True)
+        stt = t(synth.synth_tensor(0, "g3/sigt", (42,), 0.8)).to(dev).requires_grad_(True)
+        rh, rc = training.render_train(dec, buf, fr, bg, t(idx).to(dev), sh, stt, t(zs[0]).to(dev), t(za[0]).to(dev))
+        loss = ((rh - tgt) ** 2).mean() + ((rc - tgt) ** 2).mean()
+        loss.backward()
+        losses[tier] = loss.item()
+        gs = {k: q.grad for k, q in dec.named_parameters() if q.grad is not None}
+        assert len(gs) >= 60 and all(bool(torch.isfinite(g).all()) and g.shape == dict(dec.named_parameters())[k].shape for k, g in gs.items())
+        assert float(gs["blocks.3.weight"].norm()) > 0 and bool(torch.isfinite(sh.grad).all())
+        make_adam(dec.parameters(), 5e-4).step()
+        buf.net.refresh()
+        probe = torch.zeros(955242, dtype=torch.float32, device=dev)
+        for o_, shp, p_ in zip(buf.net.offsets, buf.net.shapes, buf.net.params):
+            training._FlatNet._corner(probe, o_, shp, p_).fill_(1.0)
+        assert float(buf.flat[probe == 0].abs().max()) == 0.0
+    assert abs(losses["bf16"] - losses["f32"]) <= 3e-2 * abs(losses["f32"]), losses
+
+
 @pytest.mark.parametrize("tier", ["f32"])
 def test_listener_layers_train_through_the_hip_path_vs_reference_golden(states, latents, golden, tier):
     """Decoder.forward with `signal is None` (the listener input layers fc_in_listener / fc_p_skips_listener, decoder.py:306-307,
