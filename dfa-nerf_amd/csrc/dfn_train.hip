@@ -437,8 +437,9 @@ hipError_t launch_composite_bwd_hier(const CompositeBwdArgs& A, hipStream_t st) 
 //   * NS stages, ONE barrier per step: "tile t has landed" and "everybody is done with tile t - 1" are the same barrier, behind
 //     it the stage of tile t - 1 is refilled with tile t + NS - 1 (round 5 had two barriers per step around two stages).
 // wgrad_full_kernel: the 256 x 256 GEMMs (8 of a field's 13 / 26, 89 % of its FLOPs), <8, 8, 4, 2>: wave w owns output rows
-// 64 w .. 64 w + 63 x all 256 columns (256 accumulator registers), two 64-KiB stages, one workgroup per compute unit;
-// 8 GEMMs x 32 slices = 256 workgroups = one round: 1.04-1.1 ms per field, 0.83 of the f32 MFMA peak.
+// 64 w .. 64 w + 63 x all 256 columns (256 accumulator registers), one workgroup per compute unit; 8 GEMMs x 32 slices = 256
+// workgroups = one round: 1.02-1.05 ms per field.  Its step is HALF a tile (16 points, two 32-KiB stages, 324 registers; the
+// 32-point step with two 64-KiB stages: 356 registers and 0.04-0.08 ms more per training step, profiles/r06s_*, r06u_*).
 //
 // wgrad_narrow_kernel: every GEMM that is NOT 256 x 256 (11 % of a field's weight-gradient FLOPs, but a third of its operand
 // bytes), all of them in ONE launch: one workgroup per WNItem = (GEMM, block of its row tiles, slice of the points).  (Round 5
@@ -619,19 +620,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_narrow_kernel(const WOp* ops, co
 #undef DFN_WN
 }
 
-// the 256 x 256 GEMMs (two 64-KiB stages; `full_ops`: their indices in `ops`, dfn_api.hip)
+// the 256 x 256 GEMMs (two 32-KiB stages of 16 points; `full_ops`: their indices in `ops`, dfn_api.hip)
 __global__ __launch_bounds__(256) void wgrad_full_kernel(const WOp* ops, const int* full_ops, const float* dy_T, const float* act_T,
                                                           long n_tiles, int g_rows, int a_rows, int ksplit, float* C, long c_stride,
                                                           const int* e_of, float* dbias, int n_bias) {
     extern __shared__ __attribute__((aligned(16))) char wf1_smem[];
     const WOp o = ops[full_ops[blockIdx.x / ksplit]];
-#ifdef DFN_WF_HALF
-    wgrad_lds_part<8, 8, 4, DFN_WF_HALF, DFN_WF_HALF * 32 * 1024, 16>(o, 0, blockIdx.x % ksplit, dy_T, act_T, n_tiles, g_rows, a_rows, ksplit, C,
-                                                                      c_stride, e_of, dbias, n_bias, (lds_char*)wf1_smem);
-#else
-    wgrad_lds_part<8, 8, 4, 2, 128 * 1024>(o, 0, blockIdx.x % ksplit, dy_T, act_T, n_tiles, g_rows, a_rows, ksplit, C, c_stride, e_of, dbias,
-                                           n_bias, (lds_char*)wf1_smem);
-#endif
+    wgrad_lds_part<8, 8, 4, 2, 64 * 1024, 16>(o, 0, blockIdx.x % ksplit, dy_T, act_T, n_tiles, g_rows, a_rows, ksplit, C, c_stride, e_of,
+                                              dbias, n_bias, (lds_char*)wf1_smem);
 }
 
 // hipFuncSetAttribute once per (kernel, device): a second device of the process needs it too
@@ -655,32 +651,8 @@ hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, const int* full
     if (tier != TIER_F32) return hipErrorInvalidValue;          // bf16: launch_wgrad_bf16
     const float *dy = (const float*)dy_T, *ac = (const float*)act_T;
     hipError_t e;
-    hipStream_t ns = st;
-#ifdef DFN_WG_FORK
-    // beside the 256 x 256 GEMMs, on a stream of its own (they write disjoint pieces of the partial arrays)
-    static hipStream_t side[64][3] = {};
-    static hipEvent_t ev[64][3][2] = {};
-    static const bool fork = [] { const char* v = getenv("DFN_WGRAD_FORK"); return !v || atoi(v) != 0; }();
-    int dev = 0;
-    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-    const bool forked = fork && n_full > 0 && n_nitems > 0 && dev >= 0 && dev < 64 && field >= 0 && field < 3;
-    if (forked) {
-        if (!side[dev][field]) {
-            if ((e = hipStreamCreateWithFlags(&side[dev][field], hipStreamNonBlocking)) != hipSuccess) return e;
-            for (int k = 0; k < 2; ++k)
-                if ((e = hipEventCreateWithFlags(&ev[dev][field][k], hipEventDisableTiming)) != hipSuccess) return e;
-        }
-        ns = side[dev][field];
-        if ((e = hipEventRecord(ev[dev][field][0], st)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(ns, ev[dev][field][0], 0)) != hipSuccess) return e;
-    }
-#endif
     if (n_full > 0) {           // the 256 x 256 GEMMs (8 of a field's GEMMs, 89 % of its FLOPs): one workgroup per (GEMM, slice)
-#ifdef DFN_WF_HALF
-        constexpr int lds = DFN_WF_HALF * 32 * 1024;
-#else
-        constexpr int lds = 2 * (8 + 8) * 4 * 1024;
-#endif
+        constexpr int lds = 2 * (8 + 8) * 2 * 1024;             // two stages of 16 points
         static bool done[64] = {};
         if ((e = lds_attr_once(wgrad_full_kernel, lds, done)) != hipSuccess) return e;
         hipLaunchKernelGGL(wgrad_full_kernel, dim3(n_full * ksplit), dim3(256), lds, st, ops_dev, full_ops_dev, dy, ac, NP / 32,
@@ -690,15 +662,9 @@ hipError_t launch_wgrad(int tier, int field, const WOp* ops_dev, const int* full
     if (n_nitems > 0) {         // everything else, side by side in one launch
         static bool done[64] = {};
         if ((e = lds_attr_once(wgrad_narrow_kernel, WN_LDS_BYTES, done)) != hipSuccess) return e;
-        hipLaunchKernelGGL(wgrad_narrow_kernel, dim3(n_nitems), dim3(256), WN_LDS_BYTES, ns, ops_dev, nitems_dev, dy, ac, NP / 32, g_rows,
+        hipLaunchKernelGGL(wgrad_narrow_kernel, dim3(n_nitems), dim3(256), WN_LDS_BYTES, st, ops_dev, nitems_dev, dy, ac, NP / 32, g_rows,
                            a_rows, ksplit, C, c_stride, e_of, dbias, n_bias);
         if ((e = hipGetLastError()) != hipSuccess) return e;
-#ifdef DFN_WG_FORK
-        if (forked) {
-            if ((e = hipEventRecord(ev[dev][field][1], ns)) != hipSuccess) return e;
-            if ((e = hipStreamWaitEvent(st, ev[dev][field][1], 0)) != hipSuccess) return e;
-        }
-#endif
     }
     return hipSuccess;
 }
