@@ -162,7 +162,14 @@ template <int TIER, int NTB, int KU, int T, class CT> struct PutSide {
     DFN_DEV void operator()(int ku) const {
         if (row0 < 0) return;
         const int s = tg * KU + ku;
-        if constexpr (T >= NTB) {
+        if constexpr (TIER == TIER_F32) {       // one value per store instruction: the vector's 16 NTB values over the layer's T k-steps
+#ifndef DFN_NOPUT
+            constexpr int N = 16 * NTB, PER32 = (N + T - 1) / T;
+#pragma unroll
+            for (int w = 0; w < PER32; ++w)
+                if (s * PER32 + w < N) store_val_T32(io.dy_T, io.rows, io.pass, row0, s * PER32 + w, v.v[s * PER32 + w], c);
+#endif
+        } else if constexpr (T >= NTB) {
             if (s % STRIDE == 0) tile(s / STRIDE);
         } else {
 #pragma unroll
@@ -183,7 +190,14 @@ DFN_DEV void put_scales(const BwdIO& io, int row0, const Vec<TIER, NTB>& v, Q8 (
         }
     }
 }
-template <int TIER> constexpr bool put_spread() { return TIER == TIER_BF16 && DFN_PUT_SPREAD != 0; }
+// DFN_PUT32_SPREAD: the same for the f32 tier (one wave per SIMD: a burst of 128 store instructions in front of a layer stops
+// the wave, and with it the matrix pipe, until the memory queue has drained)
+#ifndef DFN_PUT32_SPREAD
+#define DFN_PUT32_SPREAD 1
+#endif
+template <int TIER> constexpr bool put_spread() {
+    return (TIER == TIER_BF16 && DFN_PUT_SPREAD != 0) || (TIER == TIER_F32 && DFN_PUT32_SPREAD != 0);
+}
 
 // out[OT tiles] = (W^T x in) [* mask]; mask_dword0 < 0: no mask.  put_row >= 0: `in` is written to rows put_row.. of dy_T
 // on the way (PutSide)

@@ -485,6 +485,19 @@ DFN_DEV void rec_vec(const CT& c, int row0, const Vec<TIER, NT>& v) {
     else store_vec_T<TIER, NT, CT, true>(c.rec.act_T, c.rec.rows, c.rec.pass, row0, v, c);
 }
 
+// one value of an f32 vector (local slot L; tile 0 of the vector at row row0) -> its place in a tile-major array: what
+// store_tiles_T does for whole tiles, one store instruction at a time (the recorder and the dX chain spread them between MFMAs)
+template <class CT>
+DFN_DEV void store_val_T32(void* arr, int rows, long tile, int row0, int L, float x, const CT& c) {
+#ifdef DFN_REC32_NOSTORE      // timing experiment (wrong results)
+    return;
+#endif
+    gchar* ubase = uniform_ptr((float*)arr + (tile * rows + row0) * 32);
+    const int f = 32 * (L >> 4) + tile_feat(0, L & 15);
+    const unsigned voff = (unsigned)(4 * c.half * 32 + (c.lane & 31)) * 4u;
+    __builtin_nontemporal_store(x, (__attribute__((address_space(1))) float*)(ubase + f * 128 + voff));
+}
+
 // The A-fragment stream of a pass is strictly sequential (fragment f lives in slab f/32 at position f%32),
 // so fragments are prefetched PF_DEPTH ahead into a small register ring that is carried across ops and
 // layers: LDS latency hides behind the MFMAs of earlier fragments.  `fp` = index of the next fragment to
@@ -878,6 +891,42 @@ template <int TIER, int OT, int KU, class CT, bool NONNEG> struct RecSide {
     }
 };
 
+// DFN_REC32_SPREAD (training recorder, f32 tier): 1 = the 32 value stores and the ReLU bits of tile pair tg - 1 go out one by one
+// between the MFMAs of pair tg (the kernel runs ONE wave per SIMD: a burst of 32 store instructions fills the memory queue and
+// the wave - and with it the matrix pipe - waits until it drains); 0 = as one burst at the next slab hand-over.
+#ifndef DFN_REC32_SPREAD
+#define DFN_REC32_SPREAD 1
+#endif
+template <int OT, int KU, class CT> struct RecSide32 {
+    const CT& c;
+    const Vec<TIER_F32, OT>& out;
+    int rec_row, mask_dword, prev;  // mask_dword: of pair `prev` (-1: none); prev: the pair whose values go out (-1: none)
+    unsigned& bits;
+    static constexpr int VPS = (32 + KU - 1) / KU;          // values per k-step
+    DFN_DEV void operator()(int ku) const {
+        if constexpr (CT::rec_on) {
+            if (prev < 0) return;
+#pragma unroll
+            for (int w = 0; w < VPS; ++w) {
+                const int b = ku * VPS + w;
+                if (b < 32) {
+                    const float x = out.v[32 * prev + b];
+                    if (rec_row >= 0) store_val_T32(c.rec.act_T, c.rec.rows, c.rec.pass, rec_row + 64 * prev, b, x, c);
+#ifndef DFN_REC_NOMASK
+                    if (mask_dword >= 0) bits |= (x > 0.f) ? (1u << mask_pos(b)) : 0u;     // (relu(x) > 0 <=> x > 0: the accumulator's bit)
+#endif
+                }
+            }
+#ifndef DFN_REC_NOMASK
+            if (ku == KU - 1 && mask_dword >= 0) {
+                gchar* mb = uniform_ptr(c.rec.masks + ((long)c.rec.pass * c.rec.mask_dwords + mask_dword) * 64);
+                *(__attribute__((address_space(1))) unsigned*)(mb + (unsigned)c.lane * 4u) = bits;
+            }
+#endif
+        }
+    }
+};
+
 // out[OT tiles] = act( bias + W x in ), tile pairs; KU = k-units of `in` used
 template <int TIER, int OT, int KU, int NTB, bool RELU, class CT>
 DFN_DEV void layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_f32* bias, int& f, Fetch<TIER>& fe,
@@ -885,6 +934,21 @@ DFN_DEV void layer(Vec<TIER, OT>& out, const Vec<TIER, NTB>& in, const lds_f32* 
     static_assert(OT % 2 == 0, "tile pairs");
     if constexpr (CT::pipe && tier_is16(TIER) && OT >= 4 && KU >= 2) {
         layer_pipe<TIER, OT, KU, NTB, RELU>(out, in, bias, f, fe, s, c);
+        return;
+    }
+    if constexpr (CT::rec_on && TIER == TIER_F32 && (DFN_REC32_SPREAD != 0) && KU >= 8) {
+        unsigned bits = 0;
+#pragma unroll
+        for (int tg = 0; tg < OT / 2; ++tg) {
+            f32x16 acc[2];
+            acc_init<2>(acc, bias + tg * 64, c.half);
+            bits = 0;
+            gemm_group<TIER, 2, KU, NTB>(acc, in, f, fe, s, c, NoHook{},
+                                         RecSide32<OT, KU, CT>{c, out, rec_row, (rec_mask < 0 || tg == 0) ? -1 : rec_mask + tg - 1, tg - 1, bits});
+            acc_to_vec<TIER, 2, OT, RELU>(acc, out, 2 * tg);
+            if (tg == OT / 2 - 1) rec_mask_pair(c, rec_mask < 0 ? -1 : rec_mask + tg, acc);       // the last pair: a burst
+        }
+        if (rec_row >= 0) rec_vals<TIER>(c, rec_row + 64 * (OT / 2 - 1), out, OT - 2);
         return;
     }
     constexpr bool SPREAD = CT::rec_on && TIER == TIER_BF16 && (DFN_REC_SPREAD != 0);
