@@ -38,7 +38,7 @@ for f in $UNITS; do
   ( want="$HDR_HASH $(sha256sum < "$SRC/$f.hip" | cut -d' ' -f1)"
     if [ ! -f "$OBJ/$f.o" ] || [ "$(cat "$OBJ/$f.stamp" 2>/dev/null)" != "$want" ]; then
       rm -f "$OBJ/$f.stamp"
-      EXTRA=""; case "$f" in dfn_render_*) EXTRA="--save-temps=obj";; esac     # keep the ISA of the render kernels for the checks below
+      EXTRA=""; case "$f" in dfn_render_*|dfn_train|dfn_bwd_bf16) EXTRA="--save-temps=obj";; esac     # keep the ISA of the MLP kernels for the checks below
       hipcc $FLAGS $EXTRA -c "$SRC/$f.hip" -o "$OBJ/$f.o"
       echo "$want" > "$OBJ/$f.stamp"
     fi ) &
@@ -54,6 +54,10 @@ for t in bf16 bf16e f16; do
     # ... and the 16-bit inference kernels must not use scratch memory at all (stack objects, spilled VGPRs)
     python3 "$HERE/../tools/check_scratch.py" "$ISA" || { echo "build.sh: scratch memory in the $t inference kernels" >&2; exit 1; }
   fi
+done
+# the recorders' hand-written stores (dfn_mlp.h DFN_GSTORE): the hazards hipcc does not see inside inline asm
+for ISA in "$OBJ"/*-hip-amdgcn-amd-amdhsa-gfx950.s; do
+  [ -f "$ISA" ] && { python3 "$HERE/../tools/check_asm_stores.py" "$ISA" || { echo "build.sh: hazard at a hand-written store in $ISA" >&2; exit 1; }; }
 done
 rm -f "$OBJ"/*-hip-amdgcn-*.o "$OBJ"/*.hipi "$OBJ"/*.bc "$OBJ"/*.out "$OBJ"/*.resolution.txt "$OBJ"/*.hipfb "$OBJ"/*-host-*.s      # --save-temps leftovers (the device ISA stays)
 OBJS=""; for f in $UNITS; do OBJS="$OBJS $OBJ/$f.o"; done

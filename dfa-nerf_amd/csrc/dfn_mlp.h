@@ -260,6 +260,24 @@ DFN_DEV gchar* uniform_ptr(const void* p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (gchar*)(((unsigned long)hi << 32) | lo);
 }
+// A global store in its "saddr" form, written by hand: wave-uniform base in an SGPR pair + 32-bit lane offset + immediate.  From
+// `base + lane_offset + constant` hipcc builds a 64-bit vector address (v_lshl_add_u64) and emits the `off` form: two address
+// registers per lane through the memory pipeline per store instead of one.  The recorders' stores are what the f32 training kernels
+// lose their matrix pipe to (one wave per SIMD): forward 2625 -> 2584 us, dX (torso) 1284 -> 1237 us, the step 7.97 -> 7.83 ms
+// (profiles/r06x_*).  `off` = a compile-time byte offset >= 0 (what exceeds the 12-bit immediate goes to the base: scalar ALU).
+// No "memory" clobber: nothing in these kernels reads the recorded arrays back.  hipcc's hazard recogniser does not look into
+// inline asm: the 16-byte form carries its own two wait states (gfx940 family: a store of more than 8 bytes followed by a write of
+// its data registers; with ONE the MX-fp8 tiles came out wrong - 13 of 14 bf16 training tests failed, tools/r06y_run.sh).
+#define DFN_GSTORE(INSN, TAIL, ubase, voff, off, x)                                                                            \
+    do {                                                                                                                       \
+        gchar* ub_ = (ubase) + ((off) & ~4095);                                                                                \
+        asm volatile(INSN " %0, %1, %2 offset:%3" TAIL ::"v"(voff), "v"(x), "s"(ub_), "n"((off) & 4095));                      \
+    } while (0)
+#define DFN_GSTORE_B32_NT(ubase, voff, off, x) DFN_GSTORE("global_store_dword", " nt", ubase, voff, off, x)
+#define DFN_GSTORE_B32(ubase, voff, off, x) DFN_GSTORE("global_store_dword", "", ubase, voff, off, x)
+#define DFN_GSTORE_B64_NT(ubase, voff, off, x) DFN_GSTORE("global_store_dwordx2", " nt", ubase, voff, off, x)
+#define DFN_GSTORE_B128_NT(ubase, voff, off, x) DFN_GSTORE("global_store_dwordx4", " nt\n\ts_nop 1", ubase, voff, off, x)
+
 // ---- MX-fp8 recording (the 16-bit TRAINING tier) -----------------------------------------------------------------------
 // What the forward records for the backward (act_T) and what the dX chain leaves for the weight-gradient GEMMs (dy_T) is
 // written ONCE and read ONCE, 3 GB each way per 2048-ray step in bf16: the training step is bound by that traffic, not by
@@ -390,7 +408,7 @@ DFN_DEV void store_tile4(void* arr, int rows, long tile, int row0, const Vec<TIE
 #endif
     gchar* ubase = uniform_ptr((char*)arr + tile * act_tile_bytes(rows, true) + (long)row0 * 16);
     const unsigned voff = (unsigned)((c.lane & 31) * 16 + c.half * 8);
-    __builtin_nontemporal_store(out, (__attribute__((address_space(1))) u32x2_*)(ubase + (t - t_first) * 512 + voff));
+    DFN_GSTORE_B64_NT(ubase, voff, (t - t_first) * 512, out);
 }
 // act_T tile store / scale store in the build's activation format
 template <int NT, class CT>
@@ -424,7 +442,7 @@ DFN_DEV void store_tile8(void* arr, int rows, long tile, int row0, const Vec<TIE
 #endif
     gchar* ubase = uniform_ptr((char*)arr + tile * rec8_tile_bytes(rows) + (long)row0 * 32);
     const unsigned voff = (unsigned)((c.lane & 31) * 32 + c.half * 16);
-    __builtin_nontemporal_store(out, (__attribute__((address_space(1))) u32x4_*)(ubase + (t - t_first) * 1024 + voff));
+    DFN_GSTORE_B128_NT(ubase, voff, (t - t_first) * 1024, out);
 }
 // the scale bytes of tiles [t0, t0 + n) of a vector whose tile t_first sits at row row0
 template <class CT>
@@ -471,7 +489,12 @@ DFN_DEV void store_tiles_T(void* arr, int rows, long tile, int row0, const Vec<T
             if ((L >> 4) >= t0 && (L >> 4) < t0 + n) {
                 const int f = 32 * ((L >> 4) - t0) + tile_feat(0, L & 15);
                 const unsigned voff = (unsigned)(4 * c.half * 32 + (c.lane & 31)) * (unsigned)sizeof(T);
-                __builtin_nontemporal_store((T)v.get(L), (__attribute__((address_space(1))) T*)(ubase + f * 32 * (int)sizeof(T) + voff));
+                if constexpr (sizeof(T) == 4) {
+                    const float x = v.get(L);
+                    DFN_GSTORE_B32_NT(ubase, voff, f * 128, x);
+                } else {
+                    __builtin_nontemporal_store((T)v.get(L), (__attribute__((address_space(1))) T*)(ubase + f * 32 * (int)sizeof(T) + voff));
+                }
             }
     }
 }
@@ -495,7 +518,7 @@ DFN_DEV void store_val_T32(void* arr, int rows, long tile, int row0, int L, floa
     gchar* ubase = uniform_ptr((float*)arr + (tile * rows + row0) * 32);
     const int f = 32 * (L >> 4) + tile_feat(0, L & 15);
     const unsigned voff = (unsigned)(4 * c.half * 32 + (c.lane & 31)) * 4u;
-    __builtin_nontemporal_store(x, (__attribute__((address_space(1))) float*)(ubase + f * 128 + voff));
+    DFN_GSTORE_B32_NT(ubase, voff, f * 128, x);
 }
 
 // The A-fragment stream of a pass is strictly sequential (fragment f lives in slab f/32 at position f%32),
@@ -759,7 +782,7 @@ DFN_DEV void rec_mask_pair(const CT& c, int mask_dword, const f32x16 (&acc)[2]) 
 #pragma unroll
             for (int b = 0; b < 32; ++b) bits |= (acc[b >> 4][b & 15] > 0.f) ? (1u << mask_pos(b)) : 0u;
             gchar* mb = uniform_ptr(c.rec.masks + ((long)c.rec.pass * c.rec.mask_dwords + mask_dword) * 64);
-            *(__attribute__((address_space(1))) unsigned*)(mb + (unsigned)c.lane * 4u) = bits;      // (ordinary: the dX kernels read these next)
+            DFN_GSTORE_B32(mb, (unsigned)c.lane * 4u, 0, bits);      // (ordinary: the dX kernels read these next)
         }
     }
 }
@@ -796,7 +819,7 @@ DFN_DEV void rec_mask_pair_packed(const CT& c, int mask_dword, const Vec<TIER, N
             return;
 #endif
             gchar* mb = uniform_ptr(c.rec.masks + ((long)c.rec.pass * c.rec.mask_dwords + mask_dword) * 64);
-            *(__attribute__((address_space(1))) unsigned*)(mb + (unsigned)c.lane * 4u) = bits;
+            DFN_GSTORE_B32(mb, (unsigned)c.lane * 4u, 0, bits);
         }
     }
 }
@@ -920,7 +943,7 @@ template <int OT, int KU, class CT> struct RecSide32 {
 #ifndef DFN_REC_NOMASK
             if (ku == KU - 1 && mask_dword >= 0) {
                 gchar* mb = uniform_ptr(c.rec.masks + ((long)c.rec.pass * c.rec.mask_dwords + mask_dword) * 64);
-                *(__attribute__((address_space(1))) unsigned*)(mb + (unsigned)c.lane * 4u) = bits;
+                DFN_GSTORE_B32(mb, (unsigned)c.lane * 4u, 0, bits);
             }
 #endif
         }
