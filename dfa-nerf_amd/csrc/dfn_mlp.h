@@ -537,8 +537,15 @@ DFN_DEV void store_val_T32(void* arr, int rows, long tile, int row0, int L, floa
 #endif
 constexpr int PF_DEPTH = DFN_PF_DEPTH;
 template <int TIER, class CT> constexpr bool use_asm_fetch() { return tier_is16(TIER) && CT::asm_fetch; }
-// (the asm fragment READS are for the 16-bit tiers only; the asm DMA alone - storing kernels - serves every tier)
-template <int TIER, class CT> constexpr bool use_asm_dma() { return CT::asm_fetch ? tier_is16(TIER) : CT::asm_dma; }
+// (the asm fragment READS are for the 16-bit tiers only.)  The asm DMA serves every kernel of the f32 tier (round 6; before,
+// this function answered tier_is16 whenever asm_fetch was on, and the f32 kernels got the builtin: a 64-bit vector address per
+// piece and, with "LDS DMA" in the function, s_waitcnt lgkmcnt(0) in front of the MFMAs that read LDS - f32 training forward
+// 2562 -> 2496 us, c2_f32 328.2 -> 318.7 ms = 0.921 -> 0.948 of the f32 MFMA peak, the same 138.47 dB; profiles/r06z_*).
+// DFN_F32_ASM_DMA = 0: the builtin again.
+#ifndef DFN_F32_ASM_DMA
+#define DFN_F32_ASM_DMA 1
+#endif
+template <int TIER, class CT> constexpr bool use_asm_dma() { return tier_is16(TIER) ? CT::asm_dma : (DFN_F32_ASM_DMA != 0 || CT::asm_dma); }
 
 #define DFN_FRAG_CASE(K)                                                                                      \
     case K:                                                                                                   \
