@@ -542,6 +542,9 @@ template <int TIER, class CT> constexpr bool use_asm_fetch() { return tier_is16(
 // piece and, with "LDS DMA" in the function, s_waitcnt lgkmcnt(0) in front of the MFMAs that read LDS - f32 training forward
 // 2562 -> 2496 us, c2_f32 328.2 -> 318.7 ms = 0.921 -> 0.948 of the f32 MFMA peak, the same 138.47 dB; profiles/r06z_*).
 // DFN_F32_ASM_DMA = 0: the builtin again.
+#ifndef DFN_F32_PIN_FRAGS
+#define DFN_F32_PIN_FRAGS 1
+#endif
 #ifndef DFN_F32_ASM_DMA
 #define DFN_F32_ASM_DMA 1
 #endif
@@ -665,6 +668,11 @@ DFN_DEV void gemm_group(f32x16 (&acc)[G], const Vec<TIER, NTB>& b, int& f, Fetch
             // (fewer live registers) and the LDS latency of every fragment is exposed: s_waitcnt lgkmcnt(0/1) in front of
             // every MFMA, matrix pipe 35 % busy in the dX kernels
             if constexpr (!ASM) __builtin_amdgcn_sched_barrier(DFN_GEMM_SCHEDBAR);
+#else
+            // f32 tier, kernels that do not record (inference, dX chain): the same pin (round 6, -DDFN_GEMM_SCHEDBAR=0 builds:
+            // c2_f32 317.8 -> 314.7 ms, dX 1230 -> 1216 us per field; the recording forward LOSES 20 us with it and stays free;
+            // profiles/r06za_*)
+            if constexpr (!ASM && TIER == TIER_F32 && !CT::rec_on && (DFN_F32_PIN_FRAGS != 0)) __builtin_amdgcn_sched_barrier(0);
 #endif
             ++f;
         }
