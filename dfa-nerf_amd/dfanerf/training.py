@@ -43,7 +43,10 @@ _SPLIT_JOIN = os.environ.get("DFN_TRAIN_SPLIT_JOIN", "1") == "1"
 # the torso field's dX chain BEFORE the head field's (1; A/B): the fields' roles in the overlapped schedule swapped.  Measured (interleaved,
 # two boxes, profiles/r05p_ab_schedule.txt): the hierarchical step -1 % on one box and +-0 on the other, the 64-sample step 7 % SLOWER (the
 # audio encoder's backward chain then starts behind the second dX chain and the next forward waits for it): off
-_TORSO_FIRST = os.environ.get("DFN_TRAIN_TORSO_FIRST", "0") == "1"
+# The f32 tier (round 6, the kernels at the end of the round: LABNOTES 10.8, three interleaved runs):
+# 7.707 -> 7.659 ms with the torso first - there the head's shorter dX chain runs beside the torso's GEMMs and the conditioning chains have a
+# millisecond of GEMMs to hide under either way - so the default depends on the tier (unset: f32 on, 16-bit off).
+_TORSO_FIRST = os.environ.get("DFN_TRAIN_TORSO_FIRST")
 # the step's loss from the training forward's epilogue (1: dfn_train_fwd*_loss) or from its own launch (0: dfn_mse_loss_u8; A/B)
 _LOSS_IN_FWD = os.environ.get("DFN_TRAIN_LOSS_IN_FWD", "1") == "1"
 
@@ -349,7 +352,7 @@ def _fused_backward(ctx, d_h, d_c):
             ev = getattr(tr, "_dsig_ev", None)
             if ev is None:
                 ev = tr._dsig_ev = (torch.cuda.Event(), torch.cuda.Event())
-        torso_first = _TORSO_FIRST
+        torso_first = (buf.tier == 0) if _TORSO_FIRST is None else _TORSO_FIRST == "1"
         if tr is not None:
             tr._torso_first = torso_first
         fa, fb = (1, 0) if torso_first else (0, 1)           # the field whose dX chain runs first / second
