@@ -708,8 +708,10 @@ static int ensure_eof(WgradEntry& w, int tier, int field) {
 
 // stages: 1 = the GEMMs (partial sums into the workspace), 2 = the reduction of the slices, 3 = both
 static int weight_grad_impl(int tier, int field, int act_format, const void* dy_T, const void* act_T, long NP, float* workspace,
-                            float* grad_flat, float* dbias, void* stream, const char* who, int stages = 3) {
+                            float* grad_flat, float* dbias, void* stream, const char* who, int stages = 3, int which = 3) {
     const bool gemm = stages & 1, red = stages & 2;
+    if (which < 1 || which > 3 || (which != 3 && (tier != DFN_TIER_F32 || red)))
+        return fail(DFN_E_ARG, std::string(who) + ": `which` selects the f32 tier's two GEMM launches (1: 256 x 256, 2: the others, 3: both)");
     if (act_format != DFN_ACT_E4M3 && act_format != DFN_ACT_E2M1)
         return fail(DFN_E_ARG, std::string(who) + ": act_format must be DFN_ACT_E4M3 or DFN_ACT_E2M1");
     if (!train_tier_ok(tier) || !train_field_ok(field) || (gemm && (!dy_T || !act_T)) || !workspace || (red && !grad_flat) ||
@@ -827,8 +829,9 @@ static int weight_grad_impl(int tier, int field, int act_format, const void* dy_
         err = launch_wgrad_bf16(field, act_format == DFN_ACT_E2M1, w.ops_dev, w.items_dev[sc], w.n_items[sc], dy_T, act_T, NP, c_parts, W,
                                 fuse ? w.eof_dev : nullptr, fuse ? b_parts : nullptr, nb, st);
     else
-        err = launch_wgrad(tier, field, w.ops_dev, w.full_ops_dev, (int)w.full_ops.size(), w.nitems_dev, (int)w.nitems.size(), dy_T, act_T,
-                           NP, ks, c_parts, W, ride ? w.eof_dev : nullptr, ride ? b_parts : nullptr, nb, st);
+        err = launch_wgrad(tier, field, w.ops_dev, w.full_ops_dev, (which & 1) ? (int)w.full_ops.size() : 0, w.nitems_dev,
+                           (which & 2) ? (int)w.nitems.size() : 0, dy_T, act_T, NP, ks, c_parts, W, ride ? w.eof_dev : nullptr,
+                           ride ? b_parts : nullptr, nb, st);
     if (err != hipSuccess) return hip_fail(err, "wgrad_kernel");
     if (!red) return DFN_OK;
     if (ride) {
@@ -891,6 +894,12 @@ int dfn_weight_bias_grad_partials(int tier, int field, int act_format, const voi
     if (!dbias) return fail(DFN_E_ARG, "dfn_weight_bias_grad_partials: dbias is NULL");
     return weight_grad_impl(tier, field, act_format, dy_T, act_T, NP, workspace, nullptr, dbias, stream,
                             "dfn_weight_bias_grad_partials", 1);
+}
+int dfn_weight_bias_grad_partials_part(int tier, int field, int act_format, const void* dy_T, const void* act_T, long NP,
+                                       float* workspace, float* dbias, int which, void* stream) {
+    if (!dbias) return fail(DFN_E_ARG, "dfn_weight_bias_grad_partials_part: dbias is NULL");
+    return weight_grad_impl(tier, field, act_format, dy_T, act_T, NP, workspace, nullptr, dbias, stream,
+                            "dfn_weight_bias_grad_partials_part", 1, which);
 }
 int dfn_weight_bias_grad_reduce(int tier, int field, long NP, float* workspace, float* grad_flat, float* dbias, void* stream) {
     if (!dbias) return fail(DFN_E_ARG, "dfn_weight_bias_grad_reduce: dbias is NULL");

@@ -105,6 +105,7 @@ def _load():
         "dfn_weight_bias_grad_fmt": (i32, [i32, i32, i32, vp, vp, lg, fp, fp, fp, vp]),
         "dfn_weight_bias_grad_partials": (i32, [i32, i32, i32, vp, vp, lg, fp, fp, vp]),
         "dfn_weight_bias_grad_reduce": (i32, [i32, i32, lg, fp, fp, fp, vp]),
+        "dfn_weight_bias_grad_partials_part": (i32, [i32, i32, i32, vp, vp, lg, fp, fp, i32, vp]),
         "dfn_bias_grad": (i32, [i32, i32, vp, lg, fp, fp, vp]),
         "dfn_zero_async": (i32, [vp, lg, vp]),
         "dfn_signal_grad": (i32, [i32, i32, fp, vp, lg, fp, fp, vp]),

@@ -47,6 +47,8 @@ _SPLIT_JOIN = os.environ.get("DFN_TRAIN_SPLIT_JOIN", "1") == "1"
 # 7.707 -> 7.659 ms with the torso first - there the head's shorter dX chain runs beside the torso's GEMMs and the conditioning chains have a
 # millisecond of GEMMs to hide under either way - so the default depends on the tier (unset: f32 on, 16-bit off).
 _TORSO_FIRST = os.environ.get("DFN_TRAIN_TORSO_FIRST")
+# f32 tier: the last field's narrow weight-gradient GEMMs on the side stream, beside its 256 x 256 launch (1) or behind it on the main stream (0: A/B)
+_NARROW_SIDE = os.environ.get("DFN_TRAIN_NARROW_SIDE", "1") == "1"
 # the step's loss from the training forward's epilogue (1: dfn_train_fwd*_loss) or from its own launch (0: dfn_mse_loss_u8; A/B)
 _LOSS_IN_FWD = os.environ.get("DFN_TRAIN_LOSS_IN_FWD", "1") == "1"
 
@@ -315,9 +317,22 @@ def _fused_backward(ctx, d_h, d_c):
         check(lib.dfn_mlp_bwd(buf.tier, f, _ptr(buf.packed_T[f]), _ptr(buf.samples), _ptr(buf.dsamples),
                               _ptr(buf.masks[f]), buf.NP, _ptr(buf.dy[f]), stream), "dfn_mlp_bwd")
 
-    def dw(f, stream, g, with_sig, before_reduce=None):
+    def dw(f, stream, g, with_sig, before_reduce=None, narrow_on=None):
         gb = C.c_void_p(g_bias.data_ptr() + (4 * buf.nb[0] if f else 0))
-        if before_reduce is None:
+        if before_reduce is not None and narrow_on is not None:
+            # f32 tier, the LAST field: its narrow GEMMs (HBM-bound, 72 KiB of LDS) on the other field's stream, beside its own 256 x 256
+            # launch (matrix-pipe-bound, 64 KiB) instead of behind it - a workgroup of each fits one compute unit, and no fifth queue
+            # (LABNOTES 10.8).  `narrow_on` = (stream, event): the event orders the side stream behind this field's dX chain.
+            n_stream, n_ev = narrow_on
+            n_ev.record(main)
+            n_stream.wait_event(n_ev)
+            for which, st_ in ((2, C.c_void_p(n_stream.cuda_stream)), (1, stream)):
+                check(lib.dfn_weight_bias_grad_partials_part(buf.tier, f, buf.act_format, _ptr(buf.dy[f]), _ptr(buf.act[f]), buf.NP,
+                                                             _ptr(buf.ws[f]), gb, which, st_), "dfn_weight_bias_grad_partials_part")
+            before_reduce()
+            check(lib.dfn_weight_bias_grad_reduce(buf.tier, f, buf.NP, _ptr(buf.ws[f]), _ptr(g), gb, stream),
+                  "dfn_weight_bias_grad_reduce")
+        elif before_reduce is None:
             check(lib.dfn_weight_bias_grad_fmt(buf.tier, f, buf.act_format, _ptr(buf.dy[f]), _ptr(buf.act[f]), buf.NP,
                                                _ptr(buf.ws[f]), _ptr(g), gb, stream), "dfn_weight_bias_grad_fmt")
         else:
@@ -396,7 +411,13 @@ def _fused_backward(ctx, d_h, d_c):
             # the main stream joins the first field's chain (GEMMs, reduction, fold backward on the side stream) in front of the
             # second's REDUCTION, not in front of its GEMMs: the cross-queue wait sat between d(signal) and a 130-us kernel that
             # does not depend on it - 17 us of the critical path (profiles/r04g_c4_timeline.txt)
-            dw(fb, st, g_flat, False, before_reduce=lambda: main.wait_stream(side))
+            narrow_on = None
+            if buf.tier == 0 and _NARROW_SIDE:
+                e_n = getattr(buf, "_ev_narrow", None)
+                if e_n is None:
+                    e_n = buf._ev_narrow = torch.cuda.Event()
+                narrow_on = (side, e_n)
+            dw(fb, st, g_flat, False, before_reduce=lambda: main.wait_stream(side), narrow_on=narrow_on)
         else:
             if over:
                 main.wait_stream(side)

@@ -45,7 +45,7 @@ extern "C" {
 #define DFN_N_DECODER_PARAMS 955242
 
 const char* dfn_last_error(void);
-/* library build info: "dfanerf <version> gfx950".  ABI notes - 0.2 (round 6): + dfn_wgrad_plan; DFN_FIELD_LISTENER accepted by the
+/* library build info: "dfanerf <version> gfx950".  ABI notes - 0.2 (round 6): + dfn_wgrad_plan, dfn_get_rays_strided, dfn_weight_bias_grad_partials_part; DFN_FIELD_LISTENER accepted by the
  * training entry points; DfnFrame.n_coarse 32 / 64 / 128.  Since round 5 (still "0.1" then): dfn_weight_bias_grad_partials only fills
  * the workspace's per-slice partials in EVERY tier - dbias is written by dfn_weight_bias_grad_reduce (a caller of _partials alone gets
  * no bias gradient; tests/test_gpu_wgrad.py holds the pair to the one-call form bit for bit). */
@@ -304,6 +304,12 @@ int dfn_weight_bias_grad_fmt(int tier, int field, int act_format, const void* dy
 int dfn_weight_bias_grad_partials(int tier, int field, int act_format, const void* dy_T, const void* act_T, long NP,
                                   float* workspace, float* dbias, void* stream);
 int dfn_weight_bias_grad_reduce(int tier, int field, long NP, float* workspace, float* grad_flat, float* dbias, void* stream);
+/* f32 tier: _partials in its two launches, for a caller that runs them on different streams - which = 1: the 256 x 256 GEMMs (89 %
+ * of a field's FLOPs, matrix-pipe-bound, 64 KiB of LDS), 2: all the others (HBM-bound, 72 KiB: a workgroup of each fits one
+ * compute unit), 3: both = _partials.  The launches write disjoint pieces of `workspace`; _reduce needs both.  (The training
+ * step puts the LAST field's narrow launch on the other field's stream, beside its 256 x 256 launch.)  16-bit tier: which = 3 only. */
+int dfn_weight_bias_grad_partials_part(int tier, int field, int act_format, const void* dy_T, const void* act_T, long NP,
+                                       float* workspace, float* dbias, int which, void* stream);
 /* Backward of dfn_fold_bias (the fold is linear; upstream it is the autograd of DEC:293-295, 311, 318, 332):
  * dbias [dfn_bias_floats] -> grad_flat (+=, layout of `params`: fc_z / fc_z_skips / fc_z_view, the signal columns
  * of fc_in / fc_p_skips / the deformation nets, every bias) and d_signal (+=, [96] head / [42] torso; may be NULL).

@@ -89,3 +89,20 @@ def test_f32_weight_and_bias_gradients_vs_float64(field, NP):
     check(lib.dfn_weight_bias_grad_reduce(0, field, NP, p(ws), p(grad2), p(dbias2), st), "reduce")
     torch.cuda.synchronize()
     assert torch.equal(grad2, grad) and torch.equal(dbias2, dbias)
+
+    # ... and the GEMM stage in its two launches, the narrow one first and on a stream of its own (what the f32 training step does with
+    # its last field): the launches write disjoint pieces of the workspace
+    grad3 = torch.zeros_like(grad)
+    dbias3 = torch.full_like(dbias, float("nan"))
+    ws.fill_(float("nan"))
+    torch.cuda.synchronize()
+    other = torch.cuda.Stream()
+    check(lib.dfn_weight_bias_grad_partials_part(0, field, 0, p(dy), p(act), NP, p(ws), p(dbias3), 2, C.c_void_p(other.cuda_stream)), "part 2")
+    check(lib.dfn_weight_bias_grad_partials_part(0, field, 0, p(dy), p(act), NP, p(ws), p(dbias3), 1, st), "part 1")
+    torch.cuda.current_stream().wait_stream(other)
+    check(lib.dfn_weight_bias_grad_reduce(0, field, NP, p(ws), p(grad3), p(dbias3), st), "reduce")
+    torch.cuda.synchronize()
+    assert torch.equal(grad3, grad) and torch.equal(dbias3, dbias)
+    # the selector is the f32 tier's: anything else is refused
+    assert lib.dfn_weight_bias_grad_partials_part(0, field, 0, p(dy), p(act), NP, p(ws), p(dbias3), 0, st) != 0
+    assert lib.dfn_weight_bias_grad_partials_part(1, field, 0, p(dy), p(act), NP, p(ws), p(dbias3), 1, st) != 0
